@@ -1,0 +1,841 @@
+// fg_engine.hip -- gfx950 kernels + engine half of the C ABI (include/fugue_amd.h).
+//
+// Data layout in HBM (all per-engine, struct-of-arrays, LAST index = chain so that the
+// 64 lanes of a wave touch 64 consecutive 8-byte words):
+//   values   [S][C]   trace cells (f64 bits or int64)              <- current state
+//   lj       [C]      log pi of the current state (HmcSession::lj_cur, hmc.rs:648)
+//   eps      [C]      running step size; frozen [C] (NaN = not frozen yet)
+//   da_mu, da_leb, da_hbar [C], da_m [C]   DualAveraging (hmc.rs:141-150)
+//   m_inv, mass_sqrt [d][C], w_mean, w_m2 [d][C], w_n [C]   (only when adapt_mass)
+//   alpha_sum [C], n_div [C]               per-chain statistics
+// One block = one wave of 64 chains; the wave's working set (site values + expression
+// temporaries + momentum) is a [(n_slots + d)][64] tile of doubles in LDS.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fg_interp.h"
+#include "fg_program.h"
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    fg_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return FG_E_HIP; } } while (0)
+
+// ======================================================================================
+// kernels
+// ======================================================================================
+struct FgChainCtx {
+    long long C;          // chains in this engine
+    uint32_t chain0;      // global id of chain 0 (RNG stream key)
+    unsigned long long seed;
+    long long *values;    // [S][C]
+};
+
+__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots) {
+    for (int j = 0; j < P.S; ++j) slots[j * FG_WAVE] = fg_as_double(X.values[(long long)j * X.C + c]);
+}
+__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots) {
+    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[j * FG_WAVE]);
+}
+
+// ---- run(PriorHandler, model) per chain: interpreters.rs:88-104 ----
+__global__ __launch_bounds__(FG_WAVE) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
+                                                        double *acc_out /*[3][C]*/, double *lj_out /*[C]*/) {
+    extern __shared__ double lds[];
+    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    for (int j = 0; j < P.n_slots; ++j) slots[j * FG_WAVE] = 0.0;
+    FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, iteration, purpose);
+    FgAcc3 A = {0.0, 0.0, 0.0};
+    fg_exec<FG_MODE_PRIOR, false>(P.ins, P.n_ins, P.pool, slots, A, &rng, nullptr, 0, live);
+    if (live) {
+        fg_store_values(P, X, c, slots);
+        if (acc_out) { acc_out[c] = A.prior; acc_out[X.C + c] = A.lik; acc_out[2 * X.C + c] = A.fac; }
+        if (lj_out) lj_out[c] = fg_total(A);
+    }
+}
+
+// ---- run(ScoreGivenTrace, model) per chain: interpreters.rs:138-163 ----
+__global__ __launch_bounds__(FG_WAVE) void k_log_joint(FgProgramDev P, FgChainCtx X, double *acc_out, double *logp_out,
+                                                       double *lj_out) {
+    extern __shared__ double lds[];
+    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    fg_load_values(P, X, c, slots);
+    FgAcc3 A = {0.0, 0.0, 0.0};
+    fg_exec<FG_MODE_SCORE, true>(P.ins, P.n_ins, P.pool, slots, A, nullptr, logp_out ? logp_out + c : nullptr, X.C, live);
+    if (live) {
+        if (acc_out) { acc_out[c] = A.prior; acc_out[X.C + c] = A.lik; acc_out[2 * X.C + c] = A.fac; }
+        if (lj_out) lj_out[c] = fg_total(A);
+    }
+}
+
+// ---- HMC building blocks ---------------------------------------------------------------
+struct FgHmcDev {
+    double *lj, *eps, *frozen, *da_mu, *da_leb, *da_hbar;
+    unsigned long long *da_m;
+    double *m_inv, *mass_sqrt, *w_mean, *w_m2;     // [d][C] or null
+    unsigned long long *w_n;
+    double *alpha_sum; unsigned long long *n_div;
+    double *p0_scratch;                             // [d][C] (eps search / injected momentum)
+    int L; double h, target; int grad_mode; int use_mass;
+};
+
+// leapfrog (hmc.rs:353-407) followed by the endpoint score (score_full, hmc.rs:283-299), as
+// ONE flat loop over model evaluations so that the interpreter has a single call site:
+//   evaluations 0 .. (L+1)*2d-1 : grad_log_joint (hmc.rs:304-329), coordinate i of gradient
+//                                 s = e / 2d, at q_i + h (even) then q_i - h (odd);
+//   last evaluation             : the full program at the endpoint.
+// q lives in `slots`, p in `pl`.  The gradient is consumed coordinate by coordinate: p_i gets
+// the trailing half-kick of step s and the leading half-kick of step s+1 as soon as g_i is
+// known -- the same operations on p_i, in the same order, as the reference's vector loops --
+// so no gradient vector is stored.  DENSE re-runs the whole program per evaluation (the
+// reference's 2d model runs per gradient); SPARSE re-runs only the statements that read
+// coordinate i (identical central difference, the cancelling terms are never formed).
+// Returns `divergent` (a non-finite force component or endpoint log-joint).
+__device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slots, double *pl, double eps, int L, double h,
+                                              bool sparse, const double *m_inv /*[d][C] column or null*/, long long C,
+                                              double &lj_end) {
+    const int d = P.d;
+    const double hk = 0.5 * eps;
+    const int n_evals = (L + 1) * 2 * d + 1;
+    bool bad = false;
+    int s = 0, i = 0, slot = 0;
+    double orig = 0.0, lp_plus = 0.0;
+    lj_end = FG_NEG_INF;
+    for (int e = 0; e < n_evals; ++e) {
+        const bool is_final = (e == n_evals - 1);
+        const bool minus = (e & 1) != 0;
+        const FgIns *prog = P.ins;
+        int n = P.n_ins;
+        if (!is_final) {
+            if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * FG_WAVE]; slots[slot * FG_WAVE] = orig + h; }
+            else slots[slot * FG_WAVE] = orig - h;
+            if (sparse) { const int o0 = P.sub_off[i]; prog = P.sub + o0; n = P.sub_off[i + 1] - o0; }
+        }
+        FgAcc3 A = {0.0, 0.0, 0.0};
+        fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, A, nullptr, nullptr, 0, false);
+        const double tot = fg_total(A);
+        if (is_final) { lj_end = tot; break; }
+        if (!minus) { lp_plus = tot; continue; }
+        slots[slot * FG_WAVE] = orig;
+        const double g = (lp_plus - tot) / (2.0 * h);            // hmc.rs:322
+        bad = bad || !fg_finite(g);
+        double p = pl[i * FG_WAVE];
+        p += hk * g;                                              // hmc.rs:389 / :400
+        if (s > 0 && s < L) p += hk * g;                          // trailing kick of step s + leading kick of s+1
+        pl[i * FG_WAVE] = p;
+        if (++i == d) {
+            i = 0;
+            if (__all(bad)) return true;                          // every lane left the support (hmc.rs:384-398)
+            if (s < L) {                                          // q += eps * M^-1 p   (hmc.rs:391-393)
+                for (int k = 0; k < d; ++k) {
+                    const int sk = P.f64_slot[k];
+                    const double mi = m_inv ? m_inv[(long long)k * C] : 1.0;
+                    slots[sk * FG_WAVE] += eps * mi * pl[k * FG_WAVE];
+                }
+            }
+            ++s;
+        }
+    }
+    return bad || !fg_finite(lj_end);
+}
+
+__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, const double *m_inv, long long C) {
+    double s = 0.0;
+    for (int i = 0; i < P.d; ++i) {
+        const double p = pl[i * FG_WAVE];
+        const double mi = m_inv ? m_inv[(long long)i * C] : 1.0;
+        s += p * p * mi;
+    }
+    return 0.5 * s;
+}
+
+// p0 ~ N(0, M): hmc.rs:436-441.  Box-Muller pairs from the chain's (iteration) stream.
+__device__ __forceinline__ void fg_draw_momentum(const FgProgramDev &P, FgStream &rng, double *pl, const double *mass_sqrt,
+                                                 long long C) {
+    for (int i = 0; i < P.d; i += 2) {
+        double z0, z1;
+        fg_rng_normal_pair(rng, z0, z1);
+        pl[i * FG_WAVE] = z0 * (mass_sqrt ? mass_sqrt[(long long)i * C] : 1.0);
+        if (i + 1 < P.d) pl[(i + 1) * FG_WAVE] = z1 * (mass_sqrt ? mass_sqrt[(long long)(i + 1) * C] : 1.0);
+    }
+}
+
+struct FgTransOut { bool accepted, divergent; double alpha, lj; };
+
+// hmc_transition (hmc.rs:419-473).  On entry: slots = current q (and discrete sites),
+// pl = p0.  On exit: slots hold the NEXT state (accepted endpoint or the restored current
+// state) and X.values is up to date.
+__device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, const FgChainCtx &X, const FgHmcDev &H, long long c,
+                                                        bool live, double *slots, double *pl, double lj_cur, double eps,
+                                                        double u) {
+    const double *mi = H.use_mass ? H.m_inv + c : nullptr;
+    const double h0 = -lj_cur + fg_kinetic(P, pl, mi, X.C);      // hmc.rs:442-443
+    double lj_new;
+    const bool div = fg_trajectory(P, slots, pl, eps, H.L, H.h, H.grad_mode == FG_GRAD_FD_SPARSE, mi, X.C, lj_new);
+    FgTransOut o;
+    o.divergent = div;
+    double ap = 0.0;
+    bool acc = false;
+    if (!div) {
+        const double h_new = -lj_new + fg_kinetic(P, pl, mi, X.C);
+        ap = fmin(exp(h0 - h_new), 1.0);                          // hmc.rs:460
+        acc = u < ap;                                             // hmc.rs:461
+    }
+    o.alpha = ap; o.accepted = acc; o.lj = acc ? lj_new : lj_cur;
+    for (int i = 0; i < P.d; ++i) {                               // commit or roll back the f64 sites
+        const int slot = P.f64_slot[i];
+        const long long g = (long long)slot * X.C + c;
+        if (acc) { if (live) X.values[g] = fg_as_i64(slots[slot * FG_WAVE]); }
+        else slots[slot * FG_WAVE] = fg_as_double(X.values[g]);
+    }
+    return o;
+}
+
+// HmcSession::step x n_steps (hmc.rs:819-919), d > 0, without the mass-matrix reset (the
+// host splits launches at that iteration).
+__global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps,
+                                                       int n_warmup, int welford_on, double *draws, int first_sample_t) {
+    extern __shared__ double lds[];
+    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    double *pl = lds + (long long)P.n_slots * FG_WAVE + threadIdx.x;
+    fg_load_values(P, X, c, slots);
+    double lj = H.lj[c], eps = H.eps[c], frozen = H.frozen[c];
+    double da_mu = H.da_mu[c], da_leb = H.da_leb[c], da_hbar = H.da_hbar[c];
+    unsigned long long da_m = H.da_m[c];
+    double asum = 0.0; unsigned long long ndiv = 0;
+    const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+
+    for (int t = 0; t < n_steps; ++t) {
+        const int iter = iter0 + t;
+        const bool warming = iter < n_warmup;
+        double e;
+        if (warming) e = eps;
+        else {                                             // frozen_or_current: hmc.rs:789-798
+            if (frozen == frozen) e = frozen;
+            else if (n_warmup > 0) e = exp(da_leb);
+            else e = eps;
+            frozen = e;
+        }
+        FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_HMC);
+        fg_draw_momentum(P, rng, pl, ms, X.C);
+        const double u = fg_rng_u01(rng);
+        const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, lj, e, u);
+        lj = o.lj;
+        asum += o.alpha; ndiv += o.divergent ? 1ull : 0ull;
+        if (warming) {                                     // DualAveraging::update: hmc.rs:168-178
+            da_m += 1ull;
+            const double m = (double)da_m;
+            const double a = o.alpha < 0.0 ? 0.0 : (o.alpha > 1.0 ? 1.0 : o.alpha);
+            const double frac = 1.0 / (m + 10.0);
+            da_hbar = (1.0 - frac) * da_hbar + frac * (H.target - a);
+            const double log_eps = da_mu - (sqrt(m) / 0.05) * da_hbar;
+            const double w = pow(m, -0.75);
+            da_leb = w * log_eps + (1.0 - w) * da_leb;
+            eps = exp(log_eps);
+            if (welford_on) {                              // Welford::push: hmc.rs:202-211
+                const unsigned long long wn = H.w_n[c] + 1ull;
+                if (live) H.w_n[c] = wn;
+                const double n = (double)wn;
+                for (int i = 0; i < P.d; ++i) {
+                    const long long g = (long long)i * X.C + c;
+                    const double x = slots[P.f64_slot[i] * FG_WAVE];
+                    double mean = H.w_mean[g];
+                    const double delta = x - mean;
+                    mean += delta / n;
+                    const double delta2 = x - mean;
+                    if (live) { H.w_mean[g] = mean; H.w_m2[g] += delta * delta2; }
+                }
+            }
+        } else if (draws && live) {                        // hmc_chain pushes the current state: hmc.rs:577-582
+            double *row = draws + (long long)(t - first_sample_t) * P.d * X.C + c;
+            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * FG_WAVE];
+        }
+    }
+    if (live) {
+        H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
+        H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
+        H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
+    }
+}
+
+// hmc_transition with injected momentum / uniform (test hook)
+__global__ __launch_bounds__(FG_WAVE) void k_hmc_transition_injected(FgProgramDev P, FgChainCtx X, FgHmcDev H, double eps,
+                                                                     const double *p0, const double *u_in, int *acc_out,
+                                                                     double *alpha_out, int *div_out) {
+    extern __shared__ double lds[];
+    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    double *pl = lds + (long long)P.n_slots * FG_WAVE + threadIdx.x;
+    fg_load_values(P, X, c, slots);
+    for (int i = 0; i < P.d; ++i) pl[i * FG_WAVE] = p0[(long long)i * X.C + c];
+    const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, H.lj[c], eps, u_in[c]);
+    if (live) {
+        H.lj[c] = o.lj;
+        if (acc_out) acc_out[c] = o.accepted;
+        if (alpha_out) alpha_out[c] = o.alpha;
+        if (div_out) div_out[c] = o.divergent;
+    }
+}
+
+// grad_log_joint (hmc.rs:304-329) at the current values (test hook)
+__global__ __launch_bounds__(FG_WAVE) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse, double *grad, int *ok) {
+    extern __shared__ double lds[];
+    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    fg_load_values(P, X, c, slots);
+    bool good = true;
+    double orig = 0.0, lp_plus = 0.0;
+    int slot = 0;
+    for (int e = 0; e < 2 * P.d; ++e) {
+        const int i = e >> 1;
+        const bool minus = (e & 1) != 0;
+        if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * FG_WAVE]; slots[slot * FG_WAVE] = orig + h; }
+        else slots[slot * FG_WAVE] = orig - h;
+        const FgIns *prog = P.ins; int n = P.n_ins;
+        if (sparse) { const int o0 = P.sub_off[i]; prog = P.sub + o0; n = P.sub_off[i + 1] - o0; }
+        FgAcc3 A = {0.0, 0.0, 0.0};
+        fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, A, nullptr, nullptr, 0, false);
+        if (!minus) { lp_plus = fg_total(A); continue; }
+        slots[slot * FG_WAVE] = orig;
+        const double g = (lp_plus - fg_total(A)) / (2.0 * h);
+        good = good && fg_finite(g);
+        if (live) grad[(long long)i * X.C + c] = g;
+    }
+    if (live && ok) ok[c] = good;
+}
+
+// find_reasonable_epsilon (hmc.rs:479-535).  Momentum comes from p0_scratch [d][C] when
+// `injected`, else from the chain's (instance) EPS stream and is written there.
+__global__ __launch_bounds__(FG_WAVE) void k_hmc_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, uint32_t instance, int injected,
+                                                          double *eps_out) {
+    extern __shared__ double lds[];
+    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    double *pl = lds + (long long)P.n_slots * FG_WAVE + threadIdx.x;
+    const double *mi = H.use_mass ? H.m_inv + c : nullptr;
+    const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+    const bool sparse = H.grad_mode == FG_GRAD_FD_SPARSE;
+    fg_load_values(P, X, c, slots);
+    if (!injected) {
+        FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, instance, FG_RNG_EPS);
+        fg_draw_momentum(P, rng, pl, ms, X.C);
+        if (live) for (int i = 0; i < P.d; ++i) H.p0_scratch[(long long)i * X.C + c] = pl[i * FG_WAVE];
+    } else {
+        for (int i = 0; i < P.d; ++i) pl[i * FG_WAVE] = H.p0_scratch[(long long)i * X.C + c];
+    }
+    // keep p0 in registers-free storage: re-read it from LDS-resident copy is impossible once
+    // the trajectory overwrites pl, so dead lanes (which did not write p0_scratch) re-derive
+    // it the same way live lanes re-read it -- from the column of the chain they mirror.
+    const double lj_q = H.lj[c];
+    const double h0 = -lj_q + fg_kinetic(P, pl, mi, X.C);
+    const double ln_half = log(0.5), ln2 = log(2.0);
+    double eps = 1.0, lr = 0.0, a = 1.0;
+    bool active = true;     // lanes still inside the doubling/halving loop
+    bool first = true;
+    unsigned iters = 0;
+    while (__any(active)) {
+        // log_ratio_at(eps_try): one leapfrog step from (q, p0)      hmc.rs:500-511
+        const double eps_try = first ? 1.0 : eps * ((a > 0.0) ? 2.0 : 0.5);   // eps * 2^a
+        double lj1;
+        const bool div = fg_trajectory(P, slots, pl, eps_try, 1, H.h, sparse, mi, X.C, lj1);
+        double lr_try = FG_NEG_INF;
+        if (!div) lr_try = h0 - (-lj1 + fg_kinetic(P, pl, mi, X.C));
+        // restore (q, p0) for the next trial
+        for (int i = 0; i < P.d; ++i) {
+            const int slot = P.f64_slot[i];
+            slots[slot * FG_WAVE] = fg_as_double(X.values[(long long)slot * X.C + c]);
+            pl[i * FG_WAVE] = H.p0_scratch[(long long)i * X.C + c];
+        }
+        if (first) {
+            lr = lr_try;
+            a = (lr > ln_half) ? 1.0 : -1.0;
+            active = a * lr > -a * ln2;
+            first = false;
+        } else if (active) {
+            eps = eps_try; lr = lr_try; iters += 1;
+            if (iters > 100 || !(eps >= 1e-12 && eps <= 1e12)) active = false;
+            else if (a > 0.0 && lr == FG_NEG_INF) { eps /= 2.0; active = false; }
+            else active = a * lr > -a * ln2;
+        }
+    }
+    if (live) eps_out[c] = fmin(fmax(eps, 1e-6), 1e3);
+}
+
+// mass-matrix reset at the warmup midpoint: Welford::variances + hmc.rs:886-894
+__global__ void k_hmc_mass_reset(FgHmcDev H, long long C, int d) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const unsigned long long n = H.w_n[c];
+    for (int i = 0; i < d; ++i) {
+        const long long g = (long long)i * C + c;
+        double v = 1.0;
+        if (n >= 2) { const double vv = H.w_m2[g] / (double)(n - 1); v = (fg_finite(vv) && vv > 1e-8) ? vv : 1.0; }
+        H.m_inv[g] = v;
+        H.mass_sqrt[g] = sqrt(1.0 / v);
+    }
+}
+// DualAveraging::new for every chain: hmc.rs:153-164
+__global__ void k_hmc_da_new(FgHmcDev H, long long C, const double *eps0) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double e = eps0[c];
+    H.eps[c] = e; H.da_mu[c] = log(10.0 * e); H.da_leb[c] = 0.0; H.da_hbar[c] = 0.0; H.da_m[c] = 0ull;
+}
+__global__ void k_fill(double *p, long long n, double v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ======================================================================================
+// engine
+// ======================================================================================
+struct fg_engine {
+    const fg_program *prog = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    long long C = 0;
+    unsigned long long seed = 0;
+    uint32_t chain0 = 0;
+    int S = 0, d = 0, n_slots = 0;
+    // device copies of the program
+    FgIns *d_ins = nullptr, *d_sub = nullptr;
+    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_vtype = nullptr;
+    double *d_pool = nullptr;
+    FgProgramDev P{};
+    FgChainCtx X{};
+    long long *d_values = nullptr;
+    double *d_acc = nullptr, *d_logp = nullptr;
+    // HMC
+    bool hmc_ready = false;
+    fg_hmc_config cfg{};
+    FgHmcDev H{};
+    std::vector<void *> hmc_allocs;
+    int n_warmup = 0, iter = 0, mass_adapt_at = -1;
+    double *d_tmp = nullptr;     // [C] scratch
+    int *d_itmp = nullptr;       // [3][C] scratch
+    size_t lds_bytes = 0;
+};
+
+namespace {
+
+int blocks_for(long long C) { return (int)((C + FG_WAVE - 1) / FG_WAVE); }
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return FG_OK;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t n) {
+    HIPCHK(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    HIPCHK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
+    return FG_OK;
+}
+template <typename T>
+int dev_upload(T **p, const std::vector<T> &v) {
+    int rc = dev_alloc(p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fg_hmc_config_default(fg_hmc_config *c) {     // HMCConfig::default, hmc.rs:125-135
+    if (!c) return;
+    c->n_leapfrog = 16; c->target_accept = 0.8; c->init_step_size = NAN; c->finite_diff_eps = 1e-5;
+    c->adapt_mass = 0; c->grad_mode = FG_GRAD_FD_DENSE;
+}
+
+fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, uint32_t chain_offset, int device) {
+    if (!p || !p->finalized) { fg_set_error("fg_engine_new: program is not finalized"); return nullptr; }
+    if (n_chains <= 0) { fg_set_error("fg_engine_new: n_chains must be positive"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fg_set_error("no HIP device available: the engine has no CPU fallback (FG_E_NO_DEVICE)"); return nullptr; }
+    if (device < 0 || device >= ndev) { fg_set_error("fg_engine_new: bad device ordinal"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fg_set_error("hipSetDevice failed"); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fg_set_error("hipGetDeviceProperties failed"); return nullptr; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fg_set_error(std::string("device arch ") + prop.gcnArchName + " is not gfx950; kernels are built for MI355X only");
+        return nullptr; }
+    fg_engine *e = new fg_engine();
+    e->prog = p; e->device = device; e->C = n_chains; e->seed = seed; e->chain0 = chain_offset;
+    e->S = (int)p->sorted_stmt.size(); e->d = (int)p->f64_slot.size(); e->n_slots = p->n_slots;
+    e->lds_bytes = (size_t)(e->n_slots + e->d + 1) * FG_WAVE * sizeof(double);
+    if (e->lds_bytes > 160 * 1024) {
+        fg_set_error("model needs more than 160 KB of LDS per wave (sites + temporaries + momentum > 319 cells)");
+        delete e; return nullptr; }
+    auto fail = [&](const char *what) { fg_set_error(std::string("fg_engine_new: ") + what + ": " + fg_last_error()); fg_engine_free(e); return (fg_engine *)nullptr; };
+    if (hipStreamCreate(&e->stream) != hipSuccess) return fail("hipStreamCreate");
+    if (dev_upload(&e->d_ins, p->ins)) return fail("upload ins");
+    if (dev_upload(&e->d_sub, p->sub)) return fail("upload sub");
+    if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
+    if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
+    if (dev_upload(&e->d_vtype, p->site_vtype)) return fail("upload vtype");
+    if (dev_upload(&e->d_pool, p->pool)) return fail("upload pool");
+    if (dev_alloc(&e->d_values, (size_t)std::max(1, e->S) * e->C)) return fail("alloc values");
+    if (dev_alloc(&e->d_acc, (size_t)3 * e->C)) return fail("alloc acc");
+    if (dev_alloc(&e->d_tmp, (size_t)e->C)) return fail("alloc tmp");
+    if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
+    e->P.ins = e->d_ins; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
+    e->P.f64_slot = e->d_f64_slot; e->P.site_vtype = e->d_vtype;
+    e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
+    e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
+    if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
+        set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
+        set_lds(k_hmc_grad, e->lds_bytes) || set_lds(k_hmc_find_eps, e->lds_bytes))
+        return fail("hipFuncSetAttribute");
+    return e;
+}
+
+void fg_engine_free(fg_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void *q : e->hmc_allocs) hipFree(q);
+    void *ptrs[] = { e->d_ins, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+                     e->d_tmp, e->d_itmp };
+    for (void *q : ptrs) if (q) hipFree(q);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+#define NEED_ENGINE(e) do { if (!(e)) { fg_set_error("null engine"); return FG_E_BAD_ARG; } \
+    if (hipSetDevice((e)->device) != hipSuccess) { fg_set_error("hipSetDevice failed"); return FG_E_HIP; } } while (0)
+
+int fg_engine_synchronize(fg_engine *e) { NEED_ENGINE(e); HIPCHK(hipStreamSynchronize(e->stream)); return FG_OK; }
+void *fg_engine_stream(fg_engine *e) { return e ? (void *)e->stream : nullptr; }
+int64_t fg_engine_n_chains(const fg_engine *e) { return e ? e->C : 0; }
+void *fg_engine_values_device(fg_engine *e) { return e ? (void *)e->d_values : nullptr; }
+
+int fg_engine_set_values(fg_engine *e, const void *h) {
+    NEED_ENGINE(e);
+    if (!h) return FG_E_BAD_ARG;
+    HIPCHK(hipMemcpyAsync(e->d_values, h, (size_t)e->S * e->C * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+int fg_engine_get_values(fg_engine *e, void *h) {
+    NEED_ENGINE(e);
+    if (!h) return FG_E_BAD_ARG;
+    HIPCHK(hipMemcpyAsync(h, e->d_values, (size_t)e->S * e->C * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+void *fg_device_alloc(fg_engine *e, size_t bytes) {
+    if (!e || hipSetDevice(e->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { fg_set_error("hipMalloc failed"); return nullptr; }
+    return p;
+}
+int fg_device_free(fg_engine *e, void *p) { NEED_ENGINE(e); HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(p)); return FG_OK; }
+int fg_device_download(fg_engine *e, void *h, const void *d, size_t bytes) {
+    NEED_ENGINE(e);
+    HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+int fg_device_upload(fg_engine *e, void *d, const void *h, size_t bytes) {
+    NEED_ENGINE(e);
+    HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+static int launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
+    hipLaunchKernelGGL(k_prior_init, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, iteration,
+                       purpose, d_acc, d_lj);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc) {
+    NEED_ENGINE(e);
+    int rc = launch_prior(e, iteration, FG_RNG_PRIOR, e->d_acc, nullptr);
+    if (rc) return rc;
+    if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp) {
+    NEED_ENGINE(e);
+    if (h_logp && !e->d_logp) { int rc = dev_alloc(&e->d_logp, (size_t)std::max(1, e->S) * e->C); if (rc) return rc; }
+    hipLaunchKernelGGL(k_log_joint, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->d_acc,
+                       h_logp ? e->d_logp : nullptr, (double *)nullptr);
+    HIPCHK(hipGetLastError());
+    if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
+    if (h_logp) HIPCHK(hipMemcpyAsync(h_logp, e->d_logp, (size_t)e->S * e->C * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ HMC host side
+static int hmc_alloc(fg_engine *e, bool mass) {
+    auto A = [&](auto **p, size_t n) { int rc = dev_alloc(p, n); if (!rc) e->hmc_allocs.push_back((void *)*p); return rc; };
+    size_t C = (size_t)e->C, d = (size_t)std::max(1, e->d);
+    if (!e->H.lj) {
+        if (A(&e->H.lj, C) || A(&e->H.eps, C) || A(&e->H.frozen, C) || A(&e->H.da_mu, C) || A(&e->H.da_leb, C) ||
+            A(&e->H.da_hbar, C) || A(&e->H.da_m, C) || A(&e->H.alpha_sum, C) || A(&e->H.n_div, C) || A(&e->H.p0_scratch, d * C))
+            return FG_E_HIP;
+    }
+    if (mass && !e->H.m_inv) {
+        if (A(&e->H.m_inv, d * C) || A(&e->H.mass_sqrt, d * C) || A(&e->H.w_mean, d * C) || A(&e->H.w_m2, d * C) || A(&e->H.w_n, C))
+            return FG_E_HIP;
+    }
+    return FG_OK;
+}
+
+static void hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg) {
+    e->cfg = *cfg;
+    e->H.L = cfg->n_leapfrog > 1 ? cfg->n_leapfrog : 1;        // hmc.rs:684
+    e->H.h = cfg->finite_diff_eps; e->H.target = cfg->target_accept;
+    e->H.grad_mode = cfg->grad_mode;
+}
+
+static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
+    hipLaunchKernelGGL(k_hmc_find_eps, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H, instance,
+                       injected, d_eps_out);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
+    NEED_ENGINE(e);
+    if (!cfg || n_warmup < 0) return FG_E_BAD_ARG;
+    if (cfg->grad_mode != FG_GRAD_FD_DENSE && cfg->grad_mode != FG_GRAD_FD_SPARSE) { fg_set_error("unknown grad_mode"); return FG_E_BAD_ARG; }
+    const bool mass = cfg->adapt_mass && n_warmup >= 4;                 // hmc.rs:704-708
+    int rc = hmc_alloc(e, mass);
+    if (rc) return rc;
+    hmc_set_cfg(e, cfg);
+    e->H.use_mass = mass ? 1 : 0;
+    e->n_warmup = n_warmup; e->iter = 0; e->mass_adapt_at = mass ? n_warmup / 2 : -1;
+    const int TB = 256, NB = (int)((e->C + TB - 1) / TB);
+    size_t C = (size_t)e->C;
+    HIPCHK(hipMemsetAsync(e->H.alpha_sum, 0, C * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->H.n_div, 0, C * 8, e->stream));
+    hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->H.frozen, (long long)C, (double)NAN);
+    if (mass) {
+        size_t dC = (size_t)e->d * C;
+        const int NBd = (int)((dC + TB - 1) / TB);
+        hipLaunchKernelGGL(k_fill, dim3(NBd), dim3(TB), 0, e->stream, e->H.m_inv, (long long)dC, 1.0);
+        hipLaunchKernelGGL(k_fill, dim3(NBd), dim3(TB), 0, e->stream, e->H.mass_sqrt, (long long)dC, 1.0);
+        HIPCHK(hipMemsetAsync(e->H.w_mean, 0, dC * 8, e->stream));
+        HIPCHK(hipMemsetAsync(e->H.w_m2, 0, dC * 8, e->stream));
+        HIPCHK(hipMemsetAsync(e->H.w_n, 0, C * 8, e->stream));
+    }
+    rc = launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->H.lj);             // hmc.rs:673-687
+    if (rc) return rc;
+    if (e->d == 0) hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->d_tmp, (long long)C, 1.0);
+    else if (!std::isnan(cfg->init_step_size)) hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->d_tmp, (long long)C, cfg->init_step_size);
+    else { rc = hmc_find_eps(e, 0, 0, e->d_tmp); if (rc) return rc; }
+    hipLaunchKernelGGL(k_hmc_da_new, dim3(NB), dim3(TB), 0, e->stream, e->H, (long long)C, (const double *)e->d_tmp);
+    HIPCHK(hipGetLastError());
+    e->hmc_ready = true;
+    return FG_OK;
+}
+
+static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t) {
+    hipLaunchKernelGGL(k_hmc_steps, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
+                       e->n_warmup, welford_on, draws, first_sample_t);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) {
+    NEED_ENGINE(e);
+    if (!e->hmc_ready) { fg_set_error("fg_hmc_step before fg_hmc_init"); return FG_E_STATE; }
+    if (n_transitions < 0) return FG_E_BAD_ARG;
+    int done = 0;
+    long long rows_written = 0;          // post-warmup rows appended to d_draws by this call
+    while (done < n_transitions) {
+        const int iter = e->iter;
+        if (e->d == 0) {                                   // fresh prior draw per step: hmc.rs:826-845
+            int rc = launch_prior(e, (uint32_t)(iter + 1), FG_RNG_PRIOR, nullptr, e->H.lj);
+            if (rc) return rc;
+            e->iter += 1; done += 1;
+            continue;
+        }
+        int n = n_transitions - done;
+        // stop a launch at the mass-adaptation iteration (its reset runs between launches)
+        if (e->mass_adapt_at >= 0 && iter < e->mass_adapt_at) n = std::min(n, e->mass_adapt_at - iter);
+        const int welford_on = (e->mass_adapt_at >= 0) ? 1 : 0;
+        const int first_sample_t = std::max(iter, e->n_warmup) - iter;      // first post-warmup t of this launch
+        const int n_rows = std::max(0, n - first_sample_t);
+        double *draws = (d_draws && n_rows > 0) ? d_draws + rows_written * (long long)e->d * e->C : nullptr;
+        int rc = hmc_launch_steps(e, iter, n, welford_on, draws, first_sample_t);
+        if (rc) return rc;
+        rows_written += n_rows;
+        e->iter += n; done += n;
+        if (e->mass_adapt_at >= 0 && e->iter == e->mass_adapt_at) {    // hmc.rs:885-908
+            const int TB = 256, NB = (int)((e->C + TB - 1) / TB);
+            hipLaunchKernelGGL(k_hmc_mass_reset, dim3(NB), dim3(TB), 0, e->stream, e->H, e->C, e->d);
+            rc = hmc_find_eps(e, 1, 0, e->d_tmp);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_hmc_da_new, dim3(NB), dim3(TB), 0, e->stream, e->H, e->C, (const double *)e->d_tmp);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return FG_OK;
+}
+
+int fg_hmc_get_stats(fg_engine *e, fg_hmc_stats *st) {
+    NEED_ENGINE(e);
+    if (!st || !e->hmc_ready) return FG_E_BAD_ARG;
+    std::vector<double> a((size_t)e->C), eps((size_t)e->C), fr((size_t)e->C), leb((size_t)e->C);
+    std::vector<unsigned long long> nd((size_t)e->C);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(a.data(), e->H.alpha_sum, a.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nd.data(), e->H.n_div, nd.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(eps.data(), e->H.eps, eps.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fr.data(), e->H.frozen, fr.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(leb.data(), e->H.da_leb, leb.size() * 8, hipMemcpyDeviceToHost));
+    double as = 0.0, es = 0.0; long long dv = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        as += a[i]; dv += (long long)nd[i];
+        double cur = eps[i];
+        if (e->iter >= e->n_warmup) cur = !std::isnan(fr[i]) ? fr[i] : (e->n_warmup > 0 ? std::exp(leb[i]) : eps[i]);
+        es += cur;
+    }
+    st->n_transitions = (long long)e->iter * e->C;
+    st->accept_rate = (e->d == 0) ? 1.0 : (st->n_transitions > 0 ? as / (double)st->n_transitions : 0.0);
+    st->mean_step_size = es / (double)e->C;
+    st->n_divergent = dv;
+    return FG_OK;
+}
+
+int fg_hmc_run(fg_engine *e, const fg_hmc_config *cfg, int n_samples, int n_warmup, double *d_draws, fg_hmc_stats *st) {
+    int rc = fg_hmc_init(e, cfg, n_warmup);
+    if (rc) return rc;
+    rc = fg_hmc_step(e, n_warmup, nullptr);
+    if (rc) return rc;
+    rc = fg_hmc_step(e, n_samples, d_draws);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (st) return fg_hmc_get_stats(e, st);
+    return FG_OK;
+}
+
+int fg_hmc_get_step_sizes(fg_engine *e, double *h_eps) {
+    NEED_ENGINE(e);
+    if (!h_eps || !e->hmc_ready) return FG_E_BAD_ARG;
+    std::vector<double> eps((size_t)e->C), fr((size_t)e->C), leb((size_t)e->C);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(eps.data(), e->H.eps, eps.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fr.data(), e->H.frozen, fr.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(leb.data(), e->H.da_leb, leb.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < eps.size(); i++)     // HmcSession::step_size, hmc.rs:771-777
+        h_eps[i] = (e->iter < e->n_warmup) ? eps[i] : (!std::isnan(fr[i]) ? fr[i] : (e->n_warmup > 0 ? std::exp(leb[i]) : eps[i]));
+    return FG_OK;
+}
+int fg_hmc_get_log_joint(fg_engine *e, double *h_lj) {
+    NEED_ENGINE(e);
+    if (!h_lj || !e->hmc_ready) return FG_E_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(h_lj, e->H.lj, (size_t)e->C * 8, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+int fg_hmc_set_step_size(fg_engine *e, double eps) {    // hmc.rs:741-747
+    NEED_ENGINE(e);
+    if (!e->hmc_ready) return FG_E_STATE;
+    eps = std::max(eps, 1e-12);
+    const int TB = 256, NB = (int)((e->C + TB - 1) / TB);
+    hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->H.eps, e->C, eps);
+    hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->H.frozen, e->C, eps);
+    HIPCHK(hipGetLastError());
+    e->n_warmup = std::min(e->n_warmup, e->iter);
+    return FG_OK;
+}
+
+int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *h_ok) {
+    NEED_ENGINE(e);
+    if (!h_grad) return FG_E_BAD_ARG;
+    double *d_g = nullptr;
+    int rc = dev_alloc(&d_g, (size_t)std::max(1, e->d) * e->C);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hmc_grad, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, h,
+                       grad_mode == FG_GRAD_FD_SPARSE ? 1 : 0, d_g, e->d_itmp);
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipMemcpyAsync(h_grad, d_g, (size_t)e->d * e->C * 8, hipMemcpyDeviceToHost, e->stream);
+    if (le == hipSuccess && h_ok) le = hipMemcpyAsync(h_ok, e->d_itmp, (size_t)e->C * 4, hipMemcpyDeviceToHost, e->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(e->stream);
+    hipFree(d_g);
+    if (le != hipSuccess) { fg_set_error(hipGetErrorString(le)); return FG_E_HIP; }
+    return FG_OK;
+}
+
+static int hmc_prepare_injected(fg_engine *e, const fg_hmc_config *cfg) {
+    if (!cfg) return FG_E_BAD_ARG;
+    int rc = hmc_alloc(e, false);
+    if (rc) return rc;
+    if (!e->hmc_ready) {      // standalone use: lj of the current values, identity mass
+        e->H.use_mass = 0;
+        hipLaunchKernelGGL(k_log_joint, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, (double *)nullptr,
+                           (double *)nullptr, e->H.lj);
+        HIPCHK(hipGetLastError());
+    }
+    hmc_set_cfg(e, cfg);
+    return FG_OK;
+}
+
+int fg_hmc_transition_injected(fg_engine *e, const fg_hmc_config *cfg, double eps, const double *h_p0, const double *h_u,
+                               int32_t *h_acc, double *h_alpha, int32_t *h_div, double *h_lj) {
+    NEED_ENGINE(e);
+    if (!h_p0 || !h_u) return FG_E_BAD_ARG;
+    int rc = hmc_prepare_injected(e, cfg);
+    if (rc) return rc;
+    size_t C = (size_t)e->C;
+    HIPCHK(hipMemcpyAsync(e->H.p0_scratch, h_p0, (size_t)e->d * C * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_tmp, h_u, C * 8, hipMemcpyHostToDevice, e->stream));
+    int *ia = e->d_itmp, *idv = e->d_itmp + C;
+    double *al = e->d_acc;
+    hipLaunchKernelGGL(k_hmc_transition_injected, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H,
+                       eps, (const double *)e->H.p0_scratch, (const double *)e->d_tmp, ia, al, idv);
+    HIPCHK(hipGetLastError());
+    if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, ia, C * 4, hipMemcpyDeviceToHost, e->stream));
+    if (h_div) HIPCHK(hipMemcpyAsync(h_div, idv, C * 4, hipMemcpyDeviceToHost, e->stream));
+    if (h_alpha) HIPCHK(hipMemcpyAsync(h_alpha, al, C * 8, hipMemcpyDeviceToHost, e->stream));
+    if (h_lj) HIPCHK(hipMemcpyAsync(h_lj, e->H.lj, C * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+int fg_hmc_find_eps_injected(fg_engine *e, const fg_hmc_config *cfg, const double *h_p0, double *h_eps) {
+    NEED_ENGINE(e);
+    if (!h_p0 || !h_eps) return FG_E_BAD_ARG;
+    int rc = hmc_prepare_injected(e, cfg);
+    if (rc) return rc;
+    size_t C = (size_t)e->C;
+    HIPCHK(hipMemcpyAsync(e->H.p0_scratch, h_p0, (size_t)e->d * C * 8, hipMemcpyHostToDevice, e->stream));
+    rc = hmc_find_eps(e, 0, 1, e->d_tmp);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_eps, e->d_tmp, C * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// fg_interp.h -- the site-program evaluator on gfx950: one wavefront lane = one chain.
+//
+// Restates `run(handler, model)` (src/runtime/handler.rs:124-209) for the two handlers the
+// hot path needs -- ScoreGivenTrace (src/runtime/interpreters.rs:138-163) and PriorHandler
+// (:88-104) -- over a flattened program.  The program counter is wave-uniform:
+//   * each 96-byte instruction is fetched with two scalar loads (s_load_dwordx16 + x8)
+//     from the constant address space, one instruction AHEAD of the one being executed,
+//     so the fetch latency hides behind the previous instruction's f64 math (there is
+//     only one wave per SIMD at 65 536 chains -- nothing else would hide it);
+//   * every branch on opcode / operand kind / flags is a scalar branch: 64 chains run in
+//     lockstep, no divergence except inside the PRIOR-mode rejection samplers.
+// Per-lane state lives in LDS as a [slots][64] tile of 8-byte cells: lane l reads slot k
+// at lds[k*64 + l] -> 64 consecutive 8-byte words per wave access, conflict-free for
+// ds_read_b64 / ds_write_b64 (MI355X_MICROARCH.md, LDS table).
+//
+// fg_exec is force-inlined and every kernel is written so that it has exactly ONE call
+// site of it (state machines around a single evaluation loop): no function-call ABI in
+// the hot path and one copy of the interpreter per kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fg_math.h"
+
+#define FG_WAVE 64
+#define FG_AS4 __attribute__((address_space(4)))
+typedef uint32_t fg_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t fg_u32x8 __attribute__((ext_vector_type(8)));
+
+struct FgAcc3 { double prior, lik, fac; };   // Trace accumulators, src/runtime/trace.rs:168-177
+
+enum { FG_MODE_SCORE = 0, FG_MODE_PRIOR = 1 };
+
+// one instruction held in 24 SGPRs
+struct FgInsRegs { fg_u32x16 a; fg_u32x8 b; };
+__device__ __forceinline__ FgInsRegs fg_fetch_ins(const FgIns *prog, int pc) {
+    const FG_AS4 char *p = (const FG_AS4 char *)(uintptr_t)(prog + pc);
+    FgInsRegs r;
+    r.a = *(const FG_AS4 fg_u32x16 *)p;
+    r.b = *(const FG_AS4 fg_u32x8 *)(p + 64);
+    return r;
+}
+__device__ __forceinline__ double fg_dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+// field accessors (layout of FgIns, fg_ir.h): dw0 op, dw1..4 opnd, dw5 aux, dw6.. imm[4], dw14.. h[5]
+#define FG_I_OP(r) ((r).a[0])
+#define FG_I_OPND(r, k) ((r).a[1 + (k)])
+#define FG_I_AUX(r) ((r).a[5])
+#define FG_I_IMM(r, k) fg_dbl((r).a[6 + 2 * (k)], (r).a[7 + 2 * (k)])
+__device__ __forceinline__ double fg_ins_h(const FgInsRegs &r, int k) {
+    return k == 0 ? fg_dbl(r.a[14], r.a[15]) : fg_dbl(r.b[2 * k - 2], r.b[2 * k - 1]);
+}
+
+__device__ __forceinline__ double fg_operand(uint32_t w, double imm, const double *slots, const double *pool) {
+    const uint32_t kind = FG_OPND_KIND(w), idx = FG_OPND_IDX(w);
+    if (kind == FG_OPND_IMM) return imm;
+    if (kind == FG_OPND_SLOT_F) return slots[idx * FG_WAVE];
+    if (kind == FG_OPND_SLOT_I) return (double)fg_as_i64(slots[idx * FG_WAVE]);
+    return pool[idx];
+}
+
+// Integer value of an observed expression (`Value::as_bool` / `as_index`,
+// crates/fugue-wasm/src/dsl.rs:68-81,1002-1021)
+__device__ __forceinline__ long long fg_int_of(double v, uint32_t vtype) {
+    if (vtype == 1u /*bool*/) return v != 0.0;
+    return fg_finite(v) ? (long long)v : 0;
+}
+
+// Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane].
+// `prog` must have one readable instruction past `n` (the host pads the arrays).
+// logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
+template <int MODE, bool WITH_LOGP>
+__device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, FgAcc3 &A,
+                                        FgStream *rng, double *logp_out, long long logp_stride, bool live) {
+    double acc = 0.0;
+    FgInsRegs I = fg_fetch_ins(prog, 0);
+    for (int pc = 0; pc < n; ++pc) {
+        const FgInsRegs Inext = fg_fetch_ins(prog, pc + 1);      // prefetch (scalar, wave-uniform)
+        const uint32_t op = FG_I_OP(I);
+        const uint32_t code = FG_INS_OPCODE(op);
+        if (code < 17u) {
+            // ---------------- sample / observe site: dist.log_prob(x) ----------------
+            const bool hoisted = (op & FG_F_HOISTED) != 0u;
+            const bool observe = (op & FG_F_OBSERVE) != 0u;
+            const uint32_t vtype = FG_INS_VTYPE(op);
+            const uint32_t xw = FG_I_OPND(I, 0);
+            const uint32_t aux = FG_I_AUX(I);
+            double lp;
+            if (code == 3u) {                            // Categorical: distribution.rs:771-791
+                const uint32_t bw = FG_I_OPND(I, 1);
+                const int K = (int)FG_I_OPND(I, 2);
+                const uint32_t base = FG_OPND_IDX(bw);
+                const bool in_pool = FG_OPND_KIND(bw) == FG_OPND_POOL;
+                long long xi;
+                if (MODE == FG_MODE_PRIOR && !observe) {
+                    // first i with cumulative[i] >= u, clamped to K-1 (partition_point(c < u))
+                    const double u = fg_rng_u01(*rng);
+                    double cum = 0.0; int idx = K;
+                    for (int i = 0; i < K; ++i) {
+                        const double pi = in_pool ? pool[base + i] : slots[(base + i) * FG_WAVE];
+                        cum += pi;
+                        if (idx == K && !(cum < u)) idx = i;
+                    }
+                    xi = idx < K - 1 ? idx : K - 1;
+                    slots[aux * FG_WAVE] = fg_as_double(xi);
+                } else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) {
+                    xi = fg_as_i64(slots[FG_OPND_IDX(xw) * FG_WAVE]);
+                } else {
+                    xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool), vtype);
+                }
+                if ((op & FG_F_INVALID) != 0u || xi < 0 || xi >= (long long)K) lp = FG_NEG_INF;
+                else if (in_pool) lp = pool[base + K + (int)xi];          // precomputed ln p (or -inf)
+                else { const double p = slots[(base + (int)xi) * FG_WAVE]; lp = p > 0.0 ? log(p) : FG_NEG_INF; }
+            } else {
+                const double p0 = fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool);
+                const double p1 = fg_operand(FG_I_OPND(I, 2), FG_I_IMM(I, 2), slots, pool);
+                const double p2 = fg_operand(FG_I_OPND(I, 3), FG_I_IMM(I, 3), slots, pool);
+                if (MODE == FG_MODE_PRIOR && !observe) {
+                    const long long cell = fg_sample_dist(code, hoisted, p0, p1, p2, *rng);
+                    slots[aux * FG_WAVE] = fg_as_double(cell);
+                }
+                double xf = 0.0; long long xi = 0;
+                if (vtype == 0u) xf = fg_operand(xw, FG_I_IMM(I, 0), slots, pool);
+                else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xi = fg_as_i64(slots[FG_OPND_IDX(xw) * FG_WAVE]);
+                else xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool), vtype);
+                if ((op & FG_F_INVALID) != 0u) lp = FG_NEG_INF;
+                else if (code == 12u && hoisted) {
+                    // Normal with constant parameters -- the hot case (distribution.rs:189-208):
+                    // ln(sigma) hoisted; (x-mu)/sigma as an exact multiply when sigma = 2^k.
+                    if (!fg_finite(xf)) lp = FG_NEG_INF;
+                    else {
+                        const double z = (op & FG_F_POW2SCALE) ? (xf - p0) * fg_ins_h(I, 4) : (xf - p0) / p1;
+                        lp = -0.5 * z * z - fg_ins_h(I, 0) - 0.5 * FG_LN_2PI;
+                    }
+                } else {
+                    const double hh[5] = { fg_ins_h(I, 0), fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4) };
+                    lp = fg_logpdf(code, hoisted, (op & FG_F_POW2SCALE) != 0u, xf, xi, p0, p1, p2, hh);
+                }
+            }
+            if (observe) A.lik += lp;                    // interpreters.rs:76-83
+            else {
+                A.prior += lp;                           // interpreters.rs:150-158
+                if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)aux * logp_stride] = lp; }
+            }
+        } else {
+            const double x0 = fg_operand(FG_I_OPND(I, 0), FG_I_IMM(I, 0), slots, pool);
+            switch (code) {
+            case FG_OP_FACTOR: A.fac += x0; break;       // Handler::on_factor
+            case FG_OP_LOAD: acc = x0; break;
+            case FG_OP_ADD: acc = acc + x0; break;
+            case FG_OP_SUB: acc = acc - x0; break;
+            case FG_OP_MUL: acc = acc * x0; break;
+            case FG_OP_DIV: acc = acc / x0; break;
+            case FG_OP_RSUB: acc = x0 - acc; break;
+            case FG_OP_RDIV: acc = x0 / acc; break;
+            case FG_OP_NEG: acc = -acc; break;
+            case FG_OP_EXP: acc = exp(acc); break;
+            case FG_OP_LN: acc = log(acc); break;
+            case FG_OP_SQRT: acc = sqrt(acc); break;
+            case FG_OP_ABS: acc = fabs(acc); break;
+            case FG_OP_FLOOR: acc = floor(acc); break;
+            case FG_OP_SIN: acc = sin(acc); break;
+            case FG_OP_COS: acc = cos(acc); break;
+            case FG_OP_TANH: acc = tanh(acc); break;
+            case FG_OP_POW: acc = pow(acc, x0); break;
+            case FG_OP_RPOW: acc = pow(x0, acc); break;
+            case FG_OP_MIN: acc = fmin(acc, x0); break;
+            case FG_OP_MAX: acc = fmax(acc, x0); break;
+            case FG_OP_CLAMP: acc = fg_clamp(acc, x0, fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool)); break;
+            case FG_OP_MAC: { const double t = x0 * fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool);
+                              acc = acc + t; break; }
+            case FG_OP_STORE: slots[FG_I_AUX(I) * FG_WAVE] = acc; break;
+            case FG_OP_GATHER: { const int k = (int)FG_I_OPND(I, 1);
+                                 const bool ok = (acc >= 0.0) && (acc < (double)k) && (acc == floor(acc));
+                                 const int j = ok ? (int)acc : 0;
+                                 const double v = slots[(FG_I_AUX(I) + j) * FG_WAVE];
+                                 acc = ok ? v : NAN; break; }
+            case FG_OP_CONSTLIK: A.lik += FG_I_IMM(I, 0); break;
+            default: break;
+            }
+        }
+        I = Inext;
+    }
+}
+
+// total_log_weight (src/runtime/trace.rs:198-200)
+__device__ __forceinline__ double fg_total(const FgAcc3 &A) { return A.prior + A.lik + A.fac; }

@@ -1,0 +1,66 @@
+// fg_ir.h -- device IR of a flattened site program (shared by the host compiler and the
+// gfx950 kernels).
+//
+// One instruction is 96 bytes = 24 dwords, fetched by a wave with scalar loads (the
+// program counter is wave-uniform: every lane = one chain runs the SAME program on its
+// own column of the [slots x 64] LDS tile).
+#pragma once
+#include <stdint.h>
+
+// operand word: kind in bits 31:30, index in bits 29:0
+enum : uint32_t { FG_OPND_IMM = 0u, FG_OPND_SLOT_F = 1u, FG_OPND_SLOT_I = 2u, FG_OPND_POOL = 3u };
+#define FG_OPND(kind, idx) ((uint32_t)(((uint32_t)(kind) << 30) | ((uint32_t)(idx) & 0x3fffffffu)))
+#define FG_OPND_KIND(o) ((o) >> 30)
+#define FG_OPND_IDX(o) ((o) & 0x3fffffffu)
+
+// opcodes.  0..16 = distribution kinds (include/fugue_amd.h order)
+enum : uint32_t {
+    FG_OP_FACTOR = 32,   // log_factors += x
+    FG_OP_LOAD = 40,     // acc = x
+    FG_OP_ADD, FG_OP_SUB, FG_OP_MUL, FG_OP_DIV,   // acc = acc (op) x
+    FG_OP_RSUB, FG_OP_RDIV,                       // acc = x (op) acc
+    FG_OP_NEG, FG_OP_EXP, FG_OP_LN, FG_OP_SQRT, FG_OP_ABS, FG_OP_FLOOR, FG_OP_SIN, FG_OP_COS, FG_OP_TANH,
+    FG_OP_POW, FG_OP_RPOW,                        // acc = pow(acc, x) / pow(x, acc)
+    FG_OP_MIN, FG_OP_MAX,
+    FG_OP_CLAMP,         // acc = clamp(acc, x, p0)
+    FG_OP_MAC,           // acc = acc + x * p0   (two roundings, as the expression tree)
+    FG_OP_STORE,         // slot[aux] = acc
+    FG_OP_GATHER,        // acc = slot[aux + (int)acc] for 0 <= acc < n (n = opnd[1] raw), else NaN
+    FG_OP_CONSTLIK       // log_likelihood += imm[0]  (observe with constant params and value)
+};
+// flags in op bits 8..
+enum : uint32_t {
+    FG_F_OBSERVE = 1u << 8,        // else SAMPLE
+    FG_F_HOISTED = 1u << 9,        // all parameters constant: guards checked, h[] valid
+    FG_F_INVALID = 1u << 10,       // constant parameters are invalid: log-density is -inf
+    FG_F_POW2SCALE = 1u << 11,     // hoisted scale is 2^k: h[4] = 1/scale, (x-loc)/scale == (x-loc)*h[4] exactly
+    FG_F_VTYPE_SHIFT = 12          // 3 bits: FG_F64..FG_I64
+};
+#define FG_INS_OPCODE(op) ((op) & 0xffu)
+#define FG_INS_VTYPE(op) (((op) >> FG_F_VTYPE_SHIFT) & 7u)
+
+struct FgIns {
+    uint32_t op;        // opcode | flags
+    uint32_t opnd[4];   // x, p0, p1, p2   (Categorical: p0 = probability base, p1 = K raw)
+    uint32_t aux;       // sample: site slot; STORE/GATHER: slot
+    double   imm[4];    // immediates of x, p0, p1, p2 (IMM kind)
+    double   h[5];      // hoisted constants (FG_F_HOISTED), per distribution (fg_math.h)
+};
+static_assert(sizeof(FgIns) == 96, "FgIns must be 96 bytes");
+
+// A compiled program as the kernels see it.
+struct FgProgramDev {
+    const FgIns  *ins;       // full program, n_ins
+    const FgIns  *sub;       // concatenated per-coordinate sub-programs (sparse FD)
+    const int    *sub_off;   // [d+1] offsets into sub
+    const double *pool;      // data arrays + constant tables
+    const int    *f64_slot;  // [d] slot (= sorted site index) of each f64 coordinate
+    const int    *site_vtype;// [S]
+    int n_ins, n_slots, S, d;
+};
+
+// RNG stream purposes (counter word 3); shared spec with the test oracle
+enum : uint32_t {
+    FG_RNG_PRIOR = 1, FG_RNG_HMC = 2, FG_RNG_EPS = 3, FG_RNG_MH = 4,
+    FG_RNG_SMC_RESAMPLE = 5, FG_RNG_SMC_REJUV = 6, FG_RNG_SMC_PRIOR = 7
+};

@@ -1,0 +1,381 @@
+// fg_math.h -- scalar building blocks of the engine, usable from host (program compiler:
+// constant folding / hoisting) and device (gfx950 kernels): the 17 log-densities of
+// /root/reference/src/core/distribution.rs with their guard order and left-to-right
+// evaluation order, the Philox4x32-10 counter RNG and the prior samplers.
+//
+// Build with -ffp-contract=off: the reference (Rust) never fuses a*b+c.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include "fg_ir.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FG_HD __host__ __device__ __forceinline__
+#else
+#define FG_HD inline
+#endif
+
+#define FG_LN_2PI 1.8378770664093456   /* distribution.rs:206 */
+#define FG_LN_PI 1.1447298858494002    /* distribution.rs:1372 */
+#define FG_LN_2 0.6931471805599453
+#define FG_NEG_INF (-INFINITY)
+#define FG_MIN_POSITIVE 2.2250738585072014e-308
+#define FG_F64_MAX 1.7976931348623157e308
+#define FG_I64_MIN (-9223372036854775807LL - 1LL)
+#define FG_I64_MAX 9223372036854775807LL
+
+FG_HD bool fg_finite(double x) { return isfinite(x); }
+FG_HD double fg_lgamma(double x) { return lgamma(x); }
+FG_HD long long fg_f2i_sat(double v) {   // Rust `as i64`
+    if (v != v) return 0;
+    if (v >= 9223372036854775807.0) return FG_I64_MAX;
+    if (v <= -9223372036854775808.0) return FG_I64_MIN;
+    return (long long)v;
+}
+FG_HD double fg_as_double(long long bits) { union { long long i; double d; } u; u.i = bits; return u.d; }
+FG_HD long long fg_as_i64(double d) { union { long long i; double d; } u; u.d = d; return u.i; }
+FG_HD double fg_clamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }  // NaN stays
+
+// ---------------------------------------------------------------------------------------
+// Hoisting: when every parameter of a site is a compile-time constant the host evaluates
+// the parameter guards once and precomputes the parameter-only sub-terms, in the
+// reference's own evaluation order, into h[0..4].  Returns false when the constant
+// parameters are invalid (log-density identically -inf).
+// ---------------------------------------------------------------------------------------
+FG_HD bool fg_hoist(uint32_t kind, double p0, double p1, double p2, double *h) {
+    h[0] = h[1] = h[2] = h[3] = h[4] = 0.0;
+    switch (kind) {
+    case 12: /* Normal */    if (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0)) return false; h[0] = log(p1); return true;
+    case 15: /* Uniform */   if (p0 >= p1 || !fg_finite(p0) || !fg_finite(p1)) return false;
+                             { double w = p1 - p0; if (w <= 0.0) return false; h[0] = -log(w); } return true;
+    case 11: /* LogNormal */ if (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0)) return false; h[0] = log(p1); return true;
+    case 7:  /* Exponential*/if (p0 <= 0.0 || !fg_finite(p0)) return false; h[0] = log(p0); return true;
+    case 0:  /* Bernoulli */ if (p0 < 0.0 || p0 > 1.0 || !fg_finite(p0)) return false;
+                             h[0] = (p0 <= 0.0) ? FG_NEG_INF : log(p0); h[1] = (p0 >= 1.0) ? FG_NEG_INF : log(1.0 - p0); return true;
+    case 1:  /* Beta */      if (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1)) return false;
+                             h[0] = fg_lgamma(p0) + fg_lgamma(p1) - fg_lgamma(p0 + p1); return true;
+    case 8:  /* Gamma */     if (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1)) return false;
+                             h[0] = log(p1); h[1] = fg_lgamma(p0); return true;
+    case 2:  /* Binomial */  if (!fg_finite(p1) || !(p1 >= 0.0 && p1 <= 1.0)) return false;
+                             { double n = (double)(unsigned long long)p0; h[0] = fg_lgamma(n + 1.0);
+                               h[1] = (p1 > 0.0) ? log(p1) : FG_NEG_INF; h[2] = (p1 < 1.0) ? log(1.0 - p1) : FG_NEG_INF; } return true;
+    case 13: /* Poisson */   if (p0 <= 0.0 || !fg_finite(p0)) return false; h[0] = log(p0); return true;
+    case 14: /* StudentT */  if (p0 <= 0.0 || p2 <= 0.0 || !fg_finite(p0) || !fg_finite(p2) || !fg_finite(p1)) return false;
+                             h[0] = fg_lgamma((p0 + 1.0) / 2.0) - fg_lgamma(p0 / 2.0) - 0.5 * (log(p0) + FG_LN_PI) - log(p2); return true;
+    case 4:  /* Cauchy */    if (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0)) return false; h[0] = -FG_LN_PI - log(p1); return true;
+    case 10: /* Laplace */   if (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0)) return false; h[0] = -log(2.0 * p1); return true;
+    case 16: /* Weibull */   if (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1)) return false;
+                             h[1] = log(p1); h[0] = log(p0) - p0 * h[1]; return true;
+    case 5:  /* ChiSquared */if (p0 <= 0.0 || !fg_finite(p0)) return false;
+                             { double hk = p0 / 2.0; h[0] = -hk * FG_LN_2 - fg_lgamma(hk); } return true;
+    case 9:  /* InvGamma */  if (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1)) return false;
+                             h[0] = p0 * log(p1) - fg_lgamma(p0); return true;
+    default: return true;    // Categorical / DiscreteUniform are handled by the compiler
+    }
+}
+
+// scale = 2^k (|k| <= 500): x / scale == x * (1/scale) bit for bit, so the hot loop may multiply
+FG_HD bool fg_pow2_scale(double s) { int e; return s > 0.0 && fg_finite(s) && frexp(s, &e) == 0.5 && e > -500 && e < 500; }
+// index of the scale parameter of a location-scale family, or -1
+FG_HD int fg_scale_param(uint32_t kind) { return (kind == 12u || kind == 11u || kind == 4u || kind == 10u) ? 1 : (kind == 14u ? 2 : -1); }
+
+// DiscreteUniform count -> -ln(n): distribution.rs:1917-1932
+FG_HD double fg_du_logp(long long lo, long long hi) {
+    if (lo == FG_I64_MIN && hi == FG_I64_MAX) return -(64.0 * FG_LN_2);
+    unsigned long long cnt = (unsigned long long)hi - (unsigned long long)lo + 1ull;   // < 2^64 here
+    return -log((double)cnt);
+}
+
+// ---------------------------------------------------------------------------------------
+// log-density of a non-Categorical distribution.  xf / xi: the value as f64 / i64
+// (only the one matching the distribution's value type is read).  `hoisted` is
+// wave-uniform on the device.
+// ---------------------------------------------------------------------------------------
+FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1, double p2,
+                       const double *h) {
+    switch (kind) {
+    case 12: { /* Normal: distribution.rs:189-208 */
+        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        double z = pow2 ? (xf - p0) * h[4] : (xf - p0) / p1;
+        double ls = hoisted ? h[0] : log(p1);
+        return -0.5 * z * z - ls - 0.5 * FG_LN_2PI; }
+    case 15: { /* Uniform: :309-330 */
+        if (!hoisted && (p0 >= p1 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (xf < p0 || xf >= p1) return FG_NEG_INF;
+        if (hoisted) return h[0];
+        double w = p1 - p0;
+        if (w <= 0.0) return FG_NEG_INF;
+        return -log(w); }
+    case 11: { /* LogNormal: :413-434 */
+        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (xf <= 0.0 || !fg_finite(xf)) return FG_NEG_INF;
+        double lx = log(xf);
+        double z = pow2 ? (lx - p0) * h[4] : (lx - p0) / p1;
+        double ls = hoisted ? h[0] : log(p1);
+        return -0.5 * z * z - lx - ls - 0.5 * FG_LN_2PI; }
+    case 7: { /* Exponential: :503-518 */
+        if (!hoisted && (p0 <= 0.0 || !fg_finite(p0))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (xf < 0.0) return FG_NEG_INF;
+        double lr = hoisted ? h[0] : log(p0);
+        return lr - p0 * xf; }
+    case 0: { /* Bernoulli: :598-619 */
+        if (hoisted) return xi ? h[0] : h[1];
+        if (p0 < 0.0 || p0 > 1.0 || !fg_finite(p0)) return FG_NEG_INF;
+        if (xi) return (p0 <= 0.0) ? FG_NEG_INF : log(p0);
+        return (p0 >= 1.0) ? FG_NEG_INF : log(1.0 - p0); }
+    case 1: { /* Beta: :897-956 */
+        if (!hoisted && (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (!(xf >= 0.0 && xf <= 1.0)) return FG_NEG_INF;
+        double lb = hoisted ? h[0] : (fg_lgamma(p0) + fg_lgamma(p1) - fg_lgamma(p0 + p1));
+        if (xf == 0.0) return (p0 > 1.0) ? FG_NEG_INF : ((p0 < 1.0) ? INFINITY : -lb);
+        if (xf == 1.0) return (p1 > 1.0) ? FG_NEG_INF : ((p1 < 1.0) ? INFINITY : -lb);
+        double ln_x = log(xf);
+        double ln_1mx = log(1.0 - xf);
+        return (p0 - 1.0) * ln_x + (p1 - 1.0) * ln_1mx - lb; }
+    case 8: { /* Gamma(shape, rate): :1039-1068 */
+        if (!hoisted && (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (xf <= 0.0) return FG_NEG_INF;
+        double log_rate = hoisted ? h[0] : log(p1);
+        double log_x = log(xf);
+        double lg = hoisted ? h[1] : fg_lgamma(p0);
+        return p0 * log_rate + (p0 - 1.0) * log_x - p1 * xf - lg; }
+    case 2: { /* Binomial(n, p): :1138-1165 */
+        if (!hoisted && (!fg_finite(p1) || !(p1 >= 0.0 && p1 <= 1.0))) return FG_NEG_INF;
+        if (xi < 0) return FG_NEG_INF;
+        unsigned long long n = (unsigned long long)p0, k = (unsigned long long)xi;
+        if (k > n) return FG_NEG_INF;
+        if (p1 == 0.0) return (k == 0) ? 0.0 : FG_NEG_INF;
+        if (p1 == 1.0) return (k == n) ? 0.0 : FG_NEG_INF;
+        double lgn = hoisted ? h[0] : fg_lgamma((double)n + 1.0);
+        double lbc = lgn - fg_lgamma((double)k + 1.0) - fg_lgamma((double)(n - k) + 1.0);
+        double lp = hoisted ? h[1] : log(p1);
+        double lq = hoisted ? h[2] : log(1.0 - p1);
+        return lbc + ((double)k) * lp + ((double)(n - k)) * lq; }
+    case 13: { /* Poisson: :1237-1257 */
+        if (!hoisted && (p0 <= 0.0 || !fg_finite(p0))) return FG_NEG_INF;
+        if (xi < 0) return FG_NEG_INF;
+        if (p0 > 700.0 && xi == 0) return -p0;
+        double kf = (double)xi;
+        double ll = hoisted ? h[0] : log(p0);
+        double lf = fg_lgamma(kf + 1.0);
+        return kf * ll - p0 - lf; }
+    case 14: { /* StudentT(df, loc, scale): :1362-1381 */
+        if (!hoisted && (p0 <= 0.0 || p2 <= 0.0 || !fg_finite(p0) || !fg_finite(p2) || !fg_finite(p1))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        double z = pow2 ? (xf - p1) * h[4] : (xf - p1) / p2;
+        double pre = hoisted ? h[0]
+                             : (fg_lgamma((p0 + 1.0) / 2.0) - fg_lgamma(p0 / 2.0) - 0.5 * (log(p0) + FG_LN_PI) - log(p2));
+        return pre - 0.5 * (p0 + 1.0) * log1p(z * z / p0); }
+    case 4: { /* Cauchy: :1451-1459 */
+        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        double z = pow2 ? (xf - p0) * h[4] : (xf - p0) / p1;
+        double pre = hoisted ? h[0] : (-FG_LN_PI - log(p1));
+        return pre - log1p(z * z); }
+    case 10: { /* Laplace: :1535-1541 */
+        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        double pre = hoisted ? h[0] : -log(2.0 * p1);
+        return pow2 ? pre - fabs(xf - p0) * h[4] : pre - fabs(xf - p0) / p1; }
+    case 16: { /* Weibull(shape, scale): :1618-1644 */
+        if (!hoisted && (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (xf < 0.0) return FG_NEG_INF;
+        if (xf == 0.0) return (p0 > 1.0) ? FG_NEG_INF : ((p0 < 1.0) ? INFINITY : -(hoisted ? h[1] : log(p1)));
+        double pre = hoisted ? h[0] : (log(p0) - p0 * log(p1));
+        return pre + (p0 - 1.0) * log(xf) - pow(xf / p1, p0); }
+    case 5: { /* ChiSquared(k): :1699-1709 */
+        if (!hoisted && (p0 <= 0.0 || !fg_finite(p0))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (xf <= 0.0) return FG_NEG_INF;
+        double hk = p0 / 2.0;
+        double pre = hoisted ? h[0] : (-hk * FG_LN_2 - fg_lgamma(hk));
+        return pre + (hk - 1.0) * log(xf) - xf / 2.0; }
+    case 9: { /* InverseGamma(shape, rate): :1789-1806 */
+        if (!hoisted && (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;
+        if (!fg_finite(xf)) return FG_NEG_INF;
+        if (xf <= 0.0) return FG_NEG_INF;
+        double pre = hoisted ? h[0] : (p0 * log(p1) - fg_lgamma(p0));
+        return pre - (p0 + 1.0) * log(xf) - p1 / xf; }
+    case 6: { /* DiscreteUniform(lo, hi): :1917-1932; hoisted bounds are exact i64 bit patterns */
+        long long lo = hoisted ? fg_as_i64(p0) : fg_f2i_sat(p0);
+        long long hi = hoisted ? fg_as_i64(p1) : fg_f2i_sat(p1);
+        if (hi < lo) return FG_NEG_INF;
+        if (xi < lo || xi > hi) return FG_NEG_INF;
+        return hoisted ? h[0] : fg_du_logp(lo, hi); }
+    default: return NAN;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 stream: key = seed, counter = (chain, block, iteration, purpose).
+// Each call to fg_rng_block yields two u64 and advances `block`.
+// ---------------------------------------------------------------------------------------
+struct FgStream { uint32_t k0, k1, c0, c1, c2, c3; };
+
+FG_HD uint32_t fg_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
+FG_HD void fg_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *o) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = fg_mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = fg_mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+FG_HD FgStream fg_stream(unsigned long long seed, uint32_t chain, uint32_t iter, uint32_t purpose) {
+    FgStream s; s.k0 = (uint32_t)seed; s.k1 = (uint32_t)(seed >> 32); s.c0 = chain; s.c1 = 0; s.c2 = iter; s.c3 = purpose;
+    return s;
+}
+FG_HD void fg_rng_block(FgStream &s, unsigned long long &a, unsigned long long &b) {
+    uint32_t o[4];
+    fg_philox4x32_10(s.c0, s.c1, s.c2, s.c3, s.k0, s.k1, o);
+    s.c1 += 1;
+    a = (unsigned long long)o[0] | ((unsigned long long)o[1] << 32);
+    b = (unsigned long long)o[2] | ((unsigned long long)o[3] << 32);
+}
+// rand 0.8 `Standard` f64: 53 bits scaled into [0,1)
+FG_HD double fg_u01_of(unsigned long long x) { return (double)(x >> 11) * 0x1.0p-53; }
+FG_HD double fg_rng_u01(FgStream &s) { unsigned long long a, b; fg_rng_block(s, a, b); return fg_u01_of(a); }
+FG_HD void fg_rng_normal_pair(FgStream &s, double &z0, double &z1) {   // Box-Muller, u1 in (0,1]
+    unsigned long long a, b; fg_rng_block(s, a, b);
+    double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53;
+    double u2 = fg_u01_of(b);
+    double r = sqrt(-2.0 * log(u1));
+    double th = 2.0 * M_PI * u2;
+    z0 = r * cos(th); z1 = r * sin(th);
+}
+FG_HD double fg_rng_normal(FgStream &s) { double a, b; fg_rng_normal_pair(s, a, b); return a; }
+// gaussian_z: /root/reference/src/inference/mh.rs:128-132
+FG_HD double fg_gaussian_z_of(unsigned long long a, unsigned long long b) {
+    double u1 = fmax(fg_u01_of(a), 1e-10);
+    double u2 = fg_u01_of(b);
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+FG_HD double fg_rng_gaussian_z(FgStream &s) { unsigned long long a, b; fg_rng_block(s, a, b); return fg_gaussian_z_of(a, b); }
+// gen_range(0..n): widening multiply (bias < n * 2^-64)
+FG_HD uint32_t fg_pick(unsigned long long r, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__umul64hi(r, (unsigned long long)n);
+#else
+    return (uint32_t)(((unsigned __int128)r * n) >> 64);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// Samplers (`Distribution::sample`, distribution.rs:183-188 ... 1899-1916).  rand_distr's
+// algorithms are not pinned by any reference test; these are exact samplers that consume
+// the Philox stream in a fixed order (the test oracle uses the identical order).
+// ---------------------------------------------------------------------------------------
+FG_HD double fg_smp_gamma(double shape, double scale, FgStream &s) {   // Marsaglia-Tsang
+    double boost = 1.0, k = shape;
+    if (k < 1.0) { double u = fg_rng_u01(s); boost = pow(1.0 - u, 1.0 / k); k += 1.0; }
+    double d = k - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int it = 0; it < 1000; it++) {
+        double x = fg_rng_normal(s);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = 1.0 - fg_rng_u01(s);
+        double x2 = x * x;
+        if (u < 1.0 - 0.0331 * x2 * x2) return d * v * scale * boost;
+        if (log(u) < 0.5 * x2 + d * (1.0 - v + log(v))) return d * v * scale * boost;
+    }
+    return d * scale * boost;
+}
+FG_HD long long fg_smp_poisson(double lambda, FgStream &s) {
+    if (lambda < 30.0) {
+        double L = exp(-lambda), p = 1.0; long long k = 0;
+        do { k++; p *= fg_rng_u01(s); } while (p > L && k < 100000);
+        return k - 1;
+    }
+    double slam = sqrt(lambda), loglam = log(lambda);   // PTRS
+    double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 100000; it++) {
+        unsigned long long ra, rb; fg_rng_block(s, ra, rb);
+        double U = fg_u01_of(ra) - 0.5, V = 1.0 - fg_u01_of(rb);
+        double us = 0.5 - fabs(U);
+        double kf = floor((2.0 * a / us + b) * U + lambda + 0.43);
+        if (us >= 0.07 && V <= vr) return (long long)kf;
+        if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lambda + kf * loglam - fg_lgamma(kf + 1.0)) return (long long)kf;
+    }
+    return (long long)lambda;
+}
+FG_HD long long fg_smp_binomial(unsigned long long n, double p, FgStream &s) {
+    if (p <= 0.0 || n == 0) return 0;
+    if (p >= 1.0) return (long long)n;
+    bool flip = p > 0.5; double q = flip ? 1.0 - p : p; double nd = (double)n;
+    long long k;
+    if (nd * q < 10.0) {   // BINV
+        double sq = q / (1.0 - q), a = (nd + 1.0) * sq, r = pow(1.0 - q, nd);
+        double u = fg_rng_u01(s); k = 0;
+        while (u > r && k < (long long)n) { u -= r; k++; r *= (a / (double)k - sq); }
+    } else {               // BTRS with exact lgamma acceptance
+        double spq = sqrt(nd * q * (1.0 - q));
+        double b = 1.15 + 2.53 * spq, a = -0.0873 + 0.0248 * b + 0.01 * q;
+        double c = nd * q + 0.5, vr = 0.92 - 4.2 / b, alpha = (2.83 + 5.1 / b) * spq;
+        double m = floor((nd + 1.0) * q), lpq = log(q / (1.0 - q));
+        double hm = fg_lgamma(m + 1.0) + fg_lgamma(nd - m + 1.0);
+        k = (long long)m;
+        for (int it = 0; it < 100000; it++) {
+            unsigned long long ra, rb; fg_rng_block(s, ra, rb);
+            double U = fg_u01_of(ra) - 0.5, V = 1.0 - fg_u01_of(rb);
+            double us = 0.5 - fabs(U);
+            double kf = floor((2.0 * a / us + b) * U + c);
+            if (kf < 0.0 || kf > nd) continue;
+            if (us >= 0.07 && V <= vr) { k = (long long)kf; break; }
+            double lv = log(V * alpha / (a / (us * us) + b));
+            if (lv <= hm - fg_lgamma(kf + 1.0) - fg_lgamma(nd - kf + 1.0) + (kf - m) * lpq) { k = (long long)kf; break; }
+        }
+    }
+    return flip ? (long long)n - k : k;
+}
+// Draw from a non-Categorical distribution; the result is a raw 8-byte cell
+// (double bits for f64 distributions, the integer otherwise).
+FG_HD long long fg_sample_dist(uint32_t kind, bool hoisted, double p0, double p1, double p2, FgStream &s) {
+    switch (kind) {
+    case 12: return fg_as_i64((p1 <= 0.0) ? NAN : p0 + p1 * fg_rng_normal(s));
+    case 15: return fg_as_i64((p0 >= p1 || !fg_finite(p0) || !fg_finite(p1)) ? NAN : p0 + (p1 - p0) * fg_rng_u01(s));
+    case 11: return fg_as_i64((p1 <= 0.0) ? NAN : exp(p0 + p1 * fg_rng_normal(s)));
+    case 7:  return fg_as_i64((p0 <= 0.0) ? NAN : -log(1.0 - fg_rng_u01(s)) / p0);
+    case 0:  return (p0 < 0.0 || p0 > 1.0 || !fg_finite(p0)) ? 0 : (long long)(fg_rng_u01(s) < p0);
+    case 1: { if (p0 <= 0.0 || p1 <= 0.0) return fg_as_i64(NAN);
+              double x = fg_smp_gamma(p0, 1.0, s), y = fg_smp_gamma(p1, 1.0, s); return fg_as_i64(x / (x + y)); }
+    case 8:  return fg_as_i64((p0 <= 0.0 || p1 <= 0.0) ? NAN : fg_smp_gamma(p0, 1.0 / p1, s));
+    case 2:  return fg_smp_binomial((unsigned long long)p0, p1, s);
+    case 13: return (p0 <= 0.0 || !fg_finite(p0)) ? 0 : fg_smp_poisson(p0, s);
+    case 14: { if (p0 <= 0.0 || p2 <= 0.0) return fg_as_i64(NAN);
+               double z = fg_rng_normal(s), c2 = fg_smp_gamma(p0 / 2.0, 2.0, s);
+               return fg_as_i64(p1 + p2 * (z / sqrt(c2 / p0))); }
+    case 4:  return fg_as_i64((p1 <= 0.0) ? NAN : p0 + p1 * tan(M_PI * (fg_rng_u01(s) - 0.5)));
+    case 10: { if (p1 <= 0.0) return fg_as_i64(NAN);
+               double u = fg_rng_u01(s) - 0.5;
+               double sg = (u < 0.0) ? -1.0 : 1.0;
+               return fg_as_i64(p0 - p1 * sg * log(1.0 - 2.0 * fabs(u))); }
+    case 16: return fg_as_i64((p0 <= 0.0 || p1 <= 0.0) ? NAN : p1 * pow(-log(1.0 - fg_rng_u01(s)), 1.0 / p0));
+    case 5:  return fg_as_i64((p0 <= 0.0) ? NAN : fg_smp_gamma(p0 / 2.0, 2.0, s));
+    case 9:  return fg_as_i64((p0 <= 0.0 || p1 <= 0.0) ? NAN : 1.0 / fg_smp_gamma(p0, 1.0 / p1, s));
+    case 6: { long long lo = hoisted ? fg_as_i64(p0) : fg_f2i_sat(p0), hi = hoisted ? fg_as_i64(p1) : fg_f2i_sat(p1);
+              if (hi < lo) return lo;
+              unsigned long long a, b; fg_rng_block(s, a, b);
+              if (lo == FG_I64_MIN && hi == FG_I64_MAX) return (long long)a;
+              unsigned long long cnt = (unsigned long long)hi - (unsigned long long)lo + 1ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+              unsigned long long off = __umul64hi(a, cnt);
+#else
+              unsigned long long off = (unsigned long long)(((unsigned __int128)a * cnt) >> 64);
+#endif
+              return (long long)((unsigned long long)lo + off); }
+    default: return 0;
+    }
+}

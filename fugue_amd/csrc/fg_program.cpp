@@ -1,0 +1,458 @@
+// fg_program.cpp -- host side of the boundary: builds a fixed-structure site program from
+// sample/observe/factor calls (include/fugue_amd.h) and compiles it to the device IR
+// (fg_ir.h).  Replaces, for the hot path, the reference's per-evaluation model rebuild +
+// trampoline (src/core/model.rs:20-131, src/runtime/handler.rs:124-209): the program is
+// flattened ONCE; every later "model run" is a pass of the interpreter kernels over it.
+//
+// Host-only code (no device calls): usable and tested without a GPU.
+#include "fg_program.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+void fg_set_error(const std::string &s) { g_err = s; }
+extern "C" const char *fg_last_error(void) { return g_err.c_str(); }
+extern "C" int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+namespace {
+
+int vtype_of_dist(int dist) {
+    switch (dist) {
+    case FG_BERNOULLI: return FG_BOOL;
+    case FG_CATEGORICAL: return FG_USIZE;
+    case FG_BINOMIAL: case FG_POISSON: return FG_U64;
+    case FG_DISCRETEUNIFORM: return FG_I64;
+    default: return FG_F64;
+    }
+}
+int n_params_of_dist(int dist) {
+    switch (dist) {
+    case FG_BERNOULLI: case FG_CHISQUARED: case FG_EXPONENTIAL: case FG_POISSON: return 1;
+    case FG_STUDENTT: return 3;
+    case FG_CATEGORICAL: return -1;
+    default: return 2;
+    }
+}
+
+double fold_unary(int op, double x) {
+    switch (op) {
+    case FG_T_NEG: return -x; case FG_T_EXP: return std::exp(x); case FG_T_LN: return std::log(x);
+    case FG_T_SQRT: return std::sqrt(x); case FG_T_ABS: return std::fabs(x); case FG_T_FLOOR: return std::floor(x);
+    case FG_T_SIN: return std::sin(x); case FG_T_COS: return std::cos(x); case FG_T_TANH: return std::tanh(x);
+    }
+    return NAN;
+}
+double fold_binary(int op, double x, double y) {
+    switch (op) {
+    case FG_T_ADD: return x + y; case FG_T_SUB: return x - y; case FG_T_MUL: return x * y; case FG_T_DIV: return x / y;
+    case FG_T_POW: return std::pow(x, y); case FG_T_MIN: return std::fmin(x, y); case FG_T_MAX: return std::fmax(x, y);
+    }
+    return NAN;
+}
+
+}  // namespace
+
+// ---- postfix tokens -> expression tree (constant subtrees folded with the host libm) ----
+int fg_program::parse(const fg_tok *toks, int n) {
+    std::vector<int> st;
+    for (int i = 0; i < n; i++) {
+        const fg_tok &t = toks[i];
+        FgNode nd{};
+        nd.op = t.op;
+        switch (t.op) {
+        case FG_T_CONST: nd.is_const = true; nd.cval = t.imm; break;
+        case FG_T_SITE:
+            if (t.a < 0 || t.a >= n_samples) { fg_set_error("expression references an unknown site handle"); return -1; }
+            nd.a = t.a; break;
+        case FG_T_DATA:
+            if (t.a < 0 || t.a >= (int)data.size() || t.b < 0 || t.b >= (int)data[t.a].size()) {
+                fg_set_error("data reference out of range"); return -1; }
+            nd.op = FG_T_CONST; nd.is_const = true; nd.cval = data[t.a][t.b]; break;
+        case FG_T_NEG: case FG_T_EXP: case FG_T_LN: case FG_T_SQRT: case FG_T_ABS: case FG_T_FLOOR:
+        case FG_T_SIN: case FG_T_COS: case FG_T_TANH: {
+            if (st.empty()) { fg_set_error("malformed expression (unary)"); return -1; }
+            int a = st.back(); st.pop_back();
+            nd.kids = {a};
+            if (nodes[a].is_const) { nd.op = FG_T_CONST; nd.is_const = true; nd.cval = fold_unary(t.op, nodes[a].cval); nd.kids.clear(); }
+            break; }
+        case FG_T_ADD: case FG_T_SUB: case FG_T_MUL: case FG_T_DIV: case FG_T_POW: case FG_T_MIN: case FG_T_MAX: {
+            if (st.size() < 2) { fg_set_error("malformed expression (binary)"); return -1; }
+            int b = st.back(); st.pop_back(); int a = st.back(); st.pop_back();
+            nd.kids = {a, b};
+            if (nodes[a].is_const && nodes[b].is_const) {
+                nd.op = FG_T_CONST; nd.is_const = true; nd.cval = fold_binary(t.op, nodes[a].cval, nodes[b].cval); nd.kids.clear(); }
+            break; }
+        case FG_T_CLAMP: {
+            if (st.size() < 3) { fg_set_error("malformed expression (clamp)"); return -1; }
+            int hi = st.back(); st.pop_back(); int lo = st.back(); st.pop_back(); int x = st.back(); st.pop_back();
+            nd.kids = {x, lo, hi};
+            if (nodes[x].is_const && nodes[lo].is_const && nodes[hi].is_const) {
+                double v = nodes[x].cval, l = nodes[lo].cval, h = nodes[hi].cval;
+                nd.op = FG_T_CONST; nd.is_const = true; nd.cval = v < l ? l : (v > h ? h : v); nd.kids.clear(); }
+            break; }
+        case FG_T_SELECT: {
+            int k = t.a;
+            if (k < 1 || (int)st.size() < k + 1) { fg_set_error("malformed expression (select)"); return -1; }
+            std::vector<int> opts(st.end() - k, st.end());
+            st.resize(st.size() - k);
+            int idx = st.back(); st.pop_back();
+            nd.kids.push_back(idx);
+            nd.kids.insert(nd.kids.end(), opts.begin(), opts.end());
+            if (nodes[idx].is_const) {
+                double di = nodes[idx].cval;
+                if (!(di >= 0.0) || di >= (double)k || di != std::floor(di)) { nd.op = FG_T_CONST; nd.is_const = true; nd.cval = NAN; nd.kids.clear(); }
+                else { st.push_back(opts[(int)di]); continue; }
+            }
+            break; }
+        default: fg_set_error("unknown expression token"); return -1;
+        }
+        nodes.push_back(nd);
+        st.push_back((int)nodes.size() - 1);
+    }
+    if (st.size() != 1) { fg_set_error("malformed expression (stack)"); return -1; }
+    return st[0];
+}
+
+void fg_program::collect_sites(int node, std::vector<int> &out) const {
+    const FgNode &n = nodes[node];
+    if (n.op == FG_T_SITE) out.push_back(n.a);
+    for (int k : n.kids) collect_sites(k, out);
+}
+
+// ---- code generation: accumulator machine over the LDS slot file ----
+struct FgGen {
+    const fg_program &P;
+    std::vector<FgIns> &out;
+    int temp_next, temp_max;
+    FgGen(const fg_program &p, std::vector<FgIns> &o) : P(p), out(o), temp_next(p.n_samples), temp_max(p.n_samples) {}
+
+    int new_temp(int n = 1) { int t = temp_next; temp_next += n; temp_max = std::max(temp_max, temp_next); return t; }
+    static FgIns blank(uint32_t op) { FgIns I; std::memset(&I, 0, sizeof(I)); I.op = op; return I; }
+    bool is_leaf(int node) const { int op = P.nodes[node].op; return op == FG_T_CONST || op == FG_T_SITE; }
+    // operand word (+ immediate) of a leaf
+    void leaf_operand(int node, uint32_t &word, double &imm) const {
+        const FgNode &n = P.nodes[node];
+        if (n.op == FG_T_CONST) { word = FG_OPND(FG_OPND_IMM, 0); imm = n.cval; return; }
+        int slot = P.handle_to_sorted[n.a];
+        word = FG_OPND(P.site_vtype[slot] == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, slot);
+        imm = 0.0;
+    }
+    void emit1(uint32_t op, int operand_node) {          // op with one leaf operand
+        FgIns I = blank(op);
+        leaf_operand(operand_node, I.opnd[0], I.imm[0]);
+        out.push_back(I);
+    }
+    void emit_slot(uint32_t op, int slot) {               // op with a temp-slot operand
+        FgIns I = blank(op);
+        I.opnd[0] = FG_OPND(FG_OPND_SLOT_F, slot);
+        out.push_back(I);
+    }
+    void store(int slot) { FgIns I = blank(FG_OP_STORE); I.aux = (uint32_t)slot; out.push_back(I); }
+
+    // leaves the value of `node` in the accumulator
+    void gen(int node) {
+        const FgNode &n = P.nodes[node];
+        switch (n.op) {
+        case FG_T_CONST: case FG_T_SITE: emit1(FG_OP_LOAD, node); return;
+        case FG_T_NEG: gen(n.kids[0]); out.push_back(blank(FG_OP_NEG)); return;
+        case FG_T_EXP: gen(n.kids[0]); out.push_back(blank(FG_OP_EXP)); return;
+        case FG_T_LN: gen(n.kids[0]); out.push_back(blank(FG_OP_LN)); return;
+        case FG_T_SQRT: gen(n.kids[0]); out.push_back(blank(FG_OP_SQRT)); return;
+        case FG_T_ABS: gen(n.kids[0]); out.push_back(blank(FG_OP_ABS)); return;
+        case FG_T_FLOOR: gen(n.kids[0]); out.push_back(blank(FG_OP_FLOOR)); return;
+        case FG_T_SIN: gen(n.kids[0]); out.push_back(blank(FG_OP_SIN)); return;
+        case FG_T_COS: gen(n.kids[0]); out.push_back(blank(FG_OP_COS)); return;
+        case FG_T_TANH: gen(n.kids[0]); out.push_back(blank(FG_OP_TANH)); return;
+        case FG_T_ADD: case FG_T_SUB: case FG_T_MUL: case FG_T_DIV: case FG_T_POW: case FG_T_MIN: case FG_T_MAX: {
+            int L = n.kids[0], R = n.kids[1];
+            uint32_t fwd, rev; bool comm = false;
+            switch (n.op) {
+            case FG_T_ADD: fwd = rev = FG_OP_ADD; comm = true; break;
+            case FG_T_MUL: fwd = rev = FG_OP_MUL; comm = true; break;
+            case FG_T_MIN: fwd = rev = FG_OP_MIN; comm = true; break;
+            case FG_T_MAX: fwd = rev = FG_OP_MAX; comm = true; break;
+            case FG_T_SUB: fwd = FG_OP_SUB; rev = FG_OP_RSUB; break;
+            case FG_T_DIV: fwd = FG_OP_DIV; rev = FG_OP_RDIV; break;
+            default: fwd = FG_OP_POW; rev = FG_OP_RPOW; break;
+            }
+            (void)comm;
+            // acc + a*b with leaf a, b: one MAC (two roundings, identical to the tree)
+            if (n.op == FG_T_ADD && P.nodes[R].op == FG_T_MUL && is_leaf(P.nodes[R].kids[0]) && is_leaf(P.nodes[R].kids[1])) {
+                gen(L);
+                FgIns I = blank(FG_OP_MAC);
+                leaf_operand(P.nodes[R].kids[0], I.opnd[0], I.imm[0]);
+                leaf_operand(P.nodes[R].kids[1], I.opnd[1], I.imm[1]);
+                out.push_back(I);
+                return;
+            }
+            if (is_leaf(R)) { gen(L); emit1(fwd, R); return; }
+            if (is_leaf(L)) { gen(R); emit1(rev, L); return; }
+            gen(R);
+            int t = new_temp();
+            store(t);
+            gen(L);
+            emit_slot(fwd, t);
+            return; }
+        case FG_T_CLAMP: {
+            int lo = n.kids[1], hi = n.kids[2];
+            FgIns I = blank(FG_OP_CLAMP);
+            if (is_leaf(lo)) leaf_operand(lo, I.opnd[0], I.imm[0]);
+            else { gen(lo); int t = new_temp(); store(t); I.opnd[0] = FG_OPND(FG_OPND_SLOT_F, t); }
+            if (is_leaf(hi)) leaf_operand(hi, I.opnd[1], I.imm[1]);
+            else { gen(hi); int t = new_temp(); store(t); I.opnd[1] = FG_OPND(FG_OPND_SLOT_F, t); }
+            gen(n.kids[0]);
+            out.push_back(I);
+            return; }
+        case FG_T_SELECT: {
+            int k = (int)n.kids.size() - 1;
+            int base = new_temp(k);
+            for (int i = 0; i < k; i++) { gen(n.kids[1 + i]); store(base + i); }
+            gen(n.kids[0]);
+            FgIns I = blank(FG_OP_GATHER);
+            I.aux = (uint32_t)base; I.opnd[1] = (uint32_t)k;
+            out.push_back(I);
+            return; }
+        }
+    }
+    // operand for a distribution parameter / observed value
+    void operand(int node, uint32_t &word, double &imm) {
+        if (is_leaf(node)) { leaf_operand(node, word, imm); return; }
+        gen(node);
+        int t = new_temp();
+        store(t);
+        word = FG_OPND(FG_OPND_SLOT_F, t); imm = 0.0;
+    }
+};
+
+static bool categorical_const_valid(const std::vector<double> &p) {   // distribution.rs:679-715
+    if (p.empty()) return false;
+    double sum = 0.0;
+    for (double v : p) sum += v;
+    if (std::fabs(sum - 1.0) > 1e-6) return false;
+    for (double v : p) if (!std::isfinite(v) || v < 0.0) return false;
+    return true;
+}
+
+void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &temp_max) {
+    FgGen G(*this, out);
+    if (s.kind == 2) {                                   // factor
+        FgIns I = FgGen::blank(FG_OP_FACTOR);
+        G.operand(s.value, I.opnd[0], I.imm[0]);
+        out.push_back(I);
+        temp_max = std::max(temp_max, G.temp_max);
+        return;
+    }
+    uint32_t op = (uint32_t)s.dist | ((uint32_t)s.vtype << FG_F_VTYPE_SHIFT);
+    if (s.kind == 1) op |= FG_F_OBSERVE;
+    FgIns I = FgGen::blank(op);
+    bool params_const = true;
+    for (int p : s.params) params_const = params_const && nodes[p].is_const;
+
+    if (s.dist == FG_CATEGORICAL) {
+        int K = (int)s.params.size();
+        I.opnd[2] = (uint32_t)K;
+        if (params_const) {
+            std::vector<double> pr;
+            for (int p : s.params) pr.push_back(nodes[p].cval);
+            int base = (int)pool.size();
+            for (double v : pr) pool.push_back(v);
+            for (double v : pr) pool.push_back(v > 0.0 ? std::log(v) : -INFINITY);   // distribution.rs:785-791
+            I.opnd[1] = FG_OPND(FG_OPND_POOL, base);
+            I.op |= FG_F_HOISTED;
+            if (!categorical_const_valid(pr)) I.op |= FG_F_INVALID;
+        } else {
+            int base = G.new_temp(K);
+            for (int k = 0; k < K; k++) { G.gen(s.params[k]); G.store(base + k); }
+            I.opnd[1] = FG_OPND(FG_OPND_SLOT_F, base);
+        }
+    } else {
+        for (size_t k = 0; k < s.params.size(); k++) G.operand(s.params[k], I.opnd[1 + k], I.imm[1 + k]);
+        if (params_const) {
+            double p0 = s.params.size() > 0 ? nodes[s.params[0]].cval : 0.0;
+            double p1 = s.params.size() > 1 ? nodes[s.params[1]].cval : 0.0;
+            double p2 = s.params.size() > 2 ? nodes[s.params[2]].cval : 0.0;
+            I.op |= FG_F_HOISTED;
+            if (s.dist == FG_DISCRETEUNIFORM) {
+                long long lo = fg_f2i_sat(p0), hi = fg_f2i_sat(p1);
+                if (s.exact_bounds) { lo = s.lo; hi = s.hi; }
+                I.imm[1] = fg_as_double(lo); I.imm[2] = fg_as_double(hi);
+                I.h[0] = (hi < lo) ? -INFINITY : fg_du_logp(lo, hi);
+            } else if (!fg_hoist((uint32_t)s.dist, p0, p1, p2, I.h)) {
+                I.op |= FG_F_INVALID;
+            } else {
+                const int sp = fg_scale_param((uint32_t)s.dist);
+                const double sc = sp == 1 ? p1 : p2;
+                if (sp >= 0 && fg_pow2_scale(sc)) { I.op |= FG_F_POW2SCALE; I.h[4] = 1.0 / sc; }
+            }
+        }
+    }
+    if (s.kind == 0) {                                   // sample: x is the site's own slot
+        I.aux = (uint32_t)s.sorted;
+        I.opnd[0] = FG_OPND(s.vtype == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, s.sorted);
+    } else {
+        G.operand(s.value, I.opnd[0], I.imm[0]);
+    }
+    out.push_back(I);
+    temp_max = std::max(temp_max, G.temp_max);
+}
+
+int fg_program::finalize() {
+    // site order = lexicographic order of the address bytes (src/core/address.rs:150-157)
+    std::vector<int> order;
+    for (int i = 0; i < (int)stmts.size(); i++) if (stmts[i].kind == 0) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return stmts[a].addr < stmts[b].addr; });
+    for (size_t j = 0; j + 1 < order.size(); j++)
+        if (stmts[order[j]].addr == stmts[order[j + 1]].addr) {
+            fg_set_error("address `" + stmts[order[j]].addr + "` was sampled twice (AddressConflict)");
+            return FG_ERR_ADDRESS_CONFLICT;   // the panic of interpreters.rs:23-33
+        }
+    int S = (int)order.size();
+    sorted_stmt = order;
+    handle_to_sorted.assign(S, 0);
+    site_vtype.assign(S, 0);
+    f64_slot.clear();
+    for (int j = 0; j < S; j++) {
+        FgStmt &s = stmts[order[j]];
+        s.sorted = j;
+        handle_to_sorted[s.handle] = j;
+        site_vtype[j] = s.vtype;
+        if (s.vtype == FG_F64) f64_slot.push_back(j);
+    }
+    // compile every statement; remember its instruction range and the sites it reads
+    ins.clear(); sub.clear(); sub_off.clear(); pool.clear();
+    int temp_max = S;
+    std::vector<std::pair<int, int>> range(stmts.size());
+    std::vector<std::vector<int>> reads(stmts.size());
+    for (size_t i = 0; i < stmts.size(); i++) {
+        int b = (int)ins.size();
+        compile_stmt(stmts[i], ins, temp_max);
+        range[i] = {b, (int)ins.size()};
+        std::vector<int> hs;
+        for (int p : stmts[i].params) collect_sites(p, hs);
+        if (stmts[i].kind != 0 && stmts[i].value >= 0) collect_sites(stmts[i].value, hs);
+        if (stmts[i].kind == 0) hs.push_back(stmts[i].handle);
+        for (int h : hs) reads[i].push_back(handle_to_sorted[h]);
+    }
+    n_slots = temp_max;
+    // per-coordinate sub-programs for the sparse finite difference
+    sub_off.push_back(0);
+    for (int slot : f64_slot) {
+        for (size_t i = 0; i < stmts.size(); i++)
+            if (std::find(reads[i].begin(), reads[i].end(), slot) != reads[i].end())
+                sub.insert(sub.end(), ins.begin() + range[i].first, ins.begin() + range[i].second);
+        sub_off.push_back((int)sub.size());
+    }
+    if (pool.empty()) pool.push_back(0.0);
+    // the kernels prefetch one instruction ahead: keep one readable no-op past each array
+    n_ins = (int)ins.size();
+    ins.push_back(FgGen::blank(0xffu));
+    sub.push_back(FgGen::blank(0xffu));
+    finalized = true;
+    return FG_OK;
+}
+
+// =================================== C ABI ===================================
+extern "C" {
+
+fg_program *fg_program_new(void) { return new fg_program(); }
+void fg_program_free(fg_program *p) { delete p; }
+
+int fg_program_data(fg_program *p, const char *name, const double *v, int64_t n) {
+    if (!p || (n > 0 && !v) || n < 0) { fg_set_error("fg_program_data: bad argument"); return FG_E_BAD_ARG; }
+    p->data.emplace_back(v, v + n);
+    p->data_names.emplace_back(name ? name : "");
+    return (int)p->data.size() - 1;
+}
+
+static int add_dist_stmt(fg_program *p, int kind, const char *addr, int dist, const fg_tok *toks, const int32_t *plen,
+                         int n_params, const fg_tok *value, int n_value) {
+    if (!p || !addr || dist < 0 || dist >= FG_N_DISTS || n_params < 0) { fg_set_error("bad argument"); return FG_E_BAD_ARG; }
+    int want = n_params_of_dist(dist);
+    if (want >= 0 && n_params != want) { fg_set_error("wrong number of distribution parameters"); return FG_E_BAD_ARG; }
+    if (dist == FG_CATEGORICAL && (n_params < 1 || n_params > 64)) {
+        fg_set_error("Categorical takes 1..64 probabilities"); return n_params < 1 ? FG_ERR_INVALID_PROBABILITY : FG_E_LIMIT; }
+    FgStmt s;
+    s.kind = kind; s.dist = dist; s.addr = addr; s.vtype = vtype_of_dist(dist);
+    int off = 0;
+    for (int k = 0; k < n_params; k++) {
+        int r = p->parse(toks + off, plen[k]);
+        if (r < 0) return FG_E_BAD_ARG;
+        s.params.push_back(r);
+        off += plen[k];
+    }
+    if (kind == 1) {
+        int r = p->parse(value, n_value);
+        if (r < 0) return FG_E_BAD_ARG;
+        s.value = r;
+    }
+    if (dist == FG_CATEGORICAL) {       // constructor validation of constant probabilities
+        bool allc = true; std::vector<double> pr;
+        for (int q : s.params) { allc = allc && p->nodes[q].is_const; pr.push_back(p->nodes[q].cval); }
+        if (allc && !categorical_const_valid(pr)) { fg_set_error("Categorical: invalid probability vector"); return FG_ERR_INVALID_PROBABILITY; }
+    }
+    p->finalized = false;
+    if (kind == 0) { s.handle = p->n_samples++; p->stmts.push_back(s); return s.handle; }
+    p->n_observes++;
+    p->stmts.push_back(s);
+    return FG_OK;
+}
+
+int fg_program_sample(fg_program *p, const char *addr, int dist, const fg_tok *toks, const int32_t *plen, int n_params) {
+    return add_dist_stmt(p, 0, addr, dist, toks, plen, n_params, nullptr, 0);
+}
+int fg_program_observe(fg_program *p, const char *addr, int dist, const fg_tok *toks, const int32_t *plen, int n_params,
+                       const fg_tok *value, int n_value) {
+    if (!value || n_value <= 0) { fg_set_error("observe needs a value expression"); return FG_E_BAD_ARG; }
+    return add_dist_stmt(p, 1, addr, dist, toks, plen, n_params, value, n_value);
+}
+int fg_program_factor(fg_program *p, const fg_tok *toks, int n) {
+    if (!p || !toks || n <= 0) { fg_set_error("bad argument"); return FG_E_BAD_ARG; }
+    FgStmt s; s.kind = 2; s.dist = -1; s.vtype = FG_F64;
+    int r = p->parse(toks, n);
+    if (r < 0) return FG_E_BAD_ARG;
+    s.value = r;
+    p->stmts.push_back(s);
+    p->finalized = false;
+    return FG_OK;
+}
+int fg_program_finalize(fg_program *p) { if (!p) return FG_E_BAD_ARG; return p->finalize(); }
+
+#define NEED_FINAL(p) do { if (!(p) || !(p)->finalized) { fg_set_error("program is not finalized"); return FG_E_NOT_FINALIZED; } } while (0)
+int fg_program_n_sites(const fg_program *p) { NEED_FINAL(p); return (int)p->sorted_stmt.size(); }
+int fg_program_n_f64(const fg_program *p) { NEED_FINAL(p); return (int)p->f64_slot.size(); }
+int fg_program_n_observe(const fg_program *p) { NEED_FINAL(p); return p->n_observes; }
+int fg_program_n_instructions(const fg_program *p) { NEED_FINAL(p); return p->n_ins; }
+int fg_program_n_slots(const fg_program *p) { NEED_FINAL(p); return p->n_slots; }
+int fg_program_site_name(const fg_program *p, int j, char *buf, int len) {
+    NEED_FINAL(p);
+    if (j < 0 || j >= (int)p->sorted_stmt.size()) return FG_ERR_ADDRESS_NOT_FOUND;
+    const std::string &a = p->stmts[p->sorted_stmt[j]].addr;
+    if (buf && len > 0) { int n = std::min<int>(len - 1, (int)a.size()); std::memcpy(buf, a.data(), n); buf[n] = 0; }
+    return (int)a.size() + 1;
+}
+int fg_program_site_vtype(const fg_program *p, int j) {
+    NEED_FINAL(p);
+    if (j < 0 || j >= (int)p->site_vtype.size()) return FG_ERR_ADDRESS_NOT_FOUND;
+    return p->site_vtype[j];
+}
+int fg_program_site_of_handle(const fg_program *p, int h) {
+    NEED_FINAL(p);
+    if (h < 0 || h >= (int)p->handle_to_sorted.size()) return FG_ERR_ADDRESS_NOT_FOUND;
+    return p->handle_to_sorted[h];
+}
+int fg_program_f64_site(const fg_program *p, int k) {
+    NEED_FINAL(p);
+    if (k < 0 || k >= (int)p->f64_slot.size()) return FG_ERR_ADDRESS_NOT_FOUND;
+    return p->f64_slot[k];
+}
+int fg_program_dep_count(const fg_program *p, int k) {
+    NEED_FINAL(p);
+    if (k < 0 || k >= (int)p->f64_slot.size()) return FG_ERR_ADDRESS_NOT_FOUND;
+    return p->sub_off[k + 1] - p->sub_off[k];
+}
+
+}  // extern "C"

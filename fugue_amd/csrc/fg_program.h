@@ -1,0 +1,42 @@
+// fg_program.h -- internal definition of the opaque fg_program handle.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/fugue_amd.h"
+#include "fg_math.h"
+
+struct FgNode {
+    int op = 0, a = 0, b = 0;
+    bool is_const = false;
+    double cval = 0.0;
+    std::vector<int> kids;
+};
+struct FgStmt {
+    int kind = 0;            // 0 sample, 1 observe, 2 factor
+    int dist = -1, vtype = 0;
+    std::string addr;
+    std::vector<int> params; // expression roots
+    int value = -1;          // observe value / factor log-weight root
+    int handle = -1, sorted = -1;
+    bool exact_bounds = false; long long lo = 0, hi = 0;   // DiscreteUniform with exact i64 bounds
+};
+struct fg_program {
+    std::vector<std::vector<double>> data;
+    std::vector<std::string> data_names;
+    std::vector<FgNode> nodes;
+    std::vector<FgStmt> stmts;
+    int n_samples = 0, n_observes = 0;
+    // compiled
+    bool finalized = false;
+    std::vector<int> sorted_stmt, handle_to_sorted, site_vtype, f64_slot, sub_off;
+    std::vector<FgIns> ins, sub;
+    std::vector<double> pool;
+    int n_slots = 0, n_ins = 0;
+
+    int  parse(const fg_tok *toks, int n);
+    void collect_sites(int node, std::vector<int> &out) const;
+    void compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &temp_max);
+    int  finalize();
+};
+void fg_set_error(const std::string &s);

@@ -1,0 +1,360 @@
+"""ctypes binding of the C ABI (include/fugue_amd.h) + lowering of a `model.Program`
+description onto it.  This is host plumbing only: every density, gradient and transition is
+computed by the HIP kernels in fugue_amd/lib/libfugue_amd.so.  There is no CPU fallback --
+loading fails loudly when the library is missing, and engine creation fails loudly when no
+gfx950 device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import model as M
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfugue_amd.so")
+
+
+class fg_tok(C.Structure):
+    _fields_ = [("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("reserved", C.c_int32), ("imm", C.c_double)]
+
+
+class fg_hmc_config(C.Structure):
+    _fields_ = [("n_leapfrog", C.c_int32), ("target_accept", C.c_double), ("init_step_size", C.c_double),
+                ("finite_diff_eps", C.c_double), ("adapt_mass", C.c_int32), ("grad_mode", C.c_int32)]
+
+
+class fg_hmc_stats(C.Structure):
+    _fields_ = [("accept_rate", C.c_double), ("mean_step_size", C.c_double), ("n_divergent", C.c_int64),
+                ("n_transitions", C.c_int64)]
+
+
+TOK = {"const": 0, "site": 1, "data": 2, "neg": 3, "exp": 4, "ln": 5, "sqrt": 6, "abs": 7, "floor": 8, "sin": 9,
+       "cos": 10, "tanh": 11, "add": 12, "sub": 13, "mul": 14, "div": 15, "pow": 16, "min": 17, "max": 18,
+       "clamp": 19, "select": 20}
+GRAD_FD_DENSE, GRAD_FD_SPARSE = 0, 1
+
+# every symbol include/fugue_amd.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "fg_program_new", "fg_program_free", "fg_program_data", "fg_program_sample", "fg_program_observe",
+    "fg_program_factor", "fg_program_finalize", "fg_program_n_sites", "fg_program_n_f64", "fg_program_n_observe",
+    "fg_program_n_instructions", "fg_program_n_slots", "fg_program_site_name", "fg_program_site_vtype",
+    "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_last_error", "fg_abi_version",
+    "fg_engine_new", "fg_engine_free", "fg_engine_synchronize", "fg_engine_stream", "fg_engine_n_chains",
+    "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint",
+    "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
+    "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
+    "fg_hmc_find_eps_injected", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
+]
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"fugue_amd error {code}: {message}")
+        self.code = code
+
+
+def lib():
+    """Loads libfugue_amd.so (building it in-tree first if hipcc is available and it is stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _b
+        _b.build()
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    tp = C.POINTER(fg_tok)
+    L.fg_last_error.restype = C.c_char_p
+    L.fg_program_new.restype = vp
+    L.fg_program_free.argtypes = [vp]
+    L.fg_program_data.argtypes = [vp, C.c_char_p, dp, C.c_int64]
+    L.fg_program_sample.argtypes = [vp, C.c_char_p, C.c_int, tp, ip, C.c_int]
+    L.fg_program_observe.argtypes = [vp, C.c_char_p, C.c_int, tp, ip, C.c_int, tp, C.c_int]
+    L.fg_program_factor.argtypes = [vp, tp, C.c_int]
+    for f in ("fg_program_finalize", "fg_program_n_sites", "fg_program_n_f64", "fg_program_n_observe",
+              "fg_program_n_instructions", "fg_program_n_slots"):
+        getattr(L, f).argtypes = [vp]
+    L.fg_program_site_name.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
+    for f in ("fg_program_site_vtype", "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count"):
+        getattr(L, f).argtypes = [vp, C.c_int]
+    L.fg_engine_new.restype = vp
+    L.fg_engine_new.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_int]
+    L.fg_engine_free.argtypes = [vp]
+    L.fg_engine_synchronize.argtypes = [vp]
+    L.fg_engine_stream.restype = vp
+    L.fg_engine_stream.argtypes = [vp]
+    L.fg_engine_n_chains.restype = C.c_int64
+    L.fg_engine_n_chains.argtypes = [vp]
+    L.fg_engine_set_values.argtypes = [vp, vp]
+    L.fg_engine_get_values.argtypes = [vp, vp]
+    L.fg_engine_values_device.restype = vp
+    L.fg_engine_values_device.argtypes = [vp]
+    L.fg_prior_init.argtypes = [vp, C.c_uint32, dp]
+    L.fg_log_joint.argtypes = [vp, dp, dp]
+    L.fg_hmc_config_default.argtypes = [C.POINTER(fg_hmc_config)]
+    L.fg_hmc_init.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_int]
+    L.fg_hmc_step.argtypes = [vp, C.c_int, vp]
+    L.fg_hmc_run.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_int, C.c_int, vp, C.POINTER(fg_hmc_stats)]
+    L.fg_hmc_get_stats.argtypes = [vp, C.POINTER(fg_hmc_stats)]
+    L.fg_hmc_get_step_sizes.argtypes = [vp, dp]
+    L.fg_hmc_get_log_joint.argtypes = [vp, dp]
+    L.fg_hmc_set_step_size.argtypes = [vp, C.c_double]
+    L.fg_hmc_grad.argtypes = [vp, C.c_double, C.c_int, dp, ip]
+    L.fg_hmc_transition_injected.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_double, dp, dp, ip, dp, ip, dp]
+    L.fg_hmc_find_eps_injected.argtypes = [vp, C.POINTER(fg_hmc_config), dp, dp]
+    L.fg_device_alloc.restype = vp
+    L.fg_device_alloc.argtypes = [vp, C.c_size_t]
+    L.fg_device_free.argtypes = [vp, vp]
+    L.fg_device_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.fg_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().fg_last_error().decode("utf-8", "replace")
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise EngineError(rc, last_error())
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def hmc_config(n_leapfrog=16, target_accept=0.8, init_step_size=None, finite_diff_eps=1e-5, adapt_mass=False,
+               grad_mode=GRAD_FD_DENSE) -> fg_hmc_config:
+    """`HMCConfig` (/root/reference/src/inference/hmc.rs:106-135), same defaults."""
+    return fg_hmc_config(int(n_leapfrog), float(target_accept),
+                         float("nan") if init_step_size is None else float(init_step_size),
+                         float(finite_diff_eps), int(bool(adapt_mass)), int(grad_mode))
+
+
+# --------------------------------------------------------------------------------------
+def _postfix(e: M.Expr, out: List[fg_tok]):
+    if e.op == "const":
+        out.append(fg_tok(TOK["const"], 0, 0, 0, e.value))
+    elif e.op == "site":
+        out.append(fg_tok(TOK["site"], e.a, 0, 0, 0.0))
+    elif e.op == "data":
+        out.append(fg_tok(TOK["data"], e.a, e.b, 0, 0.0))
+    elif e.op == "select":
+        for a in e.args:
+            _postfix(a, out)
+        out.append(fg_tok(TOK["select"], len(e.args) - 1, 0, 0, 0.0))
+    else:
+        for a in e.args:
+            _postfix(a, out)
+        out.append(fg_tok(TOK[e.op], 0, 0, 0, 0.0))
+
+
+def _tok_array(toks: List[fg_tok]):
+    arr = (fg_tok * max(1, len(toks)))()
+    for i, t in enumerate(toks):
+        arr[i] = t
+    return arr
+
+
+class CompiledProgram:
+    """A finalized `fg_program` (site program) built from a `model.Program` description."""
+
+    def __init__(self, program: M.Program):
+        L = lib()
+        self.program = program
+        self.h = L.fg_program_new()
+        for name, arr in zip(program.data_names, program.data):
+            a = np.ascontiguousarray(arr, dtype=np.float64)
+            rc = L.fg_program_data(self.h, name.encode(), _dp(a), a.size)
+            if rc < 0:
+                raise EngineError(rc, last_error())
+        for st in program.stmts:
+            if st.kind == M.FACTOR:
+                toks: List[fg_tok] = []
+                _postfix(st.value, toks)
+                _check(L.fg_program_factor(self.h, _tok_array(toks), len(toks)))
+                continue
+            toks, lens = [], []
+            for p in st.dist.params:
+                n0 = len(toks)
+                _postfix(p, toks)
+                lens.append(len(toks) - n0)
+            plen = (C.c_int32 * max(1, len(lens)))(*lens)
+            if st.kind == M.SAMPLE:
+                rc = L.fg_program_sample(self.h, st.addr.encode("utf-8"), st.dist.kind, _tok_array(toks), plen, len(lens))
+                if rc < 0 or rc != st.handle:
+                    raise EngineError(rc, last_error())
+            else:
+                vt: List[fg_tok] = []
+                _postfix(st.value, vt)
+                _check(L.fg_program_observe(self.h, st.addr.encode("utf-8"), st.dist.kind, _tok_array(toks), plen,
+                                            len(lens), _tok_array(vt), len(vt)))
+        rc = L.fg_program_finalize(self.h)
+        if rc != 0:
+            msg = last_error()
+            L.fg_program_free(self.h)
+            self.h = None
+            raise M.FugueError(msg, rc) if rc > 0 else EngineError(rc, msg)
+        self.S = L.fg_program_n_sites(self.h)
+        self.d = L.fg_program_n_f64(self.h)
+        self.O = L.fg_program_n_observe(self.h)
+        self.n_instructions = L.fg_program_n_instructions(self.h)
+        self.n_slots = L.fg_program_n_slots(self.h)
+        buf = C.create_string_buffer(4096)
+        self.site_names = []
+        for j in range(self.S):
+            L.fg_program_site_name(self.h, j, buf, 4096)
+            self.site_names.append(buf.value.decode("utf-8"))
+        self.site_vtypes = [L.fg_program_site_vtype(self.h, j) for j in range(self.S)]
+        self.f64_sites = [L.fg_program_f64_site(self.h, k) for k in range(self.d)]
+        self.dep_counts = [L.fg_program_dep_count(self.h, k) for k in range(self.d)]
+
+    def site_of_handle(self, h: int) -> int:
+        return lib().fg_program_site_of_handle(self.h, h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().fg_program_free(self.h)
+        except Exception:
+            pass
+
+    # cells helpers (same convention as the oracle wrapper: int64 raw view) ---------------
+    def cells(self, values: Sequence) -> np.ndarray:
+        out = np.zeros(self.S, dtype=np.int64)
+        for j, v in enumerate(values):
+            out[j] = np.array([v], dtype=np.float64).view(np.int64)[0] if self.site_vtypes[j] == 0 else int(v)
+        return out
+
+
+def compile_model(model_or_fn) -> CompiledProgram:
+    prog = model_or_fn if isinstance(model_or_fn, M.Program) else M.trace_model(model_or_fn)
+    return CompiledProgram(prog)
+
+
+class Engine:
+    """`fg_engine`: n_chains chains of one program on one MI355X."""
+
+    def __init__(self, compiled: CompiledProgram, n_chains: int, seed: int, chain_offset: int = 0, device: int = 0):
+        L = lib()
+        self.cp = compiled
+        self.C = int(n_chains)
+        self.h = L.fg_engine_new(compiled.h, self.C, int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain_offset), int(device))
+        if not self.h:
+            raise EngineError(-1, last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().fg_engine_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def S(self): return self.cp.S
+    @property
+    def d(self): return self.cp.d
+
+    def synchronize(self):
+        _check(lib().fg_engine_synchronize(self.h))
+
+    def set_values(self, cells: np.ndarray):
+        a = np.ascontiguousarray(cells, dtype=np.int64)
+        assert a.shape == (self.S, self.C), a.shape
+        _check(lib().fg_engine_set_values(self.h, a.ctypes.data))
+
+    def get_values(self) -> np.ndarray:
+        a = np.zeros((max(1, self.S), self.C), dtype=np.int64)
+        _check(lib().fg_engine_get_values(self.h, a.ctypes.data))
+        return a[:self.S]
+
+    def prior_init(self, iteration: int = 0) -> np.ndarray:
+        acc = np.zeros((3, self.C))
+        _check(lib().fg_prior_init(self.h, iteration, _dp(acc)))
+        return acc
+
+    def log_joint(self, want_logp: bool = False):
+        acc = np.zeros((3, self.C))
+        logp = np.zeros((max(1, self.S), self.C)) if want_logp else None
+        _check(lib().fg_log_joint(self.h, _dp(acc), _dp(logp) if want_logp else None))
+        return (acc, logp[:self.S]) if want_logp else acc
+
+    # ---- HMC ----------------------------------------------------------------------------
+    def hmc_init(self, cfg: fg_hmc_config, n_warmup: int):
+        _check(lib().fg_hmc_init(self.h, C.byref(cfg), int(n_warmup)))
+
+    def hmc_step(self, n: int, d_draws: Optional[int] = None):
+        _check(lib().fg_hmc_step(self.h, int(n), d_draws))
+
+    def hmc_run(self, cfg: fg_hmc_config, n_samples: int, n_warmup: int, d_draws: Optional[int] = None) -> fg_hmc_stats:
+        st = fg_hmc_stats()
+        _check(lib().fg_hmc_run(self.h, C.byref(cfg), int(n_samples), int(n_warmup), d_draws, C.byref(st)))
+        return st
+
+    def hmc_stats(self) -> fg_hmc_stats:
+        st = fg_hmc_stats()
+        _check(lib().fg_hmc_get_stats(self.h, C.byref(st)))
+        return st
+
+    def hmc_step_sizes(self) -> np.ndarray:
+        a = np.zeros(self.C)
+        _check(lib().fg_hmc_get_step_sizes(self.h, _dp(a)))
+        return a
+
+    def hmc_log_joint(self) -> np.ndarray:
+        a = np.zeros(self.C)
+        _check(lib().fg_hmc_get_log_joint(self.h, _dp(a)))
+        return a
+
+    def hmc_set_step_size(self, eps: float):
+        _check(lib().fg_hmc_set_step_size(self.h, float(eps)))
+
+    def hmc_grad(self, h: float = 1e-5, grad_mode: int = GRAD_FD_DENSE):
+        g = np.zeros((max(1, self.d), self.C))
+        ok = np.zeros(self.C, dtype=np.int32)
+        _check(lib().fg_hmc_grad(self.h, float(h), int(grad_mode), _dp(g), ok.ctypes.data_as(C.POINTER(C.c_int32))))
+        return g[:self.d], ok.astype(bool)
+
+    def hmc_transition_injected(self, cfg: fg_hmc_config, eps: float, p0: np.ndarray, u: np.ndarray):
+        p0 = np.ascontiguousarray(p0, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert p0.shape == (self.d, self.C) and u.shape == (self.C,)
+        acc = np.zeros(self.C, dtype=np.int32)
+        div = np.zeros(self.C, dtype=np.int32)
+        alpha, lj = np.zeros(self.C), np.zeros(self.C)
+        ip = C.POINTER(C.c_int32)
+        _check(lib().fg_hmc_transition_injected(self.h, C.byref(cfg), float(eps), _dp(p0), _dp(u), acc.ctypes.data_as(ip),
+                                                _dp(alpha), div.ctypes.data_as(ip), _dp(lj)))
+        return acc.astype(bool), alpha, div.astype(bool), lj
+
+    def hmc_find_eps_injected(self, cfg: fg_hmc_config, p0: np.ndarray) -> np.ndarray:
+        p0 = np.ascontiguousarray(p0, dtype=np.float64)
+        eps = np.zeros(self.C)
+        _check(lib().fg_hmc_find_eps_injected(self.h, C.byref(cfg), _dp(p0), _dp(eps)))
+        return eps
+
+    # ---- raw device buffers ---------------------------------------------------------------
+    def device_alloc(self, nbytes: int) -> int:
+        p = lib().fg_device_alloc(self.h, int(nbytes))
+        if not p:
+            raise EngineError(-2, last_error())
+        return p
+
+    def device_free(self, ptr: int):
+        _check(lib().fg_device_free(self.h, ptr))
+
+    def download(self, ptr: int, shape, dtype=np.float64) -> np.ndarray:
+        out = np.zeros(shape, dtype=dtype)
+        _check(lib().fg_device_download(self.h, out.ctypes.data, ptr, out.nbytes))
+        return out

@@ -1,0 +1,197 @@
+/*
+ * fugue_amd.h -- C ABI of the MI355X-native many-chain / many-particle engine for
+ * Fugue's `src/inference` hot path (hmc_chain, adaptive_mcmc_chain, adaptive_smc).
+ *
+ * The reference (alexnodeland/fugue, crate fugue-ppl 0.2.0) has no FFI for this path:
+ * the boundary today is Rust generics.  Each entry point below names the reference
+ * interface it replaces (file:line under /root/reference); INTEGRATION.md shows the
+ * `extern "C"` block and the `GpuBackend` shim a maintainer would add on the Rust side.
+ *
+ * Conventions
+ *   - plain C types only; handles are opaque; every `int` return is 0 on success, a
+ *     reference `ErrorCode` value (src/error.rs:40-59: 100-106, 301, 302, 500, 600) for
+ *     model errors, or a negative FG_E_* for engine / HIP failures.  fg_last_error()
+ *     returns a thread-local message.
+ *   - `h_` pointers are host memory, `d_` pointers are device (HBM) memory of the
+ *     engine's device.  All [a][b] arrays are row-major with the LAST index = chain
+ *     (struct-of-arrays: [sites x chains], site-major so a wavefront's 64 lanes read 64
+ *     consecutive chains).
+ *   - trace cells are 8 bytes: f64 sites hold the double, bool/u64/usize/i64 sites hold
+ *     an int64 (bool 0/1) -- the flattened `ChoiceValue` (src/runtime/trace.rs:32-43).
+ *   - site order everywhere = lexicographic order of the address strings = the
+ *     reference's `BTreeMap<Address, Choice>` order (src/core/address.rs:150-157);
+ *     f64 coordinate order (HMC `q`) is that order restricted to f64 sites
+ *     (src/inference/hmc.rs:238-248).
+ *   - there is NO CPU fallback: every engine call fails with FG_E_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef FUGUE_AMD_H
+#define FUGUE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_ABI_VERSION 1
+
+/* engine errors (negative); model errors reuse the reference ErrorCode numbers */
+enum {
+    FG_OK = 0,
+    FG_E_NO_DEVICE = -1,      /* no usable HIP device / wrong arch */
+    FG_E_HIP = -2,            /* a HIP runtime call failed */
+    FG_E_BAD_ARG = -3,
+    FG_E_NOT_FINALIZED = -4,
+    FG_E_STATE = -5,          /* call order (e.g. hmc_step before hmc_init) */
+    FG_E_UNSUPPORTED = -6,
+    FG_E_LIMIT = -7           /* model exceeds an engine limit (LDS budget, K > 64, ...) */
+};
+enum {
+    FG_ERR_INVALID_PROBABILITY = 102, FG_ERR_INVALID_COUNT = 106,
+    FG_ERR_ADDRESS_CONFLICT = 301, FG_ERR_UNEXPECTED_STRUCTURE = 302,
+    FG_ERR_ADDRESS_NOT_FOUND = 500, FG_ERR_TYPE_MISMATCH = 600
+};
+
+/* the 17 distributions, in the order of the crate-root re-export (src/lib.rs:18-22) */
+enum {
+    FG_BERNOULLI = 0, FG_BETA, FG_BINOMIAL, FG_CATEGORICAL, FG_CAUCHY, FG_CHISQUARED,
+    FG_DISCRETEUNIFORM, FG_EXPONENTIAL, FG_GAMMA, FG_INVERSEGAMMA, FG_LAPLACE, FG_LOGNORMAL,
+    FG_NORMAL, FG_POISSON, FG_STUDENTT, FG_UNIFORM, FG_WEIBULL, FG_N_DISTS
+};
+/* ChoiceValue tags (src/runtime/trace.rs:32-43) */
+enum { FG_F64 = 0, FG_BOOL = 1, FG_U64 = 2, FG_USIZE = 3, FG_I64 = 4 };
+
+/* ------------------------------------------------------------------ site programs
+ * Replaces: `Model<A>` + `Handler` + `run` (src/core/model.rs:20-131,
+ * src/runtime/handler.rs:29-209).  A model is flattened ONCE into a fixed-structure
+ * site program; parameters that depend on earlier sites are postfix expressions over
+ * the DSL's operator set (crates/fugue-wasm/src/dsl.rs:92-102,569-582).            */
+enum {
+    FG_T_CONST = 0,  /* push imm */
+    FG_T_SITE,       /* push value of sample site `a` (handle from fg_program_sample), as f64 */
+    FG_T_DATA,       /* push data[a][b] */
+    FG_T_NEG, FG_T_EXP, FG_T_LN, FG_T_SQRT, FG_T_ABS, FG_T_FLOOR, FG_T_SIN, FG_T_COS, FG_T_TANH,
+    FG_T_ADD, FG_T_SUB, FG_T_MUL, FG_T_DIV, FG_T_POW, FG_T_MIN, FG_T_MAX,
+    FG_T_CLAMP,      /* x lo hi -> f64::clamp */
+    FG_T_SELECT      /* idx opt0 .. opt{a-1} -> opt[idx]  (a = number of options) */
+};
+typedef struct fg_tok { int32_t op; int32_t a; int32_t b; int32_t reserved; double imm; } fg_tok;
+
+typedef struct fg_program fg_program;
+
+fg_program *fg_program_new(void);
+void        fg_program_free(fg_program *p);
+/* named data arrays (DSL `{"y":[...]}`, dsl.rs:1066-1106); returns the array id >= 0 */
+int fg_program_data(fg_program *p, const char *name, const double *h_values, int64_t n);
+/* `sample(addr, dist)` (src/core/model.rs:144-266).  `toks` holds the parameter
+ * expressions back to back, `param_len[i]` tokens each (Categorical: one per
+ * probability, 1..64).  Returns the site handle >= 0 (program order), or an error. */
+int fg_program_sample(fg_program *p, const char *addr_utf8, int dist, const fg_tok *toks,
+                      const int32_t *param_len, int n_params);
+/* `observe(addr, dist, value)` (model.rs:381-424) */
+int fg_program_observe(fg_program *p, const char *addr_utf8, int dist, const fg_tok *toks,
+                       const int32_t *param_len, int n_params, const fg_tok *value, int n_value);
+/* `factor(logw)` (model.rs:426-431) */
+int fg_program_factor(fg_program *p, const fg_tok *toks, int n);
+/* sorts sites by address, rejects duplicate addresses (AddressConflict = 301, the panic of
+ * src/runtime/interpreters.rs:23-33), compiles the device program. */
+int fg_program_finalize(fg_program *p);
+int fg_program_n_sites(const fg_program *p);      /* S */
+int fg_program_n_f64(const fg_program *p);        /* d */
+int fg_program_n_observe(const fg_program *p);    /* O */
+int fg_program_n_instructions(const fg_program *p);
+int fg_program_n_slots(const fg_program *p);      /* S + expression temporaries */
+/* coordinate order == reference BTreeMap order; returns bytes needed incl. NUL */
+int fg_program_site_name(const fg_program *p, int sorted_idx, char *buf, int buf_len);
+int fg_program_site_vtype(const fg_program *p, int sorted_idx);
+int fg_program_site_of_handle(const fg_program *p, int handle);
+int fg_program_f64_site(const fg_program *p, int k);
+/* number of instructions re-evaluated when f64 coordinate k is perturbed (sparse FD) */
+int fg_program_dep_count(const fg_program *p, int k);
+
+const char *fg_last_error(void);
+int         fg_abi_version(void);
+
+/* ------------------------------------------------------------------ engine
+ * One engine = one batch of `n_chains` independent chains (or particles) of one program
+ * on one GPU, with its own HIP stream.  Chain c uses the counter-based RNG stream
+ * (seed, chain_offset + c): results do not depend on how chains are sharded over GPUs. */
+typedef struct fg_engine fg_engine;
+
+fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed,
+                         uint32_t chain_offset, int device_ordinal);
+void  fg_engine_free(fg_engine *e);
+int   fg_engine_synchronize(fg_engine *e);
+void *fg_engine_stream(fg_engine *e);                       /* hipStream_t */
+int64_t fg_engine_n_chains(const fg_engine *e);
+/* current trace values, cells [S][C] */
+int fg_engine_set_values(fg_engine *e, const void *h_cells);
+int fg_engine_get_values(fg_engine *e, void *h_cells);
+void *fg_engine_values_device(fg_engine *e);                 /* d_cells [S][C] */
+
+/* `run(PriorHandler, model)` per chain (src/runtime/interpreters.rs:88-104): draws every
+ * site from its prior, scores it; h_acc (optional) gets [3][C] = log_prior,
+ * log_likelihood, log_factors.  `iteration` selects the RNG sub-stream. */
+int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc);
+/* `run(ScoreGivenTrace, model)` per chain (interpreters.rs:138-163) on the engine's current
+ * values; h_acc [3][C]; h_logp (optional) [S][C] fresh per-site log-densities. */
+int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp);
+
+/* ------------------------------------------------------------------ HMC
+ * Replaces hmc_chain / HmcSession (src/inference/hmc.rs:566-583, 643-920). */
+enum { FG_GRAD_FD_DENSE = 0,   /* hmc.rs:304-329 verbatim: 2d full model runs per gradient */
+       FG_GRAD_FD_SPARSE = 1   /* same central difference, re-evaluating only the terms that
+                                  depend on the perturbed coordinate */ };
+typedef struct fg_hmc_config {      /* HMCConfig, hmc.rs:106-135 (same defaults) */
+    int32_t n_leapfrog;             /* 16 */
+    double  target_accept;          /* 0.8 */
+    double  init_step_size;         /* NaN = None: Hoffman-Gelman Alg. 4 (hmc.rs:479-535) */
+    double  finite_diff_eps;        /* 1e-5 */
+    int32_t adapt_mass;             /* 0 */
+    int32_t grad_mode;              /* FG_GRAD_FD_* (engine extension; 0 = reference) */
+} fg_hmc_config;
+typedef struct fg_hmc_stats {
+    double  accept_rate;            /* mean acceptance probability over chains x transitions */
+    double  mean_step_size;         /* mean over chains of the step size in use */
+    int64_t n_divergent;
+    int64_t n_transitions;          /* chains x transitions executed so far */
+} fg_hmc_stats;
+void fg_hmc_config_default(fg_hmc_config *cfg);
+/* HmcSession::new (hmc.rs:667-729): prior draw, positions, initial step size */
+int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup);
+/* HmcSession::step x n (hmc.rs:819-919).  Post-warmup positions are appended to
+ * d_draws [n][d][C] when non-NULL (rows of warmup transitions are left untouched). */
+int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws);
+/* hmc_chain (hmc.rs:566-583): init + n_warmup + n_samples; d_draws [n_samples][d][C] */
+int fg_hmc_run(fg_engine *e, const fg_hmc_config *cfg, int n_samples, int n_warmup,
+               double *d_draws, fg_hmc_stats *h_stats);
+int fg_hmc_get_stats(fg_engine *e, fg_hmc_stats *h_stats);
+int fg_hmc_get_step_sizes(fg_engine *e, double *h_eps /*[C]*/);
+int fg_hmc_get_log_joint(fg_engine *e, double *h_lj /*[C]*/);
+/* set_step_size (hmc.rs:741-747) for every chain */
+int fg_hmc_set_step_size(fg_engine *e, double eps);
+/* test / diagnostics hooks under injected randomness -------------------------------- */
+/* grad_log_joint (hmc.rs:304-329) at the engine's current values; h_grad [d][C], h_ok [C] */
+int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *h_ok);
+/* hmc_transition (hmc.rs:419-473) with momentum h_p0 [d][C] and uniform h_u [C] injected
+ * and one step size for all chains; outputs are host arrays [C] (any may be NULL).
+ * The engine's values / log-joint advance exactly as a real transition would. */
+int fg_hmc_transition_injected(fg_engine *e, const fg_hmc_config *cfg, double eps,
+                               const double *h_p0, const double *h_u, int32_t *h_accepted,
+                               double *h_alpha, int32_t *h_divergent, double *h_lj);
+/* find_reasonable_epsilon (hmc.rs:479-535) with momentum injected; h_eps [C] */
+int fg_hmc_find_eps_injected(fg_engine *e, const fg_hmc_config *cfg, const double *h_p0,
+                             double *h_eps);
+
+/* raw device memory helpers so a host without a HIP binding can own draw buffers */
+void *fg_device_alloc(fg_engine *e, size_t bytes);
+int   fg_device_free(fg_engine *e, void *d_ptr);
+int   fg_device_download(fg_engine *e, void *h_dst, const void *d_src, size_t bytes);
+int   fg_device_upload(fg_engine *e, void *d_dst, const void *h_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUGUE_AMD_H */

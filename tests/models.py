@@ -1,0 +1,76 @@
+"""Model zoo shared by the CPU and GPU tests (descriptions only)."""
+import numpy as np
+
+from fugue_amd import model as M
+from fugue_amd import workloads as W
+
+
+def all_dists_model() -> M.Program:
+    """Every distribution once with site-dependent parameters (non-hoisted path) and once with
+    constant parameters (hoisted path), plus expressions, factor and select."""
+    P = M.Program()
+    a = P.sample(M.addr("a"), M.Normal(0.0, 1.0))
+    s = P.sample(M.addr("s"), M.Gamma(2.0, 1.5))
+    b = P.sample(M.addr("b"), M.Beta(2.0, 3.0))
+    u = P.sample(M.addr("u"), M.Uniform(-2.0, 2.0))
+    ln = P.sample(M.addr("ln"), M.LogNormal(a, s))
+    e = P.sample(M.addr("e"), M.Exponential(s))
+    be = P.sample(M.addr("be"), M.Bernoulli(b))
+    cat = P.sample(M.addr("cat"), M.Categorical([b, 1.0 - b]))
+    cat2 = P.sample(M.addr("cat", 2), M.Categorical([0.2, 0.3, 0.5]))
+    bi = P.sample(M.addr("bi"), M.Binomial(10, b))
+    po = P.sample(M.addr("po"), M.Poisson(s * 2.0))
+    t = P.sample(M.addr("t"), M.StudentT(3.0 + s, a, s))
+    c = P.sample(M.addr("c"), M.Cauchy(a, s))
+    la = P.sample(M.addr("la"), M.Laplace(a, s))
+    w = P.sample(M.addr("w"), M.Weibull(1.0 + s, 1.0 + e))
+    ch = P.sample(M.addr("ch"), M.ChiSquared(1.0 + s))
+    ig = P.sample(M.addr("ig"), M.InverseGamma(2.0 + s, 1.0 + s))
+    du = P.sample(M.addr("du"), M.DiscreteUniform(-2, 5))
+    # hoisted observes (constant parameters)
+    P.observe(M.addr("o", 0), M.Normal(0.3, 0.5), a)
+    P.observe(M.addr("o", 1), M.Normal(0.3, 0.7), 0.25)
+    P.observe(M.addr("o", 2), M.LogNormal(0.1, 2.0), ln)
+    P.observe(M.addr("o", 3), M.Exponential(1.3), e)
+    P.observe(M.addr("o", 4), M.Bernoulli(0.3), be)
+    P.observe(M.addr("o", 5), M.Beta(2.5, 1.5), b)
+    P.observe(M.addr("o", 6), M.Gamma(3.0, 2.0), s)
+    P.observe(M.addr("o", 7), M.Binomial(12, 0.4), bi)
+    P.observe(M.addr("o", 8), M.Poisson(3.5), po)
+    P.observe(M.addr("o", 9), M.StudentT(4.0, 0.5, 2.0), t)
+    P.observe(M.addr("o", 10), M.Cauchy(0.5, 0.25), c)
+    P.observe(M.addr("o", 11), M.Laplace(-0.5, 4.0), la)
+    P.observe(M.addr("o", 12), M.Weibull(1.5, 2.0), w)
+    P.observe(M.addr("o", 13), M.ChiSquared(4.0), ch)
+    P.observe(M.addr("o", 14), M.InverseGamma(3.0, 2.0), ig)
+    P.observe(M.addr("o", 15), M.DiscreteUniform(-3, 8), du)
+    P.observe(M.addr("o", 16), M.Uniform(-3.0, 3.0), u)
+    P.observe(M.addr("o", 17), M.Categorical([0.1, 0.2, 0.3, 0.4]), cat2)
+    # expressions
+    P.observe(M.addr("o", 18), M.Normal(M.select(cat2, [a, u, b]), 1.0), 0.3)
+    P.observe(M.addr("o", 19), M.Normal(M.exp(-M.fabs(a)) + M.sqrt(s) * M.tanh(u) - M.ln(1.0 + e) / (2.0 + M.cos(c)),
+                                        M.fmax(0.1, M.fmin(s, 3.0)) ** 1.5), 0.7)
+    P.observe(M.addr("o", 20), M.Normal((a * 0.5 + u * 0.25 + b * 2.0).clamp(-1.0, 1.0), 1.0 + M.floor(s) + M.sin(a) ** 2.0), -0.2)
+    P.observe(M.addr("o", 21), M.Poisson(M.exp(0.3 * a) + cat), 2)
+    P.factor(-0.5 * a * a + 0.1 * u)
+    return P
+
+
+def f64_values_for(orc_model, rng: np.random.Generator, n_chains: int) -> np.ndarray:
+    """Random but in-support cells [S][C] for `all_dists_model`-like programs: draw from the prior."""
+    cells = np.zeros((orc_model.S, n_chains), dtype=np.int64)
+    for c in range(n_chains):
+        v, _, _ = orc_model.run_prior(int(rng.integers(1 << 30)), c)
+        cells[:, c] = v
+    return cells
+
+
+ZOO = {
+    "readme": lambda: W.readme_normal(),
+    "normal32": lambda: W.normal_sites(32),
+    "coin": lambda: W.coin_flip(),
+    "refmodel8": lambda: W.reference_model(8),
+    "ridge": lambda: W.ridge_regression(*W.ridge_data(24, 4)[:2]),
+    "mixture": lambda: W.mixture(W.mixture_data(10)[0]),
+    "alldists": all_dists_model,
+}

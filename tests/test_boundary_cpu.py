@@ -1,0 +1,96 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol that
+include/fugue_amd.h declares, the host-side program compiler orders sites like the reference's
+BTreeMap, rejects what the reference panics on, and refuses to run without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fugue_amd import engine as E
+from fugue_amd import model as M
+from fugue_amd import workloads as W
+from tests.models import ZOO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fugue_amd.h")).read()
+    declared = set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fg_tok"}
+    lib = ctypes.CDLL(E.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(E.ABI_SYMBOLS), declared ^ set(E.ABI_SYMBOLS)
+    assert E.lib().fg_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", list(ZOO))
+def test_site_order_is_lexicographic_and_matches_oracle(oracle, name):
+    prog = ZOO[name]()
+    cp = E.compile_model(prog)
+    om = oracle.OracleModel(prog)
+    assert cp.site_names == sorted(prog.sample_addresses(), key=lambda s: s.encode())
+    assert cp.site_names == om.site_names and cp.site_vtypes == om.site_vtypes
+    assert (cp.S, cp.d, cp.O) == (om.S, om.d, om.O)
+
+
+def test_indexed_addresses_sort_as_strings():
+    cp = E.compile_model(W.normal_sites(12))
+    assert cp.site_names[:4] == ["x#0", "x#1", "x#10", "x#11"]      # "x#10" < "x#2" (address.rs:150-157)
+    assert M.addr("a#b", "c\\d") == "a\\#b#c\\\\d"                   # escape_addr_segment (address.rs:189-223)
+
+
+def test_duplicate_address_is_rejected():
+    P = M.Program()
+    P.sample(M.addr("x"), M.Normal(0, 1))
+    P.sample(M.addr("x"), M.Normal(0, 1))
+    with pytest.raises(M.FugueError) as ei:
+        E.compile_model(P)
+    assert ei.value.code == M.ErrorCode.AddressConflict           # 301, interpreters.rs:23-33
+
+
+def test_constructor_validation_codes():
+    for ctor, code in [(lambda: M.Normal(0, -1), 101), (lambda: M.Normal(float("nan"), 1), 100),
+                       (lambda: M.Bernoulli(1.5), 102), (lambda: M.Uniform(2, 1), 103), (lambda: M.Beta(0, 1), 104),
+                       (lambda: M.Gamma(1, 0), 105), (lambda: M.Categorical([0.5, 0.6]), 102),
+                       (lambda: M.DiscreteUniform(3, 1), 103), (lambda: M.Poisson(0), 105)]:
+        with pytest.raises(M.FugueError) as ei:
+            ctor()
+        assert ei.value.code == code
+
+
+def test_structure_varying_model_is_refused():
+    def model():
+        return M.sample(M.addr("b"), M.Bernoulli(0.5)).bind(
+            lambda b: M.sample(M.addr("x"), M.Normal(0, 1)) if b else M.pure(0.0))
+    with pytest.raises(M.StructureError):
+        M.trace_model(model)
+
+
+def test_sparse_dependency_counts():
+    cp = E.compile_model(W.normal_sites(32))
+    assert cp.n_instructions == 64 and cp.dep_counts == [2] * 32      # own prior + own observation
+    cp = E.compile_model(W.reference_model(8))                        # mu feeds every x#i prior
+    mu = cp.site_names.index("mu")
+    assert cp.dep_counts[cp.f64_sites.index(mu)] == 8 and min(cp.dep_counts) == 2
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    """The product has no CPU fallback: without a device engine creation fails loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(E.EngineError) as ei:
+        E.Engine(E.compile_model(W.readme_normal()), 64, seed=1)
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fugue_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "fugue_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
