@@ -203,7 +203,8 @@ __device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, c
 // HmcSession::step x n_steps (hmc.rs:819-919), d > 0, without the mass-matrix reset (the
 // host splits launches at that iteration).
 __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps,
-                                                       int n_warmup, int welford_on, double *draws, int first_sample_t) {
+                                                       int n_warmup, int welford_on, double *draws, int first_sample_t,
+                                                       double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
     const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
     const bool live = chain < X.C;
@@ -234,6 +235,14 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCt
         const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, lj, e, u);
         lj = o.lj;
         asum += o.alpha; ndiv += o.divergent ? 1ull : 0ull;
+        if (live && info) {                                // HmcStepInfo: hmc.rs:587-602
+            double *r = info + (long long)t * 4 * X.C + c;
+            r[0] = o.accepted ? 1.0 : 0.0; r[X.C] = o.divergent ? 1.0 : 0.0; r[2 * X.C] = o.alpha; r[3 * X.C] = e;
+        }
+        if (live && pos_all) {
+            double *row = pos_all + (long long)t * P.d * X.C + c;
+            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * FG_WAVE];
+        }
         if (warming) {                                     // DualAveraging::update: hmc.rs:168-178
             da_m += 1ull;
             const double m = (double)da_m;
@@ -659,14 +668,15 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
     return FG_OK;
 }
 
-static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t) {
+static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t,
+                            double *pos_all = nullptr, double *info = nullptr) {
     hipLaunchKernelGGL(k_hmc_steps, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
-                       e->n_warmup, welford_on, draws, first_sample_t);
+                       e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     HIPCHK(hipGetLastError());
     return FG_OK;
 }
 
-int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) {
+static int hmc_step_impl(fg_engine *e, int n_transitions, double *d_draws, double *d_pos_all, double *d_info) {
     NEED_ENGINE(e);
     if (!e->hmc_ready) { fg_set_error("fg_hmc_step before fg_hmc_init"); return FG_E_STATE; }
     if (n_transitions < 0) return FG_E_BAD_ARG;
@@ -675,6 +685,7 @@ int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) {
     while (done < n_transitions) {
         const int iter = e->iter;
         if (e->d == 0) {                                   // fresh prior draw per step: hmc.rs:826-845
+            if (d_pos_all || d_info) { fg_set_error("fg_hmc_step_info: model has no continuous sites"); return FG_E_UNSUPPORTED; }
             int rc = launch_prior(e, (uint32_t)(iter + 1), FG_RNG_PRIOR, nullptr, e->H.lj);
             if (rc) return rc;
             e->iter += 1; done += 1;
@@ -687,7 +698,9 @@ int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) {
         const int first_sample_t = std::max(iter, e->n_warmup) - iter;      // first post-warmup t of this launch
         const int n_rows = std::max(0, n - first_sample_t);
         double *draws = (d_draws && n_rows > 0) ? d_draws + rows_written * (long long)e->d * e->C : nullptr;
-        int rc = hmc_launch_steps(e, iter, n, welford_on, draws, first_sample_t);
+        int rc = hmc_launch_steps(e, iter, n, welford_on, draws, first_sample_t,
+                                  d_pos_all ? d_pos_all + (long long)done * e->d * e->C : nullptr,
+                                  d_info ? d_info + (long long)done * 4 * e->C : nullptr);
         if (rc) return rc;
         rows_written += n_rows;
         e->iter += n; done += n;
@@ -701,6 +714,11 @@ int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) {
         }
     }
     return FG_OK;
+}
+
+int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) { return hmc_step_impl(e, n_transitions, d_draws, nullptr, nullptr); }
+int fg_hmc_step_info(fg_engine *e, int n_transitions, double *d_positions, double *d_info) {
+    return hmc_step_impl(e, n_transitions, nullptr, d_positions, d_info);
 }
 
 int fg_hmc_get_stats(fg_engine *e, fg_hmc_stats *st) {
@@ -757,6 +775,14 @@ int fg_hmc_get_log_joint(fg_engine *e, double *h_lj) {
     if (!h_lj || !e->hmc_ready) return FG_E_BAD_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(h_lj, e->H.lj, (size_t)e->C * 8, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+int fg_hmc_get_mass(fg_engine *e, double *h_m_inv) {
+    NEED_ENGINE(e);
+    if (!h_m_inv || !e->hmc_ready) return FG_E_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->H.use_mass) HIPCHK(hipMemcpy(h_m_inv, e->H.m_inv, (size_t)e->d * e->C * 8, hipMemcpyDeviceToHost));
+    else for (size_t i = 0; i < (size_t)e->d * e->C; i++) h_m_inv[i] = 1.0;
     return FG_OK;
 }
 int fg_hmc_set_step_size(fg_engine *e, double eps) {    // hmc.rs:741-747

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_last_error", "fg_abi_version",
     "fg_engine_new", "fg_engine_free", "fg_engine_synchronize", "fg_engine_stream", "fg_engine_n_chains",
     "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint",
-    "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
+    "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
 ]
@@ -100,6 +100,8 @@ def lib():
     L.fg_hmc_config_default.argtypes = [C.POINTER(fg_hmc_config)]
     L.fg_hmc_init.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_int]
     L.fg_hmc_step.argtypes = [vp, C.c_int, vp]
+    L.fg_hmc_step_info.argtypes = [vp, C.c_int, vp, vp]
+    L.fg_hmc_get_mass.argtypes = [vp, dp]
     L.fg_hmc_run.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_int, C.c_int, vp, C.POINTER(fg_hmc_stats)]
     L.fg_hmc_get_stats.argtypes = [vp, C.POINTER(fg_hmc_stats)]
     L.fg_hmc_get_step_sizes.argtypes = [vp, dp]
@@ -296,6 +298,25 @@ class Engine:
 
     def hmc_step(self, n: int, d_draws: Optional[int] = None):
         _check(lib().fg_hmc_step(self.h, int(n), d_draws))
+
+    def hmc_step_info(self, n: int):
+        """n transitions with HmcStepInfo: returns positions [n][d][C] and a dict of [n][C] arrays."""
+        n = int(n)
+        d_pos = self.device_alloc(max(1, n * self.d * self.C) * 8)
+        d_info = self.device_alloc(max(1, n * 4 * self.C) * 8)
+        try:
+            _check(lib().fg_hmc_step_info(self.h, n, d_pos, d_info))
+            pos = self.download(d_pos, (n, self.d, self.C))
+            info = self.download(d_info, (n, 4, self.C))
+        finally:
+            self.device_free(d_pos)
+            self.device_free(d_info)
+        return pos, dict(accepted=info[:, 0] != 0, divergent=info[:, 1] != 0, accept_prob=info[:, 2], step_size=info[:, 3])
+
+    def hmc_mass(self) -> np.ndarray:
+        a = np.zeros((max(1, self.d), self.C))
+        _check(lib().fg_hmc_get_mass(self.h, _dp(a)))
+        return a[:self.d]
 
     def hmc_run(self, cfg: fg_hmc_config, n_samples: int, n_warmup: int, d_draws: Optional[int] = None) -> fg_hmc_stats:
         st = fg_hmc_stats()

@@ -164,12 +164,18 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup);
 /* HmcSession::step x n (hmc.rs:819-919).  Post-warmup positions are appended to
  * d_draws [n][d][C] when non-NULL (rows of warmup transitions are left untouched). */
 int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws);
+/* HmcSession::step x n returning every transition's HmcStepInfo (hmc.rs:587-602,803-805):
+ * d_positions [n][d][C] = position after each transition (warmup included), d_info [n][4][C] =
+ * accepted (0/1), divergent (0/1), accept_prob, step_size.  Either may be NULL. */
+int fg_hmc_step_info(fg_engine *e, int n_transitions, double *d_positions, double *d_info);
 /* hmc_chain (hmc.rs:566-583): init + n_warmup + n_samples; d_draws [n_samples][d][C] */
 int fg_hmc_run(fg_engine *e, const fg_hmc_config *cfg, int n_samples, int n_warmup,
                double *d_draws, fg_hmc_stats *h_stats);
 int fg_hmc_get_stats(fg_engine *e, fg_hmc_stats *h_stats);
 int fg_hmc_get_step_sizes(fg_engine *e, double *h_eps /*[C]*/);
 int fg_hmc_get_log_joint(fg_engine *e, double *h_lj /*[C]*/);
+/* current diagonal inverse mass (HmcSession::m_inv, hmc.rs:652): h_m_inv [d][C] (all 1 without adapt_mass) */
+int fg_hmc_get_mass(fg_engine *e, double *h_m_inv);
 /* set_step_size (hmc.rs:741-747) for every chain */
 int fg_hmc_set_step_size(fg_engine *e, double eps);
 /* test / diagnostics hooks under injected randomness -------------------------------- */

@@ -144,6 +144,8 @@ void   orc_hmc_transition(const orc_model *m, const orc_cell *base,
 double orc_find_reasonable_epsilon(const orc_model *m, const orc_cell *base,
                                    const double *q, double lj_q, double h,
                                    const double *m_inv, const double *p0);
+void   orc_hmc_momentum(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t purpose,
+                        const double *mass_sqrt, int d, double *p0, double *u);
 double orc_dual_averaging_run(double eps0, double target, const double *alphas,
                               int n, double *eps_trace, double *frozen);
 

@@ -130,6 +130,7 @@ def lib():
                                      C.c_double, dp, dp, ip, dp, ip]
     L.orc_find_reasonable_epsilon.restype = C.c_double
     L.orc_find_reasonable_epsilon.argtypes = [vp, vp, dp, C.c_double, C.c_double, dp, dp]
+    L.orc_hmc_momentum.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp, C.c_int, dp, dp]
     L.orc_dual_averaging_run.restype = C.c_double
     L.orc_dual_averaging_run.argtypes = [C.c_double, C.c_double, dp, C.c_int, dp, dp]
     L.orc_hmc_run.argtypes = [vp, C.POINTER(HmcConfig), C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int,
@@ -430,6 +431,15 @@ def adapt_update(scale, log_scale, acc, tot, accepted, target=0.44, gamma=0.7):
     a, t = C.c_int64(acc), C.c_int64(tot)
     lib().orc_adapt_update(C.byref(s), C.byref(ls), C.byref(a), C.byref(t), int(accepted), target, gamma)
     return s.value, ls.value, a.value, t.value
+
+
+def hmc_momentum(seed, chain, it, d, mass_sqrt=None, purpose=2):
+    """(p0[d], u) of HMC transition `it` of chain `chain` (purpose 2) / eps-search instance (purpose 3)."""
+    p0 = np.zeros(max(1, d))
+    u = C.c_double()
+    ms = _d(mass_sqrt) if mass_sqrt is not None else None
+    lib().orc_hmc_momentum(seed, chain, it, purpose, _dp(ms) if ms is not None else None, d, _dp(p0), C.byref(u))
+    return p0[:d], u.value
 
 
 def dual_averaging(eps0, target, alphas):

@@ -166,6 +166,19 @@ static void draw_momentum(orc_stream *st, const double *mass_sqrt, int d, double
     }
 }
 
+/* The momentum (p0 = z * mass_sqrt, hmc.rs:436-441) and accept uniform of transition `iter`
+ * of chain `chain` (purpose = ORC_RNG_HMC), or of eps-search instance `iter` (ORC_RNG_EPS). */
+void orc_hmc_momentum(uint64_t seed, uint32_t chain, uint32_t iter, uint32_t purpose, const double *mass_sqrt, int d,
+                      double *p0, double *u) {
+    orc_stream st;
+    double *ones = NULL;
+    if (!mass_sqrt) { ones = (double *)malloc(((size_t)d + 1) * sizeof(double)); for (int i = 0; i < d; i++) ones[i] = 1.0; mass_sqrt = ones; }
+    orc_stream_init(&st, seed, chain, iter, purpose);
+    draw_momentum(&st, mass_sqrt, d, p0);
+    if (u) *u = orc_stream_u01(&st);
+    free(ones);
+}
+
 /* one chain of hmc_chain (hmc.rs:566-583) via the HmcSession state machine
  * (hmc.rs:667-729, 819-919). */
 static void hmc_one_chain(const orc_model *m, const orc_hmc_config *cfg, uint64_t seed, uint32_t chain,

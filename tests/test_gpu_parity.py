@@ -150,45 +150,155 @@ def test_find_reasonable_epsilon_injected(oracle, name):
     assert mism <= 1, mism        # a log-ratio within 1e-9 of ln 0.5 / ln 2 may tip the other way
 
 
+def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, target=0.8, mass_at=None):
+    """Teacher-forced replay of one chain: every GPU transition is re-done by the oracle from the
+    GPU's own previous state with the GPU's own step size, so ulp-level differences cannot
+    compound through the (chaotic) step-size feedback.  Returns the number of knife-edge flips."""
+    d = cp.d
+    cells = cells0.copy()
+    q = _f64(cells[om.f64_sites]).copy()
+    lj = om.log_joint_at(cells, q)
+    m_inv = np.ones(d)
+    flips = 0
+    for t in range(pos.shape[0]):
+        if mass_at is not None and t == mass_at:         # hmc.rs:885-908
+            m_inv = np.var(pos[:t, :, chain], axis=0, ddof=1)
+            m_inv = np.where(np.isfinite(m_inv) & (m_inv > 1e-8), m_inv, 1.0)
+            p0e, _ = oracle.hmc_momentum(seed, chain, 1, d, np.sqrt(1.0 / m_inv), purpose=3)
+            eps_reset = om.find_reasonable_epsilon(cells, q, lj, p0e, m_inv=m_inv)
+            assert info["step_size"][t, chain] == pytest.approx(eps_reset, rel=1e-12)
+        eps = info["step_size"][t, chain]
+        p0, u = oracle.hmc_momentum(seed, chain, t, d, np.sqrt(1.0 / m_inv))
+        qo, ljo, oacc, oalpha, odiv = om.hmc_transition(cells, q, lj, eps, cfg_L, p0, u, m_inv=m_inv)
+        assert odiv == bool(info["divergent"][t, chain])
+        if not odiv:
+            _close(info["accept_prob"][t, chain], oalpha, 1e-6, 1e-9)
+            if oacc != bool(info["accepted"][t, chain]):
+                assert abs(u - oalpha) < 1e-6
+                flips += 1
+            else:
+                # the force is a central difference with h = 1e-5: one ulp of log pi (|lj| ~ 1e2 -> 1e-14) becomes
+                # 1e-14 / 2h ~ 1e-9 of force noise per evaluation, ~1e-8 of position after L steps
+                _close(pos[t, :, chain], qo, 1e-6, 1e-7)
+        q = pos[t, :, chain].copy()                        # teacher forcing: continue from the GPU state
+        for k, j in enumerate(om.f64_sites):
+            cells[j] = q[k:k + 1].view(np.int64)[0]
+        lj = om.log_joint_at(cells, q)
+    return flips
+
+
 @pytest.mark.parametrize("name,mode", [("readme", E.GRAD_FD_DENSE), ("normal32", E.GRAD_FD_DENSE),
                                        ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_DENSE),
-                                       ("ridge", E.GRAD_FD_SPARSE)])
-def test_hmc_chain_matches_oracle(oracle, name, mode):
-    """hmc_chain end to end (prior init, eps search, dual averaging, frozen sampling) vs the
-    oracle run on the same Philox streams: every recorded draw within 1e-6 relative."""
+                                       ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE)])
+def test_hmc_session_matches_oracle_teacher_forced(oracle, name, mode):
+    """HmcSession (hmc.rs:667-920) step by step: prior init, Alg. 4 step size, every transition's
+    HmcStepInfo, the dual-averaging recursion and the frozen step size -- each checked against
+    the oracle given the GPU's own previous state."""
     cp, om = _pair(oracle, name)
-    C, nw, ns = 96, 30, 20
-    cfg = E.hmc_config(grad_mode=mode, n_leapfrog=8)
+    C, nw, n, L, seed, c0 = 64, 14, 24, 6, 5, 7
+    cfg = E.hmc_config(grad_mode=mode, n_leapfrog=L)
+    eng = E.Engine(cp, C, seed=seed, chain_offset=c0)
+    eng.hmc_init(cfg, nw)
+    cells0 = eng.get_values()
+    eps0 = eng.hmc_step_sizes()
+    lj0 = eng.hmc_log_joint()
+    pos, info = eng.hmc_step_info(n)
+    flips = 0
+    for c in range(C):
+        ocells, oacc, _ = om.run_prior(seed, c0 + c)                        # HmcSession::new, hmc.rs:673-687
+        for j in range(cp.S):
+            if cp.site_vtypes[j] == 0:
+                _close(_f64(cells0[j:j + 1, c]), _f64(ocells[j:j + 1]), 1e-11, 1e-300)
+            else:
+                assert cells0[j, c] == ocells[j]
+        _close(lj0[c], oacc.sum(), 1e-9, 1e-9)
+        q0 = _f64(cells0[om.f64_sites, c])
+        p0e, _ = oracle.hmc_momentum(seed, c0 + c, 0, cp.d, purpose=3)
+        assert eps0[c] == om.find_reasonable_epsilon(cells0[:, c], q0, om.log_joint_at(cells0[:, c], q0), p0e)
+        # DualAveraging (hmc.rs:141-184) fed with the GPU's acceptance probabilities
+        _, tr, frozen = oracle.dual_averaging(eps0[c], 0.8, info["accept_prob"][:nw, c])
+        assert info["step_size"][0, c] == eps0[c]
+        _close(info["step_size"][1:nw, c], tr[:nw - 1], 1e-12)
+        _close(info["step_size"][nw:, c], np.full(n - nw, frozen), 1e-12)    # frozen kernel: hmc.rs:789-798
+    for c in range(C):
+        f = _replay_chain(oracle, om, cp, seed, c, cells0[:, c], pos, info, L, nw) if c0 == 0 else \
+            _replay_chain_offset(oracle, om, cp, seed, c0, c, cells0[:, c], pos, info, L, nw)
+        flips += f
+    assert flips <= 1
+    _close(eng.hmc_step_sizes(), info["step_size"][-1], 0.0)
+
+
+def _replay_chain_offset(oracle, om, cp, seed, c0, c, cells0, pos, info, L, nw, mass_at=None):
+    """_replay_chain for an engine whose chain 0 has global id c0 (RNG streams use global ids)."""
+    sub_pos, sub_info = pos[:, :, c:c + 1], {k: v[:, c:c + 1] for k, v in info.items()}
+
+    class _Shift:
+        def __getattr__(self, k):
+            return getattr(oracle, k)
+
+        @staticmethod
+        def hmc_momentum(seed_, chain, it, d, mass_sqrt=None, purpose=2):
+            return oracle.hmc_momentum(seed_, c0 + c, it, d, mass_sqrt, purpose)
+    return _replay_chain(_Shift(), om, cp, seed, 0, cells0, sub_pos, sub_info, L, nw, mass_at=mass_at)
+
+
+def test_hmc_free_running_short_chain_matches_oracle(oracle):
+    """hmc_chain end to end without teacher forcing, kept short: ocml-vs-glibc ulp differences
+    enter the finite-difference force (x 1/2h = 5e4) and are amplified several-fold per
+    transition by the step-size feedback (measured on normal32: 3e-10 after 1 transition, chains
+    fully decorrelated after 25 adaptive ones), so only the first transitions can be compared
+    draw for draw; the long adaptive run is covered by the teacher-forced test above."""
+    cp, om = _pair(oracle, "normal32")
+    C, nw, ns = 96, 3, 3
     eng = E.Engine(cp, C, seed=5, chain_offset=7)
     d_draws = eng.device_alloc(ns * cp.d * C * 8)
-    st = eng.hmc_run(cfg, ns, nw, d_draws)
+    st = eng.hmc_run(E.hmc_config(n_leapfrog=8), ns, nw, d_draws)
     draws = eng.download(d_draws, (ns, cp.d, C))
     eng.device_free(d_draws)
-    ocfg = oracle.HmcConfig.default(n_leapfrog=8)
-    odraws, ofinal, oeps, ost = om.hmc_run(5, C, nw, ns, ocfg, chain0=7, n_threads=8)
-    bad = ~np.isclose(draws, odraws, rtol=1e-6, atol=1e-8)
-    bad_chains = np.unique(np.nonzero(bad)[2])
-    assert len(bad_chains) <= 1, (len(bad_chains), draws[bad][:4], odraws[bad][:4])
-    _close(eng.hmc_step_sizes()[np.setdiff1d(np.arange(C), bad_chains)],
-           oeps[np.setdiff1d(np.arange(C), bad_chains)], 1e-6)
-    assert abs(st.accept_rate - ost.accept_rate) < 2e-3
-    assert st.n_divergent == ost.n_divergent or len(bad_chains) > 0
+    odraws, _, oeps, ost = om.hmc_run(5, C, nw, ns, oracle.HmcConfig.default(n_leapfrog=8), chain0=7, n_threads=8)
+    bad_chains = np.unique(np.nonzero(~np.isclose(draws, odraws, rtol=1e-4, atol=1e-5))[2])
+    assert len(bad_chains) <= 1, (bad_chains, np.abs(draws - odraws).max())
+    assert abs(st.accept_rate - ost.accept_rate) < 1e-3
 
 
-def test_hmc_mass_adaptation_matches_oracle(oracle):
-    """adapt_mass path (Welford, reset at n_warmup/2, second eps search; hmc.rs:882-908)."""
+@pytest.mark.parametrize("name", ["readme", "normal32"])
+def test_hmc_fixed_step_long_chain_matches_oracle(oracle, name):
+    """No adaptation (n_warmup = 0, pinned step size): 60 free-running transitions stay within 1e-6."""
+    cp, om = _pair(oracle, name)
+    C, ns = 64, 60
+    cfg = E.hmc_config(n_leapfrog=8, init_step_size=0.15, grad_mode=E.GRAD_FD_SPARSE)
+    eng = E.Engine(cp, C, seed=11)
+    d_draws = eng.device_alloc(ns * cp.d * C * 8)
+    eng.hmc_run(cfg, ns, 0, d_draws)
+    draws = eng.download(d_draws, (ns, cp.d, C))
+    odraws, _, _, _ = om.hmc_run(11, C, 0, ns, oracle.HmcConfig.default(n_leapfrog=8, init_step_size=0.15), n_threads=8)
+    bad_chains = np.unique(np.nonzero(~np.isclose(draws, odraws, rtol=1e-6, atol=1e-8))[2])
+    assert len(bad_chains) <= 1, bad_chains
+
+
+def test_hmc_mass_adaptation_teacher_forced(oracle):
+    """adapt_mass path (Welford variances, reset at n_warmup/2, second eps search with the new
+    mass, new DualAveraging; hmc.rs:882-908), replayed transition by transition."""
     prog = W.normal_sites(6)
     cp, om = E.compile_model(prog), oracle.OracleModel(prog)
-    C, nw, ns = 64, 40, 10
-    cfg = E.hmc_config(adapt_mass=True, n_leapfrog=6)
-    eng = E.Engine(cp, C, seed=9)
-    d_draws = eng.device_alloc(ns * cp.d * C * 8)
-    eng.hmc_run(cfg, ns, nw, d_draws)
-    draws = eng.download(d_draws, (ns, cp.d, C))
-    ocfg = oracle.HmcConfig.default(adapt_mass=1, n_leapfrog=6)
-    odraws, _, _, _ = om.hmc_run(9, C, nw, ns, ocfg, n_threads=8)
-    bad_chains = np.unique(np.nonzero(~np.isclose(draws, odraws, rtol=1e-5, atol=1e-7))[2])
-    assert len(bad_chains) <= 1, bad_chains
+    C, nw, n, L, seed = 64, 16, 22, 6, 9
+    cfg = E.hmc_config(adapt_mass=True, n_leapfrog=L)
+    eng = E.Engine(cp, C, seed=seed)
+    eng.hmc_init(cfg, nw)
+    cells0 = eng.get_values()
+    pos, info = eng.hmc_step_info(n)
+    m_inv = eng.hmc_mass()
+    flips = 0
+    for c in range(C):
+        var = np.var(pos[:nw // 2, :, c], axis=0, ddof=1)
+        _close(m_inv[:, c], np.where(var > 1e-8, var, 1.0), 1e-10)
+        flips += _replay_chain(oracle, om, cp, seed, c, cells0[:, c], pos, info, L, nw, mass_at=nw // 2)
+        # second dual-averaging run restarts from the re-tuned step size
+        e_reset = info["step_size"][nw // 2, c]
+        _, tr, frozen = oracle.dual_averaging(e_reset, 0.8, info["accept_prob"][nw // 2:nw, c])
+        _close(info["step_size"][nw // 2 + 1:nw, c], tr[:nw - nw // 2 - 1], 1e-12)
+        _close(info["step_size"][nw:, c], np.full(n - nw, frozen), 1e-12)
+    assert flips <= 1
 
 
 def test_hmc_posterior_closed_form():
