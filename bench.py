@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+Workload (BASELINE.json configs[1] + north_star): `hmc_chain` on the 32-site conjugate Normal
+model (x#i ~ N(0,1); y#i ~ N(x#i, 0.5) observed at 0.2 i - 1), 65 536 chains per GPU,
+HMCConfig::default() (L = 16 leapfrog steps per transition, h = 1e-5, target accept 0.8).
+
+A bench "step" = ONE HMC transition (16 leapfrog steps + 17 gradient evaluations + the endpoint
+score + accept/reject + adaptation) of EVERY chain.  `--warmup W` untimed transitions are the
+chain's adaptive warmup (dual averaging), the `--steps K` timed ones are post-warmup sampling
+transitions whose draws are appended to a [K][d][C] buffer in HBM, exactly what `hmc_chain`
+returns.  value = chains x K x L / time = leapfrog-steps/s over all GPUs (weak scaling: every
+rank runs its own 65 536 chains; no data-path collective; the cross-chain R-hat all-gather of
+per-chain moments runs after the timed region).
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     -- the dominant kernel (k_hmc_steps) against the HBM roof, algorithmic bytes
+                  32*d B per leapfrog step / HIP-event time; the kernel is
+                  f64-VALU bound by construction (state lives in LDS), see `valu_f64`.
+  cpu_baseline -- the CPU oracle (restatement of the reference algorithm, dense FD) timed on
+                  this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+N_SITES = 32
+CHAINS_PER_GPU = 65536
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz / 2 (f64 half rate)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--grad", choices=["fd_sparse", "fd_dense"], default="fd_sparse")
+    ap.add_argument("--launch", type=int, default=25, help="transitions fused per kernel launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chains", type=int, default=512)
+    ap.add_argument("--cpu-transitions", type=int, default=24)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/: per-chain sequential, interpretive, dense central FD exactly as
+    hmc.rs:304-329) on a bounded sample of the same workload, all host cores."""
+    from fugue_amd import workloads as W
+    from oracle import oracle as orc
+    om = orc.OracleModel(W.normal_sites(N_SITES))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nw = args.cpu_transitions // 2
+    ns = args.cpu_transitions - nw
+    t0 = time.perf_counter()
+    _, _, _, st = om.hmc_run(1, args.cpu_chains, nw, ns, orc.HmcConfig.default(), n_threads=cores, want_draws=False)
+    dt = time.perf_counter() - t0
+    lf = args.cpu_chains * args.cpu_transitions * 16
+    return {"value": lf / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_chains} chains x {args.cpu_transitions} transitions (L=16, dense FD) of the same model, "
+                      f"{dt:.1f} s wall; C restatement, not the Rust binary",
+            "published_reference": "none for HMC; MH 65k chain-steps/s/thread on Apple Silicon (benches/f_perf.rs:24-28)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from fugue_amd import engine as E, workloads as W
+    C, K, Wn, L = args.chains, args.steps, args.warmup, 16
+    cp = E.compile_model(W.normal_sites(N_SITES))
+    d = cp.d
+    mode = E.GRAD_FD_SPARSE if args.grad == "fd_sparse" else E.GRAD_FD_DENSE
+    cfg = E.hmc_config(grad_mode=mode)
+    eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=local_rank)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)                    # kernels + torch events share one stream
+    draws = torch.empty((K, d, C), dtype=torch.float64, device=f"cuda:{local_rank}")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: HmcSession::new + W adaptive warmup transitions
+    eng.hmc_init(cfg, Wn)
+    done = 0
+    while done < Wn:
+        n = min(args.launch, Wn - done)
+        eng.hmc_step(n)
+        done += n
+    barrier()
+    # timed: exactly K sampling transitions
+    events = []
+    t0 = time.perf_counter()
+    done = 0
+    while done < K:
+        n = min(args.launch, K - done)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.hmc_step(n, draws[done].data_ptr())
+        e1.record(stream)
+        events.append((e0, e1, n))
+        done += n
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    launch_ms = float(np.mean([ms for ms, (_, _, n) in zip(kernel_ms, events) if n == events[0][2]]))
+    n_launch = events[0][2]
+
+    # correctness of what was timed: posterior mean / variance against the closed form
+    st = eng.hmc_stats()
+    m = draws.mean(dim=(0, 2)).cpu().numpy()
+    v = draws.var(dim=(0, 2)).cpu().numpy()
+    _, tm, tv = W.normal_sites_truth(N_SITES)
+    mean_err, var_err = float(np.abs(m - tm).max()), float(np.abs(v - tv).max())
+
+    total_lf = world * C * K * L
+    value = total_lf / dt
+    # ---- roofline of the dominant kernel (k_hmc_steps) -----------------------------------
+    alg_bytes_per_launch = C * n_launch * (L * 32 * d + 8 * d + 16)       # 32*d B / leapfrog step (+ draw row, lj, eps)
+    achieved_gbs = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    evals_per_transition = (2 * d * (L + 1)) * (2 if mode == E.GRAD_FD_SPARSE else 2 * N_SITES) + 2 * N_SITES   # log-pdf evaluations
+    flops_per_logpdf = 8.0                                                 # Normal log-pdf ~ 8 flops (ln sigma hoisted)
+    achieved_tflops = C * n_launch * evals_per_transition * flops_per_logpdf / (launch_ms * 1e-3) / 1e12
+    out = {
+        "metric": "hmc_leapfrog_steps_per_sec", "value": value, "unit": "leapfrog-steps/s", "n_gpus": world,
+        "steps": K, "warmup": Wn, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C2-normal32: hmc_chain, 32-site conjugate Normal (x#i~N(0,1), y#i~N(x#i,0.5)=0.2i-1), "
+                               f"{C} chains/GPU, L=16, HMCConfig::default", "chains_per_gpu": C, "n_sites": N_SITES,
+                   "n_leapfrog": L, "grad": args.grad, "transitions_per_launch": n_launch,
+                   "sharding": f"chains x{world}" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "k_hmc_steps",
+                     "avg_launch_ms": launch_ms,
+                     "note": "state is LDS-resident for the whole launch: the kernel is f64-VALU bound, not HBM bound (see valu_f64)"},
+        "valu_f64": {"achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS,
+                     "logpdf_evals_per_transition": evals_per_transition, "flops_per_logpdf": flops_per_logpdf},
+        "check": {"posterior_mean_max_abs_err": mean_err, "posterior_var_max_abs_err": var_err,
+                  "accept_rate": st.accept_rate, "mean_step_size": st.mean_step_size, "n_divergent": int(st.n_divergent)},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -420,6 +420,7 @@ struct fg_engine {
     const fg_program *prog = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     long long C = 0;
     unsigned long long seed = 0;
     uint32_t chain0 = 0;
@@ -528,7 +529,7 @@ void fg_engine_free(fg_engine *e) {
     void *ptrs[] = { e->d_ins, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
-    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -537,6 +538,13 @@ void fg_engine_free(fg_engine *e) {
 
 int fg_engine_synchronize(fg_engine *e) { NEED_ENGINE(e); HIPCHK(hipStreamSynchronize(e->stream)); return FG_OK; }
 void *fg_engine_stream(fg_engine *e) { return e ? (void *)e->stream : nullptr; }
+int fg_engine_set_stream(fg_engine *e, void *hip_stream) {
+    NEED_ENGINE(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) HIPCHK(hipStreamDestroy(e->stream));
+    e->stream = (hipStream_t)hip_stream; e->own_stream = false;
+    return FG_OK;
+}
 int64_t fg_engine_n_chains(const fg_engine *e) { return e ? e->C : 0; }
 void *fg_engine_values_device(fg_engine *e) { return e ? (void *)e->d_values : nullptr; }
 

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "fg_program_factor", "fg_program_finalize", "fg_program_n_sites", "fg_program_n_f64", "fg_program_n_observe",
     "fg_program_n_instructions", "fg_program_n_slots", "fg_program_site_name", "fg_program_site_vtype",
     "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_last_error", "fg_abi_version",
-    "fg_engine_new", "fg_engine_free", "fg_engine_synchronize", "fg_engine_stream", "fg_engine_n_chains",
+    "fg_engine_new", "fg_engine_free", "fg_engine_synchronize", "fg_engine_stream", "fg_engine_set_stream", "fg_engine_n_chains",
     "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint",
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
@@ -89,6 +89,7 @@ def lib():
     L.fg_engine_synchronize.argtypes = [vp]
     L.fg_engine_stream.restype = vp
     L.fg_engine_stream.argtypes = [vp]
+    L.fg_engine_set_stream.argtypes = [vp, vp]
     L.fg_engine_n_chains.restype = C.c_int64
     L.fg_engine_n_chains.argtypes = [vp]
     L.fg_engine_set_values.argtypes = [vp, vp]
@@ -267,6 +268,9 @@ class Engine:
     def S(self): return self.cp.S
     @property
     def d(self): return self.cp.d
+
+    def set_stream(self, hip_stream: int):
+        _check(lib().fg_engine_set_stream(self.h, hip_stream))
 
     def synchronize(self):
         _check(lib().fg_engine_synchronize(self.h))

@@ -125,6 +125,8 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed,
 void  fg_engine_free(fg_engine *e);
 int   fg_engine_synchronize(fg_engine *e);
 void *fg_engine_stream(fg_engine *e);                       /* hipStream_t */
+/* run on a caller-owned hipStream_t (e.g. PyTorch's current stream) instead of the engine's own */
+int   fg_engine_set_stream(fg_engine *e, void *hip_stream);
 int64_t fg_engine_n_chains(const fg_engine *e);
 /* current trace values, cells [S][C] */
 int fg_engine_set_values(fg_engine *e, const void *h_cells);
