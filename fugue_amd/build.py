@@ -42,6 +42,8 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     for f in SOURCES:
         p = os.path.join(CSRC, f)
         srcs += (["-x", "hip", p] if f.endswith((".hip", ".cpp")) else [p])
+    if os.environ.get("FG_MIN_WAVES"):
+        extra = list(extra) + ["-DFG_MIN_WAVES=" + os.environ["FG_MIN_WAVES"]]
     cmd = [hipcc()] + FLAGS + list(extra) + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,43 +35,45 @@ struct FgChainCtx {
     long long *values;    // [S][C]
 };
 
-__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots) {
-    for (int j = 0; j < P.S; ++j) slots[j * FG_WAVE] = fg_as_double(X.values[(long long)j * X.C + c]);
+__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
+    for (int j = 0; j < P.S; ++j) slots[j * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
 }
-__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots) {
-    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[j * FG_WAVE]);
+__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
+    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[j * tw]);
 }
 
 // ---- run(PriorHandler, model) per chain: interpreters.rs:88-104 ----
-__global__ __launch_bounds__(FG_WAVE) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
                                                         double *acc_out /*[3][C]*/, double *lj_out /*[C]*/) {
     extern __shared__ double lds[];
-    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
-    for (int j = 0; j < P.n_slots; ++j) slots[j * FG_WAVE] = 0.0;
+    for (int j = 0; j < P.n_slots; ++j) slots[j * tw] = 0.0;
     FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, iteration, purpose);
     FgAcc3 A = {0.0, 0.0, 0.0};
-    fg_exec<FG_MODE_PRIOR, false>(P.ins, P.n_ins, P.pool, slots, A, &rng, nullptr, 0, live);
+    fg_exec<FG_MODE_PRIOR, false>(P.ins, P.n_ins, P.pool, slots, tw, A, &rng, nullptr, 0, live);
     if (live) {
-        fg_store_values(P, X, c, slots);
+        fg_store_values(P, X, c, slots, tw);
         if (acc_out) { acc_out[c] = A.prior; acc_out[X.C + c] = A.lik; acc_out[2 * X.C + c] = A.fac; }
         if (lj_out) lj_out[c] = fg_total(A);
     }
 }
 
 // ---- run(ScoreGivenTrace, model) per chain: interpreters.rs:138-163 ----
-__global__ __launch_bounds__(FG_WAVE) void k_log_joint(FgProgramDev P, FgChainCtx X, double *acc_out, double *logp_out,
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint(FgProgramDev P, FgChainCtx X, double *acc_out, double *logp_out,
                                                        double *lj_out) {
     extern __shared__ double lds[];
-    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
-    fg_load_values(P, X, c, slots);
+    fg_load_values(P, X, c, slots, tw);
     FgAcc3 A = {0.0, 0.0, 0.0};
-    fg_exec<FG_MODE_SCORE, true>(P.ins, P.n_ins, P.pool, slots, A, nullptr, logp_out ? logp_out + c : nullptr, X.C, live);
+    fg_exec<FG_MODE_SCORE, true>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, logp_out ? logp_out + c : nullptr, X.C, live);
     if (live) {
         if (acc_out) { acc_out[c] = A.prior; acc_out[X.C + c] = A.lik; acc_out[2 * X.C + c] = A.fac; }
         if (lj_out) lj_out[c] = fg_total(A);
@@ -100,7 +103,7 @@ struct FgHmcDev {
 // reference's 2d model runs per gradient); SPARSE re-runs only the statements that read
 // coordinate i (identical central difference, the cancelling terms are never formed).
 // Returns `divergent` (a non-finite force component or endpoint log-joint).
-__device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slots, double *pl, double eps, int L, double h,
+__device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slots, double *pl, int tw, double eps, int L, double h,
                                               bool sparse, const double *m_inv /*[d][C] column or null*/, long long C,
                                               double &lj_end) {
     const int d = P.d;
@@ -116,22 +119,22 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
         const FgIns *prog = P.ins;
         int n = P.n_ins;
         if (!is_final) {
-            if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * FG_WAVE]; slots[slot * FG_WAVE] = orig + h; }
-            else slots[slot * FG_WAVE] = orig - h;
+            if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * tw]; slots[slot * tw] = orig + h; }
+            else slots[slot * tw] = orig - h;
             if (sparse) { const int o0 = P.sub_off[i]; prog = P.sub + o0; n = P.sub_off[i + 1] - o0; }
         }
         FgAcc3 A = {0.0, 0.0, 0.0};
-        fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, A, nullptr, nullptr, 0, false);
+        fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         const double tot = fg_total(A);
         if (is_final) { lj_end = tot; break; }
         if (!minus) { lp_plus = tot; continue; }
-        slots[slot * FG_WAVE] = orig;
+        slots[slot * tw] = orig;
         const double g = (lp_plus - tot) / (2.0 * h);            // hmc.rs:322
         bad = bad || !fg_finite(g);
-        double p = pl[i * FG_WAVE];
+        double p = pl[i * tw];
         p += hk * g;                                              // hmc.rs:389 / :400
         if (s > 0 && s < L) p += hk * g;                          // trailing kick of step s + leading kick of s+1
-        pl[i * FG_WAVE] = p;
+        pl[i * tw] = p;
         if (++i == d) {
             i = 0;
             if (__all(bad)) return true;                          // every lane left the support (hmc.rs:384-398)
@@ -139,7 +142,7 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
                 for (int k = 0; k < d; ++k) {
                     const int sk = P.f64_slot[k];
                     const double mi = m_inv ? m_inv[(long long)k * C] : 1.0;
-                    slots[sk * FG_WAVE] += eps * mi * pl[k * FG_WAVE];
+                    slots[sk * tw] += eps * mi * pl[k * tw];
                 }
             }
             ++s;
@@ -148,10 +151,10 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
     return bad || !fg_finite(lj_end);
 }
 
-__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, const double *m_inv, long long C) {
+__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, int tw, const double *m_inv, long long C) {
     double s = 0.0;
     for (int i = 0; i < P.d; ++i) {
-        const double p = pl[i * FG_WAVE];
+        const double p = pl[i * tw];
         const double mi = m_inv ? m_inv[(long long)i * C] : 1.0;
         s += p * p * mi;
     }
@@ -159,13 +162,13 @@ __device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double
 }
 
 // p0 ~ N(0, M): hmc.rs:436-441.  Box-Muller pairs from the chain's (iteration) stream.
-__device__ __forceinline__ void fg_draw_momentum(const FgProgramDev &P, FgStream &rng, double *pl, const double *mass_sqrt,
+__device__ __forceinline__ void fg_draw_momentum(const FgProgramDev &P, FgStream &rng, double *pl, int tw, const double *mass_sqrt,
                                                  long long C) {
     for (int i = 0; i < P.d; i += 2) {
         double z0, z1;
         fg_rng_normal_pair(rng, z0, z1);
-        pl[i * FG_WAVE] = z0 * (mass_sqrt ? mass_sqrt[(long long)i * C] : 1.0);
-        if (i + 1 < P.d) pl[(i + 1) * FG_WAVE] = z1 * (mass_sqrt ? mass_sqrt[(long long)(i + 1) * C] : 1.0);
+        pl[i * tw] = z0 * (mass_sqrt ? mass_sqrt[(long long)i * C] : 1.0);
+        if (i + 1 < P.d) pl[(i + 1) * tw] = z1 * (mass_sqrt ? mass_sqrt[(long long)(i + 1) * C] : 1.0);
     }
 }
 
@@ -175,18 +178,18 @@ struct FgTransOut { bool accepted, divergent; double alpha, lj; };
 // pl = p0.  On exit: slots hold the NEXT state (accepted endpoint or the restored current
 // state) and X.values is up to date.
 __device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, const FgChainCtx &X, const FgHmcDev &H, long long c,
-                                                        bool live, double *slots, double *pl, double lj_cur, double eps,
+                                                        bool live, double *slots, double *pl, int tw, double lj_cur, double eps,
                                                         double u) {
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
-    const double h0 = -lj_cur + fg_kinetic(P, pl, mi, X.C);      // hmc.rs:442-443
+    const double h0 = -lj_cur + fg_kinetic(P, pl, tw, mi, X.C);      // hmc.rs:442-443
     double lj_new;
-    const bool div = fg_trajectory(P, slots, pl, eps, H.L, H.h, H.grad_mode == FG_GRAD_FD_SPARSE, mi, X.C, lj_new);
+    const bool div = fg_trajectory(P, slots, pl, tw, eps, H.L, H.h, H.grad_mode == FG_GRAD_FD_SPARSE, mi, X.C, lj_new);
     FgTransOut o;
     o.divergent = div;
     double ap = 0.0;
     bool acc = false;
     if (!div) {
-        const double h_new = -lj_new + fg_kinetic(P, pl, mi, X.C);
+        const double h_new = -lj_new + fg_kinetic(P, pl, tw, mi, X.C);
         ap = fmin(exp(h0 - h_new), 1.0);                          // hmc.rs:460
         acc = u < ap;                                             // hmc.rs:461
     }
@@ -194,24 +197,25 @@ __device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, c
     for (int i = 0; i < P.d; ++i) {                               // commit or roll back the f64 sites
         const int slot = P.f64_slot[i];
         const long long g = (long long)slot * X.C + c;
-        if (acc) { if (live) X.values[g] = fg_as_i64(slots[slot * FG_WAVE]); }
-        else slots[slot * FG_WAVE] = fg_as_double(X.values[g]);
+        if (acc) { if (live) X.values[g] = fg_as_i64(slots[slot * tw]); }
+        else slots[slot * tw] = fg_as_double(X.values[g]);
     }
     return o;
 }
 
 // HmcSession::step x n_steps (hmc.rs:819-919), d > 0, without the mass-matrix reset (the
 // host splits launches at that iteration).
-__global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps,
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps,
                                                        int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                        double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
-    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
-    double *pl = lds + (long long)P.n_slots * FG_WAVE + threadIdx.x;
-    fg_load_values(P, X, c, slots);
+    double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
+    fg_load_values(P, X, c, slots, tw);
     double lj = H.lj[c], eps = H.eps[c], frozen = H.frozen[c];
     double da_mu = H.da_mu[c], da_leb = H.da_leb[c], da_hbar = H.da_hbar[c];
     unsigned long long da_m = H.da_m[c];
@@ -230,9 +234,9 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCt
             frozen = e;
         }
         FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_HMC);
-        fg_draw_momentum(P, rng, pl, ms, X.C);
+        fg_draw_momentum(P, rng, pl, tw, ms, X.C);
         const double u = fg_rng_u01(rng);
-        const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, lj, e, u);
+        const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, tw, lj, e, u);
         lj = o.lj;
         asum += o.alpha; ndiv += o.divergent ? 1ull : 0ull;
         if (live && info) {                                // HmcStepInfo: hmc.rs:587-602
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCt
         }
         if (live && pos_all) {
             double *row = pos_all + (long long)t * P.d * X.C + c;
-            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * FG_WAVE];
+            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * tw];
         }
         if (warming) {                                     // DualAveraging::update: hmc.rs:168-178
             da_m += 1ull;
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCt
                 const double n = (double)wn;
                 for (int i = 0; i < P.d; ++i) {
                     const long long g = (long long)i * X.C + c;
-                    const double x = slots[P.f64_slot[i] * FG_WAVE];
+                    const double x = slots[P.f64_slot[i] * tw];
                     double mean = H.w_mean[g];
                     const double delta = x - mean;
                     mean += delta / n;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCt
             }
         } else if (draws && live) {                        // hmc_chain pushes the current state: hmc.rs:577-582
             double *row = draws + (long long)(t - first_sample_t) * P.d * X.C + c;
-            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * FG_WAVE];
+            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * tw];
         }
     }
     if (live) {
@@ -280,18 +284,19 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_steps(FgProgramDev P, FgChainCt
 }
 
 // hmc_transition with injected momentum / uniform (test hook)
-__global__ __launch_bounds__(FG_WAVE) void k_hmc_transition_injected(FgProgramDev P, FgChainCtx X, FgHmcDev H, double eps,
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_injected(FgProgramDev P, FgChainCtx X, FgHmcDev H, double eps,
                                                                      const double *p0, const double *u_in, int *acc_out,
                                                                      double *alpha_out, int *div_out) {
     extern __shared__ double lds[];
-    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
-    double *pl = lds + (long long)P.n_slots * FG_WAVE + threadIdx.x;
-    fg_load_values(P, X, c, slots);
-    for (int i = 0; i < P.d; ++i) pl[i * FG_WAVE] = p0[(long long)i * X.C + c];
-    const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, H.lj[c], eps, u_in[c]);
+    double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
+    fg_load_values(P, X, c, slots, tw);
+    for (int i = 0; i < P.d; ++i) pl[i * tw] = p0[(long long)i * X.C + c];
+    const FgTransOut o = fg_hmc_transition(P, X, H, c, live, slots, pl, tw, H.lj[c], eps, u_in[c]);
     if (live) {
         H.lj[c] = o.lj;
         if (acc_out) acc_out[c] = o.accepted;
@@ -301,27 +306,28 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_transition_injected(FgProgramDe
 }
 
 // grad_log_joint (hmc.rs:304-329) at the current values (test hook)
-__global__ __launch_bounds__(FG_WAVE) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse, double *grad, int *ok) {
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse, double *grad, int *ok) {
     extern __shared__ double lds[];
-    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
-    fg_load_values(P, X, c, slots);
+    fg_load_values(P, X, c, slots, tw);
     bool good = true;
     double orig = 0.0, lp_plus = 0.0;
     int slot = 0;
     for (int e = 0; e < 2 * P.d; ++e) {
         const int i = e >> 1;
         const bool minus = (e & 1) != 0;
-        if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * FG_WAVE]; slots[slot * FG_WAVE] = orig + h; }
-        else slots[slot * FG_WAVE] = orig - h;
+        if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * tw]; slots[slot * tw] = orig + h; }
+        else slots[slot * tw] = orig - h;
         const FgIns *prog = P.ins; int n = P.n_ins;
         if (sparse) { const int o0 = P.sub_off[i]; prog = P.sub + o0; n = P.sub_off[i + 1] - o0; }
         FgAcc3 A = {0.0, 0.0, 0.0};
-        fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, A, nullptr, nullptr, 0, false);
+        fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         if (!minus) { lp_plus = fg_total(A); continue; }
-        slots[slot * FG_WAVE] = orig;
+        slots[slot * tw] = orig;
         const double g = (lp_plus - fg_total(A)) / (2.0 * h);
         good = good && fg_finite(g);
         if (live) grad[(long long)i * X.C + c] = g;
@@ -331,30 +337,31 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_grad(FgProgramDev P, FgChainCtx
 
 // find_reasonable_epsilon (hmc.rs:479-535).  Momentum comes from p0_scratch [d][C] when
 // `injected`, else from the chain's (instance) EPS stream and is written there.
-__global__ __launch_bounds__(FG_WAVE) void k_hmc_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, uint32_t instance, int injected,
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, uint32_t instance, int injected,
                                                           double *eps_out) {
     extern __shared__ double lds[];
-    const long long chain = (long long)blockIdx.x * FG_WAVE + threadIdx.x;
+    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
-    double *pl = lds + (long long)P.n_slots * FG_WAVE + threadIdx.x;
+    double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
     const bool sparse = H.grad_mode == FG_GRAD_FD_SPARSE;
-    fg_load_values(P, X, c, slots);
+    fg_load_values(P, X, c, slots, tw);
     if (!injected) {
         FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, instance, FG_RNG_EPS);
-        fg_draw_momentum(P, rng, pl, ms, X.C);
-        if (live) for (int i = 0; i < P.d; ++i) H.p0_scratch[(long long)i * X.C + c] = pl[i * FG_WAVE];
+        fg_draw_momentum(P, rng, pl, tw, ms, X.C);
+        if (live) for (int i = 0; i < P.d; ++i) H.p0_scratch[(long long)i * X.C + c] = pl[i * tw];
     } else {
-        for (int i = 0; i < P.d; ++i) pl[i * FG_WAVE] = H.p0_scratch[(long long)i * X.C + c];
+        for (int i = 0; i < P.d; ++i) pl[i * tw] = H.p0_scratch[(long long)i * X.C + c];
     }
     // keep p0 in registers-free storage: re-read it from LDS-resident copy is impossible once
     // the trajectory overwrites pl, so dead lanes (which did not write p0_scratch) re-derive
     // it the same way live lanes re-read it -- from the column of the chain they mirror.
     const double lj_q = H.lj[c];
-    const double h0 = -lj_q + fg_kinetic(P, pl, mi, X.C);
+    const double h0 = -lj_q + fg_kinetic(P, pl, tw, mi, X.C);
     const double ln_half = log(0.5), ln2 = log(2.0);
     double eps = 1.0, lr = 0.0, a = 1.0;
     bool active = true;     // lanes still inside the doubling/halving loop
@@ -364,14 +371,14 @@ __global__ __launch_bounds__(FG_WAVE) void k_hmc_find_eps(FgProgramDev P, FgChai
         // log_ratio_at(eps_try): one leapfrog step from (q, p0)      hmc.rs:500-511
         const double eps_try = first ? 1.0 : eps * ((a > 0.0) ? 2.0 : 0.5);   // eps * 2^a
         double lj1;
-        const bool div = fg_trajectory(P, slots, pl, eps_try, 1, H.h, sparse, mi, X.C, lj1);
+        const bool div = fg_trajectory(P, slots, pl, tw, eps_try, 1, H.h, sparse, mi, X.C, lj1);
         double lr_try = FG_NEG_INF;
-        if (!div) lr_try = h0 - (-lj1 + fg_kinetic(P, pl, mi, X.C));
+        if (!div) lr_try = h0 - (-lj1 + fg_kinetic(P, pl, tw, mi, X.C));
         // restore (q, p0) for the next trial
         for (int i = 0; i < P.d; ++i) {
             const int slot = P.f64_slot[i];
-            slots[slot * FG_WAVE] = fg_as_double(X.values[(long long)slot * X.C + c]);
-            pl[i * FG_WAVE] = H.p0_scratch[(long long)i * X.C + c];
+            slots[slot * tw] = fg_as_double(X.values[(long long)slot * X.C + c]);
+            pl[i * tw] = H.p0_scratch[(long long)i * X.C + c];
         }
         if (first) {
             lr = lr_try;
@@ -442,11 +449,23 @@ struct fg_engine {
     double *d_tmp = nullptr;     // [C] scratch
     int *d_itmp = nullptr;       // [3][C] scratch
     size_t lds_bytes = 0;
+    int tw = 64;               // tile width (threads per block)
 };
 
 namespace {
 
-int blocks_for(long long C) { return (int)((C + FG_WAVE - 1) / FG_WAVE); }
+// Tile width = lanes per wave that own a chain (= threads per block).  Measured on MI355X
+// (profiles/round1_occupancy_sweep.txt): spreading 65 536 chains over narrower waves to get
+// 2-4 waves per SIMD does NOT help -- the interpreter is bound by scalar/branch instruction
+// ISSUE (one scalar unit per SIMD slot), not by latency, so co-resident waves do not overlap
+// and narrower waves only waste lanes.  Full 64-lane tiles are the default; FG_TILE_WIDTH
+// overrides it for experiments.
+int tile_width_for(long long C) {
+    (void)C;
+    const char *env = getenv("FG_TILE_WIDTH");
+    if (env) { int v = atoi(env); if (v == 16 || v == 32 || v == 64) return v; }
+    return 64;
+}
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
@@ -494,7 +513,9 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     fg_engine *e = new fg_engine();
     e->prog = p; e->device = device; e->C = n_chains; e->seed = seed; e->chain0 = chain_offset;
     e->S = (int)p->sorted_stmt.size(); e->d = (int)p->f64_slot.size(); e->n_slots = p->n_slots;
-    e->lds_bytes = (size_t)(e->n_slots + e->d + 1) * FG_WAVE * sizeof(double);
+    e->tw = tile_width_for(e->C);
+    e->lds_bytes = (size_t)(e->n_slots + e->d + 1) * e->tw * sizeof(double);
+    while (e->lds_bytes > 160 * 1024 && e->tw > 16) { e->tw >>= 1; e->lds_bytes >>= 1; }
     if (e->lds_bytes > 160 * 1024) {
         fg_set_error("model needs more than 160 KB of LDS per wave (sites + temporaries + momentum > 319 cells)");
         delete e; return nullptr; }
@@ -584,7 +605,7 @@ int fg_device_upload(fg_engine *e, void *d, const void *h, size_t bytes) {
 }
 
 static int launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
-    hipLaunchKernelGGL(k_prior_init, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, iteration,
+    hipLaunchKernelGGL(k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, iteration,
                        purpose, d_acc, d_lj);
     HIPCHK(hipGetLastError());
     return FG_OK;
@@ -602,7 +623,7 @@ int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc) {
 int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp) {
     NEED_ENGINE(e);
     if (h_logp && !e->d_logp) { int rc = dev_alloc(&e->d_logp, (size_t)std::max(1, e->S) * e->C); if (rc) return rc; }
-    hipLaunchKernelGGL(k_log_joint, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->d_acc,
+    hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->d_acc,
                        h_logp ? e->d_logp : nullptr, (double *)nullptr);
     HIPCHK(hipGetLastError());
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
@@ -635,7 +656,7 @@ static void hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg) {
 }
 
 static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
-    hipLaunchKernelGGL(k_hmc_find_eps, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H, instance,
+    hipLaunchKernelGGL(k_hmc_find_eps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, instance,
                        injected, d_eps_out);
     HIPCHK(hipGetLastError());
     return FG_OK;
@@ -678,7 +699,7 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
 
 static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t,
                             double *pos_all = nullptr, double *info = nullptr) {
-    hipLaunchKernelGGL(k_hmc_steps, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
+    hipLaunchKernelGGL(k_hmc_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
                        e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     HIPCHK(hipGetLastError());
     return FG_OK;
@@ -811,7 +832,7 @@ int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *
     double *d_g = nullptr;
     int rc = dev_alloc(&d_g, (size_t)std::max(1, e->d) * e->C);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hmc_grad, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, h,
+    hipLaunchKernelGGL(k_hmc_grad, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, h,
                        grad_mode == FG_GRAD_FD_SPARSE ? 1 : 0, d_g, e->d_itmp);
     hipError_t le = hipGetLastError();
     if (le == hipSuccess) le = hipMemcpyAsync(h_grad, d_g, (size_t)e->d * e->C * 8, hipMemcpyDeviceToHost, e->stream);
@@ -828,7 +849,7 @@ static int hmc_prepare_injected(fg_engine *e, const fg_hmc_config *cfg) {
     if (rc) return rc;
     if (!e->hmc_ready) {      // standalone use: lj of the current values, identity mass
         e->H.use_mass = 0;
-        hipLaunchKernelGGL(k_log_joint, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, (double *)nullptr,
+        hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, (double *)nullptr,
                            (double *)nullptr, e->H.lj);
         HIPCHK(hipGetLastError());
     }
@@ -847,7 +868,7 @@ int fg_hmc_transition_injected(fg_engine *e, const fg_hmc_config *cfg, double ep
     HIPCHK(hipMemcpyAsync(e->d_tmp, h_u, C * 8, hipMemcpyHostToDevice, e->stream));
     int *ia = e->d_itmp, *idv = e->d_itmp + C;
     double *al = e->d_acc;
-    hipLaunchKernelGGL(k_hmc_transition_injected, dim3(blocks_for(e->C)), dim3(FG_WAVE), e->lds_bytes, e->stream, e->P, e->X, e->H,
+    hipLaunchKernelGGL(k_hmc_transition_injected, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H,
                        eps, (const double *)e->H.p0_scratch, (const double *)e->d_tmp, ia, al, idv);
     HIPCHK(hipGetLastError());
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, ia, C * 4, hipMemcpyDeviceToHost, e->stream));

@@ -20,7 +20,10 @@
 #include <hip/hip_runtime.h>
 #include "fg_math.h"
 
-#define FG_WAVE 64
+#define FG_WAVE 64          /* hardware wavefront width */
+#ifndef FG_MIN_WAVES
+#define FG_MIN_WAVES 2       /* __launch_bounds__ 2nd arg: waves per SIMD the register budget must allow */
+#endif
 #define FG_AS4 __attribute__((address_space(4)))
 typedef uint32_t fg_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t fg_u32x8 __attribute__((ext_vector_type(8)));
@@ -48,11 +51,11 @@ __device__ __forceinline__ double fg_ins_h(const FgInsRegs &r, int k) {
     return k == 0 ? fg_dbl(r.a[14], r.a[15]) : fg_dbl(r.b[2 * k - 2], r.b[2 * k - 1]);
 }
 
-__device__ __forceinline__ double fg_operand(uint32_t w, double imm, const double *slots, const double *pool) {
+__device__ __forceinline__ double fg_operand(uint32_t w, double imm, const double *slots, const double *pool, int tw) {
     const uint32_t kind = FG_OPND_KIND(w), idx = FG_OPND_IDX(w);
     if (kind == FG_OPND_IMM) return imm;
-    if (kind == FG_OPND_SLOT_F) return slots[idx * FG_WAVE];
-    if (kind == FG_OPND_SLOT_I) return (double)fg_as_i64(slots[idx * FG_WAVE]);
+    if (kind == FG_OPND_SLOT_F) return slots[idx * tw];
+    if (kind == FG_OPND_SLOT_I) return (double)fg_as_i64(slots[idx * tw]);
     return pool[idx];
 }
 
@@ -63,11 +66,12 @@ __device__ __forceinline__ long long fg_int_of(double v, uint32_t vtype) {
     return fg_finite(v) ? (long long)v : 0;
 }
 
-// Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane].
+// Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane]; `tw` = tile width
+// (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have one readable instruction past `n` (the host pads the arrays).
 // logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
 template <int MODE, bool WITH_LOGP>
-__device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, FgAcc3 &A,
+__device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, int tw, FgAcc3 &A,
                                         FgStream *rng, double *logp_out, long long logp_stride, bool live) {
     double acc = 0.0;
     FgInsRegs I = fg_fetch_ins(prog, 0);
@@ -94,32 +98,32 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                     const double u = fg_rng_u01(*rng);
                     double cum = 0.0; int idx = K;
                     for (int i = 0; i < K; ++i) {
-                        const double pi = in_pool ? pool[base + i] : slots[(base + i) * FG_WAVE];
+                        const double pi = in_pool ? pool[base + i] : slots[(base + i) * tw];
                         cum += pi;
                         if (idx == K && !(cum < u)) idx = i;
                     }
                     xi = idx < K - 1 ? idx : K - 1;
-                    slots[aux * FG_WAVE] = fg_as_double(xi);
+                    slots[aux * tw] = fg_as_double(xi);
                 } else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) {
-                    xi = fg_as_i64(slots[FG_OPND_IDX(xw) * FG_WAVE]);
+                    xi = fg_as_i64(slots[FG_OPND_IDX(xw) * tw]);
                 } else {
-                    xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool), vtype);
+                    xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw), vtype);
                 }
                 if ((op & FG_F_INVALID) != 0u || xi < 0 || xi >= (long long)K) lp = FG_NEG_INF;
                 else if (in_pool) lp = pool[base + K + (int)xi];          // precomputed ln p (or -inf)
-                else { const double p = slots[(base + (int)xi) * FG_WAVE]; lp = p > 0.0 ? log(p) : FG_NEG_INF; }
+                else { const double p = slots[(base + (int)xi) * tw]; lp = p > 0.0 ? log(p) : FG_NEG_INF; }
             } else {
-                const double p0 = fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool);
-                const double p1 = fg_operand(FG_I_OPND(I, 2), FG_I_IMM(I, 2), slots, pool);
-                const double p2 = fg_operand(FG_I_OPND(I, 3), FG_I_IMM(I, 3), slots, pool);
+                const double p0 = fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw);
+                const double p1 = fg_operand(FG_I_OPND(I, 2), FG_I_IMM(I, 2), slots, pool, tw);
+                const double p2 = fg_operand(FG_I_OPND(I, 3), FG_I_IMM(I, 3), slots, pool, tw);
                 if (MODE == FG_MODE_PRIOR && !observe) {
                     const long long cell = fg_sample_dist(code, hoisted, p0, p1, p2, *rng);
-                    slots[aux * FG_WAVE] = fg_as_double(cell);
+                    slots[aux * tw] = fg_as_double(cell);
                 }
                 double xf = 0.0; long long xi = 0;
-                if (vtype == 0u) xf = fg_operand(xw, FG_I_IMM(I, 0), slots, pool);
-                else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xi = fg_as_i64(slots[FG_OPND_IDX(xw) * FG_WAVE]);
-                else xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool), vtype);
+                if (vtype == 0u) xf = fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw);
+                else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xi = fg_as_i64(slots[FG_OPND_IDX(xw) * tw]);
+                else xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw), vtype);
                 if ((op & FG_F_INVALID) != 0u) lp = FG_NEG_INF;
                 else if (code == 12u && hoisted) {
                     // Normal with constant parameters -- the hot case (distribution.rs:189-208):
@@ -140,7 +144,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)aux * logp_stride] = lp; }
             }
         } else {
-            const double x0 = fg_operand(FG_I_OPND(I, 0), FG_I_IMM(I, 0), slots, pool);
+            const double x0 = fg_operand(FG_I_OPND(I, 0), FG_I_IMM(I, 0), slots, pool, tw);
             switch (code) {
             case FG_OP_FACTOR: A.fac += x0; break;       // Handler::on_factor
             case FG_OP_LOAD: acc = x0; break;
@@ -163,14 +167,14 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             case FG_OP_RPOW: acc = pow(x0, acc); break;
             case FG_OP_MIN: acc = fmin(acc, x0); break;
             case FG_OP_MAX: acc = fmax(acc, x0); break;
-            case FG_OP_CLAMP: acc = fg_clamp(acc, x0, fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool)); break;
-            case FG_OP_MAC: { const double t = x0 * fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool);
+            case FG_OP_CLAMP: acc = fg_clamp(acc, x0, fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw)); break;
+            case FG_OP_MAC: { const double t = x0 * fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw);
                               acc = acc + t; break; }
-            case FG_OP_STORE: slots[FG_I_AUX(I) * FG_WAVE] = acc; break;
+            case FG_OP_STORE: slots[FG_I_AUX(I) * tw] = acc; break;
             case FG_OP_GATHER: { const int k = (int)FG_I_OPND(I, 1);
                                  const bool ok = (acc >= 0.0) && (acc < (double)k) && (acc == floor(acc));
                                  const int j = ok ? (int)acc : 0;
-                                 const double v = slots[(FG_I_AUX(I) + j) * FG_WAVE];
+                                 const double v = slots[(FG_I_AUX(I) + j) * tw];
                                  acc = ok ? v : NAN; break; }
             case FG_OP_CONSTLIK: A.lik += FG_I_IMM(I, 0); break;
             default: break;
