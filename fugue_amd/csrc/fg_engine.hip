@@ -420,6 +420,90 @@ __global__ void k_fill(double *p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
+
+// ======================================================================================
+// single-site adaptive Metropolis-Hastings (src/inference/mh.rs:698-744, 938-1014)
+// ======================================================================================
+// Per-chain state in HBM:  lw [C] = log-weight of the current trace;  per (site, chain):
+// scale, log_scale [S][C] f64, acc, tot [S][C] u32 (DiminishingAdaptation, mcmc_utils.rs:30-42),
+// kind [S][C] i32 (the f64 proposal kind cache, mh.rs:330,947).
+struct FgMhDev {
+    double *lw, *scale, *log_scale;
+    uint32_t *acc, *tot;
+    int *kind;
+    const int *ov_kind; const double *ov_lo, *ov_hi;    // [S] overrides or null
+    unsigned long long *n_acc;                           // [C] accepted proposals
+    const int *rec;                                      // [n_rec] recorded sites
+    int n_rec;
+};
+
+// adaptive_mcmc_chain's step loop: n_steps x single_site_mh_step (mh.rs:698-744), exactly one
+// model run per step (mh.rs:1186-1202).  Recorded draws: [t][r][C] cells of the CURRENT state
+// after each sampling-phase step (mh.rs:1010).
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, int iter0, int n_steps,
+                                                                    int n_warmup, long long *draws, int first_sample_t) {
+    extern __shared__ double lds[];
+    const int tw = (int)blockDim.x;
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    fg_load_values(P, X, c, slots, tw);
+    double lw = M.lw[c];
+    unsigned long long nacc = 0;
+    for (int t = 0; t < n_steps; ++t) {
+        const int iter = iter0 + t;
+        const bool adapt = iter < n_warmup;
+        FgMhCtx mh;
+        FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_MH);
+        unsigned long long ra, rb;
+        fg_rng_block(rng, ra, rb);
+        const int target = (int)fg_pick(ra, (uint32_t)P.S);               // sites[rng.gen_range(0..len)]  mh.rs:716
+        const long long g = (long long)target * X.C + c;
+        mh.target = target;
+        mh.scale = M.scale[g];                                             // get_scale  mcmc_utils.rs:70-77
+        mh.kind = M.kind[g];
+        const int kind0 = mh.kind;
+        mh.rng = rng;                                                      // at block 1
+        fg_rng_block(rng, ra, rb);
+        mh.z = fg_gaussian_z_of(ra, rb);
+        mh.next_block = 2;
+        mh.lqf = 0.0; mh.lqr = 0.0;
+        mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
+        mh.old_cell = slots[target * tw];
+        FgAcc3 A = {0.0, 0.0, 0.0};
+        fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
+        const double prop_lw = fg_total(A);
+        const double log_alpha = prop_lw - lw + (mh.lqr - mh.lqf);         // + dim_term == 0 (fixed structure)  mh.rs:731-732
+        FgStream ru = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_MH);
+        ru.c1 = (uint32_t)mh.next_block;
+        const double u = fg_rng_u01(ru);                                   // only consulted when log_alpha < 0
+        const bool accept = (log_alpha >= 0.0) || (u < exp(log_alpha));    // mh.rs:733
+        if (adapt) {                                                       // DiminishingAdaptation::update  mcmc_utils.rs:88-150
+            const uint32_t tot = M.tot[g] + 1u;
+            const uint32_t acn = M.acc[g] + (accept ? 1u : 0u);
+            double sc = mh.scale, ls = M.log_scale[g];
+            if (tot >= 10u) {
+                const double rate = (double)acn / (double)tot;
+                const double step = 1.0 / pow((double)tot, 0.7);
+                ls += step * (rate - 0.44);
+                const double ns = exp(ls);
+                sc = (fg_finite(ns) && ns > 0.0) ? fmin(fmax(ns, 0.001), 100.0) : 1.0;
+                ls = (sc == 1.0) ? 0.0 : log(sc);
+            }
+            if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
+        }
+        if (live && mh.kind != kind0) M.kind[g] = mh.kind;
+        if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[target * tw]); }
+        else slots[target * tw] = mh.old_cell;
+        if (!adapt && draws && live) {
+            long long *row = draws + (long long)(t - first_sample_t) * M.n_rec * X.C + c;
+            for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
+        }
+    }
+    if (live) { M.lw[c] = lw; M.n_acc[c] += nacc; }
+}
+
 // ======================================================================================
 // engine
 // ======================================================================================
@@ -446,6 +530,12 @@ struct fg_engine {
     FgHmcDev H{};
     std::vector<void *> hmc_allocs;
     int n_warmup = 0, iter = 0, mass_adapt_at = -1;
+    // MH
+    bool mh_ready = false;
+    FgMhDev M{};
+    std::vector<void *> mh_allocs;
+    int mh_warmup = 0, mh_iter = 0;
+    int *d_rec = nullptr; int rec_cap = 0;
     double *d_tmp = nullptr;     // [C] scratch
     int *d_itmp = nullptr;       // [3][C] scratch
     size_t lds_bytes = 0;
@@ -537,7 +627,8 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
         set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
-        set_lds(k_hmc_grad, e->lds_bytes) || set_lds(k_hmc_find_eps, e->lds_bytes))
+        set_lds(k_hmc_grad, e->lds_bytes) || set_lds(k_hmc_find_eps, e->lds_bytes) ||
+        set_lds(k_mh_steps, e->lds_bytes))
         return fail("hipFuncSetAttribute");
     return e;
 }
@@ -547,6 +638,8 @@ void fg_engine_free(fg_engine *e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (void *q : e->hmc_allocs) hipFree(q);
+    for (void *q : e->mh_allocs) hipFree(q);
+    if (e->d_rec) hipFree(e->d_rec);
     void *ptrs[] = { e->d_ins, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
@@ -890,6 +983,108 @@ int fg_hmc_find_eps_injected(fg_engine *e, const fg_hmc_config *cfg, const doubl
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h_eps, e->d_tmp, C * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+
+
+// ------------------------------------------------------------------ MH host side
+int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
+    NEED_ENGINE(e);
+    if (n_warmup < 0) return FG_E_BAD_ARG;
+    size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S);
+    auto A = [&](auto **p, size_t n) { int rc = dev_alloc(p, n); if (!rc) e->mh_allocs.push_back((void *)*p); return rc; };
+    if (!e->M.lw) {
+        if (A(&e->M.lw, C) || A(&e->M.scale, S * C) || A(&e->M.log_scale, S * C) || A(&e->M.acc, S * C) || A(&e->M.tot, S * C) ||
+            A(&e->M.kind, S * C) || A(&e->M.n_acc, C))
+            return FG_E_HIP;
+    }
+    HIPCHK(hipMemsetAsync(e->M.log_scale, 0, S * C * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->M.acc, 0, S * C * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->M.tot, 0, S * C * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->M.kind, 0, S * C * 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->M.n_acc, 0, C * 8, e->stream));
+    const int TB = 256;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((S * C + TB - 1) / TB)), dim3(TB), 0, e->stream, e->M.scale, (long long)(S * C), 1.0);
+    e->M.ov_kind = nullptr; e->M.ov_lo = nullptr; e->M.ov_hi = nullptr;
+    if (overrides) {
+        std::vector<int> k(S); std::vector<double> lo(S), hi(S);
+        for (int j = 0; j < e->S; j++) {
+            k[j] = overrides[j].kind; lo[j] = overrides[j].lower; hi[j] = overrides[j].upper;
+            if (k[j] < 0 || k[j] > 4) { fg_set_error("fg_mh_init: unknown proposal kind"); return FG_E_BAD_ARG; }
+        }
+        int *dk = nullptr; double *dlo = nullptr, *dhi = nullptr;
+        if (dev_upload(&dk, k) || dev_upload(&dlo, lo) || dev_upload(&dhi, hi)) return FG_E_HIP;
+        e->mh_allocs.push_back(dk); e->mh_allocs.push_back(dlo); e->mh_allocs.push_back(dhi);
+        e->M.ov_kind = dk; e->M.ov_lo = dlo; e->M.ov_hi = dhi;
+    }
+    int rc = launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->M.lw);       // mh.rs:950-957
+    if (rc) return rc;
+    e->mh_warmup = n_warmup; e->mh_iter = 0; e->mh_ready = true;
+    return FG_OK;
+}
+
+int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec, void *d_draws) {
+    NEED_ENGINE(e);
+    if (!e->mh_ready) { fg_set_error("fg_mh_step before fg_mh_init"); return FG_E_STATE; }
+    if (n_steps < 0 || n_rec < 0 || (n_rec > 0 && !h_rec_sites)) return FG_E_BAD_ARG;
+    if (e->S == 0) { e->mh_iter += n_steps; return FG_OK; }             // no latent sites: nothing to move (mh.rs:713-715)
+    if (n_rec > 0) {
+        for (int r = 0; r < n_rec; r++)
+            if (h_rec_sites[r] < 0 || h_rec_sites[r] >= e->S) { fg_set_error("fg_mh_step: recorded site out of range"); return FG_ERR_ADDRESS_NOT_FOUND; }
+        if (n_rec > e->rec_cap) {
+            if (e->d_rec) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->d_rec)); }
+            HIPCHK(hipMalloc((void **)&e->d_rec, (size_t)n_rec * 4)); e->rec_cap = n_rec;
+        }
+        HIPCHK(hipMemcpyAsync(e->d_rec, h_rec_sites, (size_t)n_rec * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    e->M.rec = e->d_rec; e->M.n_rec = n_rec;
+    const int iter = e->mh_iter;
+    const int first_sample_t = std::max(iter, e->mh_warmup) - iter;
+    hipLaunchKernelGGL(k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->M,
+                       iter, n_steps, e->mh_warmup, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
+    HIPCHK(hipGetLastError());
+    e->mh_iter += n_steps;
+    return FG_OK;
+}
+
+int fg_mh_get_stats(fg_engine *e, fg_mh_stats *st) {
+    NEED_ENGINE(e);
+    if (!st || !e->mh_ready) return FG_E_BAD_ARG;
+    std::vector<unsigned long long> a((size_t)e->C);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(a.data(), e->M.n_acc, a.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long tot = 0;
+    for (auto v : a) tot += v;
+    st->n_steps = (long long)e->mh_iter * e->C;
+    st->accept_rate = st->n_steps > 0 ? (double)tot / (double)st->n_steps : 0.0;
+    return FG_OK;
+}
+
+int fg_mh_run(fg_engine *e, int n_samples, int n_warmup, const fg_site_proposal *overrides, const int32_t *h_rec_sites, int n_rec,
+              void *d_draws, fg_mh_stats *st) {
+    int rc = fg_mh_init(e, n_warmup, overrides);
+    if (rc) return rc;
+    rc = fg_mh_step(e, n_warmup, nullptr, 0, nullptr);
+    if (rc) return rc;
+    rc = fg_mh_step(e, n_samples, h_rec_sites, n_rec, d_draws);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (st) return fg_mh_get_stats(e, st);
+    return FG_OK;
+}
+
+int fg_mh_get_scales(fg_engine *e, double *h_scales) {
+    NEED_ENGINE(e);
+    if (!h_scales || !e->mh_ready) return FG_E_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(h_scales, e->M.scale, (size_t)e->S * e->C * 8, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+int fg_mh_get_log_weight(fg_engine *e, double *h_lw) {
+    NEED_ENGINE(e);
+    if (!h_lw || !e->mh_ready) return FG_E_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(h_lw, e->M.lw, (size_t)e->C * 8, hipMemcpyDeviceToHost));
     return FG_OK;
 }
 

