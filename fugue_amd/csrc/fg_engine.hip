@@ -10,37 +10,7 @@
 //   alpha_sum [C], n_div [C]               per-chain statistics
 // One block = one wave of 64 chains; the wave's working set (site values + expression
 // temporaries + momentum) is a [(n_slots + d)][64] tile of doubles in LDS.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "fg_interp.h"
-#include "fg_program.h"
-
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-    fg_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return FG_E_HIP; } } while (0)
-
-// ======================================================================================
-// kernels
-// ======================================================================================
-struct FgChainCtx {
-    long long C;          // chains in this engine
-    uint32_t chain0;      // global id of chain 0 (RNG stream key)
-    unsigned long long seed;
-    long long *values;    // [S][C]
-};
-
-__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
-    for (int j = 0; j < P.S; ++j) slots[j * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
-}
-__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
-    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[j * tw]);
-}
+#include "fg_engine_internal.h"
 
 // ---- run(PriorHandler, model) per chain: interpreters.rs:88-104 ----
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
@@ -81,15 +51,6 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint(FgProgramDe
 }
 
 // ---- HMC building blocks ---------------------------------------------------------------
-struct FgHmcDev {
-    double *lj, *eps, *frozen, *da_mu, *da_leb, *da_hbar;
-    unsigned long long *da_m;
-    double *m_inv, *mass_sqrt, *w_mean, *w_m2;     // [d][C] or null
-    unsigned long long *w_n;
-    double *alpha_sum; unsigned long long *n_div;
-    double *p0_scratch;                             // [d][C] (eps search / injected momentum)
-    int L; double h, target; int grad_mode; int use_mass;
-};
 
 // leapfrog (hmc.rs:353-407) followed by the endpoint score (score_full, hmc.rs:283-299), as
 // ONE flat loop over model evaluations so that the interpreter has a single call site:
@@ -415,10 +376,6 @@ __global__ void k_hmc_da_new(FgHmcDev H, long long C, const double *eps0) {
     const double e = eps0[c];
     H.eps[c] = e; H.da_mu[c] = log(10.0 * e); H.da_leb[c] = 0.0; H.da_hbar[c] = 0.0; H.da_m[c] = 0ull;
 }
-__global__ void k_fill(double *p, long long n, double v) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
 
 
 // ======================================================================================
@@ -427,15 +384,6 @@ __global__ void k_fill(double *p, long long n, double v) {
 // Per-chain state in HBM:  lw [C] = log-weight of the current trace;  per (site, chain):
 // scale, log_scale [S][C] f64, acc, tot [S][C] u32 (DiminishingAdaptation, mcmc_utils.rs:30-42),
 // kind [S][C] i32 (the f64 proposal kind cache, mh.rs:330,947).
-struct FgMhDev {
-    double *lw, *scale, *log_scale;
-    uint32_t *acc, *tot;
-    int *kind;
-    const int *ov_kind; const double *ov_lo, *ov_hi;    // [S] overrides or null
-    unsigned long long *n_acc;                           // [C] accepted proposals
-    const int *rec;                                      // [n_rec] recorded sites
-    int n_rec;
-};
 
 // adaptive_mcmc_chain's step loop: n_steps x single_site_mh_step (mh.rs:698-744), exactly one
 // model run per step (mh.rs:1186-1202).  Recorded draws: [t][r][C] cells of the CURRENT state
@@ -507,78 +455,6 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
 // ======================================================================================
 // engine
 // ======================================================================================
-struct fg_engine {
-    const fg_program *prog = nullptr;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = true;
-    long long C = 0;
-    unsigned long long seed = 0;
-    uint32_t chain0 = 0;
-    int S = 0, d = 0, n_slots = 0;
-    // device copies of the program
-    FgIns *d_ins = nullptr, *d_sub = nullptr;
-    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_vtype = nullptr;
-    double *d_pool = nullptr;
-    FgProgramDev P{};
-    FgChainCtx X{};
-    long long *d_values = nullptr;
-    double *d_acc = nullptr, *d_logp = nullptr;
-    // HMC
-    bool hmc_ready = false;
-    fg_hmc_config cfg{};
-    FgHmcDev H{};
-    std::vector<void *> hmc_allocs;
-    int n_warmup = 0, iter = 0, mass_adapt_at = -1;
-    // MH
-    bool mh_ready = false;
-    FgMhDev M{};
-    std::vector<void *> mh_allocs;
-    int mh_warmup = 0, mh_iter = 0;
-    int *d_rec = nullptr; int rec_cap = 0;
-    double *d_tmp = nullptr;     // [C] scratch
-    int *d_itmp = nullptr;       // [3][C] scratch
-    size_t lds_bytes = 0;
-    int tw = 64;               // tile width (threads per block)
-};
-
-namespace {
-
-// Tile width = lanes per wave that own a chain (= threads per block).  Measured on MI355X
-// (profiles/round1_occupancy_sweep.txt): spreading 65 536 chains over narrower waves to get
-// 2-4 waves per SIMD does NOT help -- the interpreter is bound by scalar/branch instruction
-// ISSUE (one scalar unit per SIMD slot), not by latency, so co-resident waves do not overlap
-// and narrower waves only waste lanes.  Full 64-lane tiles are the default; FG_TILE_WIDTH
-// overrides it for experiments.
-int tile_width_for(long long C) {
-    (void)C;
-    const char *env = getenv("FG_TILE_WIDTH");
-    if (env) { int v = atoi(env); if (v == 16 || v == 32 || v == 64) return v; }
-    return 64;
-}
-
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return FG_OK;
-}
-
-template <typename T>
-int dev_alloc(T **p, size_t n) {
-    HIPCHK(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
-    HIPCHK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
-    return FG_OK;
-}
-template <typename T>
-int dev_upload(T **p, const std::vector<T> &v) {
-    int rc = dev_alloc(p, v.size());
-    if (rc) return rc;
-    if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return FG_OK;
-}
-
-}  // namespace
-
 extern "C" {
 
 void fg_hmc_config_default(fg_hmc_config *c) {     // HMCConfig::default, hmc.rs:125-135
@@ -647,8 +523,6 @@ void fg_engine_free(fg_engine *e) {
     delete e;
 }
 
-#define NEED_ENGINE(e) do { if (!(e)) { fg_set_error("null engine"); return FG_E_BAD_ARG; } \
-    if (hipSetDevice((e)->device) != hipSuccess) { fg_set_error("hipSetDevice failed"); return FG_E_HIP; } } while (0)
 
 int fg_engine_synchronize(fg_engine *e) { NEED_ENGINE(e); HIPCHK(hipStreamSynchronize(e->stream)); return FG_OK; }
 void *fg_engine_stream(fg_engine *e) { return e ? (void *)e->stream : nullptr; }
@@ -697,7 +571,7 @@ int fg_device_upload(fg_engine *e, void *d, const void *h, size_t bytes) {
     return FG_OK;
 }
 
-static int launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
+int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
     hipLaunchKernelGGL(k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, iteration,
                        purpose, d_acc, d_lj);
     HIPCHK(hipGetLastError());
@@ -706,7 +580,7 @@ static int launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, doub
 
 int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc) {
     NEED_ENGINE(e);
-    int rc = launch_prior(e, iteration, FG_RNG_PRIOR, e->d_acc, nullptr);
+    int rc = fg_launch_prior(e, iteration, FG_RNG_PRIOR, e->d_acc, nullptr);
     if (rc) return rc;
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -779,7 +653,7 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
         HIPCHK(hipMemsetAsync(e->H.w_m2, 0, dC * 8, e->stream));
         HIPCHK(hipMemsetAsync(e->H.w_n, 0, C * 8, e->stream));
     }
-    rc = launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->H.lj);             // hmc.rs:673-687
+    rc = fg_launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->H.lj);             // hmc.rs:673-687
     if (rc) return rc;
     if (e->d == 0) hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->d_tmp, (long long)C, 1.0);
     else if (!std::isnan(cfg->init_step_size)) hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->d_tmp, (long long)C, cfg->init_step_size);
@@ -808,7 +682,7 @@ static int hmc_step_impl(fg_engine *e, int n_transitions, double *d_draws, doubl
         const int iter = e->iter;
         if (e->d == 0) {                                   // fresh prior draw per step: hmc.rs:826-845
             if (d_pos_all || d_info) { fg_set_error("fg_hmc_step_info: model has no continuous sites"); return FG_E_UNSUPPORTED; }
-            int rc = launch_prior(e, (uint32_t)(iter + 1), FG_RNG_PRIOR, nullptr, e->H.lj);
+            int rc = fg_launch_prior(e, (uint32_t)(iter + 1), FG_RNG_PRIOR, nullptr, e->H.lj);
             if (rc) return rc;
             e->iter += 1; done += 1;
             continue;
@@ -1017,7 +891,7 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
         e->mh_allocs.push_back(dk); e->mh_allocs.push_back(dlo); e->mh_allocs.push_back(dhi);
         e->M.ov_kind = dk; e->M.ov_lo = dlo; e->M.ov_hi = dhi;
     }
-    int rc = launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->M.lw);       // mh.rs:950-957
+    int rc = fg_launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->M.lw);       // mh.rs:950-957
     if (rc) return rc;
     e->mh_warmup = n_warmup; e->mh_iter = 0; e->mh_ready = true;
     return FG_OK;

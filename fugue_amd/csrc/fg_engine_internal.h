@@ -1,0 +1,139 @@
+// fg_engine_internal.h -- definitions shared by the engine translation units
+// (fg_engine.hip: prior/score/HMC/MH; fg_smc.hip: SMC + reductions; fg_diag.hip: diagnostics).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fg_interp.h"
+#include "fg_program.h"
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    fg_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return FG_E_HIP; } } while (0)
+
+// ======================================================================================
+// kernels
+// ======================================================================================
+struct FgChainCtx {
+    long long C;          // chains in this engine
+    uint32_t chain0;      // global id of chain 0 (RNG stream key)
+    unsigned long long seed;
+    long long *values;    // [S][C]
+};
+
+__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
+    for (int j = 0; j < P.S; ++j) slots[j * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+}
+__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
+    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[j * tw]);
+}
+
+
+static __global__ void k_fill(double *p, long long n, double v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct FgHmcDev {
+    double *lj, *eps, *frozen, *da_mu, *da_leb, *da_hbar;
+    unsigned long long *da_m;
+    double *m_inv, *mass_sqrt, *w_mean, *w_m2;     // [d][C] or null
+    unsigned long long *w_n;
+    double *alpha_sum; unsigned long long *n_div;
+    double *p0_scratch;                             // [d][C] (eps search / injected momentum)
+    int L; double h, target; int grad_mode; int use_mass;
+};
+
+struct FgMhDev {
+    double *lw, *scale, *log_scale;
+    uint32_t *acc, *tot;
+    int *kind;
+    const int *ov_kind; const double *ov_lo, *ov_hi;    // [S] overrides or null
+    unsigned long long *n_acc;                           // [C] accepted proposals
+    const int *rec;                                      // [n_rec] recorded sites
+    int n_rec;
+};
+
+struct fg_engine {
+    const fg_program *prog = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    long long C = 0;
+    unsigned long long seed = 0;
+    uint32_t chain0 = 0;
+    int S = 0, d = 0, n_slots = 0;
+    // device copies of the program
+    FgIns *d_ins = nullptr, *d_sub = nullptr;
+    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_vtype = nullptr;
+    double *d_pool = nullptr;
+    FgProgramDev P{};
+    FgChainCtx X{};
+    long long *d_values = nullptr;
+    double *d_acc = nullptr, *d_logp = nullptr;
+    // HMC
+    bool hmc_ready = false;
+    fg_hmc_config cfg{};
+    FgHmcDev H{};
+    std::vector<void *> hmc_allocs;
+    int n_warmup = 0, iter = 0, mass_adapt_at = -1;
+    // MH
+    bool mh_ready = false;
+    FgMhDev M{};
+    std::vector<void *> mh_allocs;
+    int mh_warmup = 0, mh_iter = 0;
+    int *d_rec = nullptr; int rec_cap = 0;
+    double *d_tmp = nullptr;     // [C] scratch
+    int *d_itmp = nullptr;       // [3][C] scratch
+    size_t lds_bytes = 0;
+    int tw = 64;               // tile width (threads per block)
+};
+
+namespace {
+
+// Tile width = lanes per wave that own a chain (= threads per block).  Measured on MI355X
+// (profiles/round1_occupancy_sweep.txt): spreading 65 536 chains over narrower waves to get
+// 2-4 waves per SIMD does NOT help -- the interpreter is bound by scalar/branch instruction
+// ISSUE (one scalar unit per SIMD slot), not by latency, so co-resident waves do not overlap
+// and narrower waves only waste lanes.  Full 64-lane tiles are the default; FG_TILE_WIDTH
+// overrides it for experiments.
+int tile_width_for(long long C) {
+    (void)C;
+    const char *env = getenv("FG_TILE_WIDTH");
+    if (env) { int v = atoi(env); if (v == 16 || v == 32 || v == 64) return v; }
+    return 64;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return FG_OK;
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t n) {
+    HIPCHK(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    HIPCHK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
+    return FG_OK;
+}
+template <typename T>
+int dev_upload(T **p, const std::vector<T> &v) {
+    int rc = dev_alloc(p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return FG_OK;
+}
+
+}  // namespace
+
+
+#define NEED_ENGINE(e) do { if (!(e)) { fg_set_error("null engine"); return FG_E_BAD_ARG; } \
+    if (hipSetDevice((e)->device) != hipSuccess) { fg_set_error("hipSetDevice failed"); return FG_E_HIP; } } while (0)
+
+extern "C" int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj);

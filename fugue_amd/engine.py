@@ -40,6 +40,15 @@ class fg_mh_stats(C.Structure):
     _fields_ = [("accept_rate", C.c_double), ("n_steps", C.c_int64)]
 
 
+class fg_smc_config(C.Structure):
+    _fields_ = [("resampling_method", C.c_int32), ("ess_threshold", C.c_double), ("rejuvenation_steps", C.c_int32)]
+
+
+class fg_smc_result(C.Structure):
+    _fields_ = [("log_evidence", C.c_double), ("n_steps", C.c_int32), ("n_model_runs", C.c_int64)]
+
+
+RESAMPLE_MULTINOMIAL, RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED = range(3)
 PROP_AUTO, PROP_GAUSSIAN, PROP_LOGSPACE, PROP_REFLECT, PROP_PRIOR_RESAMPLE = range(5)
 
 TOK = {"const": 0, "site": 1, "data": 2, "neg": 3, "exp": 4, "ln": 5, "sqrt": 6, "abs": 7, "floor": 8, "sin": 9,
@@ -58,7 +67,8 @@ ABI_SYMBOLS = [
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
-    "fg_mh_get_log_weight", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
+    "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_device_log_sum_exp", "fg_device_next_beta",
+    "fg_device_resample_indices", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
 ]
 
 _lib = None
@@ -128,6 +138,11 @@ def lib():
     L.fg_mh_get_stats.argtypes = [vp, C.POINTER(fg_mh_stats)]
     L.fg_mh_get_scales.argtypes = [vp, dp]
     L.fg_mh_get_log_weight.argtypes = [vp, dp]
+    L.fg_smc_config_default.argtypes = [C.POINTER(fg_smc_config)]
+    L.fg_smc_run.argtypes = [vp, C.POINTER(fg_smc_config), dp, dp, C.POINTER(fg_smc_result), dp, C.c_int]
+    L.fg_device_log_sum_exp.argtypes = [C.c_int, dp, C.c_int64, dp]
+    L.fg_device_next_beta.argtypes = [C.c_int, C.c_double, dp, dp, C.c_int64, C.c_double, dp]
+    L.fg_device_resample_indices.argtypes = [C.c_int, C.c_int, dp, C.c_int64, dp, C.POINTER(C.c_int64)]
     L.fg_device_alloc.restype = vp
     L.fg_device_alloc.argtypes = [vp, C.c_size_t]
     L.fg_device_free.argtypes = [vp, vp]
@@ -424,6 +439,16 @@ class Engine:
         _check(lib().fg_mh_get_log_weight(self.h, _dp(a)))
         return a
 
+    # ---- SMC ----------------------------------------------------------------------------
+    def smc_run(self, resampling_method=RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=0, max_betas=10000):
+        """`adaptive_smc` (/root/reference/src/inference/smc.rs:455-581) over this engine's chains as particles."""
+        cfg = fg_smc_config(int(resampling_method), float(ess_threshold), int(rejuvenation_steps))
+        res = fg_smc_result()
+        log_w, w, betas = np.zeros(self.C), np.zeros(self.C), np.zeros(max_betas)
+        _check(lib().fg_smc_run(self.h, C.byref(cfg), _dp(log_w), _dp(w), C.byref(res), _dp(betas), max_betas))
+        return dict(values=self.get_values(), log_w=log_w, weights=w, log_evidence=res.log_evidence,
+                    betas=betas[:res.n_steps], n_model_runs=res.n_model_runs)
+
     # ---- raw device buffers ---------------------------------------------------------------
     def device_alloc(self, nbytes: int) -> int:
         p = lib().fg_device_alloc(self.h, int(nbytes))
@@ -438,3 +463,27 @@ class Engine:
         out = np.zeros(shape, dtype=dtype)
         _check(lib().fg_device_download(self.h, out.ctypes.data, ptr, out.nbytes))
         return out
+
+
+# ---- population-wide device primitives (no program needed) -----------------------------------
+def device_log_sum_exp(x, device: int = 0) -> float:
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    out = C.c_double()
+    _check(lib().fg_device_log_sum_exp(device, _dp(a), a.size, C.byref(out)))
+    return out.value
+
+
+def device_next_beta(beta, log_w, ll, target_ess, device: int = 0) -> float:
+    lw = np.ascontiguousarray(log_w, dtype=np.float64)
+    l2 = np.ascontiguousarray(ll, dtype=np.float64)
+    out = C.c_double()
+    _check(lib().fg_device_next_beta(device, float(beta), _dp(lw), _dp(l2), lw.size, float(target_ess), C.byref(out)))
+    return out.value
+
+
+def device_resample_indices(method: int, weights, u, device: int = 0) -> np.ndarray:
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    uu = np.ascontiguousarray(np.atleast_1d(u), dtype=np.float64)
+    idx = np.zeros(w.size, dtype=np.int64)
+    _check(lib().fg_device_resample_indices(device, int(method), _dp(w), w.size, _dp(uu), idx.ctypes.data_as(C.POINTER(C.c_int64))))
+    return idx

@@ -214,6 +214,35 @@ int fg_mh_get_stats(fg_engine *e, fg_mh_stats *h_stats);
 int fg_mh_get_scales(fg_engine *e, double *h_scales /*[S][C]*/);     /* DiminishingAdaptation::scales */
 int fg_mh_get_log_weight(fg_engine *e, double *h_lw /*[C]*/);        /* total_log_weight of the current trace */
 
+/* ------------------------------------------------------------------ likelihood-tempered SMC
+ * Replaces adaptive_smc (src/inference/smc.rs:455-581).  Particles = the engine's n_chains. */
+enum { FG_RESAMPLE_MULTINOMIAL = 0, FG_RESAMPLE_SYSTEMATIC = 1, FG_RESAMPLE_STRATIFIED = 2 };   /* ResamplingMethod, smc.rs:133-140 */
+typedef struct fg_smc_config {      /* SMCConfig, smc.rs:172-189 (same defaults) */
+    int32_t resampling_method;      /* systematic */
+    double  ess_threshold;          /* 0.5 */
+    int32_t rejuvenation_steps;     /* 0 */
+} fg_smc_config;
+typedef struct fg_smc_result {      /* SMCResult minus the particles (smc.rs:361-366) */
+    double  log_evidence;
+    int32_t n_steps;                /* tempering steps taken */
+    int64_t n_model_runs;
+} fg_smc_result;
+void fg_smc_config_default(fg_smc_config *cfg);
+/* Runs the whole ladder.  On return the engine's values [S][N] hold the final particles;
+ * h_log_w / h_weights (optional, [N]) get the normalised log-weights / weights;
+ * h_betas (optional) the inverse-temperature ladder. */
+int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *h_weights,
+               fg_smc_result *h_result, double *h_betas, int max_betas);
+/* population-wide primitives on device `device_ordinal`, usable without a program:
+ * log_sum_exp (src/core/numerical.rs:15-38), next_beta (smc.rs:588-622) and
+ * {multinomial,systematic,stratified}_indices (smc.rs:255-314) with the uniforms injected
+ * (h_u: 1 value for systematic, n otherwise). */
+int fg_device_log_sum_exp(int device_ordinal, const double *h_x, int64_t n, double *out);
+int fg_device_next_beta(int device_ordinal, double beta, const double *h_log_w, const double *h_loglik,
+                        int64_t n, double target_ess, double *out_beta);
+int fg_device_resample_indices(int device_ordinal, int method, const double *h_weights, int64_t n,
+                               const double *h_u, int64_t *h_idx);
+
 /* raw device memory helpers so a host without a HIP binding can own draw buffers */
 void *fg_device_alloc(fg_engine *e, size_t bytes);
 int   fg_device_free(fg_engine *e, void *d_ptr);
