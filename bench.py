@@ -134,6 +134,17 @@ def main():
     launch_ms = float(np.mean([ms for ms, (_, _, n) in zip(kernel_ms, events) if n == events[0][2]]))
     n_launch = events[0][2]
 
+    # ---- after the timed region: the ONLY cross-chain step -- split R-hat / multichain ESS.  Each rank
+    # reduces its own draws to per-chain moments on its GPU; ranks all-gather those over RCCL/xGMI.
+    from fugue_amd import diagnostics as D
+    t_diag = time.perf_counter()
+    prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
+    cd = D.ChainDiagnostics(prov, device=f"cuda:{local_rank}" if world > 1 else None)
+    rhat = cd.split_rhat()
+    ess = cd.ess() if K >= 4 else np.full(d, float("nan"))
+    prov.close()
+    t_diag = time.perf_counter() - t_diag
+
     # correctness of what was timed: posterior mean / variance against the closed form
     st = eng.hmc_stats()
     m = draws.mean(dim=(0, 2)).cpu().numpy()
@@ -165,7 +176,9 @@ def main():
                      "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS,
                      "logpdf_evals_per_transition": evals_per_transition, "flops_per_logpdf": flops_per_logpdf},
         "check": {"posterior_mean_max_abs_err": mean_err, "posterior_var_max_abs_err": var_err,
-                  "accept_rate": st.accept_rate, "mean_step_size": st.mean_step_size, "n_divergent": int(st.n_divergent)},
+                  "accept_rate": st.accept_rate, "mean_step_size": st.mean_step_size, "n_divergent": int(st.n_divergent),
+                  "split_rhat_max": float(np.max(rhat)), "ess_min": float(np.min(ess)), "chains_in_rhat": int(cd.m),
+                  "diagnostics_seconds": t_diag},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_device_log_sum_exp", "fg_device_next_beta",
-    "fg_device_resample_indices", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
+    "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
 ]
 
 _lib = None
@@ -143,6 +143,8 @@ def lib():
     L.fg_device_log_sum_exp.argtypes = [C.c_int, dp, C.c_int64, dp]
     L.fg_device_next_beta.argtypes = [C.c_int, C.c_double, dp, dp, C.c_int64, C.c_double, dp]
     L.fg_device_resample_indices.argtypes = [C.c_int, C.c_int, dp, C.c_int64, dp, C.POINTER(C.c_int64)]
+    L.fg_diag_chain_moments.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.fg_diag_autocov_sums.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, dp]
     L.fg_device_alloc.restype = vp
     L.fg_device_alloc.argtypes = [vp, C.c_size_t]
     L.fg_device_free.argtypes = [vp, vp]
@@ -448,6 +450,15 @@ class Engine:
         _check(lib().fg_smc_run(self.h, C.byref(cfg), _dp(log_w), _dp(w), C.byref(res), _dp(betas), max_betas))
         return dict(values=self.get_values(), log_w=log_w, weights=w, log_evidence=res.log_evidence,
                     betas=betas[:res.n_steps], n_model_runs=res.n_model_runs)
+
+    # ---- diagnostics kernels -----------------------------------------------------------------
+    def diag_chain_moments(self, d_draws: int, n: int, d: int, d_moments: int):
+        _check(lib().fg_diag_chain_moments(self.h, d_draws, int(n), int(d), d_moments))
+
+    def diag_autocov_sums(self, d_draws: int, n: int, d: int, d_moments: int, lag0: int, n_lags: int) -> np.ndarray:
+        out = np.zeros((d, n_lags))
+        _check(lib().fg_diag_autocov_sums(self.h, d_draws, int(n), int(d), d_moments, int(lag0), int(n_lags), _dp(out)))
+        return out
 
     # ---- raw device buffers ---------------------------------------------------------------
     def device_alloc(self, nbytes: int) -> int:

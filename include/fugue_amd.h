@@ -243,6 +243,18 @@ int fg_device_next_beta(int device_ordinal, double beta, const double *h_log_w, 
 int fg_device_resample_indices(int device_ordinal, int method, const double *h_weights, int64_t n,
                                const double *h_u, int64_t *h_idx);
 
+/* ------------------------------------------------------------------ cross-chain diagnostics
+ * Per-chain statistics behind r_hat_f64 / effective_sample_size_multichain
+ * (src/inference/diagnostics.rs:218-304, src/inference/mcmc_utils.rs:214-339).  Draws stay on the
+ * GPU; only these small summaries are exchanged between GPUs (RCCL) and combined on the host. */
+/* d_draws [n][d][C] -> d_moments [d][6][C] = mean, sum of squared deviations of the full chain,
+ * of its first half and of its second half (half = n/2, middle draw dropped when n is odd). */
+int fg_diag_chain_moments(fg_engine *e, const double *d_draws, int n, int d, double *d_moments);
+/* h_sums [d][n_lags] = sum over this engine's chains of the biased lag-t autocovariances
+ * (mcmc_utils.rs:231-244) for t in [lag0, lag0 + n_lags). */
+int fg_diag_autocov_sums(fg_engine *e, const double *d_draws, int n, int d, const double *d_moments,
+                         int lag0, int n_lags, double *h_sums);
+
 /* raw device memory helpers so a host without a HIP binding can own draw buffers */
 void *fg_device_alloc(fg_engine *e, size_t bytes);
 int   fg_device_free(fg_engine *e, void *d_ptr);
