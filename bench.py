@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--grad", choices=["fd_sparse", "fd_dense"], default="fd_sparse")
     ap.add_argument("--launch", type=int, default=25, help="transitions fused per kernel launch")
+    ap.add_argument("--leapfrog", type=int, default=16, help="L (HMCConfig::default is 16; other values are for experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chains", type=int, default=512)
     ap.add_argument("--cpu-transitions", type=int, default=24)
@@ -88,11 +89,11 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from fugue_amd import engine as E, workloads as W
-    C, K, Wn, L = args.chains, args.steps, args.warmup, 16
+    C, K, Wn, L = args.chains, args.steps, args.warmup, args.leapfrog
     cp = E.compile_model(W.normal_sites(N_SITES))
     d = cp.d
     mode = E.GRAD_FD_SPARSE if args.grad == "fd_sparse" else E.GRAD_FD_DENSE
-    cfg = E.hmc_config(grad_mode=mode)
+    cfg = E.hmc_config(grad_mode=mode, n_leapfrog=L)
     eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=local_rank)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)                    # kernels + torch events share one stream

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libfugue_amd.so")
 SOURCES = ["fg_program.cpp", "fg_engine.hip", "fg_smc.hip", "fg_diag.hip"]
-HEADERS = ["fg_ir.h", "fg_math.h", "fg_interp.h", "fg_program.h", "fg_engine_internal.h", os.path.join("..", "..", "include", "fugue_amd.h")]
+HEADERS = ["fg_ir.h", "fg_math.h", "fg_interp.h", "fg_program.h", "fg_engine_internal.h", "fg_gradstream.h", os.path.join("..", "..", "include", "fugue_amd.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-DFG_BUILD", "-Wall", "-Wno-unused-function"]
 
@@ -42,6 +42,8 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     for f in SOURCES:
         p = os.path.join(CSRC, f)
         srcs += (["-x", "hip", p] if f.endswith((".hip", ".cpp")) else [p])
+    if os.environ.get("FG_EXTRA_DEFS"):
+        extra = list(extra) + ["-D" + d for d in os.environ["FG_EXTRA_DEFS"].split(",")]
     if os.environ.get("FG_MIN_WAVES"):
         extra = list(extra) + ["-DFG_MIN_WAVES=" + os.environ["FG_MIN_WAVES"]]
     cmd = [hipcc()] + FLAGS + list(extra) + srcs + ["-o", LIB]

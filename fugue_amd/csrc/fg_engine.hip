@@ -11,12 +11,13 @@
 // One block = one wave of 64 chains; the wave's working set (site values + expression
 // temporaries + momentum) is a [(n_slots + d)][64] tile of doubles in LDS.
 #include "fg_engine_internal.h"
+#include "fg_gradstream.h"
 
 // ---- run(PriorHandler, model) per chain: interpreters.rs:88-104 ----
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
                                                         double *acc_out /*[3][C]*/, double *lj_out /*[C]*/) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -36,14 +37,14 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramD
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint(FgProgramDev P, FgChainCtx X, double *acc_out, double *logp_out,
                                                        double *lj_out) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + threadIdx.x;
     fg_load_values(P, X, c, slots, tw);
     FgAcc3 A = {0.0, 0.0, 0.0};
-    fg_exec<FG_MODE_SCORE, true>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, logp_out ? logp_out + c : nullptr, X.C, live);
+    fg_exec<FG_MODE_SCORE, true>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, logp_out ? logp_out + c : nullptr, X.C, live);
     if (live) {
         if (acc_out) { acc_out[c] = A.prior; acc_out[X.C + c] = A.lik; acc_out[2 * X.C + c] = A.fac; }
         if (lj_out) lj_out[c] = fg_total(A);
@@ -72,17 +73,39 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
     const int n_evals = (L + 1) * 2 * d + 1;
     bool bad = false;
     int s = 0, i = 0, slot = 0;
+    FgCoord cd = {0, 0, 0, 0};
     double orig = 0.0, lp_plus = 0.0;
     lj_end = FG_NEG_INF;
-    for (int e = 0; e < n_evals; ++e) {
+    int e0 = 0;
+    if (sparse && P.gstream) {
+        // all force terms are fast Normals: (L+1) fused gradient passes, then only the endpoint score below
+        for (int gs = 0; gs <= L; ++gs) {
+#ifndef FG_EXP_NOSTREAM
+            bad = fg_grad_stream(P, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+#endif
+            if (__all(bad)) return true;
+#ifndef FG_EXP_NODRIFT
+            if (gs < L) {
+                if (m_inv) {                                      // q += eps * M^-1 p   (hmc.rs:391-393)
+                    for (int k = 0; k < d; ++k) slots[k * tw] += eps * m_inv[(long long)k * C] * pl[k * tw];
+                } else {                                          // identity mass: eps * 1.0 * p == eps * p exactly
+#pragma unroll 8
+                    for (int k = 0; k < d; ++k) slots[k * tw] += eps * pl[k * tw];
+                }
+            }
+#endif
+        }
+        e0 = n_evals - 1;
+    }
+    for (int e = e0; e < n_evals; ++e) {
         const bool is_final = (e == n_evals - 1);
         const bool minus = (e & 1) != 0;
-        const FgIns *prog = P.ins;
+        const FgIns *prog = P.ins_fast;
         int n = P.n_ins;
         if (!is_final) {
-            if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * tw]; slots[slot * tw] = orig + h; }
+            if (!minus) { cd = P.coord[i]; slot = cd.slot; orig = slots[slot * tw]; slots[slot * tw] = orig + h; }
             else slots[slot * tw] = orig - h;
-            if (sparse) { const int o0 = P.sub_off[i]; prog = P.sub + o0; n = P.sub_off[i + 1] - o0; }
+            if (sparse) { prog = P.sub + cd.sub_off; n = cd.sub_n; }
         }
         FgAcc3 A = {0.0, 0.0, 0.0};
         fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
@@ -101,9 +124,8 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
             if (__all(bad)) return true;                          // every lane left the support (hmc.rs:384-398)
             if (s < L) {                                          // q += eps * M^-1 p   (hmc.rs:391-393)
                 for (int k = 0; k < d; ++k) {
-                    const int sk = P.f64_slot[k];
                     const double mi = m_inv ? m_inv[(long long)k * C] : 1.0;
-                    slots[sk * tw] += eps * mi * pl[k * tw];
+                    slots[k * tw] += eps * mi * pl[k * tw];
                 }
             }
             ++s;
@@ -114,10 +136,11 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
 
 __device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, int tw, const double *m_inv, long long C) {
     double s = 0.0;
-    for (int i = 0; i < P.d; ++i) {
-        const double p = pl[i * tw];
-        const double mi = m_inv ? m_inv[(long long)i * C] : 1.0;
-        s += p * p * mi;
+    if (m_inv) {
+        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; }
+    } else {                                              // identity mass: p*p*1.0 == p*p exactly
+#pragma unroll 8
+        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p; }
     }
     return 0.5 * s;
 }
@@ -156,10 +179,9 @@ __device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, c
     }
     o.alpha = ap; o.accepted = acc; o.lj = acc ? lj_new : lj_cur;
     for (int i = 0; i < P.d; ++i) {                               // commit or roll back the f64 sites
-        const int slot = P.f64_slot[i];
-        const long long g = (long long)slot * X.C + c;
-        if (acc) { if (live) X.values[g] = fg_as_i64(slots[slot * tw]); }
-        else slots[slot * tw] = fg_as_double(X.values[g]);
+        const long long g = (long long)P.f64_site[i] * X.C + c;
+        if (acc) { if (live) X.values[g] = fg_as_i64(slots[i * tw]); }
+        else slots[i * tw] = fg_as_double(X.values[g]);
     }
     return o;
 }
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
                                                        int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                        double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
         }
         if (live && pos_all) {
             double *row = pos_all + (long long)t * P.d * X.C + c;
-            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * tw];
+            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[i * tw];
         }
         if (warming) {                                     // DualAveraging::update: hmc.rs:168-178
             da_m += 1ull;
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
                 const double n = (double)wn;
                 for (int i = 0; i < P.d; ++i) {
                     const long long g = (long long)i * X.C + c;
-                    const double x = slots[P.f64_slot[i] * tw];
+                    const double x = slots[i * tw];
                     double mean = H.w_mean[g];
                     const double delta = x - mean;
                     mean += delta / n;
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
             }
         } else if (draws && live) {                        // hmc_chain pushes the current state: hmc.rs:577-582
             double *row = draws + (long long)(t - first_sample_t) * P.d * X.C + c;
-            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[P.f64_slot[i] * tw];
+            for (int i = 0; i < P.d; ++i) row[(long long)i * X.C] = slots[i * tw];
         }
     }
     if (live) {
@@ -249,7 +271,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_inject
                                                                      const double *p0, const double *u_in, int *acc_out,
                                                                      double *alpha_out, int *div_out) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_inject
 // grad_log_joint (hmc.rs:304-329) at the current values (test hook)
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse, double *grad, int *ok) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -278,12 +300,19 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
     bool good = true;
     double orig = 0.0, lp_plus = 0.0;
     int slot = 0;
+    if (sparse && P.gstream) {
+        double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
+        for (int i = 0; i < P.d; ++i) pl[i * tw] = 0.0;
+        good = !fg_grad_stream(P, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
+        if (live && ok) ok[c] = good;
+        return;
+    }
     for (int e = 0; e < 2 * P.d; ++e) {
         const int i = e >> 1;
         const bool minus = (e & 1) != 0;
-        if (!minus) { slot = P.f64_slot[i]; orig = slots[slot * tw]; slots[slot * tw] = orig + h; }
+        if (!minus) { slot = i; orig = slots[slot * tw]; slots[slot * tw] = orig + h; }
         else slots[slot * tw] = orig - h;
-        const FgIns *prog = P.ins; int n = P.n_ins;
+        const FgIns *prog = P.ins_fast; int n = P.n_ins;
         if (sparse) { const int o0 = P.sub_off[i]; prog = P.sub + o0; n = P.sub_off[i + 1] - o0; }
         FgAcc3 A = {0.0, 0.0, 0.0};
         fg_exec<FG_MODE_SCORE, false>(prog, n, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, uint32_t instance, int injected,
                                                           double *eps_out) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;                    // tile width: lanes of this wave that own a chain
+    constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -337,8 +366,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_find_eps(FgProgra
         if (!div) lr_try = h0 - (-lj1 + fg_kinetic(P, pl, tw, mi, X.C));
         // restore (q, p0) for the next trial
         for (int i = 0; i < P.d; ++i) {
-            const int slot = P.f64_slot[i];
-            slots[slot * tw] = fg_as_double(X.values[(long long)slot * X.C + c]);
+            slots[i * tw] = fg_as_double(X.values[(long long)P.f64_site[i] * X.C + c]);
             pl[i * tw] = H.p0_scratch[(long long)i * X.C + c];
         }
         if (first) {
@@ -391,7 +419,7 @@ __global__ void k_hmc_da_new(FgHmcDev H, long long C, const double *eps0) {
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, int iter0, int n_steps,
                                                                     int n_warmup, long long *draws, int first_sample_t) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;
+    constexpr int tw = FG_WAVE;
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -408,7 +436,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         fg_rng_block(rng, ra, rb);
         const int target = (int)fg_pick(ra, (uint32_t)P.S);               // sites[rng.gen_range(0..len)]  mh.rs:716
         const long long g = (long long)target * X.C + c;
-        mh.target = target;
+        const int tslot = P.site_slot[target];                             // per-lane gather (site -> LDS slot)
+        mh.target = tslot;
         mh.scale = M.scale[g];                                             // get_scale  mcmc_utils.rs:70-77
         mh.kind = M.kind[g];
         const int kind0 = mh.kind;
@@ -418,7 +447,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         mh.next_block = 2;
         mh.lqf = 0.0; mh.lqr = 0.0;
         mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
-        mh.old_cell = slots[target * tw];
+        mh.old_cell = slots[tslot * tw];
         FgAcc3 A = {0.0, 0.0, 0.0};
         fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
         const double prop_lw = fg_total(A);
@@ -442,8 +471,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
             if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
         }
         if (live && mh.kind != kind0) M.kind[g] = mh.kind;
-        if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[target * tw]); }
-        else slots[target * tw] = mh.old_cell;
+        if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
+        else slots[tslot * tw] = mh.old_cell;
         if (!adapt && draws && live) {
             long long *row = draws + (long long)(t - first_sample_t) * M.n_rec * X.C + c;
             for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
@@ -489,16 +518,20 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (hipStreamCreate(&e->stream) != hipSuccess) return fail("hipStreamCreate");
     if (dev_upload(&e->d_ins, p->ins)) return fail("upload ins");
     if (dev_upload(&e->d_sub, p->sub)) return fail("upload sub");
+    if (dev_upload(&e->d_ins_fast, p->ins_fast)) return fail("upload ins_fast");
+    if (dev_upload(&e->d_coord, p->coord)) return fail("upload coord");
+    if (dev_upload(&e->d_gstream, p->gstream)) return fail("upload gstream");
     if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
+    if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
     if (dev_upload(&e->d_vtype, p->site_vtype)) return fail("upload vtype");
     if (dev_upload(&e->d_pool, p->pool)) return fail("upload pool");
     if (dev_alloc(&e->d_values, (size_t)std::max(1, e->S) * e->C)) return fail("alloc values");
     if (dev_alloc(&e->d_acc, (size_t)3 * e->C)) return fail("alloc acc");
     if (dev_alloc(&e->d_tmp, (size_t)e->C)) return fail("alloc tmp");
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
-    e->P.ins = e->d_ins; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
-    e->P.f64_slot = e->d_f64_slot; e->P.site_vtype = e->d_vtype;
+    e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
+    e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
@@ -516,7 +549,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->hmc_allocs) hipFree(q);
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
-    void *ptrs[] = { e->d_ins, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -594,8 +627,10 @@ int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp) {
                        h_logp ? e->d_logp : nullptr, (double *)nullptr);
     HIPCHK(hipGetLastError());
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
-    if (h_logp) HIPCHK(hipMemcpyAsync(h_logp, e->d_logp, (size_t)e->S * e->C * 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (h_logp)     // the kernel indexes rows by LDS slot; hand them back in site order
+        for (int j = 0; j < e->S; j++)
+            HIPCHK(hipMemcpy(h_logp + (size_t)j * e->C, e->d_logp + (size_t)e->prog->site_slot[j] * e->C, (size_t)e->C * 8, hipMemcpyDeviceToHost));
     return FG_OK;
 }
 
@@ -882,9 +917,10 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
     e->M.ov_kind = nullptr; e->M.ov_lo = nullptr; e->M.ov_hi = nullptr;
     if (overrides) {
         std::vector<int> k(S); std::vector<double> lo(S), hi(S);
-        for (int j = 0; j < e->S; j++) {
-            k[j] = overrides[j].kind; lo[j] = overrides[j].lower; hi[j] = overrides[j].upper;
-            if (k[j] < 0 || k[j] > 4) { fg_set_error("fg_mh_init: unknown proposal kind"); return FG_E_BAD_ARG; }
+        for (int j = 0; j < e->S; j++) {            // device tables are indexed by LDS slot
+            const int sl = e->prog->site_slot[j];
+            k[sl] = overrides[j].kind; lo[sl] = overrides[j].lower; hi[sl] = overrides[j].upper;
+            if (k[sl] < 0 || k[sl] > 4) { fg_set_error("fg_mh_init: unknown proposal kind"); return FG_E_BAD_ARG; }
         }
         int *dk = nullptr; double *dlo = nullptr, *dhi = nullptr;
         if (dev_upload(&dk, k) || dev_upload(&dlo, lo) || dev_upload(&dhi, hi)) return FG_E_HIP;
@@ -909,7 +945,9 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
             if (e->d_rec) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->d_rec)); }
             HIPCHK(hipMalloc((void **)&e->d_rec, (size_t)n_rec * 4)); e->rec_cap = n_rec;
         }
-        HIPCHK(hipMemcpyAsync(e->d_rec, h_rec_sites, (size_t)n_rec * 4, hipMemcpyHostToDevice, e->stream));
+        std::vector<int> rec_slots((size_t)n_rec);
+        for (int r = 0; r < n_rec; r++) rec_slots[r] = e->prog->site_slot[h_rec_sites[r]];
+        HIPCHK(hipMemcpy(e->d_rec, rec_slots.data(), (size_t)n_rec * 4, hipMemcpyHostToDevice));
     }
     e->M.rec = e->d_rec; e->M.n_rec = n_rec;
     const int iter = e->mh_iter;

@@ -28,10 +28,11 @@ struct FgChainCtx {
 };
 
 __device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
-    for (int j = 0; j < P.S; ++j) slots[j * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    slots[(P.n_slots - 1) * tw] = 0.0;                   // the always-zero slot (constant operands of fast opcodes)
 }
 __device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
-    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[j * tw]);
+    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[P.site_slot[j] * tw]);
 }
 
 
@@ -70,8 +71,10 @@ struct fg_engine {
     uint32_t chain0 = 0;
     int S = 0, d = 0, n_slots = 0;
     // device copies of the program
-    FgIns *d_ins = nullptr, *d_sub = nullptr;
-    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_vtype = nullptr;
+    FgIns *d_ins = nullptr, *d_ins_fast = nullptr, *d_sub = nullptr;
+    FgCoord *d_coord = nullptr;
+    FgGradRec *d_gstream = nullptr;
+    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr;
     double *d_pool = nullptr;
     FgProgramDev P{};
     FgChainCtx X{};
@@ -97,18 +100,11 @@ struct fg_engine {
 
 namespace {
 
-// Tile width = lanes per wave that own a chain (= threads per block).  Measured on MI355X
-// (profiles/round1_occupancy_sweep.txt): spreading 65 536 chains over narrower waves to get
-// 2-4 waves per SIMD does NOT help -- the interpreter is bound by scalar/branch instruction
-// ISSUE (one scalar unit per SIMD slot), not by latency, so co-resident waves do not overlap
-// and narrower waves only waste lanes.  Full 64-lane tiles are the default; FG_TILE_WIDTH
-// overrides it for experiments.
-int tile_width_for(long long C) {
-    (void)C;
-    const char *env = getenv("FG_TILE_WIDTH");
-    if (env) { int v = atoi(env); if (v == 16 || v == 32 || v == 64) return v; }
-    return 64;
-}
+// Tile width = lanes per wave that own a chain = 64.  Spreading 65 536 chains over narrower waves
+// to get 2-4 waves per SIMD was measured NOT to help (profiles/round1_occupancy_sweep.txt): a wave
+// issues one instruction (of any type) per 4 cycles and co-resident waves do not overlap here, so
+// the kernels use full 64-lane tiles and the tile stride is a compile-time constant.
+int tile_width_for(long long C) { (void)C; return FG_WAVE; }
 
 template <typename K>
 int set_lds(K kernel, size_t bytes) {

@@ -110,7 +110,22 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
         const FgInsRegs Inext = fg_fetch_ins(prog, pc + 1);      // prefetch (scalar, wave-uniform)
         const uint32_t op = FG_I_OP(I);
         const uint32_t code = FG_INS_OPCODE(op);
-        if (code < 17u) {
+        if (MODE == FG_MODE_SCORE && code == FG_OP_NORMAL_FAST) {
+            // Normal, constant sigma (distribution.rs:189-208): operands are `imm + slot` (the zero slot for
+            // constants), ln(sigma) hoisted, (x-mu)/sigma an exact multiply when sigma = 2^k.  A non-finite x or
+            // mu makes z NaN or +-inf: NaN -> -inf by the guard, +-inf -> -inf by the formula itself.
+            const double xv = FG_I_IMM(I, 0) + slots[FG_I_OPND(I, 0) * tw];
+            const double mv = FG_I_IMM(I, 1) + slots[FG_I_OPND(I, 1) * tw];
+            const double dl = xv - mv;
+            const double z = (op & FG_F_POW2SCALE) ? dl * fg_ins_h(I, 4) : dl / FG_I_IMM(I, 2);
+            double lp = -0.5 * z * z - fg_ins_h(I, 0) - 0.5 * FG_LN_2PI;
+            lp = (z != z) ? FG_NEG_INF : lp;
+            if (op & FG_F_OBSERVE) A.lik += lp;
+            else {
+                A.prior += lp;
+                if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)FG_I_AUX(I) * logp_stride] = lp; }
+            }
+        } else if (code < 17u) {
             // ---------------- sample / observe site: dist.log_prob(x) ----------------
             const bool hoisted = (op & FG_F_HOISTED) != 0u;
             const bool observe = (op & FG_F_OBSERVE) != 0u;

@@ -15,6 +15,9 @@ enum : uint32_t { FG_OPND_IMM = 0u, FG_OPND_SLOT_F = 1u, FG_OPND_SLOT_I = 2u, FG
 
 // opcodes.  0..16 = distribution kinds (include/fugue_amd.h order)
 enum : uint32_t {
+    FG_OP_NORMAL_FAST = 20,  // Normal with constant valid sigma, x and mu each `imm + slot` (score-only programs):
+                         //   opnd[0], opnd[1] = plain slot indices of x, mu (the always-zero slot for constants),
+                         //   imm[0], imm[1] = their constants (0 for slots), imm[2] = sigma, h[0] = ln sigma, h[4] = 1/sigma
     FG_OP_FACTOR = 32,   // log_factors += x
     FG_OP_LOAD = 40,     // acc = x
     FG_OP_ADD, FG_OP_SUB, FG_OP_MUL, FG_OP_DIV,   // acc = acc (op) x
@@ -49,13 +52,38 @@ struct FgIns {
 static_assert(sizeof(FgIns) == 96, "FgIns must be 96 bytes");
 
 // A compiled program as the kernels see it.
+// per f64 coordinate: what the finite-difference force needs, in one 16-byte scalar load
+struct FgCoord { int slot, sub_off, sub_n, flags; };
+
+// One record of the fused finite-difference gradient stream (programs whose sub-programs are all
+// FG_OP_NORMAL_FAST): the instruction plus which of its operands is the perturbed coordinate.
+enum : uint32_t { FG_G_SWITCH = 1u,   // first observe record of a coordinate: stash the prior sums, restart the running sums
+                  FG_G_POW2 = 2u, FG_G_PERT_X = 4u, FG_G_PERT_M = 8u, FG_G_END = 16u,
+                  FG_G_X_CONST = 32u,  // x is a constant (ximm), no slot read
+                  FG_G_M_CONST = 64u   // mu is a constant (mimm), no slot read
+};
+struct FgGradRec {
+    uint32_t xi, mi;        // slot indices of x and mu (the zero slot for constants)
+    uint32_t flags, coord;  // FG_G_*; f64 coordinate this record belongs to
+    double ximm, mimm;      // constants of x, mu (0 for slots)
+    double sigma, inv;      // sigma and, when FG_G_POW2, 1/sigma
+    double lns;             // ln sigma
+    double half_ln_2pi;     // 0.5 * ln(2 pi) (kept in the record so that all 16 dwords of the scalar load are live)
+};
+static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
+
 struct FgProgramDev {
-    const FgIns  *ins;       // full program, n_ins
+    const FgIns  *ins;       // full program (generic opcodes only: PRIOR / MH / SCORE), n_ins
+    const FgIns  *ins_fast;  // the same program with score-only fast opcodes substituted (HMC / SMC / log-joint)
+    const FgCoord *coord;    // [d]
     const FgIns  *sub;       // concatenated per-coordinate sub-programs (sparse FD)
     const int    *sub_off;   // [d+1] offsets into sub
     const double *pool;      // data arrays + constant tables
-    const int    *f64_slot;  // [d] slot (= sorted site index) of each f64 coordinate
+    const int    *f64_site;  // [d] sorted site index of each f64 coordinate (its LDS slot is the coordinate index itself)
+    const int    *site_slot; // [S] LDS slot of each site: f64 sites first (coordinate order), then the discrete sites
     const int    *site_vtype;// [S]
+    const FgGradRec *gstream;  // fused gradient stream or null
+    int n_gstream;
     int n_ins, n_slots, S, d;
 };
 

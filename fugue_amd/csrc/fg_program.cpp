@@ -137,8 +137,8 @@ struct FgGen {
     void leaf_operand(int node, uint32_t &word, double &imm) const {
         const FgNode &n = P.nodes[node];
         if (n.op == FG_T_CONST) { word = FG_OPND(FG_OPND_IMM, 0); imm = n.cval; return; }
-        int slot = P.handle_to_sorted[n.a];
-        word = FG_OPND(P.site_vtype[slot] == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, slot);
+        const int site = P.handle_to_sorted[n.a];
+        word = FG_OPND(P.site_vtype[site] == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, P.site_slot[site]);
         imm = 0.0;
     }
     void emit1(uint32_t op, int operand_node) {          // op with one leaf operand
@@ -291,8 +291,8 @@ void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &tem
         }
     }
     if (s.kind == 0) {                                   // sample: x is the site's own slot
-        I.aux = (uint32_t)s.sorted;
-        I.opnd[0] = FG_OPND(s.vtype == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, s.sorted);
+        I.aux = (uint32_t)site_slot[s.sorted];
+        I.opnd[0] = FG_OPND(s.vtype == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, site_slot[s.sorted]);
     } else {
         G.operand(s.value, I.opnd[0], I.imm[0]);
     }
@@ -322,6 +322,14 @@ int fg_program::finalize() {
         site_vtype[j] = s.vtype;
         if (s.vtype == FG_F64) f64_slot.push_back(j);
     }
+    // LDS slot numbering: the f64 coordinates first (slot k = coordinate k, so the leapfrog loops need no
+    // index table), then the discrete sites; expression temporaries follow from slot S
+    site_slot.assign(S, 0);
+    {
+        int next = (int)f64_slot.size();
+        for (int k = 0; k < (int)f64_slot.size(); k++) site_slot[f64_slot[k]] = k;
+        for (int j = 0; j < S; j++) if (site_vtype[j] != FG_F64) site_slot[j] = next++;
+    }
     // compile every statement; remember its instruction range and the sites it reads
     ins.clear(); sub.clear(); sub_off.clear(); pool.clear();
     int temp_max = S;
@@ -337,19 +345,82 @@ int fg_program::finalize() {
         if (stmts[i].kind == 0) hs.push_back(stmts[i].handle);
         for (int h : hs) reads[i].push_back(handle_to_sorted[h]);
     }
-    n_slots = temp_max;
-    // per-coordinate sub-programs for the sparse finite difference
+    // slot `temp_max` is the always-zero slot read by the constant operands of the fast opcodes
+    const int zero_slot = temp_max;
+    n_slots = temp_max + 1;
+    // score-only variant: Normal sites with a constant valid sigma and (constant | f64 slot) x, mu
+    ins_fast = ins;
+    for (FgIns &I : ins_fast) {
+        if (FG_INS_OPCODE(I.op) != (uint32_t)FG_NORMAL || (I.op & FG_F_INVALID)) continue;
+        const uint32_t kx = FG_OPND_KIND(I.opnd[0]), km = FG_OPND_KIND(I.opnd[1]), ks = FG_OPND_KIND(I.opnd[2]);
+        const double sg = I.imm[2];
+        if (ks != FG_OPND_IMM || !(sg > 0.0) || !std::isfinite(sg)) continue;
+        if ((kx != FG_OPND_IMM && kx != FG_OPND_SLOT_F) || (km != FG_OPND_IMM && km != FG_OPND_SLOT_F)) continue;
+        if (km == FG_OPND_IMM && !std::isfinite(I.imm[1])) continue;
+        FgIns F = FgGen::blank(FG_OP_NORMAL_FAST | (I.op & FG_F_OBSERVE));
+        F.opnd[0] = kx == FG_OPND_IMM ? (uint32_t)zero_slot : FG_OPND_IDX(I.opnd[0]);
+        F.opnd[1] = km == FG_OPND_IMM ? (uint32_t)zero_slot : FG_OPND_IDX(I.opnd[1]);
+        F.imm[0] = kx == FG_OPND_IMM ? I.imm[0] : 0.0;
+        F.imm[1] = km == FG_OPND_IMM ? I.imm[1] : 0.0;
+        F.imm[2] = sg;
+        F.aux = I.aux;
+        F.h[0] = std::log(sg);                                   // ln(sigma), distribution.rs:207
+        if (fg_pow2_scale(sg)) { F.op |= FG_F_POW2SCALE; F.h[4] = 1.0 / sg; }
+        I = F;
+    }
+    // per-coordinate sub-programs for the sparse finite difference (built from the score-only variant)
     sub_off.push_back(0);
+    coord.clear();
     for (int slot : f64_slot) {
         for (size_t i = 0; i < stmts.size(); i++)
             if (std::find(reads[i].begin(), reads[i].end(), slot) != reads[i].end())
-                sub.insert(sub.end(), ins.begin() + range[i].first, ins.begin() + range[i].second);
+                sub.insert(sub.end(), ins_fast.begin() + range[i].first, ins_fast.begin() + range[i].second);
+        FgCoord cd; cd.slot = (int)coord.size(); cd.sub_off = sub_off.back(); cd.sub_n = (int)sub.size() - sub_off.back(); cd.flags = 0;
+        coord.push_back(cd);
         sub_off.push_back((int)sub.size());
+    }
+    // fused FD gradient stream: possible when every statement that reads an f64 coordinate is a fast Normal
+    gstream.clear(); n_gstream = 0;
+    {
+        bool ok = !f64_slot.empty();
+        for (size_t k = 0; k < sub.size() && ok; k++) ok = FG_INS_OPCODE(sub[k].op) == FG_OP_NORMAL_FAST;
+        for (size_t k = 0; k < f64_slot.size() && ok; k++) ok = coord[k].sub_n > 0;
+        if (ok) {
+            // log_prior and log_likelihood are separate accumulators (trace.rs:168-177), so within one coordinate
+            // the prior records may be emitted before the observe records without changing either sum
+            for (size_t k = 0; k < f64_slot.size(); k++) {
+                const uint32_t ps = (uint32_t)k;          // LDS slot of coordinate k
+                std::vector<int> order;
+                for (int pass = 0; pass < 2; pass++)
+                    for (int j = 0; j < coord[k].sub_n; j++)
+                        if (((sub[coord[k].sub_off + j].op & FG_F_OBSERVE) != 0u) == (pass == 1)) order.push_back(j);
+                bool seen_obs = false;
+                for (size_t q = 0; q < order.size(); q++) {
+                    const FgIns &F = sub[coord[k].sub_off + order[q]];
+                    const bool obs = (F.op & FG_F_OBSERVE) != 0u;
+                    FgGradRec r; std::memset(&r, 0, sizeof(r));
+                    r.xi = F.opnd[0]; r.mi = F.opnd[1]; r.coord = (uint32_t)k;
+                    r.flags = ((obs && !seen_obs) ? FG_G_SWITCH : 0u) | ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) |
+                              (r.xi == ps ? FG_G_PERT_X : 0u) | (r.mi == ps ? FG_G_PERT_M : 0u) |
+                              (q + 1 == order.size() ? FG_G_END : 0u) |
+                              (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | (r.mi == (uint32_t)zero_slot ? FG_G_M_CONST : 0u);
+                    seen_obs = seen_obs || obs;
+                    r.ximm = F.imm[0]; r.mimm = F.imm[1]; r.sigma = F.imm[2]; r.inv = F.h[4]; r.lns = F.h[0];
+                    r.half_ln_2pi = 0.5 * FG_LN_2PI;
+                    gstream.push_back(r);
+                }
+            }
+            n_gstream = (int)gstream.size();
+            FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
+            pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2; pad.half_ln_2pi = 0.5 * FG_LN_2PI;
+            for (int q = 0; q < 4; q++) gstream.push_back(pad);   // the stream is read 3 records ahead
+        }
     }
     if (pool.empty()) pool.push_back(0.0);
     // the kernels prefetch one instruction ahead: keep one readable no-op past each array
     n_ins = (int)ins.size();
     ins.push_back(FgGen::blank(0xffu));
+    ins_fast.push_back(FgGen::blank(0xffu));
     sub.push_back(FgGen::blank(0xffu));
     finalized = true;
     return FG_OK;

@@ -29,8 +29,11 @@ struct fg_program {
     int n_samples = 0, n_observes = 0;
     // compiled
     bool finalized = false;
-    std::vector<int> sorted_stmt, handle_to_sorted, site_vtype, f64_slot, sub_off;
-    std::vector<FgIns> ins, sub;
+    std::vector<int> sorted_stmt, handle_to_sorted, site_vtype, f64_slot /* sorted site index of coordinate k */, site_slot /* LDS slot of site j */, sub_off;
+    std::vector<FgIns> ins, ins_fast, sub;
+    std::vector<FgCoord> coord;
+    std::vector<FgGradRec> gstream;   // empty unless every sub-program is all-fast
+    int n_gstream = 0;
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
 

@@ -217,7 +217,7 @@ struct FgSmcDev {
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_smc_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st,
                                                                       uint32_t move_id) {
     extern __shared__ double lds[];
-    const int tw = (int)blockDim.x;
+    constexpr int tw = FG_WAVE;
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
@@ -228,16 +228,16 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_smc_rejuv(FgProgramDe
     unsigned long long ra, rb;
     fg_rng_block(rng, ra, rb);
     const int k = (int)fg_pick(ra, (uint32_t)P.d);            // f64_sites[rng.gen_range(0..len)]  smc.rs:650
-    const int site = P.f64_slot[k];
+    const int site = P.f64_site[k];                           // sorted site index (adaptation / values row)
     const double scale = M.scale[site];                       // get_scale  smc.rs:651
     const double z = fg_rng_normal(rng);                      // Normal(0,1).sample  smc.rs:655
-    const double cur = slots[site * tw];
+    const double cur = slots[k * tw];                         // LDS slot of coordinate k is k
     const double prop = cur + scale * z;
     double pri[2], lik[2];
     for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed: two model runs  smc.rs:662-675
-        slots[site * tw] = pass ? prop : cur;
+        slots[k * tw] = pass ? prop : cur;
         FgAcc3 A = {0.0, 0.0, 0.0};
-        fg_exec<FG_MODE_SCORE, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
+        fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         pri[pass] = A.prior; lik[pass] = A.lik + A.fac;
     }
     const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
