@@ -42,14 +42,15 @@ F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz /
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--grad", choices=["fd_sparse", "fd_dense"], default="fd_sparse")
     ap.add_argument("--launch", type=int, default=25, help="transitions fused per kernel launch")
     ap.add_argument("--leapfrog", type=int, default=16, help="L (HMCConfig::default is 16; other values are for experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-chains", type=int, default=512)
+    ap.add_argument("--no-extras", action="store_true", help="skip the MH / SMC / dense-FD side measurements")
+    ap.add_argument("--cpu-chains", type=int, default=4096)
     ap.add_argument("--cpu-transitions", type=int, default=24)
     return ap.parse_args()
 
@@ -71,6 +72,55 @@ def cpu_baseline(args):
             "sample": f"{args.cpu_chains} chains x {args.cpu_transitions} transitions (L=16, dense FD) of the same model, "
                       f"{dt:.1f} s wall; C restatement, not the Rust binary",
             "published_reference": "none for HMC; MH 65k chain-steps/s/thread on Apple Silicon (benches/f_perf.rs:24-28)"}
+
+
+def measured_traffic(chains, n_launch, grad):
+    """HBM bytes per launch of k_hmc_steps from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    profiles/round1_hbm_traffic.json); only reported when the run matches the profiled configuration."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")))
+        c = p["config"]
+        if (c["chains"], c["transitions_per_launch"], c["grad"]) == (chains, n_launch, grad):
+            return p["sampling_launch_bytes"]["total"]
+    except Exception:
+        pass
+    return None
+
+
+def extras(args, E, W, dev):
+    """Side measurements reported next to the headline (not part of `value`): the reference-verbatim dense
+    finite difference, the MH half of BASELINE.json's metric (chain-steps/s at 65 536 chains) and C4 (SMC)."""
+    import torch
+    out = {}
+    C = args.chains
+    # (1) dense FD: hmc.rs:304-329 verbatim -- 2*d full model runs per gradient
+    cp = E.compile_model(W.normal_sites(N_SITES))
+    eng = E.Engine(cp, C, seed=1, device=dev)
+    eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_FD_DENSE), 0)
+    eng.hmc_step(2); eng.synchronize()
+    t0 = time.perf_counter(); eng.hmc_step(10); eng.synchronize(); dt = time.perf_counter() - t0
+    out["hmc_fd_dense_leapfrog_steps_per_sec"] = C * 10 * 16 / dt
+    eng.close()
+    # (2) adaptive_mcmc_chain on the reference's own bench model (benches/f_perf.rs:78-109: 20 sample + 19 observe sites)
+    cp = E.compile_model(W.reference_model(20))
+    eng = E.Engine(cp, C, seed=1, device=dev)
+    eng.mh_init(100)
+    eng.mh_step(100); eng.synchronize()
+    t0 = time.perf_counter(); eng.mh_step(400); eng.synchronize(); dt = time.perf_counter() - t0
+    out["mh_chain_steps_per_sec"] = C * 400 / dt
+    out["mh_accept_rate"] = eng.mh_stats().accept_rate
+    out["mh_workload"] = f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91), {C} chains; published CPU: 65k chain-steps/s/thread"
+    eng.close()
+    # (3) C4: adaptive_smc, 1 048 576 particles, Systematic / 0.5 / 3 rejuvenation moves
+    cp = E.compile_model(W.smc_normal())
+    eng = E.Engine(cp, 1 << 20, seed=42, device=dev)
+    eng.smc_run(rejuvenation_steps=3)
+    t0 = time.perf_counter(); r = eng.smc_run(rejuvenation_steps=3); dt = time.perf_counter() - t0
+    out["smc_1m_particles_seconds"] = dt
+    out["smc_particle_moves_per_sec"] = (r["n_model_runs"] - (1 << 20)) / 2 / dt
+    out["smc_log_evidence"] = r["log_evidence"]
+    eng.close()
+    return out
 
 
 def main():
@@ -170,9 +220,11 @@ def main():
                    "n_leapfrog": L, "grad": args.grad, "transitions_per_launch": n_launch,
                    "sharding": f"chains x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "k_hmc_steps",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(C, n_launch, args.grad), "kernel": "k_hmc_steps",
                      "avg_launch_ms": launch_ms,
-                     "note": "state is LDS-resident for the whole launch: the kernel is f64-VALU bound, not HBM bound (see valu_f64)"},
+                     "note": "achieved = SURVEY 8d algorithmic bytes (32*d B per leapfrog step, as if q,p round-tripped HBM) / HIP-event time; "
+                             "the kernel keeps q,p in LDS for a whole launch, so measured traffic is ~30x smaller and the kernel is "
+                             "instruction-issue / f64-VALU bound, not HBM bound (see valu_f64)"},
         "valu_f64": {"achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS,
                      "logpdf_evals_per_transition": evals_per_transition, "flops_per_logpdf": flops_per_logpdf},
@@ -181,6 +233,8 @@ def main():
                   "split_rhat_max": float(np.max(rhat)), "ess_min": float(np.min(ess)), "chains_in_rhat": int(cd.m),
                   "diagnostics_seconds": t_diag},
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["extras"] = extras(args, E, W, local_rank)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
