@@ -1,0 +1,35 @@
+"""The C++ host-side mirror (include/fugue_amd.hpp) compiled with g++ against the in-tree library."""
+import os
+import subprocess
+
+import pytest
+
+from fugue_amd import engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    E.lib()
+    exe = str(tmp_path / "test_mirror")
+    lib_dir = os.path.dirname(E.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp"),
+                    "-L", lib_dir, "-lfugue_amd", f"-Wl,-rpath,{lib_dir}", "-o", exe], check=True)
+    return exe
+
+
+def test_cpp_mirror_builds_programs_on_cpu(tmp_path):
+    import torch
+    exe = _build(tmp_path)
+    args = [exe] if torch.cuda.is_available() else [exe, "--expect-no-device"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C++ mirror OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_runs_inference_on_gpu(tmp_path):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "--gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C++ mirror OK" in r.stdout
