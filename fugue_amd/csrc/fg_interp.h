@@ -83,9 +83,9 @@ struct FgMhCtx {
 };
 // rare paths kept out of line so the interpreter stays small
 __device__ __noinline__ double fg_logpdf_cold(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1,
-                                              double p2, double h0, double h1, double h2, double h3, double h4) {
+                                              double p2, double h0, double h1, double h2, double h3, double h4, bool sh) {
     const double hh[5] = { h0, h1, h2, h3, h4 };
-    return fg_logpdf(kind, hoisted, pow2, xf, xi, p0, p1, p2, hh);
+    return fg_logpdf(kind, hoisted, pow2, xf, xi, p0, p1, p2, hh, sh);
 }
 __device__ __noinline__ long long fg_sample_cold(uint32_t kind, bool hoisted, double p0, double p1, double p2, FgStream *s) {
     return fg_sample_dist(kind, hoisted, p0, p1, p2, *s);
@@ -206,7 +206,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                     if (kind == FG_PROP_AUTO) {
                                         const double probe = ((op & FG_F_INVALID) != 0u) ? FG_NEG_INF
                                             : fg_logpdf_cold(code, hoisted, p2s, -1.0, 0, p0, p1, p2, fg_ins_h(I, 0), fg_ins_h(I, 1),
-                                                             fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4));
+                                                             fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), (op & FG_F_SCALEHOIST) != 0u);
                                         kind = (curd > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN;
                                         mh->kind = kind;
                                     }
@@ -231,10 +231,11 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                     prop = fg_as_double(fg_sample_cold(code, hoisted, p0, p1, p2, &s1));
                                     mh->next_block = (int)s1.c1;
                                     const bool inv = (op & FG_F_INVALID) != 0u;
+                                    const bool shf = (op & FG_F_SCALEHOIST) != 0u;
                                     f = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, prop, 0, p0, p1, p2, fg_ins_h(I, 0),
-                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4));
+                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), shf);
                                     r = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, curd, 0, p0, p1, p2, fg_ins_h(I, 0),
-                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4));
+                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), shf);
                                 }
                                 mh->lqf += f; mh->lqr += r;
                                 slots[aux * tw] = prop;
@@ -265,7 +266,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                     }
                 } else {
                     const double hh[5] = { fg_ins_h(I, 0), fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4) };
-                    lp = fg_logpdf(code, hoisted, (op & FG_F_POW2SCALE) != 0u, xf, xi, p0, p1, p2, hh);
+                    lp = fg_logpdf(code, hoisted, (op & FG_F_POW2SCALE) != 0u, xf, xi, p0, p1, p2, hh, (op & FG_F_SCALEHOIST) != 0u);
                 }
             }
             if (observe) A.lik += lp;                    // interpreters.rs:76-83

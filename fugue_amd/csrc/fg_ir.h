@@ -37,7 +37,9 @@ enum : uint32_t {
     FG_F_HOISTED = 1u << 9,        // all parameters constant: guards checked, h[] valid
     FG_F_INVALID = 1u << 10,       // constant parameters are invalid: log-density is -inf
     FG_F_POW2SCALE = 1u << 11,     // hoisted scale is 2^k: h[4] = 1/scale, (x-loc)/scale == (x-loc)*h[4] exactly
-    FG_F_VTYPE_SHIFT = 12          // 3 bits: FG_F64..FG_I64
+    FG_F_VTYPE_SHIFT = 12,         // 3 bits: FG_F64..FG_I64
+    FG_F_SCALEHOIST = 1u << 15     // location-scale family with a constant valid scale but a varying location:
+                                   // h[0] = the scale-only term (ln sigma, ...), h[4] = 1/scale when FG_F_POW2SCALE
 };
 #define FG_INS_OPCODE(op) ((op) & 0xffu)
 #define FG_INS_VTYPE(op) (((op) >> FG_F_VTYPE_SHIFT) & 7u)

@@ -93,13 +93,13 @@ FG_HD double fg_du_logp(long long lo, long long hi) {
 // wave-uniform on the device.
 // ---------------------------------------------------------------------------------------
 FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1, double p2,
-                       const double *h) {
+                       const double *h, bool sh = false /* scale-only hoisting: sigma guards done on the host, h[0] valid */) {
     switch (kind) {
     case 12: { /* Normal: distribution.rs:189-208 */
-        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!hoisted && ((!sh && (p1 <= 0.0 || !fg_finite(p1))) || !fg_finite(p0))) return FG_NEG_INF;
         if (!fg_finite(xf)) return FG_NEG_INF;
         double z = pow2 ? (xf - p0) * h[4] : (xf - p0) / p1;
-        double ls = hoisted ? h[0] : log(p1);
+        double ls = (hoisted || sh) ? h[0] : log(p1);
         return -0.5 * z * z - ls - 0.5 * FG_LN_2PI; }
     case 15: { /* Uniform: :309-330 */
         if (!hoisted && (p0 >= p1 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;
@@ -110,11 +110,11 @@ FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long l
         if (w <= 0.0) return FG_NEG_INF;
         return -log(w); }
     case 11: { /* LogNormal: :413-434 */
-        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!hoisted && ((!sh && (p1 <= 0.0 || !fg_finite(p1))) || !fg_finite(p0))) return FG_NEG_INF;
         if (xf <= 0.0 || !fg_finite(xf)) return FG_NEG_INF;
         double lx = log(xf);
         double z = pow2 ? (lx - p0) * h[4] : (lx - p0) / p1;
-        double ls = hoisted ? h[0] : log(p1);
+        double ls = (hoisted || sh) ? h[0] : log(p1);
         return -0.5 * z * z - lx - ls - 0.5 * FG_LN_2PI; }
     case 7: { /* Exponential: :503-518 */
         if (!hoisted && (p0 <= 0.0 || !fg_finite(p0))) return FG_NEG_INF;
@@ -173,15 +173,15 @@ FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long l
                              : (fg_lgamma((p0 + 1.0) / 2.0) - fg_lgamma(p0 / 2.0) - 0.5 * (log(p0) + FG_LN_PI) - log(p2));
         return pre - 0.5 * (p0 + 1.0) * log1p(z * z / p0); }
     case 4: { /* Cauchy: :1451-1459 */
-        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!hoisted && ((!sh && (p1 <= 0.0 || !fg_finite(p1))) || !fg_finite(p0))) return FG_NEG_INF;
         if (!fg_finite(xf)) return FG_NEG_INF;
         double z = pow2 ? (xf - p0) * h[4] : (xf - p0) / p1;
-        double pre = hoisted ? h[0] : (-FG_LN_PI - log(p1));
+        double pre = (hoisted || sh) ? h[0] : (-FG_LN_PI - log(p1));
         return pre - log1p(z * z); }
     case 10: { /* Laplace: :1535-1541 */
-        if (!hoisted && (p1 <= 0.0 || !fg_finite(p1) || !fg_finite(p0))) return FG_NEG_INF;
+        if (!hoisted && ((!sh && (p1 <= 0.0 || !fg_finite(p1))) || !fg_finite(p0))) return FG_NEG_INF;
         if (!fg_finite(xf)) return FG_NEG_INF;
-        double pre = hoisted ? h[0] : -log(2.0 * p1);
+        double pre = (hoisted || sh) ? h[0] : -log(2.0 * p1);
         return pow2 ? pre - fabs(xf - p0) * h[4] : pre - fabs(xf - p0) / p1; }
     case 16: { /* Weibull(shape, scale): :1618-1644 */
         if (!hoisted && (p0 <= 0.0 || p1 <= 0.0 || !fg_finite(p0) || !fg_finite(p1))) return FG_NEG_INF;

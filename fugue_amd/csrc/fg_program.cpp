@@ -290,6 +290,16 @@ void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &tem
             }
         }
     }
+    // scale-only hoisting: Normal / LogNormal / Cauchy / Laplace with a constant valid scale and a varying location
+    if (!params_const && (s.dist == FG_NORMAL || s.dist == FG_LOGNORMAL || s.dist == FG_CAUCHY || s.dist == FG_LAPLACE) &&
+        nodes[s.params[1]].is_const) {
+        const double sc = nodes[s.params[1]].cval;
+        if (sc > 0.0 && std::isfinite(sc)) {
+            I.op |= FG_F_SCALEHOIST;
+            I.h[0] = (s.dist == FG_CAUCHY) ? (-FG_LN_PI - std::log(sc)) : (s.dist == FG_LAPLACE) ? -std::log(2.0 * sc) : std::log(sc);
+            if (fg_pow2_scale(sc)) { I.op |= FG_F_POW2SCALE; I.h[4] = 1.0 / sc; }
+        }
+    }
     if (s.kind == 0) {                                   // sample: x is the site's own slot
         I.aux = (uint32_t)site_slot[s.sorted];
         I.opnd[0] = FG_OPND(s.vtype == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, site_slot[s.sorted]);
