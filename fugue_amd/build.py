@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libfugue_amd.so")
-SOURCES = ["fg_program.cpp", "fg_engine.hip", "fg_smc.hip", "fg_diag.hip"]
+SOURCES = ["fg_program.cpp", "fg_dsl.cpp", "fg_engine.hip", "fg_smc.hip", "fg_diag.hip"]
 HEADERS = ["fg_ir.h", "fg_math.h", "fg_interp.h", "fg_program.h", "fg_engine_internal.h", "fg_gradstream.h", os.path.join("..", "..", "include", "fugue_amd.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-DFG_BUILD", "-Wall", "-Wno-unused-function"]

@@ -228,7 +228,7 @@ struct FgGen {
     }
 };
 
-static bool categorical_const_valid(const std::vector<double> &p) {   // distribution.rs:679-715
+bool fg_categorical_const_valid(const std::vector<double> &p) {   // distribution.rs:679-715
     if (p.empty()) return false;
     double sum = 0.0;
     for (double v : p) sum += v;
@@ -263,7 +263,7 @@ void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &tem
             for (double v : pr) pool.push_back(v > 0.0 ? std::log(v) : -INFINITY);   // distribution.rs:785-791
             I.opnd[1] = FG_OPND(FG_OPND_POOL, base);
             I.op |= FG_F_HOISTED;
-            if (!categorical_const_valid(pr)) I.op |= FG_F_INVALID;
+            if (!fg_categorical_const_valid(pr)) I.op |= FG_F_INVALID;
         } else {
             int base = G.new_temp(K);
             for (int k = 0; k < K; k++) { G.gen(s.params[k]); G.store(base + k); }
@@ -473,7 +473,7 @@ static int add_dist_stmt(fg_program *p, int kind, const char *addr, int dist, co
     if (dist == FG_CATEGORICAL) {       // constructor validation of constant probabilities
         bool allc = true; std::vector<double> pr;
         for (int q : s.params) { allc = allc && p->nodes[q].is_const; pr.push_back(p->nodes[q].cval); }
-        if (allc && !categorical_const_valid(pr)) { fg_set_error("Categorical: invalid probability vector"); return FG_ERR_INVALID_PROBABILITY; }
+        if (allc && !fg_categorical_const_valid(pr)) { fg_set_error("Categorical: invalid probability vector"); return FG_ERR_INVALID_PROBABILITY; }
     }
     p->finalized = false;
     if (kind == 0) { s.handle = p->n_samples++; p->stmts.push_back(s); return s.handle; }

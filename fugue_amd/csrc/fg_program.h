@@ -36,6 +36,7 @@ struct fg_program {
     int n_gstream = 0;
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
+    std::vector<std::string> dsl_warnings;   // fg_dsl.cpp
 
     int  parse(const fg_tok *toks, int n);
     void collect_sites(int node, std::vector<int> &out) const;
@@ -43,3 +44,4 @@ struct fg_program {
     int  finalize();
 };
 void fg_set_error(const std::string &s);
+bool fg_categorical_const_valid(const std::vector<double> &p);

@@ -69,9 +69,14 @@ ABI_SYMBOLS = [
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
+    "fg_dsl_compile", "fg_dsl_warning_count", "fg_dsl_warning",
 ]
 
 _lib = None
+
+
+class DslError(ValueError):
+    """Static error of the model DSL (syntax, unknown name, arity); message as the reference words it."""
 
 
 class EngineError(RuntimeError):
@@ -150,6 +155,11 @@ def lib():
     L.fg_device_free.argtypes = [vp, vp]
     L.fg_device_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.fg_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.fg_dsl_compile.restype = vp
+    L.fg_dsl_compile.argtypes = [C.c_char_p, C.c_char_p]
+    L.fg_dsl_warning_count.argtypes = [vp]
+    L.fg_dsl_warning.restype = C.c_char_p
+    L.fg_dsl_warning.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -203,9 +213,14 @@ def _tok_array(toks: List[fg_tok]):
 class CompiledProgram:
     """A finalized `fg_program` (site program) built from a `model.Program` description."""
 
-    def __init__(self, program: M.Program):
+    def __init__(self, program: Optional[M.Program], _handle=None):
         L = lib()
         self.program = program
+        self.warnings: List[str] = []
+        if _handle is not None:           # already finalized by a native front-end (fg_dsl_compile)
+            self.h = _handle
+            self._describe()
+            return
         self.h = L.fg_program_new()
         for name, arr in zip(program.data_names, program.data):
             a = np.ascontiguousarray(arr, dtype=np.float64)
@@ -239,6 +254,24 @@ class CompiledProgram:
             L.fg_program_free(self.h)
             self.h = None
             raise M.FugueError(msg, rc) if rc > 0 else EngineError(rc, msg)
+        self._describe()
+
+    @classmethod
+    def from_dsl(cls, source: str, data=None) -> "CompiledProgram":
+        """`CompiledModel::compile(source, data_json)` of the playground DSL (crates/fugue-wasm/src/dsl.rs:1062-1120):
+        `data` is a JSON string, a dict of arrays, a bare list (bound to `data`) or None."""
+        import json
+        L = lib()
+        dj = data if isinstance(data, str) else ("" if data is None else json.dumps(data))
+        h = L.fg_dsl_compile(source.encode("utf-8"), dj.encode("utf-8"))
+        if not h:
+            raise DslError(last_error())
+        cp = cls(None, _handle=h)
+        cp.warnings = [L.fg_dsl_warning(h, i).decode("utf-8") for i in range(L.fg_dsl_warning_count(h))]
+        return cp
+
+    def _describe(self):
+        L = lib()
         self.S = L.fg_program_n_sites(self.h)
         self.d = L.fg_program_n_f64(self.h)
         self.O = L.fg_program_n_observe(self.h)

@@ -114,6 +114,15 @@ int fg_program_dep_count(const fg_program *p, int k);
 const char *fg_last_error(void);
 int         fg_abi_version(void);
 
+/* Model-language front-end: the `prob!` subset of the reference's playground
+ * (crates/fugue-wasm/src/dsl.rs:10-35 grammar, :1062-1120 CompiledModel::compile).  `data_json` is a JSON
+ * object of number/boolean arrays, a bare array (bound to `data`), "null" or NULL.  Returns a FINALIZED
+ * program, or NULL with the reference-worded message ("line N: expected .., found ..") in
+ * fg_last_error().  Warnings (out-of-bounds data index -> NaN, dsl.rs:715-722) are kept on the program. */
+fg_program *fg_dsl_compile(const char *source_utf8, const char *data_json_utf8);
+int         fg_dsl_warning_count(const fg_program *p);
+const char *fg_dsl_warning(const fg_program *p, int i);
+
 /* ------------------------------------------------------------------ engine
  * One engine = one batch of `n_chains` independent chains (or particles) of one program
  * on one GPU, with its own HIP stream.  Chain c uses the counter-based RNG stream

@@ -150,6 +150,13 @@ inline Dist DiscreteUniform(Expr lo, Expr hi) { detail::need(lo.is_const() && hi
 class Program {
   public:
     Program() : p_(fg_program_new()) {}
+    // CompiledModel::compile (crates/fugue-wasm/src/dsl.rs:1062-1120): a finalized program from `prob!`-subset source
+    static std::unique_ptr<Program> from_dsl(const std::string &source, const std::string &data_json = "") {
+        fg_program *h = fg_dsl_compile(source.c_str(), data_json.c_str());
+        if (!h) throw FugueError(fg_last_error(), ErrorCode::Engine);
+        return std::unique_ptr<Program>(new Program(h));
+    }
+    std::vector<std::string> warnings() const { std::vector<std::string> w; for (int i = 0; i < fg_dsl_warning_count(p_); ++i) w.push_back(fg_dsl_warning(p_, i)); return w; }
     ~Program() { if (p_) fg_program_free(p_); }
     Program(const Program &) = delete;
     Program &operator=(const Program &) = delete;
@@ -176,6 +183,7 @@ class Program {
     int site_index(const Address &a) const { for (int j = 0; j < n_sites(); ++j) if (site_name(j) == a) return j;
         throw FugueError("address not found: " + a, ErrorCode::TraceAddressNotFound); }
   private:
+    explicit Program(fg_program *h) : p_(h) {}
     static void pack(const Dist &d, std::vector<fg_tok> &toks, std::vector<int32_t> &lens) {
         for (auto &e : d.params) { size_t n0 = toks.size(); e.postfix(toks); lens.push_back((int32_t)(toks.size() - n0)); }
     }

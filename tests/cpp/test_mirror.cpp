@@ -52,6 +52,15 @@ int main(int argc, char **argv) {
         Program p; p.sample(addr("x"), Normal(0.0, 1.0)); p.sample(addr("x"), Normal(0.0, 1.0));
         try { p.finalize(); REQUIRE(false); } catch (const FugueError &e) { REQUIRE(e.code == 301); }
     }
+    {   // model-language front-end (crates/fugue-wasm/src/dsl.rs:1149-1187 coin model; :1233-1256 static errors)
+        auto coin = Program::from_dsl("let p <- sample(addr!(\"p\"), Beta(2.0, 2.0));\n"
+                                      "for i in 0..data.len() { observe(addr!(\"flip\", i), Bernoulli(p), data[i]); }\npure(p)",
+                                      "[1,0,1,1,0,1,1,0,1,1]");
+        REQUIRE(coin->n_sites() == 1 && coin->site_name(0) == addr("p") && fg_program_n_observe(coin->raw()) == 10 && coin->warnings().empty());
+        try { Program::from_dsl("pure(nope)"); REQUIRE(false); } catch (const FugueError &e) { REQUIRE(std::string(e.what()).find("unknown variable") != std::string::npos); }
+        try { Program::from_dsl("let x <- sample(addr!(\"x\") Normal(0,1)); pure(x)"); REQUIRE(false); }
+        catch (const FugueError &e) { REQUIRE(std::string(e.what()).find("line 1") != std::string::npos); }
+    }
     if (argc > 1 && std::strcmp(argv[1], "--gpu") == 0) {
         HMCConfig cfg;                                            // HMCConfig::default()
         ChainBatch h = hmc_chain<Expr>(42, readme_model, 200, 200, cfg, 4096);
