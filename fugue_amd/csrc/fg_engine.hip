@@ -81,7 +81,7 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
         // all force terms are fast Normals: (L+1) fused gradient passes, then only the endpoint score below
         for (int gs = 0; gs <= L; ++gs) {
 #ifndef FG_EXP_NOSTREAM
-            bad = fg_grad_stream(P, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            bad = fg_grad_stream(P.gstream, P.n_gstream, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             if (__all(bad)) return true;
 #ifndef FG_EXP_NODRIFT
@@ -266,6 +266,152 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
     }
 }
 
+// ---- multi-wave HmcSession::step for programs with a fused gradient stream ---------------------------------------
+// A single wave can issue one f64 VALU instruction per 16 cycles on gfx950 (tools/mb_clock.hip: a lone wave runs
+// dependent OR independent v_fma_f64 at 16-26 cycles each; the SIMD's f64 pipe only fills with 4 waves in flight).
+// 65 536 chains are 1 024 waves = ONE per SIMD, so a one-wave-per-tile kernel leaves 3/4 of the f64 rate unused.
+// Here a tile of 64 chains is owned by a workgroup of W waves (W = 1, 2 or 4): every coordinate's finite-difference
+// gradient, half-kick, drift and commit is independent of the other coordinates' within one leapfrog step, so wave w
+// does coordinates [seg.c[w], seg.c[w+1]) -- its run of whole coordinates of the gradient stream -- on the SHARED LDS
+// tile, with a workgroup barrier between "all p kicked" and "q drifted" (hmc.rs:389-400: the same operations per
+// coordinate in the same order; only the interleaving BETWEEN coordinates differs, and they do not interact).  The
+// sequential parts (momentum draw, Hamiltonians, endpoint score in program order, accept, dual averaging) stay on
+// wave 0.  Results are bit-identical for every W (tests/test_gpu_parity.py::test_hmc_multiwave_is_bit_identical).
+struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1]; };
+
+__global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSeg seg, int iter0, int n_steps,
+                                                                               int n_warmup, int welford_on, double *draws, int first_sample_t,
+                                                                               double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const long long chain = (long long)blockIdx.x * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + lane;
+    double *pl = lds + (long long)P.n_slots * tw + lane;
+    double *xch = lds + (long long)(P.n_slots + P.d) * tw + lane;      // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
+    const FgGradRec *gs0 = P.gstream + seg.g[wv];
+    const int gn = seg.g[wv + 1] - seg.g[wv];
+    const int d = P.d, L = H.L;
+    const double *mi = H.use_mass ? H.m_inv + c : nullptr;
+    const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+    // wave 0 owns the per-chain sampler state
+    double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
+    unsigned long long da_m = 0, ndiv = 0;
+    if (wv == 0) {
+        fg_load_values(P, X, c, slots, tw);
+        lj = H.lj[c]; eps = H.eps[c]; frozen = H.frozen[c];
+        da_mu = H.da_mu[c]; da_leb = H.da_leb[c]; da_hbar = H.da_hbar[c]; da_m = H.da_m[c];
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const int iter = iter0 + t;
+        const bool warming = iter < n_warmup;
+        double h0 = 0.0, u = 0.0;
+        if (wv == 0) {
+            double e;
+            if (warming) e = eps;
+            else {                                             // frozen_or_current: hmc.rs:789-798
+                if (frozen == frozen) e = frozen;
+                else if (n_warmup > 0) e = exp(da_leb);
+                else e = eps;
+                frozen = e;
+            }
+            FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_HMC);
+#ifndef FG_EXP_NOMOM
+            fg_draw_momentum(P, rng, pl, tw, ms, X.C);
+#endif
+            u = fg_rng_u01(rng);
+            h0 = -lj + fg_kinetic(P, pl, tw, mi, X.C);          // hmc.rs:442-443
+            xch[0] = e;
+        }
+        __syncthreads();
+        const double e = xch[0], hk = 0.5 * e;
+        bool bad = false;
+        for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
+#ifndef FG_EXP_NOSTREAM
+            if (gn > 0) bad = fg_grad_stream(gs0, gn, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+#endif
+            __syncthreads();                                     // every p kicked, every read of q done
+            if (gs < L) {
+                if (mi) { for (int k = k0; k < k1; ++k) slots[k * tw] += e * mi[(long long)k * X.C] * pl[k * tw]; }
+                else    { for (int k = k0; k < k1; ++k) slots[k * tw] += e * pl[k * tw]; }      // eps * 1.0 * p == eps * p
+                __syncthreads();
+            }
+        }
+        xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
+        __syncthreads();
+        if (wv == 0) {
+            bool div = false;
+            for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
+            FgAcc3 A = {0.0, 0.0, 0.0};
+#ifndef FG_EXP_NOSCORE
+            fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);   // score_full
+#endif
+            const double lj_new = fg_total(A);
+            div = div || !fg_finite(lj_new);
+            double ap = 0.0; bool acc = false;
+            if (!div) {
+                const double h_new = -lj_new + fg_kinetic(P, pl, tw, mi, X.C);
+                ap = fmin(exp(h0 - h_new), 1.0);                 // hmc.rs:460
+                acc = u < ap;                                    // hmc.rs:461
+            }
+            if (acc) lj = lj_new;
+            xch[tw] = acc ? 1.0 : 0.0;
+            asum += ap; ndiv += div ? 1ull : 0ull;
+            if (live && info) {                                  // HmcStepInfo: hmc.rs:587-602
+                double *r = info + (long long)t * 4 * X.C + c;
+                r[0] = acc ? 1.0 : 0.0; r[X.C] = div ? 1.0 : 0.0; r[2 * X.C] = ap; r[3 * X.C] = e;
+            }
+            if (warming) {                                       // DualAveraging::update: hmc.rs:168-178
+                da_m += 1ull;
+                const double m = (double)da_m;
+                const double a = ap < 0.0 ? 0.0 : (ap > 1.0 ? 1.0 : ap);
+                const double frac = 1.0 / (m + 10.0);
+                da_hbar = (1.0 - frac) * da_hbar + frac * (H.target - a);
+                const double log_eps = da_mu - (sqrt(m) / 0.05) * da_hbar;
+                const double w = pow(m, -0.75);
+                da_leb = w * log_eps + (1.0 - w) * da_leb;
+                eps = exp(log_eps);
+            }
+        }
+        __syncthreads();
+        const bool acc = xch[tw] != 0.0;
+        unsigned long long wn = 0;
+        if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
+        for (int i = k0; i < k1; ++i) {                           // commit or roll back this wave's f64 sites
+            const long long g = (long long)P.f64_site[i] * X.C + c;
+            if (acc) { if (live) X.values[g] = fg_as_i64(slots[i * tw]); }
+            else slots[i * tw] = fg_as_double(X.values[g]);
+            const double x = slots[i * tw];
+            if (live && pos_all) pos_all[((long long)t * d + i) * X.C + c] = x;
+            if (warming) {
+                if (welford_on) {                                 // Welford::push: hmc.rs:202-211
+                    const long long gi = (long long)i * X.C + c;
+                    const double n = (double)wn;
+                    double mean = H.w_mean[gi];
+                    const double delta = x - mean;
+                    mean += delta / n;
+                    const double delta2 = x - mean;
+                    if (live) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
+                }
+            } else if (draws && live) draws[((long long)(t - first_sample_t) * d + i) * X.C + c] = x;   // hmc.rs:577-582
+        }
+        if (warming && welford_on) {
+            __syncthreads();                                      // all waves hold the old count
+            if (wv == 0 && live) H.w_n[c] = wn;
+        }
+    }
+    if (wv == 0 && live) {
+        H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
+        H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
+        H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
+    }
+}
+
 // hmc_transition with injected momentum / uniform (test hook)
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_injected(FgProgramDev P, FgChainCtx X, FgHmcDev H, double eps,
                                                                      const double *p0, const double *u_in, int *acc_out,
@@ -303,7 +449,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
     if (sparse && P.gstream) {
         double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
         for (int i = 0; i < P.d; ++i) pl[i * tw] = 0.0;
-        good = !fg_grad_stream(P, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
+        good = !fg_grad_stream(P.gstream, P.n_gstream, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
         if (live && ok) ok[c] = good;
         return;
     }
@@ -509,7 +655,9 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->prog = p; e->device = device; e->C = n_chains; e->seed = seed; e->chain0 = chain_offset;
     e->S = (int)p->sorted_stmt.size(); e->d = (int)p->f64_slot.size(); e->n_slots = p->n_slots;
     e->tw = tile_width_for(e->C);
-    e->lds_bytes = (size_t)(e->n_slots + e->d + 1) * e->tw * sizeof(double);
+    e->n_simd = 4 * prop.multiProcessorCount;
+    if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4) e->mw_override = w; }
+    e->lds_bytes = (size_t)(e->n_slots + e->d + 2 + FG_MW_MAX) * e->tw * sizeof(double);   // slots, momentum, multi-wave exchange rows
     while (e->lds_bytes > 160 * 1024 && e->tw > 16) { e->tw >>= 1; e->lds_bytes >>= 1; }
     if (e->lds_bytes > 160 * 1024) {
         fg_set_error("model needs more than 160 KB of LDS per wave (sites + temporaries + momentum > 319 cells)");
@@ -535,7 +683,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
-        set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
+        set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_stream_steps, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
         set_lds(k_hmc_grad, e->lds_bytes) || set_lds(k_hmc_find_eps, e->lds_bytes) ||
         set_lds(k_mh_steps, e->lds_bytes))
         return fail("hipFuncSetAttribute");
@@ -701,7 +849,29 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
 
 static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t,
                             double *pos_all = nullptr, double *info = nullptr) {
-    hipLaunchKernelGGL(k_hmc_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
+    const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
+    if (e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream && e->tw == FG_WAVE) {
+        // waves per tile: aim at 4 waves per SIMD over the whole device (see k_hmc_stream_steps), at least 2 coordinates per wave
+        int W = e->mw_override > 0 ? e->mw_override : 1;
+        if (e->mw_override <= 0) while (W < FG_MW_MAX && (long long)tiles * W * 2 <= 4LL * e->n_simd && e->d >= 4 * W) W *= 2;
+        FgSeg seg;
+        const std::vector<FgGradRec> &gs = e->prog->gstream;
+        const int nrec = e->prog->n_gstream;
+        std::vector<int> cstart(e->d + 1, nrec);                 // first record of each coordinate
+        for (int k = nrec - 1; k >= 0; --k) cstart[gs[k].coord] = k;
+        for (int w = 0; w <= FG_MW_MAX; ++w) { seg.c[w] = e->d; seg.g[w] = nrec; }
+        seg.c[0] = 0; seg.g[0] = 0;
+        for (int w = 1, k = 0; w < W; ++w) {                      // cut at the coordinate boundary nearest to w/W of the records
+            const long long target = (long long)nrec * w / W;
+            while (k < e->d && cstart[k] < target) ++k;
+            seg.c[w] = k; seg.g[w] = cstart[k];
+        }
+        hipLaunchKernelGGL(k_hmc_stream_steps, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, iter0, n,
+                           e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
+        HIPCHK(hipGetLastError());
+        return FG_OK;
+    }
+    hipLaunchKernelGGL(k_hmc_steps, dim3(tiles), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
                        e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     HIPCHK(hipGetLastError());
     return FG_OK;

@@ -96,6 +96,8 @@ struct fg_engine {
     int *d_itmp = nullptr;       // [3][C] scratch
     size_t lds_bytes = 0;
     int tw = 64;               // tile width (threads per block)
+    int n_simd = 1024;         // SIMDs on the device (4 per CU)
+    int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
 
 namespace {

@@ -17,72 +17,111 @@ __device__ __forceinline__ fg_u32x16 fg_fetch_grec(const FgGradRec *g, int k) {
     return *(const FG_AS4 fg_u32x16 *)(uintptr_t)(g + k);
 }
 
-struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
+__device__ __forceinline__ double fg_uniform(double v) {
+    const long long b = __double_as_longlong(v);
+    return fg_dbl(__builtin_amdgcn_readfirstlane((uint32_t)b), __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)));
+}
 
-// one record: r = {xi, mi, flags, coord, ximm, mimm, sigma, inv, lns, 0.5 ln 2pi}; xs, ms = LDS values of
-// its operands; pv = p[coord] (pre-read).  Within a coordinate the prior records come first, then
-// the observe records (FG_G_SWITCH on the first of them): log_prior and log_likelihood are summed
-// separately and added at the end, exactly like total_log_weight (trace.rs:198-200).
-// A non-finite x or mu gives z = NaN or +-inf -> lp NaN or -inf -> a non-finite g -> divergent,
+struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
+struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
+
+// one record: r = {xi, mi, flags, coord, ximm, mimm, sigma, 1/sigma, ln sigma, maskx, maskm}; xs, ms = LDS values
+// of its operands (the always-zero slot for constants); pv = p[coord] (pre-read).  ONE straight-line form for every
+// operand combination: operand value = slot + imm exactly as FG_OP_NORMAL_FAST forms it, perturbation = h & mask
+// (scalar), so the only branches are the rare ones (non-power-of-two sigma, first observe record, last record).
+// Within a coordinate the prior records come first, then the observe records (FG_G_SWITCH on the first of them):
+// log_prior and log_likelihood are summed separately and added at the end, exactly like total_log_weight
+// (trace.rs:198-200).  A non-finite x or mu gives z = NaN or +-inf -> lp NaN or -inf -> a non-finite g -> divergent,
 // the same verdict as the reference's -inf log-density (hmc.rs:323-325); no guard is needed here.
-__device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, double ms, double pv, FgGradAcc &A, double h, double hk,
-                                             bool two_kicks, double *pl, int tw, double *gout, long long gstride, bool live) {
+__device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, double ms, double pv, FgGradAcc &A, const FgGradK &K,
+                                             double *pl, int tw, double *gout, long long gstride, bool live) {
     const uint32_t fl = r[2];
-    const double lns = fg_dbl(r[12], r[13]), c2 = fg_dbl(r[14], r[15]);
-    // x - mu at q_i + h and q_i - h.  A slot operand holds orig +- h when it is the perturbed coordinate
-    // (hmc.rs:317-319) and orig otherwise; a constant operand is its immediate.  (The generic fast Normal
-    // computes `imm + slot` with imm = 0 for slots and slot = 0 for constants: the same values.)
+    // x - mu at q_i + h and q_i - h: the perturbed operand holds orig +- h (hmc.rs:317-319), the other its value
+    // (a constant operand is the record's immediate, a scalar).  Four forms, four additions each, selected by
+    // scalar branches: adding the zero perturbation / the zero slot of a uniform form would give the same bits
+    // for two more f64 instructions per record, and f64 issue is what bounds this loop.
     double dlp, dlm;
-    if (fl & FG_G_M_CONST) {                              // prior-like: x = site, mu constant
-        const double mimm = fg_dbl(r[6], r[7]);
-        const double hx = (fl & FG_G_PERT_X) ? h : 0.0;
-        dlp = (xs + hx) - mimm; dlm = (xs - hx) - mimm;
-    } else if (fl & FG_G_X_CONST) {                       // likelihood-like: x observed constant, mu = site
-        const double ximm = fg_dbl(r[4], r[5]);
-        const double hm = (fl & FG_G_PERT_M) ? h : 0.0;
-        dlp = ximm - (ms + hm); dlm = ximm - (ms - hm);
-    } else {                                              // both are slots (e.g. x#i ~ N(mu, 1))
-        const double hx = (fl & FG_G_PERT_X) ? h : 0.0, hm = (fl & FG_G_PERT_M) ? h : 0.0;
-        dlp = (xs + hx) - (ms + hm); dlm = (xs - hx) - (ms - hm);
+    if (fl & FG_G_PERT_X) {
+        const double xp = xs + K.h, xm = xs - K.h;
+        if (fl & FG_G_M_CONST) { const double m = fg_dbl(r[6], r[7]); dlp = xp - m; dlm = xm - m; }
+        else if (__builtin_expect((fl & FG_G_PERT_M) != 0u, 0)) { dlp = xp - (ms + K.h); dlm = xm - (ms - K.h); }   // x and mu are the same site
+        else { dlp = xp - ms; dlm = xm - ms; }
+    } else {
+        const double mp = ms + K.h, mm = ms - K.h;
+        if (fl & FG_G_X_CONST) { const double x = fg_dbl(r[4], r[5]); dlp = x - mp; dlm = x - mm; }
+        else { dlp = xs - mp; dlm = xs - mm; }
     }
-    double zp, zm;
-    if (fl & FG_G_POW2) { const double inv = fg_dbl(r[10], r[11]); zp = dlp * inv; zm = dlm * inv; }
-    else { const double sg = fg_dbl(r[8], r[9]); zp = dlp / sg; zm = dlm / sg; }
-    const double lpp = -0.5 * zp * zp - lns - c2;       // distribution.rs:207
-    const double lpm = -0.5 * zm * zm - lns - c2;
-    if (fl & FG_G_SWITCH) {                               // a real (scalar) branch, not eight v_cndmask
+    const double inv = fg_dbl(r[10], r[11]);
+    double zp = dlp * inv, zm = dlm * inv;                 // exact quotient when sigma = 2^k
+    if (__builtin_expect(!(fl & FG_G_POW2), 0)) {          // (x - mu) / sigma, distribution.rs:205
+        const double sg = fg_dbl(r[8], r[9]);
+        if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; }
+        else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }
+    }
+    const double lns = fg_dbl(r[12], r[13]);
+    const double lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;       // distribution.rs:207
+    const double lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
+    if (__builtin_expect((fl & FG_G_SWITCH) != 0u, 0)) {  // a real (scalar) branch, not eight v_cndmask
         A.prip = A.sp; A.prim = A.sm; A.sp = 0.0; A.sm = 0.0;
         asm volatile("" ::: "memory");
     }
     A.sp += lpp; A.sm += lpm;
-    if (fl & FG_G_END) {
+    if (__builtin_expect((fl & FG_G_END) != 0u, 0)) {
         // no observe record: the running sums are the prior sums and prip = prim = 0 (= log_likelihood)
-        const double tp = A.prip + A.sp + 0.0, tm = A.prim + A.sm + 0.0;      // total_log_weight, log_factors = 0
-        const double g = (tp - tm) / (2.0 * h);
+        const double tp = A.prip + A.sp, tm = A.prim + A.sm;                 // total_log_weight (log_factors = +0.0 adds nothing)
+        const double n = tp - tm;
+        double g = fg_div_const(n, K.two_h, K.rcp_2h);                       // (lp - lm) / (2h), hmc.rs:322
+        const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
+        if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / K.two_h;   // |n| outside [2^-823, 2^953]
         A.bad = A.bad || !fg_finite(g);
-        double p = pv + hk * g;
-        if (two_kicks) p += hk * g;
+        double p = pv + K.hk * g;
+        if (K.two_kicks) p += K.hk * g;
         pl[r[3] * tw] = p;
         if (gout && live) gout[(long long)r[3] * gstride] = g;
         A.sp = A.sm = A.prip = A.prim = 0.0;
     }
 }
 
+// timing-only experiment switches (tools/exp_breakdown.sh; results are wrong by construction)
+#ifdef FG_EXP_G_NOWAIT
+#define FG_G_WAIT
+#else
+#define FG_G_WAIT __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
+#ifdef FG_EXP_G_NOLDS
+#define FG_G_LDS(RB, XB, MB, PB) XB = x0; MB = x0; PB = x0;
+#else
+#define FG_G_LDS(RB, XB, MB, PB) XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw]; PB = pl[RB[3] * tw];
+#endif
+#ifdef FG_EXP_G_NOMATH
+#define FG_G_MATH(RA, XA, MA, PA) A.sp += XA + MA + PA + fg_dbl(RA[4], RA[5]);
+#else
+#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math(RA, XA, MA, PA, A, K, pl, tw, gout, gstride, live);
+#endif
+#ifdef FG_EXP_G_NOFETCH
+#define FG_G_FETCH(RD) RD = fg_fetch_grec(g, (k + 3) & 1);
+#else
+#define FG_G_FETCH(RD) RD = fg_fetch_grec(g, k + 3);
+#endif
+
 #define FG_GSTAGE(RA, XA, MA, PA, RB, XB, MB, PB, RD)                                              \
-    __builtin_amdgcn_s_waitcnt(0xc07f);            /* lgkmcnt(0): RB, RC (issued a stage ago), XA, MA, PA have landed */ \
-    RD = fg_fetch_grec(g, k + 3);                                                                   \
-    XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw]; PB = pl[RB[3] * tw];                           \
+    FG_G_WAIT                                      /* lgkmcnt(0): RB, RC (issued a stage ago), XA, MA, PA have landed */ \
+    FG_G_FETCH(RD)                                                                                  \
+    FG_G_LDS(RB, XB, MB, PB)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    fg_grec_math(RA, XA, MA, PA, A, h, hk, two_kicks, pl, tw, gout, gstride, live);                 \
+    FG_G_MATH(RA, XA, MA, PA)                                                                       \
     if (++k >= n) break;
 
 // One gradient: every coordinate's g_i and the half-kick(s) on p_i.  Returns "some force
 // component was non-finite" for this lane.  Records are fetched THREE ahead (four rotating
 // 16-SGPR buffers), operands one ahead.
-__device__ __forceinline__ bool fg_grad_stream(const FgProgramDev &P, double *slots, double *pl, int tw, double h, double hk,
+// `g`, `n`: the whole stream (P.gstream, P.n_gstream) or one wave's run of whole coordinates of it (multi-wave HMC);
+// reading up to 3 records past `n` is safe either way (the next wave's records or the pad records).
+__device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, double *slots, double *pl, int tw, double h, double hk,
                                                bool two_kicks, double *gout, long long gstride, bool live) {
-    const FgGradRec *g = P.gstream;
-    const int n = P.n_gstream;
+    FgGradK K;
+    K.h = fg_uniform(h); K.hk = hk; K.two_kicks = two_kicks;
+    K.two_h = fg_uniform(2.0 * h); K.rcp_2h = fg_uniform(1.0 / (2.0 * h));     // wave-uniform: keep them in SGPRs, not in (spillable) VGPRs
     FgGradAcc A = {0.0, 0.0, 0.0, 0.0, false};   // running sums, stashed prior sums
     fg_u32x16 r0 = fg_fetch_grec(g, 0), r1 = fg_fetch_grec(g, 1), r2 = fg_fetch_grec(g, 2), r3;
     double x0 = slots[r0[0] * tw], m0 = slots[r0[1] * tw], p0 = pl[r0[3] * tw];

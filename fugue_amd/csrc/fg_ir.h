@@ -62,15 +62,16 @@ struct FgCoord { int slot, sub_off, sub_n, flags; };
 enum : uint32_t { FG_G_SWITCH = 1u,   // first observe record of a coordinate: stash the prior sums, restart the running sums
                   FG_G_POW2 = 2u, FG_G_PERT_X = 4u, FG_G_PERT_M = 8u, FG_G_END = 16u,
                   FG_G_X_CONST = 32u,  // x is a constant (ximm), no slot read
-                  FG_G_M_CONST = 64u   // mu is a constant (mimm), no slot read
+                  FG_G_M_CONST = 64u,  // mu is a constant (mimm), no slot read
+                  FG_G_DIV = 128u      // sigma outside the range where fg_div_const is proven exact: IEEE division
 };
 struct FgGradRec {
     uint32_t xi, mi;        // slot indices of x and mu (the zero slot for constants)
     uint32_t flags, coord;  // FG_G_*; f64 coordinate this record belongs to
-    double ximm, mimm;      // constants of x, mu (0 for slots)
-    double sigma, inv;      // sigma and, when FG_G_POW2, 1/sigma
+    double ximm, mimm;      // constants of x, mu (0 for slots): operand value = slot + imm, like FG_OP_NORMAL_FAST
+    double sigma, inv;      // sigma and RN(1/sigma) (exact when FG_G_POW2; seed of the exact-division sequence otherwise)
     double lns;             // ln sigma
-    double half_ln_2pi;     // 0.5 * ln(2 pi) (kept in the record so that all 16 dwords of the scalar load are live)
+    uint32_t maskx, maskm;  // all-ones when x / mu IS the perturbed coordinate: h_eff = h & mask, no branch
 };
 static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
 

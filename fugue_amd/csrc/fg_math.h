@@ -43,6 +43,26 @@ FG_HD double fg_clamp(double x, double lo, double hi) { return x < lo ? lo : (x 
 // reference's own evaluation order, into h[0..4].  Returns false when the constant
 // parameters are invalid (log-density identically -inf).
 // ---------------------------------------------------------------------------------------
+// a / b for a divisor b whose correctly rounded reciprocal y = RN(1/b) is known (computed once, by IEEE division, on
+// the host or per launch).  Markstein's sequence: q0 = a y is within 1.5 ulp of a/b; r = a - q b is exact in an FMA;
+// q1 = q0 + r0 y is a faithful quotient; repeating the step from a faithful quotient yields the CORRECTLY ROUNDED a/b
+// (Markstein 1990, Thm 4: needs y = RN(1/b) and a significand of b that is not all ones) -- the same bits as the
+// reference's `/`, in 5 full-rate instructions instead of the 13-instruction v_div_scale / v_rcp / v_div_fixup expansion.
+// Valid while nothing over/underflows: fg_div_const_ok(b) bounds b, callers bound a or accept that a non-finite a gives
+// NaN where IEEE gives +-inf (both are "non-finite" to every consumer on this path).  tests/test_oracle_kats.py checks
+// 1e7 random and adversarial (near-midpoint) quotients against `/` on the host build of this function.
+FG_HD double fg_div_const(double a, double b, double y) {
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-q0, b, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-q1, b, a);
+    return __builtin_fma(r1, y, q1);
+}
+FG_HD bool fg_div_const_ok(double b) {
+    unsigned long long u; __builtin_memcpy(&u, &b, 8);
+    const unsigned e = (unsigned)((u >> 52) & 0x7ffu);
+    return e > 1023u - 400u && e < 1023u + 400u && (u & 0xfffffffffffffull) != 0xfffffffffffffull;
+}
 FG_HD bool fg_hoist(uint32_t kind, double p0, double p1, double p2, double *h) {
     h[0] = h[1] = h[2] = h[3] = h[4] = 0.0;
     switch (kind) {

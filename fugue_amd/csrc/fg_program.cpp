@@ -415,14 +415,15 @@ int fg_program::finalize() {
                               (q + 1 == order.size() ? FG_G_END : 0u) |
                               (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | (r.mi == (uint32_t)zero_slot ? FG_G_M_CONST : 0u);
                     seen_obs = seen_obs || obs;
-                    r.ximm = F.imm[0]; r.mimm = F.imm[1]; r.sigma = F.imm[2]; r.inv = F.h[4]; r.lns = F.h[0];
-                    r.half_ln_2pi = 0.5 * FG_LN_2PI;
+                    r.ximm = F.imm[0]; r.mimm = F.imm[1]; r.sigma = F.imm[2]; r.inv = 1.0 / F.imm[2]; r.lns = F.h[0];
+                    if (!(F.op & FG_F_POW2SCALE) && !fg_div_const_ok(r.sigma)) r.flags |= FG_G_DIV;
+                    r.maskx = (r.flags & FG_G_PERT_X) ? 0xffffffffu : 0u; r.maskm = (r.flags & FG_G_PERT_M) ? 0xffffffffu : 0u;
                     gstream.push_back(r);
                 }
             }
             n_gstream = (int)gstream.size();
             FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
-            pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2; pad.half_ln_2pi = 0.5 * FG_LN_2PI;
+            pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2;
             for (int q = 0; q < 4; q++) gstream.push_back(pad);   // the stream is read 3 records ahead
         }
     }

@@ -74,3 +74,21 @@ ZOO = {
     "mixture": lambda: W.mixture(W.mixture_data(10)[0]),
     "alldists": all_dists_model,
 }
+
+
+def hier_normal(groups: int = 5, per_group: int = 3) -> M.Program:
+    """Hierarchical Normal with known scales: every force term is a Normal whose x and mu are sites or
+    constants, so the fused gradient stream applies, with coordinates that read EACH OTHER (mu <-> m#g)
+    and very different record counts per coordinate (mu has 1 + groups, m#g has 2 + per_group)."""
+    P = M.Program()
+    mu = P.sample(M.addr("mu"), M.Normal(0.5, 2.0))
+    rng = np.random.default_rng(3)
+    for g in range(groups):
+        m = P.sample(M.addr("m", g), M.Normal(mu, 0.7))
+        P.observe(M.addr("anchor", g), M.Normal(m, 3.0), 0.25 * g)          # mu = site, sigma not a power of two
+        for j in range(per_group):
+            P.observe(M.addr("y", g * per_group + j), M.Normal(m, 0.5 + 0.25 * j), float(rng.normal(0.3 * g, 1.0)))
+    return P
+
+
+ZOO["hier"] = hier_normal

@@ -189,7 +189,8 @@ def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, tar
 
 @pytest.mark.parametrize("name,mode", [("readme", E.GRAD_FD_DENSE), ("normal32", E.GRAD_FD_DENSE),
                                        ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_DENSE),
-                                       ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE)])
+                                       ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE),
+                                       ("hier", E.GRAD_FD_SPARSE), ("hier", E.GRAD_FD_DENSE)])
 def test_hmc_session_matches_oracle_teacher_forced(oracle, name, mode):
     """HmcSession (hmc.rs:667-920) step by step: prior init, Alg. 4 step size, every transition's
     HmcStepInfo, the dual-averaging recursion and the frozen step size -- each checked against
@@ -315,3 +316,25 @@ def test_hmc_posterior_closed_form():
     assert np.abs(draws.mean(axis=(0, 2)) - mean).max() < 1e-3
     assert np.abs(draws.var(axis=(0, 2)) - var).max() < 5e-3
     assert 0.6 < st.accept_rate < 0.95 and st.n_divergent == 0
+
+
+@pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("hier", True), ("readme", False)])
+def test_hmc_multiwave_is_bit_identical(name, adapt_mass, monkeypatch):
+    """k_hmc_stream_steps splits a tile's coordinates over 1, 2 or 4 waves; the per-coordinate operations and
+    their order are the same, so draws, step sizes, mass matrix and log-joint must agree BIT FOR BIT."""
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 192, 40, 25
+    out = []
+    for W in (1, 2, 4):
+        monkeypatch.setenv("FG_HMC_WAVES", str(W))
+        eng = E.Engine(cp, C, seed=21, chain_offset=5)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
+                    eng.hmc_mass() if adapt_mass else None))
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0

@@ -1,13 +1,14 @@
 #!/bin/bash
-# timing-only experiment builds (results are wrong by construction): which part of a gradient pass costs what
-for defs in "" "FG_EXP_NODRIFT" "FG_EXP_NOSTREAM" "FG_EXP_NODRIFT,FG_EXP_NOSTREAM"; do
+# timing-only experiment builds (results are wrong by construction): which part of a transition costs what
+for defs in "" "FG_EXP_NOSTREAM" "FG_EXP_NOSCORE" "FG_EXP_NOMOM" "FG_EXP_NOSTREAM,FG_EXP_NOSCORE,FG_EXP_NOMOM" "FG_EXP_G_NOMATH"; do
   FG_EXTRA_DEFS=$defs python fugue_amd/build.py --force > /dev/null 2>&1
-  for L in 16 64; do
-    python bench.py --steps 50 --warmup 0 --launch 25 --leapfrog $L --no-cpu-baseline 2>/dev/null | python -c "
+  for w in 1 4; do
+    FG_HMC_WAVES=$w python bench.py --steps 50 --warmup 0 --launch 25 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); print('defs=[$defs] L=$L launch_ms=%.3f' % j['roofline']['avg_launch_ms'])
+        j = json.loads(l); print('defs=[$defs] waves=$w launch_ms=%.3f' % j['roofline']['avg_launch_ms'])
 "
   done
 done
+python fugue_amd/build.py --force > /dev/null 2>&1
