@@ -311,6 +311,20 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         const int iter = iter0 + t;
         const bool warming = iter < n_warmup;
         double h0 = 0.0, u = 0.0;
+        // p0 ~ N(0, M) (hmc.rs:436-441): Box-Muller pair j of the chain's (iteration) Philox stream is block j, so the
+        // pairs are drawn by whichever wave gets them -- the values do not depend on who draws
+        FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_HMC);
+        const int n_pairs = (d + 1) >> 1;
+#ifndef FG_EXP_NOMOM
+        for (int j = wv; j < n_pairs; j += W) {
+            double z0, z1;
+            rng.c1 = (uint32_t)j;
+            fg_rng_normal_pair(rng, z0, z1);
+            const int i = 2 * j;
+            pl[i * tw] = z0 * (ms ? ms[(long long)i * X.C] : 1.0);
+            if (i + 1 < d) pl[(i + 1) * tw] = z1 * (ms ? ms[(long long)(i + 1) * X.C] : 1.0);
+        }
+#endif
         if (wv == 0) {
             double e;
             if (warming) e = eps;
@@ -320,14 +334,12 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
                 else e = eps;
                 frozen = e;
             }
-            FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_HMC);
-#ifndef FG_EXP_NOMOM
-            fg_draw_momentum(P, rng, pl, tw, ms, X.C);
-#endif
+            rng.c1 = (uint32_t)n_pairs;
             u = fg_rng_u01(rng);
-            h0 = -lj + fg_kinetic(P, pl, tw, mi, X.C);          // hmc.rs:442-443
             xch[0] = e;
         }
+        __syncthreads();
+        if (wv == 0) h0 = -lj + fg_kinetic(P, pl, tw, mi, X.C);  // hmc.rs:442-443 (all of p0, before any kick)
         __syncthreads();
         const double e = xch[0], hk = 0.5 * e;
         bool bad = false;
@@ -349,7 +361,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
             for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
             FgAcc3 A = {0.0, 0.0, 0.0};
 #ifndef FG_EXP_NOSCORE
-            fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);   // score_full
+            if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, slots, tw, A);                                    // score_full, hmc.rs:283-299
+            else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
 #endif
             const double lj_new = fg_total(A);
             div = div || !fg_finite(lj_new);
@@ -669,6 +682,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_upload(&e->d_ins_fast, p->ins_fast)) return fail("upload ins_fast");
     if (dev_upload(&e->d_coord, p->coord)) return fail("upload coord");
     if (dev_upload(&e->d_gstream, p->gstream)) return fail("upload gstream");
+    if (dev_upload(&e->d_sstream, p->sstream)) return fail("upload sstream");
     if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
     if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
@@ -678,7 +692,8 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_alloc(&e->d_acc, (size_t)3 * e->C)) return fail("alloc acc");
     if (dev_alloc(&e->d_tmp, (size_t)e->C)) return fail("alloc tmp");
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
-    e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
+    e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream;
+    e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
@@ -697,7 +712,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->hmc_allocs) hipFree(q);
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
-    void *ptrs[] = { e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);

@@ -136,3 +136,33 @@ __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, 
     __builtin_amdgcn_s_waitcnt(0xc07f);
     return A.bad;
 }
+
+// The endpoint score of an all-fast-Normal program: one record per statement in program order, the same values and
+// the same additions as FG_OP_NORMAL_FAST in the interpreter (operand = slot or immediate; z != z -> -inf guard;
+// log_prior and log_likelihood accumulated separately).  Records are fetched two ahead, operands one ahead.
+__device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, double ms, FgAcc3 &A) {
+    const uint32_t fl = r[2];
+    const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs, m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
+    const double dl = x - m, inv = fg_dbl(r[10], r[11]);
+    double z = dl * inv;
+    if (__builtin_expect(!(fl & FG_G_POW2), 0)) {
+        const double sg = fg_dbl(r[8], r[9]);
+        z = (fl & FG_G_DIV) ? dl / sg : fg_div_const(dl, sg, inv);
+    }
+    double lp = -0.5 * z * z - fg_dbl(r[12], r[13]) - 0.5 * FG_LN_2PI;
+    lp = (z != z) ? FG_NEG_INF : lp;
+    if (fl & FG_S_OBS) A.lik += lp; else A.prior += lp;
+}
+__device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n, const double *slots, int tw, FgAcc3 &A) {
+    fg_u32x16 r0 = fg_fetch_grec(g, 0), r1 = fg_fetch_grec(g, 1), r2;
+    double x0 = slots[r0[0] * tw], m0 = slots[r0[1] * tw], x1, m1;
+    for (int k = 0; k < n; ++k) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        r2 = fg_fetch_grec(g, k + 2);
+        x1 = slots[r1[0] * tw]; m1 = slots[r1[1] * tw];
+        __builtin_amdgcn_sched_barrier(0);
+        fg_score_one(r0, x0, m0, A);
+        r0 = r1; r1 = r2; x0 = x1; m0 = m1;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+}

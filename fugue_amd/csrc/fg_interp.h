@@ -118,7 +118,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             const double xv = FG_I_IMM(I, 0) + slots[FG_I_OPND(I, 0) * tw];
             const double mv = FG_I_IMM(I, 1) + slots[FG_I_OPND(I, 1) * tw];
             const double dl = xv - mv;
-            const double z = (op & FG_F_POW2SCALE) ? dl * fg_ins_h(I, 4) : dl / FG_I_IMM(I, 2);
+            double z = dl * fg_ins_h(I, 4);                                        // exact quotient when sigma = 2^k
+            if (!(op & FG_F_POW2SCALE)) z = (op & FG_F_RCPSCALE) ? fg_div_const(dl, FG_I_IMM(I, 2), fg_ins_h(I, 4)) : dl / FG_I_IMM(I, 2);
             double lp = -0.5 * z * z - fg_ins_h(I, 0) - 0.5 * FG_LN_2PI;
             lp = (z != z) ? FG_NEG_INF : lp;
             if (op & FG_F_OBSERVE) A.lik += lp;

@@ -38,6 +38,7 @@ enum : uint32_t {
     FG_F_INVALID = 1u << 10,       // constant parameters are invalid: log-density is -inf
     FG_F_POW2SCALE = 1u << 11,     // hoisted scale is 2^k: h[4] = 1/scale, (x-loc)/scale == (x-loc)*h[4] exactly
     FG_F_VTYPE_SHIFT = 12,         // 3 bits: FG_F64..FG_I64
+    FG_F_RCPSCALE = 1u << 16,      // h[4] = RN(1/scale) and fg_div_const_ok(scale): (x - loc) / scale via fg_div_const (same bits)
     FG_F_SCALEHOIST = 1u << 15     // location-scale family with a constant valid scale but a varying location:
                                    // h[0] = the scale-only term (ln sigma, ...), h[4] = 1/scale when FG_F_POW2SCALE
 };
@@ -59,7 +60,8 @@ struct FgCoord { int slot, sub_off, sub_n, flags; };
 
 // One record of the fused finite-difference gradient stream (programs whose sub-programs are all
 // FG_OP_NORMAL_FAST): the instruction plus which of its operands is the perturbed coordinate.
-enum : uint32_t { FG_G_SWITCH = 1u,   // first observe record of a coordinate: stash the prior sums, restart the running sums
+enum : uint32_t { FG_S_OBS = 1u,      // score stream: the record is an observe statement (adds to log_likelihood)
+                  FG_G_SWITCH = 1u,   // first observe record of a coordinate: stash the prior sums, restart the running sums
                   FG_G_POW2 = 2u, FG_G_PERT_X = 4u, FG_G_PERT_M = 8u, FG_G_END = 16u,
                   FG_G_X_CONST = 32u,  // x is a constant (ximm), no slot read
                   FG_G_M_CONST = 64u,  // mu is a constant (mimm), no slot read
@@ -86,7 +88,8 @@ struct FgProgramDev {
     const int    *site_slot; // [S] LDS slot of each site: f64 sites first (coordinate order), then the discrete sites
     const int    *site_vtype;// [S]
     const FgGradRec *gstream;  // fused gradient stream or null
-    int n_gstream;
+    const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
+    int n_gstream, n_sstream;
     int n_ins, n_slots, S, d;
 };
 

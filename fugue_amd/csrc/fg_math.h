@@ -49,8 +49,8 @@ FG_HD double fg_clamp(double x, double lo, double hi) { return x < lo ? lo : (x 
 // (Markstein 1990, Thm 4: needs y = RN(1/b) and a significand of b that is not all ones) -- the same bits as the
 // reference's `/`, in 5 full-rate instructions instead of the 13-instruction v_div_scale / v_rcp / v_div_fixup expansion.
 // Valid while nothing over/underflows: fg_div_const_ok(b) bounds b, callers bound a or accept that a non-finite a gives
-// NaN where IEEE gives +-inf (both are "non-finite" to every consumer on this path).  tests/test_oracle_kats.py checks
-// 1e7 random and adversarial (near-midpoint) quotients against `/` on the host build of this function.
+// NaN where IEEE gives +-inf (both are "non-finite" to every consumer on this path).  tests/cpp/test_div_const.cpp checks
+// 2e7 random and adversarial (near-midpoint) quotients against `/` on the host build of this function.
 FG_HD double fg_div_const(double a, double b, double y) {
     const double q0 = a * y;
     const double r0 = __builtin_fma(-q0, b, a);

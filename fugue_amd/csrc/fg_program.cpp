@@ -376,6 +376,7 @@ int fg_program::finalize() {
         F.aux = I.aux;
         F.h[0] = std::log(sg);                                   // ln(sigma), distribution.rs:207
         if (fg_pow2_scale(sg)) { F.op |= FG_F_POW2SCALE; F.h[4] = 1.0 / sg; }
+        else if (fg_div_const_ok(sg)) { F.op |= FG_F_RCPSCALE; F.h[4] = 1.0 / sg; }
         I = F;
     }
     // per-coordinate sub-programs for the sparse finite difference (built from the score-only variant)
@@ -425,6 +426,28 @@ int fg_program::finalize() {
             FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
             pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2;
             for (int q = 0; q < 4; q++) gstream.push_back(pad);   // the stream is read 3 records ahead
+        }
+    }
+    // score stream: when the WHOLE program is fast Normals its endpoint score (score_full, hmc.rs:283-299) is a lean
+    // pass over one 64-byte record per statement, in program order (the accumulation order of PriorHandler /
+    // ScoreGivenTrace), instead of a pass of the general interpreter
+    sstream.clear(); n_sstream = 0;
+    {
+        bool ok = !ins_fast.empty();
+        for (const FgIns &F : ins_fast) ok = ok && FG_INS_OPCODE(F.op) == FG_OP_NORMAL_FAST;
+        if (ok) {
+            for (const FgIns &F : ins_fast) {
+                FgGradRec r; std::memset(&r, 0, sizeof(r));
+                r.xi = F.opnd[0]; r.mi = F.opnd[1];
+                r.flags = ((F.op & FG_F_OBSERVE) ? FG_S_OBS : 0u) | ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) | ((F.op & (FG_F_POW2SCALE | FG_F_RCPSCALE)) ? 0u : FG_G_DIV) |
+                          (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | (r.mi == (uint32_t)zero_slot ? FG_G_M_CONST : 0u);
+                r.ximm = F.imm[0]; r.mimm = F.imm[1]; r.sigma = F.imm[2]; r.inv = 1.0 / F.imm[2]; r.lns = F.h[0];
+                sstream.push_back(r);
+            }
+            n_sstream = (int)sstream.size();
+            FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
+            pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2;
+            for (int q = 0; q < 4; q++) sstream.push_back(pad);
         }
     }
     if (pool.empty()) pool.push_back(0.0);

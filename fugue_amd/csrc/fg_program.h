@@ -34,6 +34,8 @@ struct fg_program {
     std::vector<FgCoord> coord;
     std::vector<FgGradRec> gstream;   // empty unless every sub-program is all-fast
     int n_gstream = 0;
+    std::vector<FgGradRec> sstream;   // empty unless the whole program is fast Normals
+    int n_sstream = 0;
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
     std::vector<std::string> dsl_warnings;   // fg_dsl.cpp

@@ -33,3 +33,13 @@ def test_cpp_mirror_runs_inference_on_gpu(tmp_path):
     r = subprocess.run([exe, "--gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C++ mirror OK" in r.stdout
+
+
+def test_constant_division_matches_ieee_division(tmp_path):
+    """fg_div_const (Markstein's sequence with RN(1/b)) == a / b bit for bit on 2e7 random and adversarial quotients."""
+    exe = str(tmp_path / "test_div_const")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_div_const.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches 0" in r.stdout
