@@ -297,6 +297,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
     const FgGradRec *gs0 = P.gstream + seg.g[wv];
     const int gn = seg.g[wv + 1] - seg.g[wv];
     const int d = P.d, L = H.L;
+    const bool dense = H.grad_mode == FG_GRAD_FD_DENSE;          // whole-program finite difference over the score stream
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
     // wave 0 owns the per-chain sampler state
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         bool bad = false;
         for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
 #ifndef FG_EXP_NOSTREAM
-            if (gn > 0) bad = fg_grad_stream(gs0, gn, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            if (dense) bad = fg_grad_dense_stream(P.sstream, P.n_sstream, k0, k1, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            else if (gn > 0) bad = fg_grad_stream(gs0, gn, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             __syncthreads();                                     // every p kicked, every read of q done
             if (gs < L) {
@@ -865,10 +867,17 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
 static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t,
                             double *pos_all = nullptr, double *info = nullptr) {
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
-    if (e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream && e->tw == FG_WAVE) {
-        // waves per tile: aim at 4 waves per SIMD over the whole device (see k_hmc_stream_steps), at least 2 coordinates per wave
+    const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr;
+    if (((e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
+        // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
+        // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
+        // a tile, whatever the chain count; each wave should still own at least 2 coordinates
         int W = e->mw_override > 0 ? e->mw_override : 1;
-        if (e->mw_override <= 0) while (W < FG_MW_MAX && (long long)tiles * W * 2 <= 4LL * e->n_simd && e->d >= 4 * W) W *= 2;
+        if (e->mw_override <= 0) {
+            const long long n_cu = std::max(1, e->n_simd / 4);
+            const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)e->lds_bytes, ((long long)tiles + n_cu - 1) / n_cu));
+            while (W < FG_MW_MAX && resident * W < 16 && e->d >= 4 * W) W *= 2;
+        }
         FgSeg seg;
         const std::vector<FgGradRec> &gs = e->prog->gstream;
         const int nrec = e->prog->n_gstream;
@@ -876,8 +885,9 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         for (int k = nrec - 1; k >= 0; --k) cstart[gs[k].coord] = k;
         for (int w = 0; w <= FG_MW_MAX; ++w) { seg.c[w] = e->d; seg.g[w] = nrec; }
         seg.c[0] = 0; seg.g[0] = 0;
-        for (int w = 1, k = 0; w < W; ++w) {                      // cut at the coordinate boundary nearest to w/W of the records
-            const long long target = (long long)nrec * w / W;
+        for (int w = 1, k = 0; w < W; ++w) {
+            if (dense_stream) { seg.c[w] = (int)((long long)e->d * w / W); seg.g[w] = 0; continue; }   // every coordinate costs one whole-program pass
+            const long long target = (long long)nrec * w / W;     // cut at the coordinate boundary nearest to w/W of the records
             while (k < e->d && cstart[k] < target) ++k;
             seg.c[w] = k; seg.g[w] = cstart[k];
         }

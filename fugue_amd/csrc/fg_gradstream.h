@@ -166,3 +166,63 @@ __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n,
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
+
+// grad_log_joint VERBATIM (hmc.rs:304-329) for an all-fast-Normal program: for every coordinate i of [k0, k1) the
+// WHOLE program is scored at q + h e_i and at q - h e_i (two full passes of the score stream, fused: a statement
+// that does not read q_i has the same value in both passes and is evaluated once, which changes no bit), the
+// three accumulators are summed like total_log_weight, g_i = (lp - lm) / (2h), and p_i is kicked.  Nothing is
+// written to the shared q tile -- the perturbation is applied to the operand on the fly (coordinate i lives in
+// slot i) -- so the waves of a tile can work on different coordinates at the same time.
+__device__ __forceinline__ bool fg_grad_dense_stream(const FgGradRec *g, const int n, int k0, int k1, const double *slots, double *pl, int tw,
+                                                     double h, double hk, bool two_kicks, double *gout, long long gstride, bool live) {
+    const double hu = fg_uniform(h), two_h = fg_uniform(2.0 * h), rcp_2h = fg_uniform(1.0 / (2.0 * h));
+    bool bad = false;
+    for (int i = k0; i < k1; ++i) {
+        FgAcc3 Ap = {0.0, 0.0, 0.0}, Am = {0.0, 0.0, 0.0};
+        fg_u32x16 r0 = fg_fetch_grec(g, 0), r1 = fg_fetch_grec(g, 1), r2;
+        double x0 = slots[r0[0] * tw], m0 = slots[r0[1] * tw], x1, m1;
+        for (int k = 0; k < n; ++k) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            r2 = fg_fetch_grec(g, k + 2);
+            x1 = slots[r1[0] * tw]; m1 = slots[r1[1] * tw];
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const uint32_t fl = r0[2];
+                const double x = (fl & FG_G_X_CONST) ? fg_dbl(r0[4], r0[5]) : x0, m = (fl & FG_G_M_CONST) ? fg_dbl(r0[6], r0[7]) : m0;
+                const double inv = fg_dbl(r0[10], r0[11]), lns = fg_dbl(r0[12], r0[13]);
+                const bool dep_x = r0[0] == (uint32_t)i, dep_m = r0[1] == (uint32_t)i;       // scalar: does this statement read q_i?
+                double lpp, lpm;
+                if (dep_x || dep_m) {
+                    const double hx = dep_x ? hu : 0.0, hm = dep_m ? hu : 0.0;
+                    const double dlp = (x + hx) - (m + hm), dlm = (x - hx) - (m - hm);
+                    double zp = dlp * inv, zm = dlm * inv;
+                    if (__builtin_expect(!(fl & FG_G_POW2), 0)) {
+                        const double sg = fg_dbl(r0[8], r0[9]);
+                        if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; } else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }
+                    }
+                    lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI; lpp = (zp != zp) ? FG_NEG_INF : lpp;
+                    lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI; lpm = (zm != zm) ? FG_NEG_INF : lpm;
+                } else {
+                    const double dl = x - m;
+                    double z = dl * inv;
+                    if (__builtin_expect(!(fl & FG_G_POW2), 0)) { const double sg = fg_dbl(r0[8], r0[9]); z = (fl & FG_G_DIV) ? dl / sg : fg_div_const(dl, sg, inv); }
+                    lpp = -0.5 * z * z - lns - 0.5 * FG_LN_2PI; lpp = (z != z) ? FG_NEG_INF : lpp;
+                    lpm = lpp;
+                }
+                if (fl & FG_S_OBS) { Ap.lik += lpp; Am.lik += lpm; } else { Ap.prior += lpp; Am.prior += lpm; }
+            }
+            r0 = r1; r1 = r2; x0 = x1; m0 = m1;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const double nn = fg_total(Ap) - fg_total(Am);
+        double gi = fg_div_const(nn, two_h, rcp_2h);                                   // hmc.rs:322
+        const uint32_t ne = (uint32_t)(__double_as_longlong(nn) >> 32) & 0x7fffffffu;
+        if (__builtin_expect(__any(!(nn == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) gi = nn / two_h;
+        bad = bad || !fg_finite(gi);
+        double p = pl[i * tw] + hk * gi;
+        if (two_kicks) p += hk * gi;
+        pl[i * tw] = p;
+        if (gout && live) gout[(long long)i * gstride] = gi;
+    }
+    return bad;
+}

@@ -318,8 +318,10 @@ def test_hmc_posterior_closed_form():
     assert 0.6 < st.accept_rate < 0.95 and st.n_divergent == 0
 
 
-@pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("hier", True), ("readme", False)])
-def test_hmc_multiwave_is_bit_identical(name, adapt_mass, monkeypatch):
+@pytest.mark.parametrize("name,adapt_mass,mode", [("normal32", False, E.GRAD_FD_SPARSE), ("normal32", True, E.GRAD_FD_SPARSE),
+                                                  ("hier", True, E.GRAD_FD_SPARSE), ("readme", False, E.GRAD_FD_SPARSE),
+                                                  ("normal32", True, E.GRAD_FD_DENSE), ("hier", False, E.GRAD_FD_DENSE)])
+def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """k_hmc_stream_steps splits a tile's coordinates over 1, 2 or 4 waves; the per-coordinate operations and
     their order are the same, so draws, step sizes, mass matrix and log-joint must agree BIT FOR BIT."""
     cp = E.compile_model(ZOO[name]())
@@ -329,7 +331,7 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, monkeypatch):
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
-        st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
+        st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
         draws = eng.download(d, (ns, cp.d, C))
         eng.device_free(d)
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
