@@ -14,7 +14,7 @@ rank runs its own 65 536 chains; no data-path collective; the cross-chain R-hat 
 per-chain moments runs after the timed region).
 
 One JSON line on stdout (rank 0).  Extra objects:
-  roofline     -- the dominant kernel (k_hmc_steps) against the HBM roof, algorithmic bytes
+  roofline     -- the dominant kernel (k_hmc_stream_steps) against the HBM roof, algorithmic bytes
                   32*d B per leapfrog step / HIP-event time; the kernel is
                   f64-VALU bound by construction (state lives in LDS), see `valu_f64`.
   cpu_baseline -- the CPU oracle (restatement of the reference algorithm, dense FD) timed on
@@ -75,7 +75,7 @@ def cpu_baseline(args):
 
 
 def measured_traffic(chains, n_launch, grad):
-    """HBM bytes per launch of k_hmc_steps from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    """HBM bytes per launch of the HMC kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
     profiles/round1_hbm_traffic.json); only reported when the run matches the profiled configuration."""
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", "round1_hbm_traffic.json")))
@@ -205,7 +205,7 @@ def main():
 
     total_lf = world * C * K * L
     value = total_lf / dt
-    # ---- roofline of the dominant kernel (k_hmc_steps) -----------------------------------
+    # ---- roofline of the dominant kernel (k_hmc_stream_steps) -----------------------------------
     alg_bytes_per_launch = C * n_launch * (L * 32 * d + 8 * d + 16)       # 32*d B / leapfrog step (+ draw row, lj, eps)
     achieved_gbs = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
     evals_per_transition = (2 * d * (L + 1)) * (2 if mode == E.GRAD_FD_SPARSE else 2 * N_SITES) + 2 * N_SITES   # log-pdf evaluations
@@ -220,14 +220,18 @@ def main():
                    "n_leapfrog": L, "grad": args.grad, "transitions_per_launch": n_launch,
                    "sharding": f"chains x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(C, n_launch, args.grad), "kernel": "k_hmc_steps",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(C, n_launch, args.grad), "kernel": "k_hmc_stream_steps",
                      "avg_launch_ms": launch_ms,
                      "note": "achieved = SURVEY 8d algorithmic bytes (32*d B per leapfrog step, as if q,p round-tripped HBM) / HIP-event time; "
-                             "the kernel keeps q,p in LDS for a whole launch, so measured traffic is ~30x smaller and the kernel is "
-                             "instruction-issue / f64-VALU bound, not HBM bound (see valu_f64)"},
+                             "the kernel keeps q,p in LDS for a whole launch, so measured traffic (rocprofv3 FETCH_SIZE+WRITE_SIZE, "
+                             "profiles/round1_hbm_traffic.json) is ~23x smaller and the kernel is f64-VALU / instruction-issue bound, "
+                             "not HBM bound (see valu_f64)"},
         "valu_f64": {"achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS,
-                     "logpdf_evals_per_transition": evals_per_transition, "flops_per_logpdf": flops_per_logpdf},
+                     "logpdf_evals_per_transition": evals_per_transition, "flops_per_logpdf": flops_per_logpdf,
+                     "note": "peak = guide's f64 vector FMA peak (2 flops/instr at 2.4 GHz); the log-pdf arithmetic is unfused add/mul "
+                             "(1 flop/instr, reference rounding) and the clock sits near 2.1 GHz under f64 load "
+                             "(profiles/round1_f64_issue_microbench.txt), so ~34 TFLOP/s is the attainable ceiling for this instruction mix"},
         "check": {"posterior_mean_max_abs_err": mean_err, "posterior_var_max_abs_err": var_err,
                   "accept_rate": st.accept_rate, "mean_step_size": st.mean_step_size, "n_divergent": int(st.n_divergent),
                   "split_rhat_max": float(np.max(rhat)), "ess_min": float(np.min(ess)), "chains_in_rhat": int(cd.m),

@@ -267,16 +267,18 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
 }
 
 // ---- multi-wave HmcSession::step for programs with a fused gradient stream ---------------------------------------
-// A single wave can issue one f64 VALU instruction per 16 cycles on gfx950 (tools/mb_clock.hip: a lone wave runs
-// dependent OR independent v_fma_f64 at 16-26 cycles each; the SIMD's f64 pipe only fills with 4 waves in flight).
-// 65 536 chains are 1 024 waves = ONE per SIMD, so a one-wave-per-tile kernel leaves 3/4 of the f64 rate unused.
+// One wave issues in order: with one wave per tile every scalar instruction, branch, LDS/SMEM wait and address
+// computation of the interpreter sits between the f64 VALU instructions (a lone wave needs ~6 cycles per dependent
+// f64 op, the SIMD's f64 pipe takes one per ~4.3 cycles from >= 2 waves: tools/mb_clock.hip,
+// profiles/round1_f64_issue_microbench.txt), and the LDS tile (36 KB for the 32-site model) caps a CU at 4 tiles,
+// i.e. ONE wave per SIMD however many chains there are -- nothing overlaps anything.
 // Here a tile of 64 chains is owned by a workgroup of W waves (W = 1, 2 or 4): every coordinate's finite-difference
 // gradient, half-kick, drift and commit is independent of the other coordinates' within one leapfrog step, so wave w
 // does coordinates [seg.c[w], seg.c[w+1]) -- its run of whole coordinates of the gradient stream -- on the SHARED LDS
 // tile, with a workgroup barrier between "all p kicked" and "q drifted" (hmc.rs:389-400: the same operations per
 // coordinate in the same order; only the interleaving BETWEEN coordinates differs, and they do not interact).  The
-// sequential parts (momentum draw, Hamiltonians, endpoint score in program order, accept, dual averaging) stay on
-// wave 0.  Results are bit-identical for every W (tests/test_gpu_parity.py::test_hmc_multiwave_is_bit_identical).
+// momentum pairs are drawn by all waves (counter-based RNG); the sequential parts (Hamiltonians, endpoint score in
+// program order, accept, dual averaging) stay on wave 0.  Results are bit-identical for every W (tests/test_gpu_parity.py::test_hmc_multiwave_is_bit_identical).
 struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1]; };
 
 __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSeg seg, int iter0, int n_steps,

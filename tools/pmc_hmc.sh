@@ -2,7 +2,7 @@
 # PMC passes over the HMC bench kernel (counters in their own runs, kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CMD="python3 $R/bench.py --steps 50 --warmup 25 --launch 25 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 50 --warmup 25 --launch 25 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d $R/gpurun_out/pmc1 -- $CMD > $R/gpurun_out/pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $R/gpurun_out/pmc2 -- $CMD > $R/gpurun_out/pmc2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM SQ_INST_CYCLES_SMEM --output-format csv -d $R/gpurun_out/pmc3 -- $CMD > $R/gpurun_out/pmc3.log 2>&1
