@@ -131,12 +131,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FG_BENCH_ONE_DEVICE=1 rehearses the N > 1 code path on a one-GPU box: every rank drives cuda:0 and the
+    # collectives run over gloo on host tensors (RCCL refuses two ranks on one device).  Not a measurement mode.
+    one_device = os.environ.get("FG_BENCH_ONE_DEVICE", "0") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend="nccl" if (torch.cuda.is_available() and not one_device) else "gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if one_device else f"cuda:{local_rank}"
 
     from fugue_amd import engine as E, workloads as W
     C, K, Wn, L = args.chains, args.steps, args.warmup, args.leapfrog
@@ -177,7 +183,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -190,7 +196,7 @@ def main():
     from fugue_amd import diagnostics as D
     t_diag = time.perf_counter()
     prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
-    cd = D.ChainDiagnostics(prov, device=f"cuda:{local_rank}" if world > 1 else None)
+    cd = D.ChainDiagnostics(prov, device=coll_dev if (world > 1 and not one_device) else None)
     rhat = cd.split_rhat()
     ess = cd.ess() if K >= 4 else np.full(d, float("nan"))
     prov.close()

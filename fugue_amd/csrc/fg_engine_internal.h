@@ -102,10 +102,10 @@ struct fg_engine {
 
 namespace {
 
-// Tile width = lanes per wave that own a chain = 64.  Spreading 65 536 chains over narrower waves
-// to get 2-4 waves per SIMD was measured NOT to help (profiles/round1_occupancy_sweep.txt): a wave
-// issues one instruction (of any type) per 4 cycles and co-resident waves do not overlap here, so
-// the kernels use full 64-lane tiles and the tile stride is a compile-time constant.
+// Tile width = lanes per wave that own a chain = 64.  Spreading 65 536 chains over narrower, half-empty waves was
+// measured NOT to help (profiles/round1_occupancy_sweep.txt): an instruction costs the same whatever the number of
+// active lanes, and the LDS tile, not the wave count, limits residency.  More waves per SIMD come from SHARING a tile
+// between waves instead (k_hmc_stream_steps); the tile stride stays a compile-time constant.
 int tile_width_for(long long C) { (void)C; return FG_WAVE; }
 
 template <typename K>

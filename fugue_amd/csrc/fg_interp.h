@@ -29,6 +29,7 @@
 #define FG_AS4 __attribute__((address_space(4)))
 typedef uint32_t fg_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t fg_u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t fg_u32x4 __attribute__((ext_vector_type(4)));
 
 struct FgAcc3 { double prior, lik, fac; };   // Trace accumulators, src/runtime/trace.rs:168-177
 
@@ -310,6 +311,23 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                  const double v = slots[(FG_I_AUX(I) + j) * tw];
                                  acc = ok ? v : NAN; break; }
             case FG_OP_CONSTLIK: A.lik += FG_I_IMM(I, 0); break;
+            case FG_OP_DOT: {                             // n MACs (slot x constant), terms fetched 4 at a time by scalar loads
+                const int n = (int)FG_I_OPND(I, 1);
+                const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + FG_I_AUX(I));
+                int t = 0;
+                for (; t + 4 <= n; t += 4) {
+                    const fg_u32x16 q = *(const FG_AS4 fg_u32x16 *)(tb + 16 * t);
+                    const double v0 = slots[q[0] * tw], v1 = slots[q[4] * tw], v2 = slots[q[8] * tw], v3 = slots[q[12] * tw];
+                    acc = acc + v0 * fg_dbl(q[2], q[3]);
+                    acc = acc + v1 * fg_dbl(q[6], q[7]);
+                    acc = acc + v2 * fg_dbl(q[10], q[11]);
+                    acc = acc + v3 * fg_dbl(q[14], q[15]);
+                }
+                for (; t < n; ++t) {
+                    const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+                    acc = acc + slots[q[0] * tw] * fg_dbl(q[2], q[3]);
+                }
+                break; }
             default: break;
             }
         }

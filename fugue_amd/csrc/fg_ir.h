@@ -29,7 +29,9 @@ enum : uint32_t {
     FG_OP_MAC,           // acc = acc + x * p0   (two roundings, as the expression tree)
     FG_OP_STORE,         // slot[aux] = acc
     FG_OP_GATHER,        // acc = slot[aux + (int)acc] for 0 <= acc < n (n = opnd[1] raw), else NaN
-    FG_OP_CONSTLIK       // log_likelihood += imm[0]  (observe with constant params and value)
+    FG_OP_CONSTLIK,      // log_likelihood += imm[0]  (observe with constant params and value)
+    FG_OP_DOT            // acc = (..((acc + s_0 c_0) + s_1 c_1)..) + s_{n-1} c_{n-1}: a run of n = opnd[1] MACs of an f64 slot and a
+                         //   constant (a linear predictor), terms {u32 slot, u32 0, f64 c} at pool[aux ..]; same two roundings per term
 };
 // flags in op bits 8..
 enum : uint32_t {

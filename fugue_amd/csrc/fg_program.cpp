@@ -237,13 +237,44 @@ bool fg_categorical_const_valid(const std::vector<double> &p) {   // distributio
     return true;
 }
 
+// A run of >= 4 consecutive MACs of (f64 slot) x (constant) -- the linear predictor of a regression written as
+// `mean = mean + beta[j] * x[i][j]` -- becomes one FG_OP_DOT whose terms sit in the constant pool: the same mul and add
+// per term, in the same order, without a 96-byte instruction fetch and an operand decode per term.
+static void fuse_dots(std::vector<FgIns> &out, size_t start, std::vector<double> &pool) {
+    auto term = [](const FgIns &I, uint32_t &slot, double &c) {
+        if (FG_INS_OPCODE(I.op) != FG_OP_MAC) return false;
+        const uint32_t k0 = FG_OPND_KIND(I.opnd[0]), k1 = FG_OPND_KIND(I.opnd[1]);
+        if (k0 == FG_OPND_SLOT_F && k1 == FG_OPND_IMM) { slot = FG_OPND_IDX(I.opnd[0]); c = I.imm[1]; return true; }
+        if (k0 == FG_OPND_IMM && k1 == FG_OPND_SLOT_F) { slot = FG_OPND_IDX(I.opnd[1]); c = I.imm[0]; return true; }
+        return false;
+    };
+    std::vector<FgIns> res(out.begin(), out.begin() + (long)start);
+    for (size_t i = start; i < out.size();) {
+        uint32_t slot; double c;
+        size_t j = i;
+        while (j < out.size() && term(out[j], slot, c)) ++j;
+        if (j - i < 4) { for (size_t k = i; k < std::max(j, i + 1); ++k) res.push_back(out[k]); i = std::max(j, i + 1); continue; }
+        if (pool.size() & 1) pool.push_back(0.0);                  // 16-byte aligned terms
+        FgIns D = FgGen::blank(FG_OP_DOT);
+        D.opnd[0] = FG_OPND(FG_OPND_IMM, 0);
+        D.opnd[1] = (uint32_t)(j - i);
+        D.aux = (uint32_t)pool.size();
+        for (size_t k = i; k < j; ++k) { term(out[k], slot, c); pool.push_back(fg_as_double((long long)slot)); pool.push_back(c); }
+        res.push_back(D);
+        i = j;
+    }
+    out.swap(res);
+}
+
 void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &temp_max) {
     FgGen G(*this, out);
+    const size_t start = out.size();
     if (s.kind == 2) {                                   // factor
         FgIns I = FgGen::blank(FG_OP_FACTOR);
         G.operand(s.value, I.opnd[0], I.imm[0]);
         out.push_back(I);
         temp_max = std::max(temp_max, G.temp_max);
+        fuse_dots(out, start, pool);
         return;
     }
     uint32_t op = (uint32_t)s.dist | ((uint32_t)s.vtype << FG_F_VTYPE_SHIFT);
@@ -308,6 +339,7 @@ void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &tem
     }
     out.push_back(I);
     temp_max = std::max(temp_max, G.temp_max);
+    fuse_dots(out, start, pool);
 }
 
 int fg_program::finalize() {

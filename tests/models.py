@@ -92,3 +92,4 @@ def hier_normal(groups: int = 5, per_group: int = 3) -> M.Program:
 
 
 ZOO["hier"] = hier_normal
+ZOO["ridge7"] = lambda: W.ridge_regression(*W.ridge_data(10, 7)[:2], sigma=0.8)     # FG_OP_DOT with a 4 + 3 term split, sigma not 2^k

@@ -1,0 +1,121 @@
+"""BASELINE.json's configurations at their FULL sizes, checked through properties that do not need the
+oracle to run at that size: closed-form posteriors, independence of results from how chains are sharded
+over engines (the multi-GPU layout), agreement with a numpy evaluation of the same density, and the
+oracle on a handful of chains of the full-size model."""
+import numpy as np
+import pytest
+
+from fugue_amd import diagnostics as D
+from fugue_amd import engine as E
+from fugue_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _hmc_draws(cp, C, ns, nw, seed, chain_offset=0, **cfg):
+    eng = E.Engine(cp, C, seed=seed, chain_offset=chain_offset)
+    d = eng.device_alloc(ns * cp.d * C * 8)
+    st = eng.hmc_run(E.hmc_config(**cfg), ns, nw, d)
+    prov = D.EngineMoments(eng, d, ns, cp.d)
+    cd = D.ChainDiagnostics(prov)
+    rhat, mean = cd.split_rhat(), cd.pooled_mean()
+    prov.close()
+    return eng, d, st, rhat, mean
+
+
+def test_c2_readme_model_65536_chains_1000_steps():
+    """configs[1]: conjugate Normal-Normal (README mu model), hmc_chain, 65 536 chains x 1 000 steps.
+    Posterior N(0.96, 0.2); all 65 536 chains enter split-R-hat."""
+    cp = E.compile_model(W.readme_normal())
+    C, ns = 65536, 1000
+    eng, d, st, rhat, mean = _hmc_draws(cp, C, ns, 300, seed=7, grad_mode=E.GRAD_FD_DENSE)
+    assert abs(mean[0] - 0.96) < 1e-3                               # north_star: within 1e-3 of the closed form
+    assert abs(rhat[0] - 1.0) < 0.01
+    assert 0.6 < st.accept_rate <= 1.0 and st.n_divergent == 0
+    last = eng.download(d + (ns - 1) * C * 8, (C,))
+    assert abs(last.var() - 0.2) < 0.01                             # a single draw across the chains is a posterior sample
+    eng.device_free(d)
+
+
+def test_target_model_65536_chains_and_sharding_invariance():
+    """north_star target model (32-site Normal) at 65 536 chains: posterior mean within 1e-3, and the draws of
+    chains [32768, 65536) do not depend on whether they ran in one engine of 65 536 chains or in their own engine
+    with chain_offset = 32768 -- the property that makes `--gpus N` a pure re-partition (RNG keyed by global chain id)."""
+    cp = E.compile_model(W.normal_sites(32))
+    C, ns, nw = 65536, 60, 120
+    eng, d, st, rhat, mean = _hmc_draws(cp, C, ns, nw, seed=1, grad_mode=E.GRAD_FD_SPARSE)
+    _, tm, _ = W.normal_sites_truth(32)
+    assert np.abs(mean - tm).max() < 1e-3
+    assert np.abs(rhat - 1.0).max() < 0.02 and st.n_divergent == 0      # halves of 30 draws: (n-1)/n alone is 0.967
+    whole = eng.download(d, (ns, cp.d, C))[:, :, C // 2:]
+    eng.device_free(d)
+    eng2, d2, *_ = _hmc_draws(cp, C // 2, ns, nw, seed=1, chain_offset=C // 2, grad_mode=E.GRAD_FD_SPARSE)
+    part = eng2.download(d2, (ns, cp.d, C // 2))
+    eng2.device_free(d2)
+    assert np.array_equal(whole, part)
+
+
+def test_c3_regression_1024_observations_32_coefficients(oracle):
+    """configs[2] model at full size (32 Normal coefficients, 1 024 observations; the FG_OP_DOT path): the log-joint
+    against a numpy evaluation of the same density, and one HMC transition per chain against the oracle."""
+    X, y, _ = W.ridge_data(1024, 32)
+    prog = W.ridge_regression(X, y)
+    cp, om = E.compile_model(prog), oracle.OracleModel(prog)
+    assert cp.n_instructions < 5000                                  # 4 instructions per observation, not 35
+    C = 64
+    rng = np.random.default_rng(2)
+    beta = 0.3 * rng.standard_normal((cp.d, C))
+    order = [int(n.split("#")[1]) for n in cp.site_names]            # site j holds beta#order[j] (lexicographic order)
+    eng = E.Engine(cp, C, seed=4)
+    cells = np.ascontiguousarray(beta).view(np.int64)
+    eng.set_values(cells)
+    acc = eng.log_joint()
+    b_model = np.empty_like(beta)
+    b_model[order] = beta                                           # beta#j for the design matrix columns
+    resid = (y[:, None] - X @ b_model) / 0.5
+    lik = (-0.5 * resid ** 2 - np.log(0.5) - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    pri = (-0.5 * beta ** 2 - 0.5 * np.log(2 * np.pi)).sum(axis=0)
+    assert np.allclose(acc[0], pri, rtol=1e-12) and np.allclose(acc[1], lik, rtol=1e-10)
+    for c in range(0, C, 9):
+        oacc, _ = om.run_score(cells[:, c])
+        assert np.allclose(acc[:, c], oacc, rtol=1e-12, atol=1e-12)
+    # one transition (L = 3) from these positions with injected momentum and uniform: same decision, same position
+    p0 = rng.standard_normal((cp.d, C))
+    u = rng.random(C)
+    accd, alpha, div, lj = eng.hmc_transition_injected(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=3), 0.002, p0, u)
+    newv = eng.get_values().view(np.float64)
+    for c in range(0, C, 16):
+        q = beta[:, c].copy()
+        qo, ljo, oacc, oalpha, odiv = om.hmc_transition(cells[:, c], q, om.log_joint_at(cells[:, c], q), 0.002, 3, p0[:, c].copy(), float(u[c]))
+        assert bool(accd[c]) == oacc and bool(div[c]) == odiv
+        assert abs(alpha[c] - oalpha) < 1e-5
+        assert np.allclose(newv[:, c], qo, rtol=1e-6, atol=1e-8)
+
+
+def test_c5_mixture_262144_chains():
+    """configs[4]: 4-component Gaussian mixture (Categorical + Normal sites), adaptive_mcmc_chain at 262 144 chains.
+    Assignments stay in {0..3}, the means recover the generating (-6,-2,2,6) up to label order, and two engines
+    of 131 072 chains reproduce the second half exactly."""
+    data, _ = W.mixture_data(32)
+    cp = E.compile_model(W.mixture(data))
+    C, nw, ns = 262144, 1500, 20
+    mu_sites = [cp.site_names.index(f"mu#{k}") for k in range(4)]
+    z_sites = [j for j, n in enumerate(cp.site_names) if n.startswith("z#")]
+    rec = mu_sites + z_sites
+    eng = E.Engine(cp, C, seed=11)
+    d = eng.device_alloc(ns * len(rec) * C * 8)
+    st = eng.mh_run(ns, nw, None, rec, d)
+    cells = eng.download(d, (ns, len(rec), C), dtype=np.int64)
+    eng.device_free(d)
+    z = cells[:, 4:, :]
+    assert z.min() >= 0 and z.max() <= 3                            # Categorical indices are exact integers
+    mu = np.sort(cells[:, :4, :].view(np.float64), axis=1)
+    med = np.median(mu.mean(axis=0), axis=1)
+    assert np.abs(med - np.array([-6.0, -2.0, 2.0, 6.0])).max() < 1.0
+    assert 0.1 < st.accept_rate < 0.9
+    eng2 = E.Engine(cp, C // 2, seed=11, chain_offset=C // 2)
+    d2 = eng2.device_alloc(ns * len(rec) * (C // 2) * 8)
+    eng2.mh_run(ns, nw, None, rec, d2)
+    half = eng2.download(d2, (ns, len(rec), C // 2), dtype=np.int64)
+    eng2.device_free(d2)
+    assert np.array_equal(cells[:, :, C // 2:], half)
