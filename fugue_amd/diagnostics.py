@@ -49,6 +49,34 @@ class EngineMoments:
             self._d_mom = 0
 
 
+class HostMoments:
+    """MomentProvider over host draws [n][d][C] (numpy): the same statistics the GPU kernels produce, for callers that
+    already hold the draws on the host (fugue_amd.validation) and for CPU tests of the combination logic."""
+
+    def __init__(self, draws: np.ndarray):
+        self.x = np.asarray(draws, dtype=np.float64)
+        self.n, self.d, self.C = self.x.shape
+
+    def moments(self) -> np.ndarray:
+        n, half = self.n, self.n // 2
+        out = np.zeros((self.d, 6, self.C))
+        for k, (a, b) in enumerate(((0, n), (0, half), (half, 2 * half))):
+            seg = self.x[a:b]
+            mean = seg.sum(axis=0) / max(1, b - a)
+            out[:, 2 * k] = mean
+            out[:, 2 * k + 1] = ((seg - mean) ** 2).sum(axis=0)
+        return out
+
+    def autocov_sums(self, lag0: int, n_lags: int) -> np.ndarray:
+        c = self.x - self.x.mean(axis=0, keepdims=True)
+        out = np.zeros((self.d, n_lags))
+        for k in range(n_lags):
+            lag = lag0 + k
+            if lag < self.n:
+                out[:, k] = ((c[:self.n - lag] * c[lag:]).sum(axis=0) / self.n).sum(axis=1)
+        return out
+
+
 # ---- collectives (identity when not distributed) ------------------------------------------
 def _dist(group):
     import torch.distributed as dist
