@@ -612,7 +612,24 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
         mh.old_cell = slots[tslot * tw];
         FgAcc3 A = {0.0, 0.0, 0.0};
-        fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
+        // Random-walk proposals (mh.rs:183-294, 557-567) need nothing from the model: the new value, log q(x'|x) and
+        // log q(x|x') depend only on the current value, the adapted scale, the decided kind and (Reflect) the
+        // override bounds.  When EVERY lane of the wave holds such a site the proposal is made here, per lane, and
+        // the model is then only SCORED (score stream / score-only opcodes) instead of being driven through the
+        // propose-and-score mode, whose proposal machinery would otherwise run under a partial mask at almost every
+        // sample site (64 lanes pick 64 different sites).  Undecided kinds, prior-resample kinds and Categorical
+        // sites take the general path below; both paths produce the same values.
+        const uint32_t tv = (uint32_t)P.site_vtype[target];
+        int kind_eff = FG_PROP_AUTO;
+        if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
+        const bool walk = tv == 0u ? (kind_eff == FG_PROP_GAUSSIAN || kind_eff == FG_PROP_LOGSPACE || kind_eff == FG_PROP_REFLECT)
+                                   : (tv == 1u || tv == 2u || tv == 4u);
+        if (__all(walk)) {
+            fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+            if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, slots, tw, A);
+            else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
+        } else
+            fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
         const double prop_lw = fg_total(A);
         const double log_alpha = prop_lw - lw + (mh.lqr - mh.lqf);         // + dim_term == 0 (fixed structure)  mh.rs:731-732
         FgStream ru = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_MH);

@@ -99,6 +99,43 @@ __device__ __forceinline__ double fg_logspace_lq(double from, double to, double 
     return (-0.5 * zz * zz - log(scale) - 0.5 * log(2.0 * M_PI)) - log(to);
 }
 
+// The model-independent proposals of single-site MH for the lane's target (LDS slot `aux`, value type `vtype`):
+// Gaussian / log-space / reflected random walks on f64 sites (mh.rs:183-257), the bool flip (:263-269), the u64 and
+// i64 discrete walks (:285-294, :557-567).  Shared by the propose-and-score interpreter mode and by the pre-run
+// proposal of k_mh_steps so that both produce the same values and consume the same RNG blocks.
+__device__ __forceinline__ void fg_mh_walk_proposal(FgMhCtx &mh, uint32_t vtype, int kind, int aux, double *slots, int tw) {
+    const double curd = slots[aux * tw];
+    const long long curi = fg_as_i64(curd);
+    if (vtype == 0u) {
+        double prop = curd, f = 0.0, r = 0.0;
+        if (kind == FG_PROP_GAUSSIAN) prop = curd + mh.scale * mh.z;                          // mh.rs:183-187
+        else if (kind == FG_PROP_LOGSPACE) {                                                  // mh.rs:201-224
+            if (curd <= 0.0) { prop = FG_MIN_POSITIVE; mh.next_block = 1; }
+            else { const double pr = exp(log(curd) + mh.scale * mh.z);
+                   prop = fg_finite(pr) ? fmax(pr, FG_MIN_POSITIVE) : FG_F64_MAX; }
+            f = fg_logspace_lq(curd, prop, mh.scale); r = fg_logspace_lq(prop, curd, mh.scale);
+        } else {                                                                              // Reflect: mh.rs:237-257
+            const double lo = mh.ov_lo[aux], hi = mh.ov_hi[aux];
+            double pr = curd + mh.scale * mh.z;
+            if (hi - lo <= 0.0) prop = curd;
+            else { for (int it = 0; it < 100000 && (pr < lo || pr > hi); ++it) {
+                       if (pr < lo) pr = 2.0 * lo - pr;
+                       if (pr > hi) pr = 2.0 * hi - pr; }
+                   prop = pr < lo ? lo : (pr > hi ? hi : pr); }
+        }
+        mh.lqf += f; mh.lqr += r;
+        slots[aux * tw] = prop;
+    } else if (vtype == 1u) {                // FlipProposal: mh.rs:263-269 (draws nothing)
+        slots[aux * tw] = fg_as_double(curi ? 0LL : 1LL);
+        mh.next_block = 1;
+    } else if (vtype == 2u) {                // DiscreteWalkProposal: mh.rs:285-294
+        const long long k = curi + fg_f2i_sat(round(mh.scale * mh.z));
+        slots[aux * tw] = fg_as_double(k >= 0 ? k : -k - 1);
+    } else {                                 // i64 walk: mh.rs:557-567
+        slots[aux * tw] = fg_as_double(curi + fg_f2i_sat(round(mh.scale * mh.z)));
+    }
+}
+
 // Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane]; `tw` = tile width
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have one readable instruction past `n` (the host pads the arrays).
@@ -200,7 +237,6 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                     if (__any(is_t)) {
                         if (is_t) {
                             const double curd = slots[aux * tw];
-                            const long long curi = fg_as_i64(curd);
                             const bool p2s = (op & FG_F_POW2SCALE) != 0u;
                             if (vtype == 0u) {                       // on_sample_f64: mh.rs:362-420
                                 int kind = mh->ov_kind ? mh->ov_kind[aux] : FG_PROP_AUTO;
@@ -214,43 +250,22 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                         mh->kind = kind;
                                     }
                                 }
-                                double prop = curd, f = 0.0, r = 0.0;
-                                if (kind == FG_PROP_GAUSSIAN) prop = curd + mh->scale * mh->z;        // mh.rs:183-187
-                                else if (kind == FG_PROP_LOGSPACE) {                                  // mh.rs:201-224
-                                    if (curd <= 0.0) { prop = FG_MIN_POSITIVE; mh->next_block = 1; }
-                                    else { const double pr = exp(log(curd) + mh->scale * mh->z);
-                                           prop = fg_finite(pr) ? fmax(pr, FG_MIN_POSITIVE) : FG_F64_MAX; }
-                                    f = fg_logspace_lq(curd, prop, mh->scale); r = fg_logspace_lq(prop, curd, mh->scale);
-                                } else if (kind == FG_PROP_REFLECT) {                                 // mh.rs:237-257
-                                    const double lo = mh->ov_lo[aux], hi = mh->ov_hi[aux];
-                                    double pr = curd + mh->scale * mh->z;
-                                    if (hi - lo <= 0.0) prop = curd;
-                                    else { for (int it = 0; it < 100000 && (pr < lo || pr > hi); ++it) {
-                                               if (pr < lo) pr = 2.0 * lo - pr;
-                                               if (pr > hi) pr = 2.0 * hi - pr; }
-                                           prop = pr < lo ? lo : (pr > hi ? hi : pr); }
+                                if (kind == FG_PROP_GAUSSIAN || kind == FG_PROP_LOGSPACE || kind == FG_PROP_REFLECT) {
+                                    fg_mh_walk_proposal(*mh, 0u, kind, (int)aux, slots, tw);
                                 } else {                                                              // PriorResample: mh.rs:400-403
                                     FgStream s1 = mh->rng;
-                                    prop = fg_as_double(fg_sample_cold(code, hoisted, p0, p1, p2, &s1));
+                                    const double prop = fg_as_double(fg_sample_cold(code, hoisted, p0, p1, p2, &s1));
                                     mh->next_block = (int)s1.c1;
                                     const bool inv = (op & FG_F_INVALID) != 0u;
                                     const bool shf = (op & FG_F_SCALEHOIST) != 0u;
-                                    f = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, prop, 0, p0, p1, p2, fg_ins_h(I, 0),
+                                    const double f = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, prop, 0, p0, p1, p2, fg_ins_h(I, 0),
                                                                           fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), shf);
-                                    r = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, curd, 0, p0, p1, p2, fg_ins_h(I, 0),
+                                    const double r = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, curd, 0, p0, p1, p2, fg_ins_h(I, 0),
                                                                           fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), shf);
+                                    mh->lqf += f; mh->lqr += r;
+                                    slots[aux * tw] = prop;
                                 }
-                                mh->lqf += f; mh->lqr += r;
-                                slots[aux * tw] = prop;
-                            } else if (vtype == 1u) {                // FlipProposal: mh.rs:263-269 (draws nothing)
-                                slots[aux * tw] = fg_as_double(curi ? 0LL : 1LL);
-                                mh->next_block = 1;
-                            } else if (vtype == 2u) {                // DiscreteWalkProposal: mh.rs:285-294
-                                const long long k = curi + fg_f2i_sat(round(mh->scale * mh->z));
-                                slots[aux * tw] = fg_as_double(k >= 0 ? k : -k - 1);
-                            } else {                                 // i64 walk: mh.rs:557-567
-                                slots[aux * tw] = fg_as_double(curi + fg_f2i_sat(round(mh->scale * mh->z)));
-                            }
+                            } else fg_mh_walk_proposal(*mh, vtype, 0, (int)aux, slots, tw);   // bool flip / u64 walk / i64 walk
                         }
                     }
                 }
