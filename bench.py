@@ -111,6 +111,14 @@ def extras(args, E, W, dev):
     out["mh_accept_rate"] = eng.mh_stats().accept_rate
     out["mh_workload"] = f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91), {C} chains; published CPU: 65k chain-steps/s/thread"
     eng.close()
+    # (2b) C5 on one GPU: 4-component mixture (Categorical + Normal sites), adaptive_mcmc_chain at 262 144 chains
+    data, _ = W.mixture_data(32)
+    eng = E.Engine(E.compile_model(W.mixture(data)), 262144, seed=1, device=dev)
+    eng.mh_init(200)
+    eng.mh_step(200); eng.synchronize()
+    t0 = time.perf_counter(); eng.mh_step(200); eng.synchronize(); dt = time.perf_counter() - t0
+    out["mh_mixture_262144_chain_steps_per_sec"] = 262144 * 200 / dt
+    eng.close()
     # (3) C4: adaptive_smc, 1 048 576 particles, Systematic / 0.5 / 3 rejuvenation moves
     cp = E.compile_model(W.smc_normal())
     eng = E.Engine(cp, 1 << 20, seed=42, device=dev)

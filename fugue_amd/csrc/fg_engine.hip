@@ -622,10 +622,24 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         const uint32_t tv = (uint32_t)P.site_vtype[target];
         int kind_eff = FG_PROP_AUTO;
         if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
+        const int cat_base = P.site_cat[2 * target], cat_K = P.site_cat[2 * target + 1];
         const bool walk = tv == 0u ? (kind_eff == FG_PROP_GAUSSIAN || kind_eff == FG_PROP_LOGSPACE || kind_eff == FG_PROP_REFLECT)
-                                   : (tv == 1u || tv == 2u || tv == 4u);
+                                   : (tv == 1u || tv == 2u || tv == 4u || (tv == 3u && cat_K > 0));
         if (__all(walk)) {
-            fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+            if (tv == 3u) {                                   // usize target: resample from the constant prior table (mh.rs:516-530)
+                FgStream s1 = mh.rng;
+                const double uu = fg_rng_u01(s1);
+                double cum = 0.0; int idx = cat_K;
+                for (int i = 0; i < cat_K; ++i) { cum += P.pool[cat_base + i]; if (idx == cat_K && !(cum < uu)) idx = i; }
+                const long long prop = idx < cat_K - 1 ? idx : cat_K - 1;
+                const long long cur = fg_as_i64(mh.old_cell);
+                const double pp = P.pool[cat_base + (int)prop];
+                const double pc = (cur < 0 || cur >= (long long)cat_K) ? 0.0 : P.pool[cat_base + (int)cur];
+                mh.lqf += !(pp > 0.0) ? FG_NEG_INF : log(pp);
+                mh.lqr += !(pc > 0.0) ? FG_NEG_INF : log(pc);
+                mh.next_block = (int)s1.c1;
+                slots[tslot * tw] = fg_as_double(prop);
+            } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
             if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, slots, tw, A);
             else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         } else
@@ -708,6 +722,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
     if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
     if (dev_upload(&e->d_vtype, p->site_vtype)) return fail("upload vtype");
+    if (dev_upload(&e->d_site_cat, p->site_cat)) return fail("upload site_cat");
     if (dev_upload(&e->d_pool, p->pool)) return fail("upload pool");
     if (dev_alloc(&e->d_values, (size_t)std::max(1, e->S) * e->C)) return fail("alloc values");
     if (dev_alloc(&e->d_acc, (size_t)3 * e->C)) return fail("alloc acc");
@@ -715,7 +730,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
     e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream;
     e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
-    e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype;
+    e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
@@ -733,7 +748,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->hmc_allocs) hipFree(q);
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
-    void *ptrs[] = { e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);

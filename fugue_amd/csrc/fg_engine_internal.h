@@ -74,7 +74,7 @@ struct fg_engine {
     FgIns *d_ins = nullptr, *d_ins_fast = nullptr, *d_sub = nullptr;
     FgCoord *d_coord = nullptr;
     FgGradRec *d_gstream = nullptr, *d_sstream = nullptr;
-    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr;
+    int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr, *d_site_cat = nullptr;
     double *d_pool = nullptr;
     FgProgramDev P{};
     FgChainCtx X{};

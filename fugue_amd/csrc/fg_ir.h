@@ -89,6 +89,7 @@ struct FgProgramDev {
     const int    *f64_site;  // [d] sorted site index of each f64 coordinate (its LDS slot is the coordinate index itself)
     const int    *site_slot; // [S] LDS slot of each site: f64 sites first (coordinate order), then the discrete sites
     const int    *site_vtype;// [S]
+    const int    *site_cat;  // [S][2] {pool base, K} of Categorical sites with a valid constant probability table, else -1
     const FgGradRec *gstream;  // fused gradient stream or null
     const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
     int n_gstream, n_sstream;

@@ -374,6 +374,7 @@ int fg_program::finalize() {
     }
     // compile every statement; remember its instruction range and the sites it reads
     ins.clear(); sub.clear(); sub_off.clear(); pool.clear();
+    site_cat.assign(2 * (size_t)std::max(1, S), -1);
     int temp_max = S;
     std::vector<std::pair<int, int>> range(stmts.size());
     std::vector<std::vector<int>> reads(stmts.size());
@@ -381,6 +382,13 @@ int fg_program::finalize() {
         int b = (int)ins.size();
         compile_stmt(stmts[i], ins, temp_max);
         range[i] = {b, (int)ins.size()};
+        if (stmts[i].kind == 0) {              // Categorical site with a valid constant table: prior-resample needs only the table
+            const FgIns &D = ins.back();
+            if (FG_INS_OPCODE(D.op) == (uint32_t)FG_CATEGORICAL && FG_OPND_KIND(D.opnd[1]) == FG_OPND_POOL && !(D.op & FG_F_INVALID)) {
+                site_cat[2 * stmts[i].sorted] = (int)FG_OPND_IDX(D.opnd[1]);
+                site_cat[2 * stmts[i].sorted + 1] = (int)D.opnd[2];
+            }
+        }
         std::vector<int> hs;
         for (int p : stmts[i].params) collect_sites(p, hs);
         if (stmts[i].kind != 0 && stmts[i].value >= 0) collect_sites(stmts[i].value, hs);

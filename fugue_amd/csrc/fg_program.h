@@ -38,6 +38,7 @@ struct fg_program {
     int n_sstream = 0;
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
+    std::vector<int> site_cat;               // [S][2] {pool base, K} of Categorical sites with a valid constant table, else -1
     std::vector<std::string> dsl_warnings;   // fg_dsl.cpp
 
     int  parse(const fg_tok *toks, int n);
