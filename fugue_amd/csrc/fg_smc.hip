@@ -17,6 +17,7 @@
 // all particles sequentially (smc.rs:482,544-553); here every particle of a sweep uses the
 // scales from the start of the sweep and the per-site counts are folded in once per sweep.
 #include "fg_engine_internal.h"
+#include "fg_gradstream.h"
 
 #define RED_BLOCKS 512
 #define RED_THREADS 256
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_smc_red_sum(const double *lw, c
                                                               const double *beta_ptr, const double *part_max, double *part_sum) {
     __shared__ double sh[RED_THREADS / 64];
     const double b = *b_ptr, beta = *beta_ptr;
-    double m = part_max[0];
-    for (int k = 1; k < (int)gridDim.x; ++k) m = fmax(m, part_max[k]);
+    double m = -INFINITY;                                   // max of the block maxima (max is exact: any order)
+    for (int k = threadIdx.x; k < (int)gridDim.x; k += blockDim.x) m = fmax(m, part_max[k]);
+    m = block_reduce_max(m, sh);
     double s1 = 0.0, s2 = 0.0;
     if (!(isinf(m) && m < 0.0)) {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -89,17 +91,24 @@ __global__ __launch_bounds__(RED_THREADS) void k_smc_red_sum(const double *lw, c
 // phase 0: ESS at b = 1 (smc.rs:604-607);  phase 1: one bisection step (:612-619);
 // phase 2: finish next_beta (:620-621);  phase 3: log_norm of the reweight (:517-518);
 // phase 4: plain log-sum-exp (lse1 only)
-__global__ void k_smc_finish(FgSmcScalars *st, const double *part_max, const double *part_sum, int nb, long long n, int phase) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One block of RED_THREADS threads: the block partials are combined by a fixed tree (thread t takes partials t, t + 256,
+// ...; wave shuffles; waves in order), so the result is reproducible from run to run.
+__global__ __launch_bounds__(RED_THREADS) void k_smc_finish(FgSmcScalars *st, const double *part_max, const double *part_sum, int nb, long long n, int phase) {
+    __shared__ double sh[RED_THREADS / 64];
+    if (blockIdx.x != 0) return;
     if (phase == 2) {
-        if (!st->done) st->bnew = fmin(fmax(st->hi, st->beta + 1e-9), 1.0);
-        if (st->force_one) st->bnew = 1.0;
+        if (threadIdx.x == 0) {
+            if (!st->done) st->bnew = fmin(fmax(st->hi, st->beta + 1e-9), 1.0);
+            if (st->force_one) st->bnew = 1.0;
+        }
         return;
     }
-    double m = part_max[0];
-    for (int k = 1; k < nb; ++k) m = fmax(m, part_max[k]);
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nb; ++k) { s1 += part_sum[2 * k]; s2 += part_sum[2 * k + 1]; }
+    double m = -INFINITY, s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) { m = fmax(m, part_max[k]); s1 += part_sum[2 * k]; s2 += part_sum[2 * k + 1]; }
+    m = block_reduce_max(m, sh);
+    s1 = block_reduce_sum(s1, sh);
+    s2 = block_reduce_sum(s2, sh);
+    if (threadIdx.x != 0) return;
     const bool empty = isinf(m) && m < 0.0;
     const double lse1 = (empty || s1 == 0.0) ? -INFINITY : m + log(s1);          // numerical.rs:33-37
     const double lse2 = (empty || s2 == 0.0) ? -INFINITY : 2.0 * m + log(s2);
@@ -237,7 +246,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_smc_rejuv(FgProgramDe
     for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed: two model runs  smc.rs:662-675
         slots[k * tw] = pass ? prop : cur;
         FgAcc3 A = {0.0, 0.0, 0.0};
-        fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
+        if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, slots, tw, A);
+        else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         pri[pass] = A.prior; lik[pass] = A.lik + A.fac;
     }
     const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
@@ -247,8 +257,21 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_smc_rejuv(FgProgramDe
         if (accept) X.values[(long long)site * X.C + c] = fg_as_i64(prop);
         M.lprior[c] = accept ? pri[1] : pri[0];               // the freshly scored trace is returned either way
         M.ll[c] = accept ? lik[1] : lik[0];
-        atomicAdd(&M.sw_n[site], 1u);
-        if (accept) atomicAdd(&M.sw_a[site], 1u);
+    }
+    // per-sweep proposal / accept counts, one pair of atomics per distinct site in the wave (a one-site model would
+    // otherwise send a million atomics to one address)
+    unsigned long long todo = __ballot(live);
+    const unsigned long long acc_mask = __ballot(live && accept);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int s_lead = __builtin_amdgcn_readlane(site, leader);
+        const unsigned long long same = __ballot(live && site == s_lead);
+        if ((int)threadIdx.x == leader) {
+            atomicAdd(&M.sw_n[s_lead], (unsigned int)__popcll(same));
+            const unsigned int na = (unsigned int)__popcll(same & acc_mask);
+            if (na) atomicAdd(&M.sw_a[s_lead], na);
+        }
+        todo &= ~same;
     }
 }
 // per-sweep batched DiminishingAdaptation update (see file header; oracle: adapt_update_batched)
@@ -292,7 +315,7 @@ struct Reducer {     // scratch for the two-pass reductions
         hipLaunchKernelGGL(k_smc_red_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, lw, ll, n, b_ptr, (const double *)&st->beta, part_max);
         hipLaunchKernelGGL(k_smc_red_sum, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, lw, ll, n, b_ptr, (const double *)&st->beta,
                            (const double *)part_max, part_sum);
-        hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(1), 0, s, st, (const double *)part_max, (const double *)part_sum, RED_BLOCKS, n, phase);
+        hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(RED_THREADS), 0, s, st, (const double *)part_max, (const double *)part_sum, RED_BLOCKS, n, phase);
         HIPCHK(hipGetLastError());
         return FG_OK;
     }
@@ -371,7 +394,7 @@ int fg_device_next_beta(int device, double beta, const double *h_log_w, const do
     HIPCHK(hipMemcpy(d_ll, h_ll, (size_t)n * 8, hipMemcpyHostToDevice));
     rc = R.run(nullptr, d_lw, d_ll, n, st, (const double *)&st->one, 0);
     for (int it = 0; it < 64 && !rc; ++it) rc = R.run(nullptr, d_lw, d_ll, n, st, (const double *)&st->mid, 1);
-    if (!rc) hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(1), 0, nullptr, st, (const double *)R.part_max, (const double *)R.part_sum, RED_BLOCKS, (long long)n, 2);
+    if (!rc) hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(RED_THREADS), 0, nullptr, st, (const double *)R.part_max, (const double *)R.part_sum, RED_BLOCKS, (long long)n, 2);
     if (!rc) { hipError_t e_ = hipMemcpy(&h, st, sizeof(h), hipMemcpyDeviceToHost); if (e_ != hipSuccess) rc = FG_E_HIP; else *out_beta = h.bnew; }
     (void)hipFree(d_lw); (void)hipFree(d_ll); (void)hipFree(st); R.free_all();
     return rc;
@@ -440,7 +463,7 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
             SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->one, 0));
             for (int it = 0; it < 64; ++it) SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->mid, 1));
             if (steps >= 10000) { int one = 1; SMC_HIP(hipMemcpyAsync(&st->force_one, &one, sizeof(int), hipMemcpyHostToDevice, s)); }
-            hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(1), 0, s, st, (const double *)R.part_max, (const double *)R.part_sum, RED_BLOCKS, N, 2);
+            hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(RED_THREADS), 0, s, st, (const double *)R.part_max, (const double *)R.part_sum, RED_BLOCKS, N, 2);
             // reweight + evidence (smc.rs:512-529)
             SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
             hipLaunchKernelGGL(k_smc_apply, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, d_w, N, (const FgSmcScalars *)st);
