@@ -279,7 +279,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
 // coordinate in the same order; only the interleaving BETWEEN coordinates differs, and they do not interact).  The
 // momentum pairs are drawn by all waves (counter-based RNG); the sequential parts (Hamiltonians, endpoint score in
 // program order, accept, dual averaging) stay on wave 0.  Results are bit-identical for every W (tests/test_gpu_parity.py::test_hmc_multiwave_is_bit_identical).
-struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1]; };
+struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1];
+               int separable; };   // every record of a wave reads only that wave's own coordinates (and constants): no barrier inside the leapfrog loop
 
 __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSeg seg, int iter0, int n_steps,
                                                                                int n_warmup, int welford_on, double *draws, int first_sample_t,
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
     const int gn = seg.g[wv + 1] - seg.g[wv];
     const int d = P.d, L = H.L;
     const bool dense = H.grad_mode == FG_GRAD_FD_DENSE;          // whole-program finite difference over the score stream
+    const bool sep = seg.separable != 0 && !dense;
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
     // wave 0 owns the per-chain sampler state
@@ -351,11 +353,11 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
             if (dense) bad = fg_grad_dense_stream(P.sstream, P.n_sstream, k0, k1, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
             else if (gn > 0) bad = fg_grad_stream(gs0, gn, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
-            __syncthreads();                                     // every p kicked, every read of q done
+            if (!sep) __syncthreads();                           // every p kicked, every read of q done
             if (gs < L) {
                 if (mi) { for (int k = k0; k < k1; ++k) slots[k * tw] += e * mi[(long long)k * X.C] * pl[k * tw]; }
                 else    { for (int k = k0; k < k1; ++k) slots[k * tw] += e * pl[k * tw]; }      // eps * 1.0 * p == eps * p
-                __syncthreads();
+                if (!sep) __syncthreads();
             }
         }
         xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
@@ -925,6 +927,15 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
             while (k < e->d && cstart[k] < target) ++k;
             seg.c[w] = k; seg.g[w] = cstart[k];
         }
+        // do the waves interact inside a trajectory?  Not when every record only reads coordinates of its own wave.
+        seg.separable = 1;
+        for (int w = 0; w < W && !dense_stream; ++w)
+            for (int k = seg.g[w]; k < seg.g[w + 1]; ++k) {
+                const FgGradRec &r = gs[k];
+                const bool x_ok = (r.flags & FG_G_X_CONST) || ((int)r.xi >= seg.c[w] && (int)r.xi < seg.c[w + 1]);
+                const bool m_ok = (r.flags & FG_G_M_CONST) || ((int)r.mi >= seg.c[w] && (int)r.mi < seg.c[w + 1]);
+                if (!x_ok || !m_ok) seg.separable = 0;
+            }
         hipLaunchKernelGGL(k_hmc_stream_steps, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, iter0, n,
                            e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
         HIPCHK(hipGetLastError());
