@@ -385,6 +385,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
                 double *r = info + (long long)t * 4 * X.C + c;
                 r[0] = acc ? 1.0 : 0.0; r[X.C] = div ? 1.0 : 0.0; r[2 * X.C] = ap; r[3 * X.C] = e;
             }
+#ifndef FG_EXP_NODA
             if (warming) {                                       // DualAveraging::update: hmc.rs:168-178
                 da_m += 1ull;
                 const double m = (double)da_m;
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
                 da_leb = w * log_eps + (1.0 - w) * da_leb;
                 eps = exp(log_eps);
             }
+#endif
         }
         __syncthreads();
         const bool acc = xch[tw] != 0.0;

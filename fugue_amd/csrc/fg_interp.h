@@ -35,24 +35,27 @@ struct FgAcc3 { double prior, lik, fac; };   // Trace accumulators, src/runtime/
 
 enum { FG_MODE_SCORE = 0, FG_MODE_PRIOR = 1, FG_MODE_MH = 2 };
 
-// one instruction held in 24 SGPRs
-struct FgInsRegs { fg_u32x16 a; fg_u32x8 b; };
+// One instruction = 24 dwords, fetched by ONE vector load: lane l (< 24) holds dword l, and a field is moved to an
+// SGPR with v_readlane when (and only if) it is used.  Why not scalar loads: SMEM and LDS share one counter and SMEM
+// returns out of order, so any LDS access forces s_waitcnt lgkmcnt(0) -- a scalar prefetch issued at the top of an
+// instruction is waited for at that instruction's first operand read and every interpreted instruction exposes a
+// scalar-cache round trip (PMC: 45-63 % of the wave's cycles in s_waitcnt).  Vector loads return in order on their
+// own counter (vmcnt), so instructions are fetched two ahead and the wait is usually free.
+struct FgInsRegs { uint32_t w; };
 __device__ __forceinline__ FgInsRegs fg_fetch_ins(const FgIns *prog, int pc) {
-    const FG_AS4 char *p = (const FG_AS4 char *)(uintptr_t)(prog + pc);
+    const int l = (int)(threadIdx.x & (FG_WAVE - 1));
     FgInsRegs r;
-    r.a = *(const FG_AS4 fg_u32x16 *)p;
-    r.b = *(const FG_AS4 fg_u32x8 *)(p + 64);
+    r.w = ((const uint32_t *)(prog + pc))[l < 24 ? l : 23];
     return r;
 }
 __device__ __forceinline__ double fg_dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 // field accessors (layout of FgIns, fg_ir.h): dw0 op, dw1..4 opnd, dw5 aux, dw6.. imm[4], dw14.. h[5]
-#define FG_I_OP(r) ((r).a[0])
-#define FG_I_OPND(r, k) ((r).a[1 + (k)])
-#define FG_I_AUX(r) ((r).a[5])
-#define FG_I_IMM(r, k) fg_dbl((r).a[6 + 2 * (k)], (r).a[7 + 2 * (k)])
-__device__ __forceinline__ double fg_ins_h(const FgInsRegs &r, int k) {
-    return k == 0 ? fg_dbl(r.a[14], r.a[15]) : fg_dbl(r.b[2 * k - 2], r.b[2 * k - 1]);
-}
+#define FG_I_DW(r, k) ((uint32_t)__builtin_amdgcn_readlane((int)(r).w, (k)))
+#define FG_I_OP(r) FG_I_DW(r, 0)
+#define FG_I_OPND(r, k) FG_I_DW(r, 1 + (k))
+#define FG_I_AUX(r) FG_I_DW(r, 5)
+#define FG_I_IMM(r, k) fg_dbl(FG_I_DW(r, 6 + 2 * (k)), FG_I_DW(r, 7 + 2 * (k)))
+__device__ __forceinline__ double fg_ins_h(const FgInsRegs &r, int k) { return fg_dbl(FG_I_DW(r, 14 + 2 * k), FG_I_DW(r, 15 + 2 * k)); }
 
 __device__ __forceinline__ double fg_operand(uint32_t w, double imm, const double *slots, const double *pool, int tw) {
     const uint32_t kind = FG_OPND_KIND(w), idx = FG_OPND_IDX(w);
@@ -138,15 +141,15 @@ __device__ __forceinline__ void fg_mh_walk_proposal(FgMhCtx &mh, uint32_t vtype,
 
 // Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane]; `tw` = tile width
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
-// `prog` must have one readable instruction past `n` (the host pads the arrays).
+// `prog` must have two readable instructions past `n` (the host pads the arrays).
 // logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
 template <int MODE, bool WITH_LOGP>
 __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, int tw, FgAcc3 &A,
                                         FgStream *rng, double *logp_out, long long logp_stride, bool live, FgMhCtx *mh = nullptr) {
     double acc = 0.0;
-    FgInsRegs I = fg_fetch_ins(prog, 0);
+    FgInsRegs I = fg_fetch_ins(prog, 0), Inext = fg_fetch_ins(prog, 1);
     for (int pc = 0; pc < n; ++pc) {
-        const FgInsRegs Inext = fg_fetch_ins(prog, pc + 1);      // prefetch (scalar, wave-uniform)
+        const FgInsRegs Inext2 = fg_fetch_ins(prog, pc + 2);     // two ahead, in order on vmcnt
         const uint32_t op = FG_I_OP(I);
         const uint32_t code = FG_INS_OPCODE(op);
         if (MODE == FG_MODE_SCORE && code == FG_OP_NORMAL_FAST) {
@@ -346,7 +349,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             default: break;
             }
         }
-        I = Inext;
+        I = Inext; Inext = Inext2;
     }
 }
 

@@ -491,11 +491,9 @@ int fg_program::finalize() {
         }
     }
     if (pool.empty()) pool.push_back(0.0);
-    // the kernels prefetch one instruction ahead: keep one readable no-op past each array
+    // the kernels prefetch two instructions ahead: keep two readable no-ops past each array
     n_ins = (int)ins.size();
-    ins.push_back(FgGen::blank(0xffu));
-    ins_fast.push_back(FgGen::blank(0xffu));
-    sub.push_back(FgGen::blank(0xffu));
+    for (int q = 0; q < 2; ++q) { ins.push_back(FgGen::blank(0xffu)); ins_fast.push_back(FgGen::blank(0xffu)); sub.push_back(FgGen::blank(0xffu)); }
     finalized = true;
     return FG_OK;
 }
