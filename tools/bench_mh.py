@@ -9,6 +9,7 @@ eng.mh_step(100); eng.synchronize()
 t0 = time.perf_counter(); eng.mh_step(400); eng.synchronize(); dt = time.perf_counter() - t0
 print(f"mh {C} chains: {C * 400 / dt:.3e} chain-steps/s, accept {eng.mh_stats().accept_rate:.3f}", flush=True)
 import numpy as np
+if os.environ.get("FG_MH_ONLY"): sys.exit(0)
 data, _ = W.mixture_data(32)
 C5 = int(os.environ.get("FG_CHAINS_C5", 262144))
 eng = E.Engine(E.compile_model(W.mixture(data)), C5, seed=1)
