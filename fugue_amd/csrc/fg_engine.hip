@@ -81,7 +81,7 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
         // all force terms are fast Normals: (L+1) fused gradient passes, then only the endpoint score below
         for (int gs = 0; gs <= L; ++gs) {
 #ifndef FG_EXP_NOSTREAM
-            bad = fg_grad_stream(P.gstream, P.n_gstream, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            bad = fg_grad_stream(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             if (__all(bad)) return true;
 #ifndef FG_EXP_NODRIFT
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
 #ifndef FG_EXP_NOSTREAM
             if (dense) bad = fg_grad_dense_stream(P.sstream, P.n_sstream, k0, k1, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
-            else if (gn > 0) bad = fg_grad_stream(gs0, gn, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            else if (gn > 0) bad = fg_grad_stream(gs0, gn, P.pool, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             if (!sep) __syncthreads();                           // every p kicked, every read of q done
             if (gs < L) {
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
             for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
             FgAcc3 A = {0.0, 0.0, 0.0};
 #ifndef FG_EXP_NOSCORE
-            if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, slots, tw, A);                                    // score_full, hmc.rs:283-299
+            if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, P.pool, slots, tw, A);                                    // score_full, hmc.rs:283-299
             else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
 #endif
             const double lj_new = fg_total(A);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
     if (sparse && P.gstream) {
         double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
         for (int i = 0; i < P.d; ++i) pl[i * tw] = 0.0;
-        good = !fg_grad_stream(P.gstream, P.n_gstream, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
+        good = !fg_grad_stream(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
         if (live && ok) ok[c] = good;
         return;
     }
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
                 mh.next_block = (int)s1.c1;
                 slots[tslot * tw] = fg_as_double(prop);
             } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
-            if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, slots, tw, A);
+            if (P.sstream) fg_score_stream(P.sstream, P.n_sstream, P.pool, slots, tw, A);
             else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         } else
             fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
@@ -905,7 +905,7 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
 static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t,
                             double *pos_all = nullptr, double *info = nullptr) {
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
-    const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr;
+    const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr && !e->prog->sstream_has_lin;
     if (((e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
@@ -936,7 +936,7 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
                 const FgGradRec &r = gs[k];
                 const bool x_ok = (r.flags & FG_G_X_CONST) || ((int)r.xi >= seg.c[w] && (int)r.xi < seg.c[w + 1]);
                 const bool m_ok = (r.flags & FG_G_M_CONST) || ((int)r.mi >= seg.c[w] && (int)r.mi < seg.c[w + 1]);
-                if (!x_ok || !m_ok) seg.separable = 0;
+                if (!x_ok || !m_ok || (r.flags & FG_G_LIN)) seg.separable = 0;   // a linear predictor reads many coordinates
             }
         hipLaunchKernelGGL(k_hmc_stream_steps, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, iter0, n,
                            e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);

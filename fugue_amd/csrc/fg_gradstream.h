@@ -22,6 +22,47 @@ __device__ __forceinline__ double fg_uniform(double v) {
     return fg_dbl(__builtin_amdgcn_readfirstlane((uint32_t)b), __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)));
 }
 
+// ---- linear predictors (FG_G_LIN): mu = c0 + s_0 c_0 + s_1 c_1 + ... in term order, two roundings per term like the
+// interpreter's LOAD / FG_OP_DOT sequence it replaces.  Terms {u32 slot, u32 0, f64 c} are read four at a time with
+// scalar loads; with 4 waves on the SIMD the exposed load latency of one wave is covered by the others.
+__device__ __forceinline__ double fg_lin_prefix(const FG_AS4 char *tb, uint32_t t0, uint32_t t1, const double *slots, int tw, double mu) {
+    uint32_t t = t0;
+    for (; t + 4 <= t1; t += 4) {
+        const fg_u32x16 q = *(const FG_AS4 fg_u32x16 *)(tb + 16 * t);
+        const double v0 = slots[q[0] * tw], v1 = slots[q[4] * tw], v2 = slots[q[8] * tw], v3 = slots[q[12] * tw];
+        mu = mu + v0 * fg_dbl(q[2], q[3]);
+        mu = mu + v1 * fg_dbl(q[6], q[7]);
+        mu = mu + v2 * fg_dbl(q[10], q[11]);
+        mu = mu + v3 * fg_dbl(q[14], q[15]);
+    }
+    for (; t < t1; ++t) {
+        const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+        mu = mu + slots[q[0] * tw] * fg_dbl(q[2], q[3]);
+    }
+    return mu;
+}
+// mean of a FG_G_LIN record (score: all terms)
+__device__ __forceinline__ double fg_lin_mu(const fg_u32x16 &r, const double *pool, const double *slots, int tw) {
+    const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + r[14]);
+    return fg_lin_prefix(tb, 0u, r[15], slots, tw, fg_dbl(r[6], r[7]));
+}
+// means at q_i + h and q_i - h: the terms before the first one that reads q_i are common to both, from there on the
+// two sums are carried side by side (a term that does not read q_i contributes the same product to both)
+__device__ __forceinline__ void fg_lin_mu_dual(const fg_u32x16 &r, const double *pool, const double *slots, int tw, double h,
+                                               double &mup, double &mum) {
+    const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + r[14]);
+    const uint32_t n = r[15], pos = r[2] >> 16, ci = r[3];
+    const double mu = fg_lin_prefix(tb, 0u, pos < n ? pos : n, slots, tw, fg_dbl(r[6], r[7]));
+    double mp = mu, mm = mu;
+    for (uint32_t t = pos; t < n; ++t) {
+        const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+        const double v = slots[q[0] * tw], c = fg_dbl(q[2], q[3]);
+        if (q[0] == ci) { mp = mp + (v + h) * c; mm = mm + (v - h) * c; }      // the perturbed slot holds orig +- h (hmc.rs:317-319)
+        else { const double pr = v * c; mp = mp + pr; mm = mm + pr; }
+    }
+    mup = mp; mum = mm;
+}
+
 struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
 struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
 
@@ -34,14 +75,20 @@ struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-unifo
 // (trace.rs:198-200).  A non-finite x or mu gives z = NaN or +-inf -> lp NaN or -inf -> a non-finite g -> divergent,
 // the same verdict as the reference's -inf log-density (hmc.rs:323-325); no guard is needed here.
 __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, double ms, double pv, FgGradAcc &A, const FgGradK &K,
-                                             double *pl, int tw, double *gout, long long gstride, bool live) {
+                                             const double *pool, const double *slots, double *pl, int tw, double *gout, long long gstride, bool live) {
     const uint32_t fl = r[2];
     // x - mu at q_i + h and q_i - h: the perturbed operand holds orig +- h (hmc.rs:317-319), the other its value
     // (a constant operand is the record's immediate, a scalar).  Four forms, four additions each, selected by
     // scalar branches: adding the zero perturbation / the zero slot of a uniform form would give the same bits
     // for two more f64 instructions per record, and f64 issue is what bounds this loop.
     double dlp, dlm;
-    if (fl & FG_G_PERT_X) {
+    if (__builtin_expect((fl & FG_G_LIN) != 0u, 0)) {      // linear predictor: both means, then x - mu
+        double mup, mum;
+        fg_lin_mu_dual(r, pool, slots, tw, K.h, mup, mum);
+        const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
+        const double hx = (fl & FG_G_PERT_X) ? K.h : 0.0;
+        dlp = (x + hx) - mup; dlm = (x - hx) - mum;
+    } else if (fl & FG_G_PERT_X) {
         const double xp = xs + K.h, xm = xs - K.h;
         if (fl & FG_G_M_CONST) { const double m = fg_dbl(r[6], r[7]); dlp = xp - m; dlm = xm - m; }
         else if (__builtin_expect((fl & FG_G_PERT_M) != 0u, 0)) { dlp = xp - (ms + K.h); dlm = xm - (ms - K.h); }   // x and mu are the same site
@@ -96,7 +143,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 #ifdef FG_EXP_G_NOMATH
 #define FG_G_MATH(RA, XA, MA, PA) A.sp += XA + MA + PA + fg_dbl(RA[4], RA[5]);
 #else
-#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math(RA, XA, MA, PA, A, K, pl, tw, gout, gstride, live);
+#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
 #endif
 #ifdef FG_EXP_G_NOFETCH
 #define FG_G_FETCH(RD) RD = fg_fetch_grec(g, (k + 3) & 1);
@@ -117,7 +164,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 // 16-SGPR buffers), operands one ahead.
 // `g`, `n`: the whole stream (P.gstream, P.n_gstream) or one wave's run of whole coordinates of it (multi-wave HMC);
 // reading up to 3 records past `n` is safe either way (the next wave's records or the pad records).
-__device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, double *slots, double *pl, int tw, double h, double hk,
+__device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, const double *pool, double *slots, double *pl, int tw, double h, double hk,
                                                bool two_kicks, double *gout, long long gstride, bool live) {
     FgGradK K;
     K.h = fg_uniform(h); K.hk = hk; K.two_kicks = two_kicks;
@@ -140,9 +187,11 @@ __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, 
 // The endpoint score of an all-fast-Normal program: one record per statement in program order, the same values and
 // the same additions as FG_OP_NORMAL_FAST in the interpreter (operand = slot or immediate; z != z -> -inf guard;
 // log_prior and log_likelihood accumulated separately).  Records are fetched two ahead, operands one ahead.
-__device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, double ms, FgAcc3 &A) {
+__device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     const uint32_t fl = r[2];
-    const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs, m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
+    const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
+    double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
+    if (__builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
     const double dl = x - m, inv = fg_dbl(r[10], r[11]);
     double z = dl * inv;
     if (__builtin_expect(!(fl & FG_G_POW2), 0)) {
@@ -153,7 +202,7 @@ __device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, doub
     lp = (z != z) ? FG_NEG_INF : lp;
     if (fl & FG_S_OBS) A.lik += lp; else A.prior += lp;
 }
-__device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n, const double *slots, int tw, FgAcc3 &A) {
+__device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     fg_u32x16 r0 = fg_fetch_grec(g, 0), r1 = fg_fetch_grec(g, 1), r2;
     double x0 = slots[r0[0] * tw], m0 = slots[r0[1] * tw], x1, m1;
     for (int k = 0; k < n; ++k) {
@@ -161,7 +210,7 @@ __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n,
         r2 = fg_fetch_grec(g, k + 2);
         x1 = slots[r1[0] * tw]; m1 = slots[r1[1] * tw];
         __builtin_amdgcn_sched_barrier(0);
-        fg_score_one(r0, x0, m0, A);
+        fg_score_one(r0, x0, m0, pool, slots, tw, A);
         r0 = r1; r1 = r2; x0 = x1; m0 = m1;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

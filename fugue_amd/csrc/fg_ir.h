@@ -67,7 +67,9 @@ enum : uint32_t { FG_S_OBS = 1u,      // score stream: the record is an observe 
                   FG_G_POW2 = 2u, FG_G_PERT_X = 4u, FG_G_PERT_M = 8u, FG_G_END = 16u,
                   FG_G_X_CONST = 32u,  // x is a constant (ximm), no slot read
                   FG_G_M_CONST = 64u,  // mu is a constant (mimm), no slot read
-                  FG_G_DIV = 128u      // sigma outside the range where fg_div_const is proven exact: IEEE division
+                  FG_G_DIV = 128u,     // sigma outside the range where fg_div_const is proven exact: IEEE division
+                  FG_G_LIN = 256u      // mu = mimm + sum_t slot[s_t] c_t: maskx = pool offset of the terms {u32 s, u32 0, f64 c},
+                                       //   maskm = their number, flags >> 16 = first term that reads the record's coordinate
 };
 struct FgGradRec {
     uint32_t xi, mi;        // slot indices of x and mu (the zero slot for constants)
@@ -75,7 +77,7 @@ struct FgGradRec {
     double ximm, mimm;      // constants of x, mu (0 for slots): operand value = slot + imm, like FG_OP_NORMAL_FAST
     double sigma, inv;      // sigma and RN(1/sigma) (exact when FG_G_POW2; seed of the exact-division sequence otherwise)
     double lns;             // ln sigma
-    uint32_t maskx, maskm;  // all-ones when x / mu IS the perturbed coordinate: h_eff = h & mask, no branch
+    uint32_t maskx, maskm;  // FG_G_LIN: pool offset / number of the linear predictor's terms (else unused)
 };
 static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
 

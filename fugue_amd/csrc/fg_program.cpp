@@ -430,63 +430,109 @@ int fg_program::finalize() {
         coord.push_back(cd);
         sub_off.push_back((int)sub.size());
     }
-    // fused FD gradient stream: possible when every statement that reads an f64 coordinate is a fast Normal
+    // ---- statement shapes the record streams understand --------------------------------------------------------
+    //   FAST: one FG_OP_NORMAL_FAST instruction (x, mu each an f64 slot or a constant, constant sigma);
+    //   LIN : a Normal with constant sigma whose mean is a linear predictor,  LOAD c0; {MAC | DOT}...; STORE t;
+    //         NORMAL_FAST(x, mu = slot t)  --  mu = (..((c0 + s_0 c_0) + s_1 c_1)..): its terms go to the pool once.
+    struct Shape { int kind = 0; FgIns F; double init = 0.0; uint32_t toff = 0, tn = 0; std::vector<uint32_t> tslot; };
+    std::vector<Shape> shape(stmts.size());
+    for (size_t i = 0; i < stmts.size(); i++) {
+        const int b = range[i].first, e = range[i].second;
+        Shape &sh = shape[i];
+        if (e - b == 1 && FG_INS_OPCODE(ins_fast[b].op) == FG_OP_NORMAL_FAST) { sh.kind = 1; sh.F = ins_fast[b]; continue; }
+        if (e - b < 4 || FG_INS_OPCODE(ins_fast[e - 1].op) != FG_OP_NORMAL_FAST) continue;
+        const FgIns &L = ins_fast[b], &St = ins_fast[e - 2], &F = ins_fast[e - 1];
+        if (FG_INS_OPCODE(L.op) != FG_OP_LOAD || FG_OPND_KIND(L.opnd[0]) != FG_OPND_IMM) continue;
+        if (FG_INS_OPCODE(St.op) != FG_OP_STORE || F.opnd[1] != St.aux || (int)St.aux < S || F.opnd[0] == St.aux || F.imm[1] != 0.0) continue;
+        std::vector<double> terms;
+        bool ok = true;
+        for (int k = b + 1; k < e - 2 && ok; k++) {
+            const FgIns &I = ins_fast[k];
+            if (FG_INS_OPCODE(I.op) == FG_OP_DOT) {
+                for (uint32_t t = 0; t < I.opnd[1]; t++) { terms.push_back(pool[I.aux + 2 * t]); terms.push_back(pool[I.aux + 2 * t + 1]); }
+            } else if (FG_INS_OPCODE(I.op) == FG_OP_MAC) {
+                const uint32_t k0 = FG_OPND_KIND(I.opnd[0]), k1 = FG_OPND_KIND(I.opnd[1]);
+                if (k0 == FG_OPND_SLOT_F && k1 == FG_OPND_IMM) { terms.push_back(fg_as_double((long long)FG_OPND_IDX(I.opnd[0]))); terms.push_back(I.imm[1]); }
+                else if (k0 == FG_OPND_IMM && k1 == FG_OPND_SLOT_F) { terms.push_back(fg_as_double((long long)FG_OPND_IDX(I.opnd[1]))); terms.push_back(I.imm[0]); }
+                else ok = false;
+            } else ok = false;
+        }
+        if (!ok || terms.empty() || terms.size() / 2 > 0xffffu) continue;
+        for (size_t t = 0; t < terms.size(); t += 2) { const uint32_t sl = (uint32_t)fg_as_i64(terms[t]); if ((int)sl >= (int)f64_slot.size()) ok = false; sh.tslot.push_back(sl); }
+        if (!ok) { sh.tslot.clear(); continue; }                       // every term must be an f64 coordinate (slot k = coordinate k)
+        if (pool.size() & 1) pool.push_back(0.0);
+        sh.kind = 2; sh.F = F; sh.init = L.imm[0]; sh.toff = (uint32_t)pool.size(); sh.tn = (uint32_t)(terms.size() / 2);
+        pool.insert(pool.end(), terms.begin(), terms.end());
+    }
+    for (int q = 0; q < 8; q++) pool.push_back(0.0);                   // term groups are read 4 at a time
+    auto make_rec = [&](const Shape &sh, int coord_k /* -1: score record */) {
+        const FgIns &F = sh.F;
+        FgGradRec r; std::memset(&r, 0, sizeof(r));
+        r.xi = F.opnd[0]; r.mi = sh.kind == 2 ? (uint32_t)zero_slot : F.opnd[1];
+        r.flags = ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) | ((F.op & (FG_F_POW2SCALE | FG_F_RCPSCALE)) ? 0u : FG_G_DIV) |
+                  (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | ((sh.kind == 1 && r.mi == (uint32_t)zero_slot) ? FG_G_M_CONST : 0u);
+        r.ximm = F.imm[0]; r.mimm = sh.kind == 2 ? sh.init : F.imm[1]; r.sigma = F.imm[2]; r.inv = 1.0 / F.imm[2]; r.lns = F.h[0];
+        if (sh.kind == 2) {
+            uint32_t pos = sh.tn;                                      // first term that reads the coordinate (tn: none)
+            if (coord_k >= 0) for (uint32_t t = 0; t < sh.tn; t++) if (sh.tslot[t] == (uint32_t)coord_k) { pos = t; break; }
+            r.flags |= FG_G_LIN | (pos << 16);
+            r.maskx = sh.toff; r.maskm = sh.tn;                        // LIN: pool offset and number of terms
+        }
+        if (coord_k >= 0) {
+            r.coord = (uint32_t)coord_k;
+            if (r.xi == (uint32_t)coord_k) r.flags |= FG_G_PERT_X;
+            if (sh.kind == 1 && r.mi == (uint32_t)coord_k) r.flags |= FG_G_PERT_M;
+        }
+        return r;
+    };
+    FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
+    pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2;
+    // fused FD gradient stream: possible when every statement that reads an f64 coordinate is FAST or LIN
     gstream.clear(); n_gstream = 0;
     {
         bool ok = !f64_slot.empty();
-        for (size_t k = 0; k < sub.size() && ok; k++) ok = FG_INS_OPCODE(sub[k].op) == FG_OP_NORMAL_FAST;
-        for (size_t k = 0; k < f64_slot.size() && ok; k++) ok = coord[k].sub_n > 0;
+        std::vector<std::vector<int>> dep(f64_slot.size());          // statements reading coordinate k, program order
+        for (size_t k = 0; k < f64_slot.size() && ok; k++) {
+            for (size_t i = 0; i < stmts.size(); i++)
+                if (std::find(reads[i].begin(), reads[i].end(), f64_slot[k]) != reads[i].end()) { dep[k].push_back((int)i); ok = ok && shape[i].kind != 0; }
+            ok = ok && !dep[k].empty();
+        }
         if (ok) {
             // log_prior and log_likelihood are separate accumulators (trace.rs:168-177), so within one coordinate
             // the prior records may be emitted before the observe records without changing either sum
             for (size_t k = 0; k < f64_slot.size(); k++) {
-                const uint32_t ps = (uint32_t)k;          // LDS slot of coordinate k
                 std::vector<int> order;
                 for (int pass = 0; pass < 2; pass++)
-                    for (int j = 0; j < coord[k].sub_n; j++)
-                        if (((sub[coord[k].sub_off + j].op & FG_F_OBSERVE) != 0u) == (pass == 1)) order.push_back(j);
+                    for (int i : dep[k]) if (((shape[i].F.op & FG_F_OBSERVE) != 0u) == (pass == 1)) order.push_back(i);
                 bool seen_obs = false;
                 for (size_t q = 0; q < order.size(); q++) {
-                    const FgIns &F = sub[coord[k].sub_off + order[q]];
-                    const bool obs = (F.op & FG_F_OBSERVE) != 0u;
-                    FgGradRec r; std::memset(&r, 0, sizeof(r));
-                    r.xi = F.opnd[0]; r.mi = F.opnd[1]; r.coord = (uint32_t)k;
-                    r.flags = ((obs && !seen_obs) ? FG_G_SWITCH : 0u) | ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) |
-                              (r.xi == ps ? FG_G_PERT_X : 0u) | (r.mi == ps ? FG_G_PERT_M : 0u) |
-                              (q + 1 == order.size() ? FG_G_END : 0u) |
-                              (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | (r.mi == (uint32_t)zero_slot ? FG_G_M_CONST : 0u);
+                    const bool obs = (shape[order[q]].F.op & FG_F_OBSERVE) != 0u;
+                    FgGradRec r = make_rec(shape[order[q]], (int)k);
+                    if (obs && !seen_obs) r.flags |= FG_G_SWITCH;
+                    if (q + 1 == order.size()) r.flags |= FG_G_END;
                     seen_obs = seen_obs || obs;
-                    r.ximm = F.imm[0]; r.mimm = F.imm[1]; r.sigma = F.imm[2]; r.inv = 1.0 / F.imm[2]; r.lns = F.h[0];
-                    if (!(F.op & FG_F_POW2SCALE) && !fg_div_const_ok(r.sigma)) r.flags |= FG_G_DIV;
-                    r.maskx = (r.flags & FG_G_PERT_X) ? 0xffffffffu : 0u; r.maskm = (r.flags & FG_G_PERT_M) ? 0xffffffffu : 0u;
                     gstream.push_back(r);
                 }
             }
             n_gstream = (int)gstream.size();
-            FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
-            pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2;
             for (int q = 0; q < 4; q++) gstream.push_back(pad);   // the stream is read 3 records ahead
         }
     }
-    // score stream: when the WHOLE program is fast Normals its endpoint score (score_full, hmc.rs:283-299) is a lean
-    // pass over one 64-byte record per statement, in program order (the accumulation order of PriorHandler /
-    // ScoreGivenTrace), instead of a pass of the general interpreter
-    sstream.clear(); n_sstream = 0;
+    // score stream: when the WHOLE program is FAST / LIN statements its endpoint score (score_full, hmc.rs:283-299)
+    // is a lean pass over one 64-byte record per statement, in program order (the accumulation order of
+    // PriorHandler / ScoreGivenTrace), instead of a pass of the general interpreter
+    sstream.clear(); n_sstream = 0; sstream_has_lin = false;
     {
-        bool ok = !ins_fast.empty();
-        for (const FgIns &F : ins_fast) ok = ok && FG_INS_OPCODE(F.op) == FG_OP_NORMAL_FAST;
+        bool ok = !stmts.empty();
+        for (const Shape &sh : shape) ok = ok && sh.kind != 0;
         if (ok) {
-            for (const FgIns &F : ins_fast) {
-                FgGradRec r; std::memset(&r, 0, sizeof(r));
-                r.xi = F.opnd[0]; r.mi = F.opnd[1];
-                r.flags = ((F.op & FG_F_OBSERVE) ? FG_S_OBS : 0u) | ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) | ((F.op & (FG_F_POW2SCALE | FG_F_RCPSCALE)) ? 0u : FG_G_DIV) |
-                          (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | (r.mi == (uint32_t)zero_slot ? FG_G_M_CONST : 0u);
-                r.ximm = F.imm[0]; r.mimm = F.imm[1]; r.sigma = F.imm[2]; r.inv = 1.0 / F.imm[2]; r.lns = F.h[0];
+            for (const Shape &sh : shape) {
+                FgGradRec r = make_rec(sh, -1);
+                if (sh.F.op & FG_F_OBSERVE) r.flags |= FG_S_OBS;
+                sstream_has_lin = sstream_has_lin || sh.kind == 2;
                 sstream.push_back(r);
             }
             n_sstream = (int)sstream.size();
-            FgGradRec pad; std::memset(&pad, 0, sizeof(pad));
-            pad.xi = pad.mi = (uint32_t)zero_slot; pad.sigma = 1.0; pad.inv = 1.0; pad.flags = FG_G_POW2;
             for (int q = 0; q < 4; q++) sstream.push_back(pad);
         }
     }

@@ -320,7 +320,8 @@ def test_hmc_posterior_closed_form():
 
 @pytest.mark.parametrize("name,adapt_mass,mode", [("normal32", False, E.GRAD_FD_SPARSE), ("normal32", True, E.GRAD_FD_SPARSE),
                                                   ("hier", True, E.GRAD_FD_SPARSE), ("readme", False, E.GRAD_FD_SPARSE),
-                                                  ("normal32", True, E.GRAD_FD_DENSE), ("hier", False, E.GRAD_FD_DENSE)])
+                                                  ("normal32", True, E.GRAD_FD_DENSE), ("hier", False, E.GRAD_FD_DENSE),
+                                                  ("ridge7", True, E.GRAD_FD_SPARSE), ("ridge", False, E.GRAD_FD_SPARSE)])   # linear-predictor records
 def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """k_hmc_stream_steps splits a tile's coordinates over 1, 2 or 4 waves; the per-coordinate operations and
     their order are the same, so draws, step sizes, mass matrix and log-joint must agree BIT FOR BIT."""
