@@ -74,6 +74,7 @@ struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-unifo
 // log_prior and log_likelihood are summed separately and added at the end, exactly like total_log_weight
 // (trace.rs:198-200).  A non-finite x or mu gives z = NaN or +-inf -> lp NaN or -inf -> a non-finite g -> divergent,
 // the same verdict as the reference's -inf log-density (hmc.rs:323-325); no guard is needed here.
+template <bool LIN>
 __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, double ms, double pv, FgGradAcc &A, const FgGradK &K,
                                              const double *pool, const double *slots, double *pl, int tw, double *gout, long long gstride, bool live) {
     const uint32_t fl = r[2];
@@ -82,7 +83,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
     // scalar branches: adding the zero perturbation / the zero slot of a uniform form would give the same bits
     // for two more f64 instructions per record, and f64 issue is what bounds this loop.
     double dlp, dlm;
-    if (__builtin_expect((fl & FG_G_LIN) != 0u, 0)) {      // linear predictor: both means, then x - mu
+    if (LIN && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) {   // linear predictor: both means, then x - mu
         double mup, mum;
         fg_lin_mu_dual(r, pool, slots, tw, K.h, mup, mum);
         const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
@@ -143,7 +144,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 #ifdef FG_EXP_G_NOMATH
 #define FG_G_MATH(RA, XA, MA, PA) A.sp += XA + MA + PA + fg_dbl(RA[4], RA[5]);
 #else
-#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
+#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math<LIN>(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
 #endif
 #ifdef FG_EXP_G_NOFETCH
 #define FG_G_FETCH(RD) RD = fg_fetch_grec(g, (k + 3) & 1);
@@ -164,6 +165,9 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 // 16-SGPR buffers), operands one ahead.
 // `g`, `n`: the whole stream (P.gstream, P.n_gstream) or one wave's run of whole coordinates of it (multi-wave HMC);
 // reading up to 3 records past `n` is safe either way (the next wave's records or the pad records).
+// LIN = false instantiates the loop without the linear-predictor branch: the 128-VGPR multi-wave kernel is sensitive to
+// every register the hot loop holds, and most programs have no such record.
+template <bool LIN>
 __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, const double *pool, double *slots, double *pl, int tw, double h, double hk,
                                                bool two_kicks, double *gout, long long gstride, bool live) {
     FgGradK K;
@@ -187,11 +191,12 @@ __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, 
 // The endpoint score of an all-fast-Normal program: one record per statement in program order, the same values and
 // the same additions as FG_OP_NORMAL_FAST in the interpreter (operand = slot or immediate; z != z -> -inf guard;
 // log_prior and log_likelihood accumulated separately).  Records are fetched two ahead, operands one ahead.
+template <bool LIN>
 __device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     const uint32_t fl = r[2];
     const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
     double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
-    if (__builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
+    if (LIN && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
     const double dl = x - m, inv = fg_dbl(r[10], r[11]);
     double z = dl * inv;
     if (__builtin_expect(!(fl & FG_G_POW2), 0)) {
@@ -202,6 +207,7 @@ __device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, doub
     lp = (z != z) ? FG_NEG_INF : lp;
     if (fl & FG_S_OBS) A.lik += lp; else A.prior += lp;
 }
+template <bool LIN>
 __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     fg_u32x16 r0 = fg_fetch_grec(g, 0), r1 = fg_fetch_grec(g, 1), r2;
     double x0 = slots[r0[0] * tw], m0 = slots[r0[1] * tw], x1, m1;
@@ -210,7 +216,7 @@ __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n,
         r2 = fg_fetch_grec(g, k + 2);
         x1 = slots[r1[0] * tw]; m1 = slots[r1[1] * tw];
         __builtin_amdgcn_sched_barrier(0);
-        fg_score_one(r0, x0, m0, pool, slots, tw, A);
+        fg_score_one<LIN>(r0, x0, m0, pool, slots, tw, A);
         r0 = r1; r1 = r2; x0 = x1; m0 = m1;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

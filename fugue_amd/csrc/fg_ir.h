@@ -95,6 +95,7 @@ struct FgProgramDev {
     const FgGradRec *gstream;  // fused gradient stream or null
     const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
     int n_gstream, n_sstream;
+    int sstream_lin;           // the score stream holds linear-predictor records (FG_G_LIN)
     int n_ins, n_slots, S, d;
 };
 
