@@ -81,7 +81,7 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
         // all force terms are fast Normals: (L+1) fused gradient passes, then only the endpoint score below
         for (int gs = 0; gs <= L; ++gs) {
 #ifndef FG_EXP_NOSTREAM
-            bad = fg_grad_stream<true>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            bad = fg_grad_stream<2>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             if (__all(bad)) return true;
 #ifndef FG_EXP_NODRIFT
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
 struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1];
                int separable; };   // every record of a wave reads only that wave's own coordinates (and constants): no barrier inside the leapfrog loop
 
-template <bool LIN>
+template <int RK>
 __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSeg seg, int iter0, int n_steps,
                                                                                int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                                double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
 #ifndef FG_EXP_NOSTREAM
             if (dense) bad = fg_grad_dense_stream(P.sstream, P.n_sstream, k0, k1, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
-            else if (gn > 0) bad = fg_grad_stream<LIN>(gs0, gn, P.pool, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            else if (gn > 0) bad = fg_grad_stream<RK>(gs0, gn, P.pool, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             if (!sep) __syncthreads();                           // every p kicked, every read of q done
             if (gs < L) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
             for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
             FgAcc3 A = {0.0, 0.0, 0.0};
 #ifndef FG_EXP_NOSCORE
-            if (P.sstream) fg_score_stream<LIN>(P.sstream, P.n_sstream, P.pool, slots, tw, A);                               // score_full, hmc.rs:283-299
+            if (P.sstream) fg_score_stream<RK>(P.sstream, P.n_sstream, P.pool, slots, tw, A);                               // score_full, hmc.rs:283-299
             else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
 #endif
             const double lj_new = fg_total(A);
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
     if (sparse && P.gstream) {
         double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
         for (int i = 0; i < P.d; ++i) pl[i * tw] = 0.0;
-        good = !fg_grad_stream<true>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
+        good = !fg_grad_stream<2>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
         if (live && ok) ok[c] = good;
         return;
     }
@@ -645,8 +645,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
                 mh.next_block = (int)s1.c1;
                 slots[tslot * tw] = fg_as_double(prop);
             } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
-            if (P.sstream && !P.sstream_lin) fg_score_stream<false>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
-            else if (P.sstream) fg_score_stream<true>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
+            if (P.sstream && P.sstream_kinds == 0) fg_score_stream<0>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
+            else if (P.sstream) fg_score_stream<2>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
             else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         } else
             fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
@@ -735,12 +735,12 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_alloc(&e->d_tmp, (size_t)e->C)) return fail("alloc tmp");
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
     e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream;
-    e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_lin = p->sstream_has_lin ? 1 : 0; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
+    e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_kinds = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0); e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
-        set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_stream_steps<true>, e->lds_bytes) || set_lds(k_hmc_stream_steps<false>, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
+        set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_stream_steps<0>, e->lds_bytes) || set_lds(k_hmc_stream_steps<1>, e->lds_bytes) || set_lds(k_hmc_stream_steps<2>, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
         set_lds(k_hmc_grad, e->lds_bytes) || set_lds(k_hmc_find_eps, e->lds_bytes) ||
         set_lds(k_mh_steps, e->lds_bytes))
         return fail("hipFuncSetAttribute");
@@ -907,7 +907,7 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
 static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t,
                             double *pos_all = nullptr, double *info = nullptr) {
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
-    const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr && !e->prog->sstream_has_lin;
+    const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr && e->P.sstream_kinds == 0;
     if (((e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
@@ -940,12 +940,12 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
                 const bool m_ok = (r.flags & FG_G_M_CONST) || ((int)r.mi >= seg.c[w] && (int)r.mi < seg.c[w + 1]);
                 if (!x_ok || !m_ok || (r.flags & FG_G_LIN)) seg.separable = 0;   // a linear predictor reads many coordinates
             }
-        bool has_lin = e->prog->sstream_has_lin;
-        for (int k = 0; k < nrec && !has_lin; ++k) has_lin = (gs[k].flags & FG_G_LIN) != 0u;
-        if (has_lin) hipLaunchKernelGGL(k_hmc_stream_steps<true>, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, iter0, n,
-                                        e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
-        else hipLaunchKernelGGL(k_hmc_stream_steps<false>, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, iter0, n,
-                                e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
+        int rk = e->P.sstream_kinds;                             // record kinds present in either stream
+        for (int k = 0; k < nrec && rk < 2; ++k) rk = std::max(rk, (gs[k].flags & FG_G_GEN) ? 2 : ((gs[k].flags & FG_G_LIN) ? 1 : 0));
+#define FG_LAUNCH_STREAM(RK) hipLaunchKernelGGL(k_hmc_stream_steps<RK>, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, \
+                                                iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
+        if (rk == 2) FG_LAUNCH_STREAM(2); else if (rk == 1) FG_LAUNCH_STREAM(1); else FG_LAUNCH_STREAM(0);
+#undef FG_LAUNCH_STREAM
         HIPCHK(hipGetLastError());
         return FG_OK;
     }

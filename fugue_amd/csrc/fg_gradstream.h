@@ -63,6 +63,32 @@ __device__ __forceinline__ void fg_lin_mu_dual(const fg_u32x16 &r, const double 
     mup = mp; mum = mm;
 }
 
+// ---- general distribution records (FG_G_GEN): any of the 17 log-densities with leaf operands, evaluated by the same
+// fg_logpdf the interpreter calls (same guards, same evaluation order), at q_i + h and q_i - h (n_signs = 2) or once.
+__device__ __forceinline__ void fg_gen_lp(const fg_u32x16 &r, double xs, const double *slots, int tw, double h, int n_signs, double *lp_out) {
+    const uint32_t fl = r[2], kind = (fl >> 16) & 0xffu, ci = r[3];
+    if (fl & FG_G_GEN_INVALID) { lp_out[0] = FG_NEG_INF; lp_out[1] = FG_NEG_INF; return; }
+    const bool xint = (fl & FG_G_GEN_XINT) != 0u, hoisted = (fl & FG_G_GEN_HOISTED) != 0u, sh = (fl & FG_G_GEN_SH) != 0u;
+    const double xv = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
+    const long long xi = xint ? fg_as_i64(xv) : 0;
+    const double xf = xint ? 0.0 : xv;
+    const bool dual = n_signs == 2;
+    const bool px = dual && !xint && !(fl & FG_G_X_CONST) && r[0] == ci;
+    double p[3]; bool pp[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (fl & (FG_G_GEN_P0SLOT << q)) { const uint32_t idx = r[6 + 2 * q]; p[q] = slots[idx * tw]; pp[q] = dual && idx == ci; }
+        else { p[q] = fg_dbl(r[6 + 2 * q], r[7 + 2 * q]); pp[q] = false; }
+    }
+    const double hh[5] = { fg_dbl(r[12], r[13]), fg_dbl(r[14], r[15]), 0.0, 0.0, 0.0 };
+#pragma nounroll
+    for (int s = 0; s < n_signs; ++s) {                      // the perturbed operand holds orig +- h (hmc.rs:317-319)
+        const double hs = dual ? (s == 0 ? h : -h) : 0.0;
+        lp_out[s] = fg_logpdf(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1],
+                              pp[2] ? p[2] + hs : p[2], hh, sh);
+    }
+}
+
 struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
 struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
 
@@ -74,7 +100,7 @@ struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-unifo
 // log_prior and log_likelihood are summed separately and added at the end, exactly like total_log_weight
 // (trace.rs:198-200).  A non-finite x or mu gives z = NaN or +-inf -> lp NaN or -inf -> a non-finite g -> divergent,
 // the same verdict as the reference's -inf log-density (hmc.rs:323-325); no guard is needed here.
-template <bool LIN>
+template <int RK>
 __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, double ms, double pv, FgGradAcc &A, const FgGradK &K,
                                              const double *pool, const double *slots, double *pl, int tw, double *gout, long long gstride, bool live) {
     const uint32_t fl = r[2];
@@ -82,8 +108,14 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
     // (a constant operand is the record's immediate, a scalar).  Four forms, four additions each, selected by
     // scalar branches: adding the zero perturbation / the zero slot of a uniform form would give the same bits
     // for two more f64 instructions per record, and f64 issue is what bounds this loop.
+    double lpp, lpm;
+    if (RK >= 2 && __builtin_expect((fl & FG_G_GEN) != 0u, 0)) {   // general distribution record: fg_logpdf at both signs
+        double lp2[2];
+        fg_gen_lp(r, xs, slots, tw, K.h, 2, lp2);
+        lpp = lp2[0]; lpm = lp2[1];
+    } else {
     double dlp, dlm;
-    if (LIN && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) {   // linear predictor: both means, then x - mu
+    if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) {   // linear predictor: both means, then x - mu
         double mup, mum;
         fg_lin_mu_dual(r, pool, slots, tw, K.h, mup, mum);
         const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
@@ -107,8 +139,9 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
         else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }
     }
     const double lns = fg_dbl(r[12], r[13]);
-    const double lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;       // distribution.rs:207
-    const double lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
+    lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;       // distribution.rs:207
+    lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
+    }
     if (__builtin_expect((fl & FG_G_SWITCH) != 0u, 0)) {  // a real (scalar) branch, not eight v_cndmask
         A.prip = A.sp; A.prim = A.sm; A.sp = 0.0; A.sm = 0.0;
         asm volatile("" ::: "memory");
@@ -144,7 +177,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 #ifdef FG_EXP_G_NOMATH
 #define FG_G_MATH(RA, XA, MA, PA) A.sp += XA + MA + PA + fg_dbl(RA[4], RA[5]);
 #else
-#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math<LIN>(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
+#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math<RK>(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
 #endif
 #ifdef FG_EXP_G_NOFETCH
 #define FG_G_FETCH(RD) RD = fg_fetch_grec(g, (k + 3) & 1);
@@ -165,9 +198,10 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 // 16-SGPR buffers), operands one ahead.
 // `g`, `n`: the whole stream (P.gstream, P.n_gstream) or one wave's run of whole coordinates of it (multi-wave HMC);
 // reading up to 3 records past `n` is safe either way (the next wave's records or the pad records).
-// LIN = false instantiates the loop without the linear-predictor branch: the 128-VGPR multi-wave kernel is sensitive to
-// every register the hot loop holds, and most programs have no such record.
-template <bool LIN>
+// RK = record kinds the instantiation understands: 0 fast Normals only, 1 + linear predictors (FG_G_LIN), 2 + general
+// distribution records (FG_G_GEN).  The 128-VGPR multi-wave kernel is sensitive to every register the hot loop holds,
+// so a program only pays for the kinds it contains.
+template <int RK>
 __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, const double *pool, double *slots, double *pl, int tw, double h, double hk,
                                                bool two_kicks, double *gout, long long gstride, bool live) {
     FgGradK K;
@@ -191,23 +225,30 @@ __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, 
 // The endpoint score of an all-fast-Normal program: one record per statement in program order, the same values and
 // the same additions as FG_OP_NORMAL_FAST in the interpreter (operand = slot or immediate; z != z -> -inf guard;
 // log_prior and log_likelihood accumulated separately).  Records are fetched two ahead, operands one ahead.
-template <bool LIN>
+template <int RK>
 __device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     const uint32_t fl = r[2];
-    const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
-    double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
-    if (LIN && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
-    const double dl = x - m, inv = fg_dbl(r[10], r[11]);
-    double z = dl * inv;
-    if (__builtin_expect(!(fl & FG_G_POW2), 0)) {
-        const double sg = fg_dbl(r[8], r[9]);
-        z = (fl & FG_G_DIV) ? dl / sg : fg_div_const(dl, sg, inv);
+    double lp;
+    if (RK >= 2 && __builtin_expect((fl & FG_G_GEN) != 0u, 0)) {
+        double lp2[2];
+        fg_gen_lp(r, xs, slots, tw, 0.0, 1, lp2);
+        lp = lp2[0];
+    } else {
+        const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
+        double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
+        if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
+        const double dl = x - m, inv = fg_dbl(r[10], r[11]);
+        double z = dl * inv;
+        if (__builtin_expect(!(fl & FG_G_POW2), 0)) {
+            const double sg = fg_dbl(r[8], r[9]);
+            z = (fl & FG_G_DIV) ? dl / sg : fg_div_const(dl, sg, inv);
+        }
+        lp = -0.5 * z * z - fg_dbl(r[12], r[13]) - 0.5 * FG_LN_2PI;
+        lp = (z != z) ? FG_NEG_INF : lp;
     }
-    double lp = -0.5 * z * z - fg_dbl(r[12], r[13]) - 0.5 * FG_LN_2PI;
-    lp = (z != z) ? FG_NEG_INF : lp;
     if (fl & FG_S_OBS) A.lik += lp; else A.prior += lp;
 }
-template <bool LIN>
+template <int RK>
 __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     fg_u32x16 r0 = fg_fetch_grec(g, 0), r1 = fg_fetch_grec(g, 1), r2;
     double x0 = slots[r0[0] * tw], m0 = slots[r0[1] * tw], x1, m1;
@@ -216,7 +257,7 @@ __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n,
         r2 = fg_fetch_grec(g, k + 2);
         x1 = slots[r1[0] * tw]; m1 = slots[r1[1] * tw];
         __builtin_amdgcn_sched_barrier(0);
-        fg_score_one<LIN>(r0, x0, m0, pool, slots, tw, A);
+        fg_score_one<RK>(r0, x0, m0, pool, slots, tw, A);
         r0 = r1; r1 = r2; x0 = x1; m0 = m1;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

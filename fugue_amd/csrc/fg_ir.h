@@ -68,6 +68,9 @@ enum : uint32_t { FG_S_OBS = 1u,      // score stream: the record is an observe 
                   FG_G_X_CONST = 32u,  // x is a constant (ximm), no slot read
                   FG_G_M_CONST = 64u,  // mu is a constant (mimm), no slot read
                   FG_G_DIV = 128u,     // sigma outside the range where fg_div_const is proven exact: IEEE division
+                  FG_G_GEN = 1024u,    // any of the 17 distributions with leaf operands (fg_logpdf): layout below, kind in flags >> 16
+                  FG_G_GEN_HOISTED = 2048u, FG_G_GEN_SH = 4096u, FG_G_GEN_INVALID = 8192u, FG_G_GEN_XINT = 16384u,
+                  FG_G_GEN_P0SLOT = 1u << 24, FG_G_GEN_P1SLOT = 1u << 25, FG_G_GEN_P2SLOT = 1u << 26,
                   FG_G_LIN = 256u      // mu = mimm + sum_t slot[s_t] c_t: maskx = pool offset of the terms {u32 s, u32 0, f64 c},
                                        //   maskm = their number, flags >> 16 = first term that reads the record's coordinate
 };
@@ -79,6 +82,10 @@ struct FgGradRec {
     double lns;             // ln sigma
     uint32_t maskx, maskm;  // FG_G_LIN: pool offset / number of the linear predictor's terms (else unused)
 };
+// FG_G_GEN records reuse the 48 payload bytes as  x (imm double / int64 bits), p0, p1, p2 (imm double, or the LDS slot index in
+// the low dword when FG_G_GEN_PkSLOT), h0, h1 (hoisted constants of fg_hoist): see FgGenRec.
+struct FgGenRec { uint32_t xi, mi, flags, coord; double x; double p[3]; double h[2]; };
+static_assert(sizeof(FgGenRec) == 64, "FgGenRec must be 64 bytes");
 static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
 
 struct FgProgramDev {
@@ -95,7 +102,7 @@ struct FgProgramDev {
     const FgGradRec *gstream;  // fused gradient stream or null
     const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
     int n_gstream, n_sstream;
-    int sstream_lin;           // the score stream holds linear-predictor records (FG_G_LIN)
+    int sstream_kinds;         // record kinds in the score stream: 0 fast Normals, 1 + linear predictors, 2 + general records
     int n_ins, n_slots, S, d;
 };
 

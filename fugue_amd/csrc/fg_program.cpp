@@ -440,34 +440,80 @@ int fg_program::finalize() {
         const int b = range[i].first, e = range[i].second;
         Shape &sh = shape[i];
         if (e - b == 1 && FG_INS_OPCODE(ins_fast[b].op) == FG_OP_NORMAL_FAST) { sh.kind = 1; sh.F = ins_fast[b]; continue; }
-        if (e - b < 4 || FG_INS_OPCODE(ins_fast[e - 1].op) != FG_OP_NORMAL_FAST) continue;
+        if (e - b == 1 && stmts[i].kind != 2) {             // GEN: one distribution instruction whose operands are all leaves
+            const FgIns &D = ins_fast[b];
+            const uint32_t code = FG_INS_OPCODE(D.op);
+            bool ok = code < 17u && code != (uint32_t)FG_CATEGORICAL && code != (uint32_t)FG_DISCRETEUNIFORM;
+            const uint32_t kx = FG_OPND_KIND(D.opnd[0]);
+            const uint32_t vt0 = FG_INS_VTYPE(D.op);
+            ok = ok && (kx == FG_OPND_IMM || (kx == FG_OPND_SLOT_F && vt0 == (uint32_t)FG_F64) || (kx == FG_OPND_SLOT_I && vt0 != (uint32_t)FG_F64));
+            for (int q = 1; q <= 3 && ok; q++) { const uint32_t kq = FG_OPND_KIND(D.opnd[q]); ok = kq == FG_OPND_IMM || kq == FG_OPND_SLOT_F; }
+            if (ok && (D.op & FG_F_HOISTED) && (D.h[2] != 0.0 || D.h[3] != 0.0)) ok = false;   // only h0, h1 fit the record (Binomial with constant parameters stays out)
+            if (ok) { sh.kind = 3; sh.F = D; continue; }
+        }
+        if (e - b < 3 || FG_INS_OPCODE(ins_fast[e - 1].op) != FG_OP_NORMAL_FAST) continue;
         const FgIns &L = ins_fast[b], &St = ins_fast[e - 2], &F = ins_fast[e - 1];
-        if (FG_INS_OPCODE(L.op) != FG_OP_LOAD || FG_OPND_KIND(L.opnd[0]) != FG_OPND_IMM) continue;
+        if (FG_INS_OPCODE(L.op) != FG_OP_LOAD) continue;
         if (FG_INS_OPCODE(St.op) != FG_OP_STORE || F.opnd[1] != St.aux || (int)St.aux < S || F.opnd[0] == St.aux || F.imm[1] != 0.0) continue;
+        // every form becomes  mu = c0 + sum_t slot_t * c_t  with the same value: LOAD slot is 0 + slot*1, LOAD slot; MUL c is
+        // 0 + slot*c, `+ slot` is `+ slot*1` (a product with 1 and a sum with +0 are exact; only the sign of a zero mean can
+        // differ, which x - mu cannot see).  `+ constant` in the middle of a predictor is left to the interpreter.
         std::vector<double> terms;
+        auto push = [&](uint32_t slot, double c) { terms.push_back(fg_as_double((long long)slot)); terms.push_back(c); };
         bool ok = true;
-        for (int k = b + 1; k < e - 2 && ok; k++) {
+        int k = b + 1;
+        double init = 0.0;
+        if (FG_OPND_KIND(L.opnd[0]) == FG_OPND_IMM) init = L.imm[0];
+        else if (FG_OPND_KIND(L.opnd[0]) == FG_OPND_SLOT_F) {
+            if (k < e - 2 && FG_INS_OPCODE(ins_fast[k].op) == FG_OP_MUL && FG_OPND_KIND(ins_fast[k].opnd[0]) == FG_OPND_IMM) { push(FG_OPND_IDX(L.opnd[0]), ins_fast[k].imm[0]); ++k; }
+            else push(FG_OPND_IDX(L.opnd[0]), 1.0);
+        } else continue;
+        for (; k < e - 2 && ok; k++) {
             const FgIns &I = ins_fast[k];
-            if (FG_INS_OPCODE(I.op) == FG_OP_DOT) {
-                for (uint32_t t = 0; t < I.opnd[1]; t++) { terms.push_back(pool[I.aux + 2 * t]); terms.push_back(pool[I.aux + 2 * t + 1]); }
-            } else if (FG_INS_OPCODE(I.op) == FG_OP_MAC) {
-                const uint32_t k0 = FG_OPND_KIND(I.opnd[0]), k1 = FG_OPND_KIND(I.opnd[1]);
-                if (k0 == FG_OPND_SLOT_F && k1 == FG_OPND_IMM) { terms.push_back(fg_as_double((long long)FG_OPND_IDX(I.opnd[0]))); terms.push_back(I.imm[1]); }
-                else if (k0 == FG_OPND_IMM && k1 == FG_OPND_SLOT_F) { terms.push_back(fg_as_double((long long)FG_OPND_IDX(I.opnd[1]))); terms.push_back(I.imm[0]); }
+            const uint32_t oc = FG_INS_OPCODE(I.op), k0 = FG_OPND_KIND(I.opnd[0]), k1 = FG_OPND_KIND(I.opnd[1]);
+            if (oc == FG_OP_DOT) {
+                for (uint32_t t = 0; t < I.opnd[1]; t++) push((uint32_t)fg_as_i64(pool[I.aux + 2 * t]), pool[I.aux + 2 * t + 1]);
+            } else if (oc == FG_OP_MAC) {
+                if (k0 == FG_OPND_SLOT_F && k1 == FG_OPND_IMM) push(FG_OPND_IDX(I.opnd[0]), I.imm[1]);
+                else if (k0 == FG_OPND_IMM && k1 == FG_OPND_SLOT_F) push(FG_OPND_IDX(I.opnd[1]), I.imm[0]);
                 else ok = false;
-            } else ok = false;
+            } else if (oc == FG_OP_ADD && k0 == FG_OPND_SLOT_F) push(FG_OPND_IDX(I.opnd[0]), 1.0);
+            else ok = false;
         }
         if (!ok || terms.empty() || terms.size() / 2 > 0xffffu) continue;
-        for (size_t t = 0; t < terms.size(); t += 2) { const uint32_t sl = (uint32_t)fg_as_i64(terms[t]); if ((int)sl >= (int)f64_slot.size()) ok = false; sh.tslot.push_back(sl); }
-        if (!ok) { sh.tslot.clear(); continue; }                       // every term must be an f64 coordinate (slot k = coordinate k)
+        for (size_t t = 0; t < terms.size(); t += 2) {
+            const uint32_t sl = (uint32_t)fg_as_i64(terms[t]);
+            if ((int)sl >= (int)f64_slot.size()) ok = false;                 // every term must be an f64 coordinate (slot k = coordinate k)
+            sh.tslot.push_back(sl);
+        }
+        if (!ok) { sh.tslot.clear(); continue; }
         if (pool.size() & 1) pool.push_back(0.0);
-        sh.kind = 2; sh.F = F; sh.init = L.imm[0]; sh.toff = (uint32_t)pool.size(); sh.tn = (uint32_t)(terms.size() / 2);
+        sh.kind = 2; sh.F = F; sh.init = init; sh.toff = (uint32_t)pool.size(); sh.tn = (uint32_t)(terms.size() / 2);
         pool.insert(pool.end(), terms.begin(), terms.end());
     }
     for (int q = 0; q < 8; q++) pool.push_back(0.0);                   // term groups are read 4 at a time
     auto make_rec = [&](const Shape &sh, int coord_k /* -1: score record */) {
         const FgIns &F = sh.F;
         FgGradRec r; std::memset(&r, 0, sizeof(r));
+        if (sh.kind == 3) {
+            FgGenRec g; std::memset(&g, 0, sizeof(g));
+            const uint32_t vt = FG_INS_VTYPE(F.op), kx = FG_OPND_KIND(F.opnd[0]);
+            g.xi = kx == FG_OPND_IMM ? (uint32_t)zero_slot : FG_OPND_IDX(F.opnd[0]);
+            g.mi = (uint32_t)zero_slot;
+            g.flags = FG_G_GEN | (FG_INS_OPCODE(F.op) << 16) | (kx == FG_OPND_IMM ? FG_G_X_CONST : 0u) | (vt != (uint32_t)FG_F64 ? FG_G_GEN_XINT : 0u) |
+                      ((F.op & FG_F_HOISTED) ? FG_G_GEN_HOISTED : 0u) | ((F.op & FG_F_SCALEHOIST) ? FG_G_GEN_SH : 0u) | ((F.op & FG_F_INVALID) ? FG_G_GEN_INVALID : 0u);
+            // an observed constant of a discrete distribution is its integer value (fg_int_of, fg_interp.h)
+            if (kx == FG_OPND_IMM) g.x = vt == (uint32_t)FG_F64 ? F.imm[0]
+                                        : fg_as_double(vt == (uint32_t)FG_BOOL ? (long long)(F.imm[0] != 0.0) : (std::isfinite(F.imm[0]) ? (long long)F.imm[0] : 0LL));
+            for (int q = 0; q < 3; q++) {
+                if (FG_OPND_KIND(F.opnd[1 + q]) == FG_OPND_SLOT_F) { g.flags |= FG_G_GEN_P0SLOT << q; g.p[q] = fg_as_double((long long)FG_OPND_IDX(F.opnd[1 + q])); }
+                else g.p[q] = F.imm[1 + q];
+            }
+            g.h[0] = F.h[0]; g.h[1] = F.h[1];
+            if (coord_k >= 0) g.coord = (uint32_t)coord_k;
+            std::memcpy(&r, &g, sizeof(r));
+            return r;
+        }
         r.xi = F.opnd[0]; r.mi = sh.kind == 2 ? (uint32_t)zero_slot : F.opnd[1];
         r.flags = ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) | ((F.op & (FG_F_POW2SCALE | FG_F_RCPSCALE)) ? 0u : FG_G_DIV) |
                   (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | ((sh.kind == 1 && r.mi == (uint32_t)zero_slot) ? FG_G_M_CONST : 0u);
@@ -521,7 +567,7 @@ int fg_program::finalize() {
     // score stream: when the WHOLE program is FAST / LIN statements its endpoint score (score_full, hmc.rs:283-299)
     // is a lean pass over one 64-byte record per statement, in program order (the accumulation order of
     // PriorHandler / ScoreGivenTrace), instead of a pass of the general interpreter
-    sstream.clear(); n_sstream = 0; sstream_has_lin = false;
+    sstream.clear(); n_sstream = 0; sstream_has_lin = false; sstream_has_gen = false;
     {
         bool ok = !stmts.empty();
         for (const Shape &sh : shape) ok = ok && sh.kind != 0;
@@ -530,6 +576,7 @@ int fg_program::finalize() {
                 FgGradRec r = make_rec(sh, -1);
                 if (sh.F.op & FG_F_OBSERVE) r.flags |= FG_S_OBS;
                 sstream_has_lin = sstream_has_lin || sh.kind == 2;
+                sstream_has_gen = sstream_has_gen || sh.kind == 3;
                 sstream.push_back(r);
             }
             n_sstream = (int)sstream.size();
@@ -622,6 +669,14 @@ int fg_program_site_name(const fg_program *p, int j, char *buf, int len) {
     const std::string &a = p->stmts[p->sorted_stmt[j]].addr;
     if (buf && len > 0) { int n = std::min<int>(len - 1, (int)a.size()); std::memcpy(buf, a.data(), n); buf[n] = 0; }
     return (int)a.size() + 1;
+}
+int fg_program_stream_records(const fg_program *p, int which) {
+    if (!p || !p->finalized) return FG_E_STATE;
+    if (which == 0) return p->n_gstream;
+    if (which == 1) return p->n_sstream;
+    int k = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0);
+    for (int i = 0; i < p->n_gstream; i++) k = std::max(k, (p->gstream[i].flags & FG_G_GEN) ? 2 : ((p->gstream[i].flags & FG_G_LIN) ? 1 : 0));
+    return k;
 }
 int fg_program_site_vtype(const fg_program *p, int j) {
     NEED_FINAL(p);

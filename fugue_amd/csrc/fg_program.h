@@ -37,6 +37,7 @@ struct fg_program {
     std::vector<FgGradRec> sstream;   // empty unless the whole program is fast Normals
     int n_sstream = 0;
     bool sstream_has_lin = false;       // some record is a linear-predictor Normal (FG_G_LIN)
+    bool sstream_has_gen = false;       // some record is a general distribution record (FG_G_GEN)
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
     std::vector<int> site_cat;               // [S][2] {pool base, K} of Categorical sites with a valid constant table, else -1

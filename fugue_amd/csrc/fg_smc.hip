@@ -246,8 +246,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_smc_rejuv(FgProgramDe
     for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed: two model runs  smc.rs:662-675
         slots[k * tw] = pass ? prop : cur;
         FgAcc3 A = {0.0, 0.0, 0.0};
-        if (P.sstream && !P.sstream_lin) fg_score_stream<false>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
-        else if (P.sstream) fg_score_stream<true>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
+        if (P.sstream && P.sstream_kinds == 0) fg_score_stream<0>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
+        else if (P.sstream) fg_score_stream<2>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
         else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         pri[pass] = A.prior; lik[pass] = A.lik + A.fac;
     }

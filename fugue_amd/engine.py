@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "fg_program_new", "fg_program_free", "fg_program_data", "fg_program_sample", "fg_program_observe",
     "fg_program_factor", "fg_program_finalize", "fg_program_n_sites", "fg_program_n_f64", "fg_program_n_observe",
     "fg_program_n_instructions", "fg_program_n_slots", "fg_program_site_name", "fg_program_site_vtype",
-    "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_last_error", "fg_abi_version",
+    "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_program_stream_records", "fg_last_error", "fg_abi_version",
     "fg_engine_new", "fg_engine_free", "fg_engine_synchronize", "fg_engine_stream", "fg_engine_set_stream", "fg_engine_n_chains",
     "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint",
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
@@ -107,7 +107,7 @@ def lib():
               "fg_program_n_instructions", "fg_program_n_slots"):
         getattr(L, f).argtypes = [vp]
     L.fg_program_site_name.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
-    for f in ("fg_program_site_vtype", "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count"):
+    for f in ("fg_program_site_vtype", "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_program_stream_records"):
         getattr(L, f).argtypes = [vp, C.c_int]
     L.fg_engine_new.restype = vp
     L.fg_engine_new.argtypes = [vp, C.c_int64, C.c_uint64, C.c_uint32, C.c_int]
@@ -285,6 +285,7 @@ class CompiledProgram:
         self.site_vtypes = [L.fg_program_site_vtype(self.h, j) for j in range(self.S)]
         self.f64_sites = [L.fg_program_f64_site(self.h, k) for k in range(self.d)]
         self.dep_counts = [L.fg_program_dep_count(self.h, k) for k in range(self.d)]
+        self.stream_records = tuple(L.fg_program_stream_records(self.h, w) for w in range(3))   # (gradient, score, kinds)
 
     def site_of_handle(self, h: int) -> int:
         return lib().fg_program_site_of_handle(self.h, h)

@@ -110,6 +110,10 @@ int fg_program_site_of_handle(const fg_program *p, int handle);
 int fg_program_f64_site(const fg_program *p, int k);
 /* number of instructions re-evaluated when f64 coordinate k is perturbed (sparse FD) */
 int fg_program_dep_count(const fg_program *p, int k);
+/* record streams the compiler could build for the stream kernels (0 = the interpreter kernels are used):
+ * which = 0: records of the fused finite-difference gradient stream; 1: records of the score stream;
+ * 2: record kinds present (0 fast Normals only, 1 + linear predictors, 2 + general distribution records) */
+int fg_program_stream_records(const fg_program *p, int which);
 
 const char *fg_last_error(void);
 int         fg_abi_version(void);

@@ -93,3 +93,46 @@ def hier_normal(groups: int = 5, per_group: int = 3) -> M.Program:
 
 ZOO["hier"] = hier_normal
 ZOO["ridge7"] = lambda: W.ridge_regression(*W.ridge_data(10, 7)[:2], sigma=0.8)     # FG_OP_DOT with a 4 + 3 term split, sigma not 2^k
+
+
+def hier_scale() -> M.Program:
+    """Leaf-operand statements of many families (the general FG_G_GEN stream records): unknown scales as sites, a
+    Normal whose sigma is a site, Student-t / Gamma / Exponential / Beta / LogNormal priors, Bernoulli and Poisson
+    likelihoods whose parameter is a site."""
+    P = M.Program()
+    tau = P.sample(M.addr("tau"), M.Gamma(2.0, 2.0))
+    s = P.sample(M.addr("s"), M.Exponential(1.5))
+    mu = P.sample(M.addr("mu"), M.Normal(0.3, 5.0))
+    b = P.sample(M.addr("b"), M.Beta(2.0, 3.0))
+    ln = P.sample(M.addr("ln"), M.LogNormal(0.1, 0.7))
+    for g in range(3):
+        x = P.sample(M.addr("x", g), M.Normal(mu, tau))                  # sigma is a site
+        P.observe(M.addr("y", g), M.Normal(x, 0.5), 0.4 * g - 0.2)
+        P.observe(M.addr("t", g), M.StudentT(4.0, x, s), 0.1 * g + 0.3)  # scale is a site
+    for i, f in enumerate([1, 0, 1, 1]):
+        P.observe(M.addr("flip", i), M.Bernoulli(b), float(f))
+    P.observe(M.addr("count"), M.Poisson(ln), 3)
+    P.observe(M.addr("c"), M.Cauchy(mu, 2.0), 0.7)
+    return P
+
+
+ZOO["hier_scale"] = hier_scale
+
+
+def linreg_forms() -> M.Program:
+    """Linear predictors written the ways users write them: alpha + beta*x, beta*x + alpha, gamma*u + beta,
+    alpha + gamma -- all FG_G_LIN records (LOAD slot, MUL c, MAC, ADD slot)."""
+    P = M.Program()
+    alpha = P.sample(M.addr("alpha"), M.Normal(0.0, 2.0))
+    beta = P.sample(M.addr("beta"), M.Normal(0.0, 2.0))
+    gamma = P.sample(M.addr("gamma"), M.Normal(0.0, 1.0))
+    xs = [-1.5, -0.5, 0.25, 1.0, 2.0]
+    for i, x in enumerate(xs):
+        P.observe(M.addr("y", i), M.Normal(alpha + beta * x, 0.8), 0.4 + 0.9 * x)
+        P.observe(M.addr("z", i), M.Normal(beta * x + alpha, 0.5), 0.5 + 0.8 * x)
+        P.observe(M.addr("w", i), M.Normal(gamma * (0.3 * i - 0.4) + beta, 1.0), 0.1 * i)
+    P.observe(M.addr("v"), M.Normal(alpha + gamma, 1.0), 0.6)
+    return P
+
+
+ZOO["linreg"] = linreg_forms

@@ -35,7 +35,7 @@ def _compare(cp, draws, odraws, max_bad_chains=0):
     assert bad.sum() <= max_bad_chains, np.nonzero(bad)[0][:10]
 
 
-@pytest.mark.parametrize("name", ["readme", "coin", "refmodel8", "mixture", "alldists", "normal32"])
+@pytest.mark.parametrize("name", ["readme", "coin", "refmodel8", "mixture", "alldists", "normal32", "hier_scale", "ridge7", "linreg"])
 def test_mh_chain_matches_oracle(oracle, name):
     prog = ZOO[name]()
     cp, eng, st, draws, odraws, ofinal, oscales, ost = _run_both(oracle, prog, C=96, nw=150, ns=60, seed=13, chain0=3)

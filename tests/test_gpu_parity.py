@@ -72,7 +72,7 @@ def test_prior_init_matches_oracle(oracle, name):
         _close(acc[:, c], oacc, 1e-10, 1e-10)
 
 
-@pytest.mark.parametrize("name", ["readme", "normal32", "coin", "refmodel8", "ridge", "mixture", "alldists"])
+@pytest.mark.parametrize("name", ["readme", "normal32", "coin", "refmodel8", "ridge", "mixture", "alldists", "hier_scale", "ridge7", "linreg"])
 def test_fd_gradient_matches_oracle(oracle, name):
     """grad_log_joint (hmc.rs:304-329): dense FD vs oracle, and sparse FD vs dense.
     A central difference with h=1e-5 amplifies a 1-ulp difference in log pi by 1/(2h), so
@@ -96,7 +96,7 @@ def test_fd_gradient_matches_oracle(oracle, name):
         _close(g_sparse[fin, c], og[fin], 1e-7, tol)
 
 
-@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "ridge", "alldists"])
+@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "ridge", "alldists", "hier_scale"])
 @pytest.mark.parametrize("mode", [E.GRAD_FD_DENSE, E.GRAD_FD_SPARSE])
 def test_hmc_transition_injected(oracle, name, mode):
     """hmc_transition (hmc.rs:419-473) under injected momentum and uniform: accept decision,
@@ -190,7 +190,8 @@ def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, tar
 @pytest.mark.parametrize("name,mode", [("readme", E.GRAD_FD_DENSE), ("normal32", E.GRAD_FD_DENSE),
                                        ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_DENSE),
                                        ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE),
-                                       ("hier", E.GRAD_FD_SPARSE), ("hier", E.GRAD_FD_DENSE), ("ridge7", E.GRAD_FD_SPARSE)])
+                                       ("hier", E.GRAD_FD_SPARSE), ("hier", E.GRAD_FD_DENSE), ("ridge7", E.GRAD_FD_SPARSE),
+                                       ("hier_scale", E.GRAD_FD_SPARSE), ("linreg", E.GRAD_FD_SPARSE)])
 def test_hmc_session_matches_oracle_teacher_forced(oracle, name, mode):
     """HmcSession (hmc.rs:667-920) step by step: prior init, Alg. 4 step size, every transition's
     HmcStepInfo, the dual-averaging recursion and the frozen step size -- each checked against
@@ -321,7 +322,8 @@ def test_hmc_posterior_closed_form():
 @pytest.mark.parametrize("name,adapt_mass,mode", [("normal32", False, E.GRAD_FD_SPARSE), ("normal32", True, E.GRAD_FD_SPARSE),
                                                   ("hier", True, E.GRAD_FD_SPARSE), ("readme", False, E.GRAD_FD_SPARSE),
                                                   ("normal32", True, E.GRAD_FD_DENSE), ("hier", False, E.GRAD_FD_DENSE),
-                                                  ("ridge7", True, E.GRAD_FD_SPARSE), ("ridge", False, E.GRAD_FD_SPARSE)])   # linear-predictor records
+                                                  ("ridge7", True, E.GRAD_FD_SPARSE), ("ridge", False, E.GRAD_FD_SPARSE),     # linear-predictor records
+                                                  ("hier_scale", True, E.GRAD_FD_SPARSE), ("linreg", False, E.GRAD_FD_SPARSE)])   # general records
 def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """k_hmc_stream_steps splits a tile's coordinates over 1, 2 or 4 waves; the per-coordinate operations and
     their order are the same, so draws, step sizes, mass matrix and log-joint must agree BIT FOR BIT."""
