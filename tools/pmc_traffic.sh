@@ -14,7 +14,7 @@ for d in ("gpurun_out/pmc_fetch", "gpurun_out/pmc_write"):
         for r in csv.DictReader(open(f)):
             acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
-        if k[0].startswith("k_"):
+        if "k_" in k[0]:
             print(d, k, "mean=%.1f" % (sum(v) / len(v)), "n=%d" % len(v), "first=%.1f last=%.1f" % (v[0], v[-1]))
 PY
 cat gpurun_out/prof2/*/*kernel_stats.csv | head -4 | cut -c1-160
