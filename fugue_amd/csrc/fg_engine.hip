@@ -711,11 +711,15 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->tw = tile_width_for(e->C);
     e->n_simd = 4 * prop.multiProcessorCount;
     if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4) e->mw_override = w; }
-    e->lds_bytes = (size_t)(e->n_slots + e->d + 2 + FG_MW_MAX) * e->tw * sizeof(double);   // slots, momentum, multi-wave exchange rows
-    while (e->lds_bytes > 160 * 1024 && e->tw > 16) { e->tw >>= 1; e->lds_bytes >>= 1; }
-    if (e->lds_bytes > 160 * 1024) {
-        fg_set_error("model needs more than 160 KB of LDS per wave (sites + temporaries + momentum > 319 cells)");
+    // LDS tile of 64 chains: the score / prior / MH / SMC kernels need the slot rows only, the HMC kernels also the
+    // momentum and the multi-wave exchange rows.  A model whose slots alone exceed the 160 KB of a CU cannot run at all;
+    // one that only fits without the momentum is refused by fg_hmc_init.
+    e->lds_score = (size_t)e->n_slots * e->tw * sizeof(double);
+    e->lds_bytes = (size_t)(e->n_slots + e->d + 2 + FG_MW_MAX) * e->tw * sizeof(double);
+    if (e->lds_score > 160 * 1024) {
+        fg_set_error("model needs more than 160 KB of LDS per 64-chain tile (sites + expression temporaries > 320 cells)");
         delete e; return nullptr; }
+    const size_t lds_hmc = std::min<size_t>(e->lds_bytes, 160 * 1024);
     auto fail = [&](const char *what) { fg_set_error(std::string("fg_engine_new: ") + what + ": " + fg_last_error()); fg_engine_free(e); return (fg_engine *)nullptr; };
     if (hipStreamCreate(&e->stream) != hipSuccess) return fail("hipStreamCreate");
     if (dev_upload(&e->d_ins, p->ins)) return fail("upload ins");
@@ -739,10 +743,10 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
-    if (set_lds(k_prior_init, e->lds_bytes) || set_lds(k_log_joint, e->lds_bytes) ||
-        set_lds(k_hmc_steps, e->lds_bytes) || set_lds(k_hmc_stream_steps<0>, e->lds_bytes) || set_lds(k_hmc_stream_steps<1>, e->lds_bytes) || set_lds(k_hmc_stream_steps<2>, e->lds_bytes) || set_lds(k_hmc_transition_injected, e->lds_bytes) ||
-        set_lds(k_hmc_grad, e->lds_bytes) || set_lds(k_hmc_find_eps, e->lds_bytes) ||
-        set_lds(k_mh_steps, e->lds_bytes))
+    if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) ||
+        set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0>, lds_hmc) || set_lds(k_hmc_stream_steps<1>, lds_hmc) || set_lds(k_hmc_stream_steps<2>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
+        set_lds(k_hmc_grad, lds_hmc) || set_lds(k_hmc_find_eps, lds_hmc) ||
+        set_lds(k_mh_steps, e->lds_score))
         return fail("hipFuncSetAttribute");
     return e;
 }
@@ -810,7 +814,7 @@ int fg_device_upload(fg_engine *e, void *d, const void *h, size_t bytes) {
 }
 
 int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
-    hipLaunchKernelGGL(k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, iteration,
+    hipLaunchKernelGGL(k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, iteration,
                        purpose, d_acc, d_lj);
     HIPCHK(hipGetLastError());
     return FG_OK;
@@ -828,7 +832,7 @@ int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc) {
 int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp) {
     NEED_ENGINE(e);
     if (h_logp && !e->d_logp) { int rc = dev_alloc(&e->d_logp, (size_t)std::max(1, e->S) * e->C); if (rc) return rc; }
-    hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->d_acc,
+    hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
                        h_logp ? e->d_logp : nullptr, (double *)nullptr);
     HIPCHK(hipGetLastError());
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
@@ -869,9 +873,17 @@ static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d
     return FG_OK;
 }
 
+static int hmc_lds_ok(const fg_engine *e) {
+    if (e->lds_bytes <= 160 * 1024) return FG_OK;
+    fg_set_error("HMC needs sites + temporaries + momentum in one 160 KB LDS tile (2 * f64 sites + other slots + 6 > 320 cells); "
+                 "adaptive_mcmc_chain / adaptive_smc still run for this model");
+    return FG_E_LIMIT;
+}
+
 int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
     NEED_ENGINE(e);
     if (!cfg || n_warmup < 0) return FG_E_BAD_ARG;
+    if (int rc = hmc_lds_ok(e)) return rc;
     if (cfg->grad_mode != FG_GRAD_FD_DENSE && cfg->grad_mode != FG_GRAD_FD_SPARSE) { fg_set_error("unknown grad_mode"); return FG_E_BAD_ARG; }
     const bool mass = cfg->adapt_mass && n_warmup >= 4;                 // hmc.rs:704-708
     int rc = hmc_alloc(e, mass);
@@ -1079,6 +1091,7 @@ int fg_hmc_set_step_size(fg_engine *e, double eps) {    // hmc.rs:741-747
 int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *h_ok) {
     NEED_ENGINE(e);
     if (!h_grad) return FG_E_BAD_ARG;
+    if (int rc = hmc_lds_ok(e)) return rc;
     double *d_g = nullptr;
     int rc = dev_alloc(&d_g, (size_t)std::max(1, e->d) * e->C);
     if (rc) return rc;
@@ -1095,11 +1108,12 @@ int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *
 
 static int hmc_prepare_injected(fg_engine *e, const fg_hmc_config *cfg) {
     if (!cfg) return FG_E_BAD_ARG;
+    if (int rc0 = hmc_lds_ok(e)) return rc0;
     int rc = hmc_alloc(e, false);
     if (rc) return rc;
     if (!e->hmc_ready) {      // standalone use: lj of the current values, identity mass
         e->H.use_mass = 0;
-        hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, (double *)nullptr,
+        hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, (double *)nullptr,
                            (double *)nullptr, e->H.lj);
         HIPCHK(hipGetLastError());
     }
@@ -1200,7 +1214,7 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
     e->M.rec = e->d_rec; e->M.n_rec = n_rec;
     const int iter = e->mh_iter;
     const int first_sample_t = std::max(iter, e->mh_warmup) - iter;
-    hipLaunchKernelGGL(k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->M,
+    hipLaunchKernelGGL(k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->M,
                        iter, n_steps, e->mh_warmup, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
     HIPCHK(hipGetLastError());
     e->mh_iter += n_steps;

@@ -94,7 +94,8 @@ struct fg_engine {
     int *d_rec = nullptr; int rec_cap = 0;
     double *d_tmp = nullptr;     // [C] scratch
     int *d_itmp = nullptr;       // [3][C] scratch
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0;        // LDS tile of the HMC kernels (slots + momentum + exchange rows)
+    size_t lds_score = 0;        // LDS tile of the score / prior / MH / SMC kernels (slots only)
     int tw = 64;               // tile width (threads per block)
     int n_simd = 1024;         // SIMDs on the device (4 per CU)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)

@@ -483,8 +483,9 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
                 std::swap(M.ll, d_ll2); std::swap(M.lprior, d_lp2);
                 hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, -std::log((double)N));
                 if (e->d > 0) {
+                    SMC_TRY(set_lds(k_smc_rejuv, e->lds_score));
                     for (int r = 0; r < cfg->rejuvenation_steps; ++r) {
-                        hipLaunchKernelGGL(k_smc_rejuv, dim3((unsigned)((N + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, s, e->P, e->X, M,
+                        hipLaunchKernelGGL(k_smc_rejuv, dim3((unsigned)((N + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, s, e->P, e->X, M,
                                            (const FgSmcScalars *)st, (uint32_t)((steps - 1) * cfg->rejuvenation_steps + r));
                         hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, s, M, S);
                         n_runs += 2 * N;

@@ -119,3 +119,28 @@ def test_c5_mixture_262144_chains():
     half = eng2.download(d2, (ns, len(rec), C // 2), dtype=np.int64)
     eng2.device_free(d2)
     assert np.array_equal(cells[:, :, C // 2:], half)
+
+
+def test_lds_limits_large_models():
+    """The 64-chain LDS tile bounds the model size: 150 f64 sites still run HMC (157 KB tile), 200 f64 sites only fit
+    the score tile -- HMC is refused with FG_E_LIMIT, MH and the log-joint still run -- and 400 sites fit nothing."""
+    from fugue_amd import model as M
+    C = 128
+    cp = E.compile_model(W.normal_sites(150))
+    eng = E.Engine(cp, C, seed=2)
+    d = eng.device_alloc(4 * cp.d * C * 8)
+    st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=4), 4, 10, d)
+    assert np.isfinite(eng.download(d, (4, cp.d, C))).all() and st.n_divergent == 0
+    eng.device_free(d)
+    cp = E.compile_model(W.normal_sites(200))
+    eng = E.Engine(cp, C, seed=2)
+    with pytest.raises(E.EngineError) as ei:
+        eng.hmc_init(E.hmc_config(), 0)
+    assert ei.value.code == E.FG_E_LIMIT
+    eng.prior_init()
+    assert np.isfinite(eng.log_joint().sum(axis=0)).all()
+    st = eng.mh_run(50, 50, None, [0, 199], eng_buf := eng.device_alloc(50 * 2 * C * 8))
+    assert 0.05 < st.accept_rate < 0.95
+    eng.device_free(eng_buf)
+    with pytest.raises(E.EngineError):
+        E.Engine(E.compile_model(W.normal_sites(400)), C, seed=2)
