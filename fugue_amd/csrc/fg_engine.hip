@@ -885,6 +885,8 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
     if (!cfg || n_warmup < 0) return FG_E_BAD_ARG;
     if (int rc = hmc_lds_ok(e)) return rc;
     if (cfg->grad_mode != FG_GRAD_FD_DENSE && cfg->grad_mode != FG_GRAD_FD_SPARSE) { fg_set_error("unknown grad_mode"); return FG_E_BAD_ARG; }
+    if (cfg->n_leapfrog < 1 || cfg->n_leapfrog > 100000) { fg_set_error("n_leapfrog must be in [1, 100000] (a trajectory of 0 steps never moves: hmc.rs:385)"); return FG_E_BAD_ARG; }
+    if (!(cfg->finite_diff_eps > 0.0) || !std::isfinite(cfg->finite_diff_eps)) { fg_set_error("finite_diff_eps must be positive and finite"); return FG_E_BAD_ARG; }
     const bool mass = cfg->adapt_mass && n_warmup >= 4;                 // hmc.rs:704-708
     int rc = hmc_alloc(e, mass);
     if (rc) return rc;

@@ -343,3 +343,25 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
         for a, b in zip(out[0], o):
             assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
+
+
+def test_hmc_config_is_validated_and_tiny_engines_run():
+    """n_leapfrog = 0 (the reference's loop then never moves, hmc.rs:385) and a non-positive finite-difference step are
+    refused at the boundary; one chain, and a chain count that leaves most lanes of the last tile empty, run."""
+    cp = E.compile_model(ZOO["normal32"]())
+    eng = E.Engine(cp, 1, seed=4)
+    for bad in (E.hmc_config(n_leapfrog=0), E.hmc_config(finite_diff_eps=0.0)):
+        with pytest.raises(E.EngineError) as ei:
+            eng.hmc_init(bad, 0)
+        assert ei.value.code == E.FG_E_BAD_ARG
+    for C in (1, 65):
+        eng = E.Engine(cp, C, seed=4)
+        d = eng.device_alloc(5 * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE), 5, 10, d)
+        x = eng.download(d, (5, cp.d, C))
+        assert np.isfinite(x).all() and st.n_divergent == 0
+        eng.device_free(d)
+        ref = E.Engine(cp, 130, seed=4)                               # the same chains inside a larger engine: identical draws
+        d2 = ref.device_alloc(5 * cp.d * 130 * 8)
+        ref.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE), 5, 10, d2)
+        assert np.array_equal(ref.download(d2, (5, cp.d, 130))[:, :, :C], x)
