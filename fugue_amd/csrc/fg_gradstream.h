@@ -89,6 +89,25 @@ __device__ __forceinline__ void fg_gen_lp(const fg_u32x16 &r, double xs, const d
     }
 }
 
+// ---- mu = options[z] (FG_G_NSEL): the index site z is a discrete slot, so every lane selects its own option; the K
+// options (f64 slots or constants) are walked with scalar loads and each lane keeps the one its z names -- the value the
+// interpreter's FG_OP_GATHER returns (NaN when z is outside 0..K-1).  `ci` = perturbed coordinate or ~0u.
+__device__ __forceinline__ void fg_nsel_mu(const fg_u32x16 &r, double zs, const double *pool, const double *slots, int tw, uint32_t ci, double h,
+                                           double &mup, double &mum) {
+    const uint32_t off = r[6], K = r[7];
+    const long long zi = fg_as_i64(zs);
+    const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + off);
+    double mp = NAN, mm = NAN;
+    for (uint32_t k = 0; k < K; ++k) {
+        const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * k);
+        const double v = q[1] ? fg_dbl(q[2], q[3]) : slots[q[0] * tw];
+        const bool dep = !q[1] && q[0] == ci;                // the perturbed slot holds orig +- h (hmc.rs:317-319)
+        const double vp = dep ? v + h : v, vm = dep ? v - h : v;
+        if (zi == (long long)k) { mp = vp; mm = vm; }
+    }
+    mup = mp; mum = mm;
+}
+
 struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
 struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
 
@@ -115,7 +134,13 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
         lpp = lp2[0]; lpm = lp2[1];
     } else {
     double dlp, dlm;
-    if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) {   // linear predictor: both means, then x - mu
+    if (RK >= 2 && __builtin_expect((fl & FG_G_NSEL) != 0u, 0)) {   // mu = options[z]
+        double mup, mum;
+        fg_nsel_mu(r, ms, pool, slots, tw, r[3], K.h, mup, mum);
+        const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
+        const double hx = (fl & FG_G_PERT_X) ? K.h : 0.0;
+        dlp = (x + hx) - mup; dlm = (x - hx) - mum;
+    } else if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) {   // linear predictor: both means, then x - mu
         double mup, mum;
         fg_lin_mu_dual(r, pool, slots, tw, K.h, mup, mum);
         const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
@@ -233,9 +258,14 @@ __device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, doub
         double lp2[2];
         fg_gen_lp(r, xs, slots, tw, 0.0, 1, lp2);
         lp = lp2[0];
+    } else if (RK >= 2 && __builtin_expect((fl & FG_G_CATC) != 0u, 0)) {   // Categorical site, constant table: ln p[z] precomputed
+        const long long zi = fg_as_i64(xs);
+        const uint32_t base = r[6], K = r[7];
+        lp = (zi < 0 || zi >= (long long)K) ? FG_NEG_INF : pool[base + K + (zi < 0 || zi >= (long long)K ? 0 : (int)zi)];
     } else {
         const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
         double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
+        if (RK >= 2 && __builtin_expect((fl & FG_G_NSEL) != 0u, 0)) { double mm_; fg_nsel_mu(r, ms, pool, slots, tw, ~0u, 0.0, m, mm_); }
         if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
         const double dl = x - m, inv = fg_dbl(r[10], r[11]);
         double z = dl * inv;

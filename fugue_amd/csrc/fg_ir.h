@@ -68,6 +68,9 @@ enum : uint32_t { FG_S_OBS = 1u,      // score stream: the record is an observe 
                   FG_G_X_CONST = 32u,  // x is a constant (ximm), no slot read
                   FG_G_M_CONST = 64u,  // mu is a constant (mimm), no slot read
                   FG_G_DIV = 128u,     // sigma outside the range where fg_div_const is proven exact: IEEE division
+                  FG_G_NSEL = 1u << 27,   // Normal(x; mu = options[z], constant sigma): mi = slot of the index site z, mimm dwords = {pool offset of the
+                                          //   K option entries {u32 slot, u32 is_const, f64 constant}, K}
+                  FG_G_CATC = 1u << 28,   // Categorical site with a constant table (score stream only): xi = its slot, mimm dwords = {pool base, K}
                   FG_G_GEN = 1024u,    // any of the 17 distributions with leaf operands (fg_logpdf): layout below, kind in flags >> 16
                   FG_G_GEN_HOISTED = 2048u, FG_G_GEN_SH = 4096u, FG_G_GEN_INVALID = 8192u, FG_G_GEN_XINT = 16384u,
                   FG_G_GEN_P0SLOT = 1u << 24, FG_G_GEN_P1SLOT = 1u << 25, FG_G_GEN_P2SLOT = 1u << 26,

@@ -434,12 +434,44 @@ int fg_program::finalize() {
     //   FAST: one FG_OP_NORMAL_FAST instruction (x, mu each an f64 slot or a constant, constant sigma);
     //   LIN : a Normal with constant sigma whose mean is a linear predictor,  LOAD c0; {MAC | DOT}...; STORE t;
     //         NORMAL_FAST(x, mu = slot t)  --  mu = (..((c0 + s_0 c_0) + s_1 c_1)..): its terms go to the pool once.
-    struct Shape { int kind = 0; FgIns F; double init = 0.0; uint32_t toff = 0, tn = 0; std::vector<uint32_t> tslot; };
+    struct Shape { int kind = 0; FgIns F; double init = 0.0; uint32_t toff = 0, tn = 0; std::vector<uint32_t> tslot; uint32_t zslot = 0; };
     std::vector<Shape> shape(stmts.size());
     for (size_t i = 0; i < stmts.size(); i++) {
         const int b = range[i].first, e = range[i].second;
         Shape &sh = shape[i];
         if (e - b == 1 && FG_INS_OPCODE(ins_fast[b].op) == FG_OP_NORMAL_FAST) { sh.kind = 1; sh.F = ins_fast[b]; continue; }
+        if (e - b == 1 && stmts[i].kind != 2 && FG_INS_OPCODE(ins_fast[b].op) == (uint32_t)FG_CATEGORICAL) {   // CATC: constant-table Categorical site
+            const FgIns &D = ins_fast[b];
+            if (FG_OPND_KIND(D.opnd[1]) == FG_OPND_POOL && !(D.op & FG_F_INVALID) && FG_OPND_KIND(D.opnd[0]) == FG_OPND_SLOT_I) {
+                sh.kind = 5; sh.F = D; sh.toff = FG_OPND_IDX(D.opnd[1]); sh.tn = D.opnd[2];
+            }
+            continue;
+        }
+        {   // NSEL: K x [LOAD option; STORE base+k]; LOAD z; GATHER base, K; STORE t; NORMAL_FAST(x, mu = t)
+            const int n = e - b;
+            if (n >= 6 && FG_INS_OPCODE(ins_fast[e - 1].op) == FG_OP_NORMAL_FAST && FG_INS_OPCODE(ins_fast[e - 2].op) == FG_OP_STORE &&
+                FG_INS_OPCODE(ins_fast[e - 3].op) == FG_OP_GATHER && FG_INS_OPCODE(ins_fast[e - 4].op) == FG_OP_LOAD) {
+                const FgIns &F = ins_fast[e - 1], &St = ins_fast[e - 2], &G = ins_fast[e - 3], &Lz = ins_fast[e - 4];
+                const uint32_t K = G.opnd[1], base = G.aux;
+                bool ok = (int)K >= 1 && (int)K <= 64 && n == 2 * (int)K + 4 && F.opnd[1] == St.aux && (int)St.aux >= S && F.opnd[0] != St.aux && F.imm[1] == 0.0 &&
+                          FG_OPND_KIND(Lz.opnd[0]) == FG_OPND_SLOT_I;
+                std::vector<double> opts;
+                for (uint32_t k = 0; k < K && ok; k++) {
+                    const FgIns &Lo = ins_fast[b + 2 * k], &So = ins_fast[b + 2 * k + 1];
+                    ok = FG_INS_OPCODE(Lo.op) == FG_OP_LOAD && FG_INS_OPCODE(So.op) == FG_OP_STORE && So.aux == base + k;
+                    if (!ok) break;
+                    if (FG_OPND_KIND(Lo.opnd[0]) == FG_OPND_SLOT_F && (int)FG_OPND_IDX(Lo.opnd[0]) < (int)f64_slot.size()) { opts.push_back(fg_as_double((long long)FG_OPND_IDX(Lo.opnd[0]))); opts.push_back(0.0); }
+                    else if (FG_OPND_KIND(Lo.opnd[0]) == FG_OPND_IMM) { opts.push_back(fg_as_double((long long)zero_slot | (1LL << 32))); opts.push_back(Lo.imm[0]); }
+                    else ok = false;
+                }
+                if (ok) {
+                    if (pool.size() & 1) pool.push_back(0.0);
+                    sh.kind = 4; sh.F = F; sh.toff = (uint32_t)pool.size(); sh.tn = K; sh.zslot = FG_OPND_IDX(Lz.opnd[0]);
+                    pool.insert(pool.end(), opts.begin(), opts.end());
+                    continue;
+                }
+            }
+        }
         if (e - b == 1 && stmts[i].kind != 2) {             // GEN: one distribution instruction whose operands are all leaves
             const FgIns &D = ins_fast[b];
             const uint32_t code = FG_INS_OPCODE(D.op);
@@ -495,6 +527,12 @@ int fg_program::finalize() {
     auto make_rec = [&](const Shape &sh, int coord_k /* -1: score record */) {
         const FgIns &F = sh.F;
         FgGradRec r; std::memset(&r, 0, sizeof(r));
+        if (sh.kind == 5) {                                          // Categorical site, constant table
+            r.xi = FG_OPND_IDX(F.opnd[0]); r.mi = (uint32_t)zero_slot; r.flags = FG_G_CATC;
+            const uint32_t w[2] = { sh.toff, sh.tn }; std::memcpy(&r.mimm, w, 8);
+            r.sigma = 1.0; r.inv = 1.0;
+            return r;
+        }
         if (sh.kind == 3) {
             FgGenRec g; std::memset(&g, 0, sizeof(g));
             const uint32_t vt = FG_INS_VTYPE(F.op), kx = FG_OPND_KIND(F.opnd[0]);
@@ -518,6 +556,10 @@ int fg_program::finalize() {
         r.flags = ((F.op & FG_F_POW2SCALE) ? FG_G_POW2 : 0u) | ((F.op & (FG_F_POW2SCALE | FG_F_RCPSCALE)) ? 0u : FG_G_DIV) |
                   (r.xi == (uint32_t)zero_slot ? FG_G_X_CONST : 0u) | ((sh.kind == 1 && r.mi == (uint32_t)zero_slot) ? FG_G_M_CONST : 0u);
         r.ximm = F.imm[0]; r.mimm = sh.kind == 2 ? sh.init : F.imm[1]; r.sigma = F.imm[2]; r.inv = 1.0 / F.imm[2]; r.lns = F.h[0];
+        if (sh.kind == 4) {                                          // mu = options[z]
+            r.mi = sh.zslot; r.flags |= FG_G_NSEL; r.flags &= ~(uint32_t)FG_G_M_CONST;
+            const uint32_t w[2] = { sh.toff, sh.tn }; std::memcpy(&r.mimm, w, 8);
+        }
         if (sh.kind == 2) {
             uint32_t pos = sh.tn;                                      // first term that reads the coordinate (tn: none)
             if (coord_k >= 0) for (uint32_t t = 0; t < sh.tn; t++) if (sh.tslot[t] == (uint32_t)coord_k) { pos = t; break; }
@@ -576,7 +618,7 @@ int fg_program::finalize() {
                 FgGradRec r = make_rec(sh, -1);
                 if (sh.F.op & FG_F_OBSERVE) r.flags |= FG_S_OBS;
                 sstream_has_lin = sstream_has_lin || sh.kind == 2;
-                sstream_has_gen = sstream_has_gen || sh.kind == 3;
+                sstream_has_gen = sstream_has_gen || sh.kind >= 3;
                 sstream.push_back(r);
             }
             n_sstream = (int)sstream.size();

@@ -96,7 +96,7 @@ def test_fd_gradient_matches_oracle(oracle, name):
         _close(g_sparse[fin, c], og[fin], 1e-7, tol)
 
 
-@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "ridge", "alldists", "hier_scale"])
+@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "ridge", "alldists", "hier_scale", "mixture"])
 @pytest.mark.parametrize("mode", [E.GRAD_FD_DENSE, E.GRAD_FD_SPARSE])
 def test_hmc_transition_injected(oracle, name, mode):
     """hmc_transition (hmc.rs:419-473) under injected momentum and uniform: accept decision,
@@ -191,7 +191,7 @@ def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, tar
                                        ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_DENSE),
                                        ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE),
                                        ("hier", E.GRAD_FD_SPARSE), ("hier", E.GRAD_FD_DENSE), ("ridge7", E.GRAD_FD_SPARSE),
-                                       ("hier_scale", E.GRAD_FD_SPARSE), ("linreg", E.GRAD_FD_SPARSE)])
+                                       ("hier_scale", E.GRAD_FD_SPARSE), ("linreg", E.GRAD_FD_SPARSE), ("mixture", E.GRAD_FD_SPARSE)])
 def test_hmc_session_matches_oracle_teacher_forced(oracle, name, mode):
     """HmcSession (hmc.rs:667-920) step by step: prior init, Alg. 4 step size, every transition's
     HmcStepInfo, the dual-averaging recursion and the frozen step size -- each checked against
