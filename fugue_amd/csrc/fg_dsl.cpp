@@ -115,7 +115,10 @@ const struct { const char *name; int kind, lo, hi; } DISTS[] = {    // dist_arit
 
 EP parse_expr(Lexer &lx);
 EP mk(Expr::K k) { auto e = std::make_shared<Expr>(); e->k = k; return e; }
+struct Depth { int &d; explicit Depth(int &x) : d(x) { if (++d > 200) throw DslError{"expression or block nesting deeper than 200"}; } ~Depth() { --d; } };
+int g_depth = 0;      // parser recursion guard (single-threaded use under fg_dsl_compile)
 EP parse_primary(Lexer &lx) {
+    Depth guard(g_depth);
     const Tok t = lx.peek();
     if (t.t == T::Num) { lx.next(); EP e = mk(t.dotted ? Expr::Num : Expr::Int); e->num = t.v; e->i = (long long)t.v; return e; }
     if (t.t == T::Sym && t.s == "(") { lx.next(); EP e = parse_expr(lx); lx.expect_sym(")"); return e; }
@@ -174,6 +177,7 @@ void parse_dist(Lexer &lx, Stmt &s) {
     throw DslError{"unknown distribution `" + s.dist + "`"};
 }
 SP parse_stmt(Lexer &lx) {
+    Depth guard(g_depth);
     auto s = std::make_shared<Stmt>();
     s->line = lx.line_of(lx.peek().byte);
     if (lx.eat_kw("let")) {
@@ -274,6 +278,8 @@ std::string make_addr(const Stmt &s, Env &env) {
 
 struct Builder {
     fg_program *p; std::vector<std::string> warnings;
+    long long n_emitted = 0;      // statements emitted so far: the model is unrolled at build time, so bound it
+    void count() { if (++n_emitted > (1LL << 20)) throw DslError{"model unrolls to more than 1048576 statements"}; }
     // Parameters that are build-time numbers and fail the distribution's constructor: the reference keeps the
     // model alive and kills the weight (dsl.rs:961-977 sample, :1002-1006 observe).  Returns the message or "".
     std::string dist_toks(const Stmt &s, Env &env, int &kind, std::vector<fg_tok> &toks, std::vector<int32_t> &lens) {
@@ -294,11 +300,12 @@ struct Builder {
         for (auto &sp : stmts) {
             const Stmt &s = *sp;
             switch (s.k) {
-            case Stmt::LetExpr: env.vars[s.name] = eval(s.expr, env); break;
-            case Stmt::Factor: { Val v = eval(s.expr, env); auto t = v.toks();
+            case Stmt::LetExpr: count(); env.vars[s.name] = eval(s.expr, env); break;
+            case Stmt::Factor: { count(); Val v = eval(s.expr, env); auto t = v.toks();
                 if (v.numeric() && std::isnan(v.as_f64())) t = { fg_tok{FG_T_CONST, 0, 0, 0, -INFINITY} };      // NaN -> -inf, dsl.rs:911-913
                 if (fg_program_factor(p, t.data(), (int)t.size())) throw DslError{fg_last_error()}; break; }
             case Stmt::SampleLet: case Stmt::Observe: {
+                count();
                 int kind = 0; std::vector<fg_tok> toks; std::vector<int32_t> lens;
                 const std::string a = make_addr(s, env);
                 const std::string bad = dist_toks(s, env, kind, toks, lens);
@@ -332,7 +339,7 @@ struct Builder {
                 if (!lo.as_index(l)) { env.warn("`for` lower bound is not an integer"); l = 0; }      // dsl.rs:1010-1017
                 if (!hi.as_index(h)) { env.warn("`for` upper bound is not an integer"); h = 0; }
                 const bool had = env.vars.count(s.name) != 0; const Val saved = had ? env.vars[s.name] : Val();
-                for (long long i = l; i < h; i++) { env.vars[s.name] = vi(i); run(s.body, env); }
+                for (long long i = l; i < h; i++) { count(); env.vars[s.name] = vi(i); run(s.body, env); }
                 if (had) env.vars[s.name] = saved; else env.vars.erase(s.name);
                 break; }
             }
@@ -373,6 +380,7 @@ extern "C" {
 fg_program *fg_dsl_compile(const char *source_utf8, const char *data_json_utf8) {
     if (!source_utf8) { fg_set_error("fg_dsl_compile: null source"); return nullptr; }
     fg_program *p = fg_program_new();
+    g_depth = 0;
     try {
         Lexer lx(source_utf8);
         std::vector<SP> stmts; EP ret;

@@ -108,3 +108,15 @@ def test_duplicate_address_is_reported():
     with pytest.raises(E.DslError) as ei:
         E.CompiledProgram.from_dsl('for i in 0..2 { let v <- sample(addr!("v"), Normal(0, 1)); } pure(0)')
     assert "sampled twice" in str(ei.value)
+
+
+def test_build_time_limits():
+    """The model is unrolled when it is built, so runaway sizes are refused instead of exhausting memory."""
+    with pytest.raises(E.DslError) as ei:
+        E.CompiledProgram.from_dsl('for i in 0..2000000 { factor(0.0); } pure(0)')
+    assert "1048576 statements" in str(ei.value)
+    with pytest.raises(E.DslError) as ei:
+        E.CompiledProgram.from_dsl("pure(" + "(" * 500 + "1" + ")" * 500 + ")")
+    assert "nesting" in str(ei.value)
+    with pytest.raises(E.DslError):                      # an empty loop with a huge trip count is bounded too
+        E.CompiledProgram.from_dsl('for i in 0..9000000000 { } pure(0)')
