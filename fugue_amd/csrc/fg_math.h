@@ -271,7 +271,13 @@ FG_HD void fg_rng_normal_pair(FgStream &s, double &z0, double &z1) {   // Box-Mu
     double u2 = fg_u01_of(b);
     double r = sqrt(-2.0 * log(u1));
     double th = 2.0 * M_PI * u2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double sn, cs;
+    sincos(th, &sn, &cs);                    // one argument reduction for both (the same values as cos() and sin())
+    z0 = r * cs; z1 = r * sn;
+#else
     z0 = r * cos(th); z1 = r * sin(th);
+#endif
 }
 FG_HD double fg_rng_normal(FgStream &s) { double a, b; fg_rng_normal_pair(s, a, b); return a; }
 // gaussian_z: /root/reference/src/inference/mh.rs:128-132
