@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
-    ap.add_argument("--grad", choices=["fd_sparse", "fd_dense"], default="fd_sparse")
+    ap.add_argument("--grad", choices=["fd_sparse", "fd_dense", "analytic"], default="fd_sparse",
+                    help="fd_sparse / fd_dense: the reference's central difference; analytic: closed-form derivative (not the reference's arithmetic)")
     ap.add_argument("--launch", type=int, default=25, help="transitions fused per kernel launch")
     ap.add_argument("--leapfrog", type=int, default=16, help="L (HMCConfig::default is 16; other values are for experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,6 +101,13 @@ def extras(args, E, W, dev):
     eng.hmc_step(2); eng.synchronize()
     t0 = time.perf_counter(); eng.hmc_step(10); eng.synchronize(); dt = time.perf_counter() - t0
     out["hmc_fd_dense_leapfrog_steps_per_sec"] = C * 10 * 16 / dt
+    eng.close()
+    # (1b) closed-form gradient (FG_GRAD_ANALYTIC; north_star "where available analytic"): NOT the reference's arithmetic
+    eng = E.Engine(cp, C, seed=1, device=dev)
+    eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_ANALYTIC), 0)
+    eng.hmc_step(25); eng.synchronize()
+    t0 = time.perf_counter(); eng.hmc_step(100); eng.synchronize(); dt = time.perf_counter() - t0
+    out["hmc_analytic_leapfrog_steps_per_sec"] = C * 100 * 16 / dt
     eng.close()
     # (2) adaptive_mcmc_chain on the reference's own bench model (benches/f_perf.rs:78-109: 20 sample + 19 observe sites)
     cp = E.compile_model(W.reference_model(20))
@@ -156,7 +164,7 @@ def main():
     C, K, Wn, L = args.chains, args.steps, args.warmup, args.leapfrog
     cp = E.compile_model(W.normal_sites(N_SITES))
     d = cp.d
-    mode = E.GRAD_FD_SPARSE if args.grad == "fd_sparse" else E.GRAD_FD_DENSE
+    mode = {"fd_sparse": E.GRAD_FD_SPARSE, "fd_dense": E.GRAD_FD_DENSE, "analytic": E.GRAD_ANALYTIC}[args.grad]
     cfg = E.hmc_config(grad_mode=mode, n_leapfrog=L)
     eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=local_rank)
     stream = torch.cuda.current_stream()

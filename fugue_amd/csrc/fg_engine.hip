@@ -167,7 +167,7 @@ __device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, c
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double h0 = -lj_cur + fg_kinetic(P, pl, tw, mi, X.C);      // hmc.rs:442-443
     double lj_new;
-    const bool div = fg_trajectory(P, slots, pl, tw, eps, H.L, H.h, H.grad_mode == FG_GRAD_FD_SPARSE, mi, X.C, lj_new);
+    const bool div = fg_trajectory(P, slots, pl, tw, eps, H.L, H.h, H.grad_mode != FG_GRAD_FD_DENSE, mi, X.C, lj_new);
     FgTransOut o;
     o.divergent = div;
     double ap = 0.0;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
 struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1];
                int separable; };   // every record of a wave reads only that wave's own coordinates (and constants): no barrier inside the leapfrog loop
 
-template <int RK>
+template <int RK, bool AN>
 __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSeg seg, int iter0, int n_steps,
                                                                                int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                                double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
 #ifndef FG_EXP_NOSTREAM
             if (dense) bad = fg_grad_dense_stream(P.sstream, P.n_sstream, k0, k1, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
-            else if (gn > 0) bad = fg_grad_stream<RK>(gs0, gn, P.pool, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
+            else if (gn > 0) bad = fg_grad_stream<RK, AN>(gs0, gn, P.pool, slots, pl, tw, H.h, hk, gs > 0 && gs < L, nullptr, 0, false) || bad;
 #endif
             if (!sep) __syncthreads();                           // every p kicked, every read of q done
             if (gs < L) {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_inject
 }
 
 // grad_log_joint (hmc.rs:304-329) at the current values (test hook)
-__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse, double *grad, int *ok) {
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse /* 2: analytic */, double *grad, int *ok) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
     if (sparse && P.gstream) {
         double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
         for (int i = 0; i < P.d; ++i) pl[i * tw] = 0.0;
-        good = !fg_grad_stream<2>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
+        if (sparse == 2) good = !fg_grad_stream<1, true>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
+        else good = !fg_grad_stream<2>(P.gstream, P.n_gstream, P.pool, slots, pl, tw, h, 0.0, false, grad + c, X.C, live);
         if (live && ok) ok[c] = good;
         return;
     }
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_find_eps(FgProgra
     double *pl = lds + (long long)P.n_slots * tw + threadIdx.x;
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
-    const bool sparse = H.grad_mode == FG_GRAD_FD_SPARSE;
+    const bool sparse = H.grad_mode != FG_GRAD_FD_DENSE;       // the step-size search of FG_GRAD_ANALYTIC uses the sparse finite difference
     fg_load_values(P, X, c, slots, tw);
     if (!injected) {
         FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, instance, FG_RNG_EPS);
@@ -744,7 +745,8 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) ||
-        set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0>, lds_hmc) || set_lds(k_hmc_stream_steps<1>, lds_hmc) || set_lds(k_hmc_stream_steps<2>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
+        set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false>, lds_hmc) ||
+        set_lds(k_hmc_stream_steps<0, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
         set_lds(k_hmc_grad, lds_hmc) || set_lds(k_hmc_find_eps, lds_hmc) ||
         set_lds(k_mh_steps, e->lds_score))
         return fail("hipFuncSetAttribute");
@@ -884,7 +886,10 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
     NEED_ENGINE(e);
     if (!cfg || n_warmup < 0) return FG_E_BAD_ARG;
     if (int rc = hmc_lds_ok(e)) return rc;
-    if (cfg->grad_mode != FG_GRAD_FD_DENSE && cfg->grad_mode != FG_GRAD_FD_SPARSE) { fg_set_error("unknown grad_mode"); return FG_E_BAD_ARG; }
+    if (cfg->grad_mode != FG_GRAD_FD_DENSE && cfg->grad_mode != FG_GRAD_FD_SPARSE && cfg->grad_mode != FG_GRAD_ANALYTIC) { fg_set_error("unknown grad_mode"); return FG_E_BAD_ARG; }
+    if (cfg->grad_mode == FG_GRAD_ANALYTIC && (e->d == 0 || !e->P.gstream || fg_program_stream_records(e->prog, 2) > 1 || e->tw != FG_WAVE)) {
+        fg_set_error("FG_GRAD_ANALYTIC needs every force term to be a Normal with constant sigma whose mean is a site, a constant or a linear predictor");
+        return FG_E_UNSUPPORTED; }
     if (cfg->n_leapfrog < 1 || cfg->n_leapfrog > 100000) { fg_set_error("n_leapfrog must be in [1, 100000] (a trajectory of 0 steps never moves: hmc.rs:385)"); return FG_E_BAD_ARG; }
     if (!(cfg->finite_diff_eps > 0.0) || !std::isfinite(cfg->finite_diff_eps)) { fg_set_error("finite_diff_eps must be positive and finite"); return FG_E_BAD_ARG; }
     const bool mass = cfg->adapt_mass && n_warmup >= 4;                 // hmc.rs:704-708
@@ -922,7 +927,8 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
                             double *pos_all = nullptr, double *info = nullptr) {
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
     const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr && e->P.sstream_kinds == 0;
-    if (((e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
+    const bool analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
+    if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
         // a tile, whatever the chain count; each wave should still own at least 2 coordinates
@@ -956,9 +962,14 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
             }
         int rk = e->P.sstream_kinds;                             // record kinds present in either stream
         for (int k = 0; k < nrec && rk < 2; ++k) rk = std::max(rk, (gs[k].flags & FG_G_GEN) ? 2 : ((gs[k].flags & FG_G_LIN) ? 1 : 0));
-#define FG_LAUNCH_STREAM(RK) hipLaunchKernelGGL(k_hmc_stream_steps<RK>, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, \
+#define FG_LAUNCH_STREAM(RK) hipLaunchKernelGGL(k_hmc_stream_steps<RK FG_AN>, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, \
                                                 iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
-        if (rk == 2) FG_LAUNCH_STREAM(2); else if (rk == 1) FG_LAUNCH_STREAM(1); else FG_LAUNCH_STREAM(0);
+#define FG_AN , false
+        if (!analytic) { if (rk == 2) FG_LAUNCH_STREAM(2); else if (rk == 1) FG_LAUNCH_STREAM(1); else FG_LAUNCH_STREAM(0); }
+#undef FG_AN
+#define FG_AN , true
+        else { if (rk == 1) FG_LAUNCH_STREAM(1); else FG_LAUNCH_STREAM(0); }
+#undef FG_AN
 #undef FG_LAUNCH_STREAM
         HIPCHK(hipGetLastError());
         return FG_OK;
@@ -1094,11 +1105,13 @@ int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *
     NEED_ENGINE(e);
     if (!h_grad) return FG_E_BAD_ARG;
     if (int rc = hmc_lds_ok(e)) return rc;
+    if (grad_mode == FG_GRAD_ANALYTIC && (!e->P.gstream || fg_program_stream_records(e->prog, 2) > 1)) {
+        fg_set_error("FG_GRAD_ANALYTIC is not available for this program"); return FG_E_UNSUPPORTED; }
     double *d_g = nullptr;
     int rc = dev_alloc(&d_g, (size_t)std::max(1, e->d) * e->C);
     if (rc) return rc;
     hipLaunchKernelGGL(k_hmc_grad, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, h,
-                       grad_mode == FG_GRAD_FD_SPARSE ? 1 : 0, d_g, e->d_itmp);
+                       grad_mode == FG_GRAD_ANALYTIC ? 2 : (grad_mode == FG_GRAD_FD_SPARSE ? 1 : 0), d_g, e->d_itmp);
     hipError_t le = hipGetLastError();
     if (le == hipSuccess) le = hipMemcpyAsync(h_grad, d_g, (size_t)e->d * e->C * 8, hipMemcpyDeviceToHost, e->stream);
     if (le == hipSuccess && h_ok) le = hipMemcpyAsync(h_ok, e->d_itmp, (size_t)e->C * 4, hipMemcpyDeviceToHost, e->stream);

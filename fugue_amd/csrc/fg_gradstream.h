@@ -119,10 +119,38 @@ struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-unifo
 // log_prior and log_likelihood are summed separately and added at the end, exactly like total_log_weight
 // (trace.rs:198-200).  A non-finite x or mu gives z = NaN or +-inf -> lp NaN or -inf -> a non-finite g -> divergent,
 // the same verdict as the reference's -inf log-density (hmc.rs:323-325); no guard is needed here.
-template <int RK>
+template <int RK, bool AN>
 __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, double ms, double pv, FgGradAcc &A, const FgGradK &K,
                                              const double *pool, const double *slots, double *pl, int tw, double *gout, long long gstride, bool live) {
     const uint32_t fl = r[2];
+    if (AN) {                                              // FG_GRAD_ANALYTIC: d/dq_i of -(x - mu)^2 / (2 sigma^2), one evaluation
+        const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
+        double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms, ci = (fl & FG_G_PERT_M) ? 1.0 : 0.0;
+        if (RK >= 1 && (fl & FG_G_LIN)) {                  // d mu / d q_i = sum of the coefficients of the terms that read q_i
+            const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + r[14]);
+            m = fg_dbl(r[6], r[7]); ci = 0.0;
+            for (uint32_t t = 0; t < r[15]; ++t) {
+                const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+                const double c = fg_dbl(q[2], q[3]);
+                m = m + slots[q[0] * tw] * c;
+                if (q[0] == r[3]) ci += c;
+            }
+        }
+        const double inv = fg_dbl(r[10], r[11]), sg = fg_dbl(r[8], r[9]);
+        const double dl = x - m;
+        const double w = (fl & FG_G_POW2) ? (dl * inv) * inv : (dl / sg) / sg;       // (x - mu) / sigma^2
+        A.sp += ((fl & FG_G_PERT_X) ? ci - 1.0 : ci) * w;                             // d lp / d mu = +w, d lp / d x = -w
+        if (fl & FG_G_END) {
+            const double g = A.sp;
+            A.bad = A.bad || !fg_finite(g);
+            double p = pv + K.hk * g;
+            if (K.two_kicks) p += K.hk * g;
+            pl[r[3] * tw] = p;
+            if (gout && live) gout[(long long)r[3] * gstride] = g;
+            A.sp = 0.0;
+        }
+        return;
+    }
     // x - mu at q_i + h and q_i - h: the perturbed operand holds orig +- h (hmc.rs:317-319), the other its value
     // (a constant operand is the record's immediate, a scalar).  Four forms, four additions each, selected by
     // scalar branches: adding the zero perturbation / the zero slot of a uniform form would give the same bits
@@ -202,7 +230,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 #ifdef FG_EXP_G_NOMATH
 #define FG_G_MATH(RA, XA, MA, PA) A.sp += XA + MA + PA + fg_dbl(RA[4], RA[5]);
 #else
-#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math<RK>(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
+#define FG_G_MATH(RA, XA, MA, PA) fg_grec_math<RK, AN>(RA, XA, MA, PA, A, K, pool, slots, pl, tw, gout, gstride, live);
 #endif
 #ifdef FG_EXP_G_NOFETCH
 #define FG_G_FETCH(RD) RD = fg_fetch_grec(g, (k + 3) & 1);
@@ -226,7 +254,7 @@ __device__ __forceinline__ void fg_grec_math(const fg_u32x16 &r, double xs, doub
 // RK = record kinds the instantiation understands: 0 fast Normals only, 1 + linear predictors (FG_G_LIN), 2 + general
 // distribution records (FG_G_GEN).  The 128-VGPR multi-wave kernel is sensitive to every register the hot loop holds,
 // so a program only pays for the kinds it contains.
-template <int RK>
+template <int RK, bool AN = false>
 __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, const double *pool, double *slots, double *pl, int tw, double h, double hk,
                                                bool two_kicks, double *gout, long long gstride, bool live) {
     FgGradK K;

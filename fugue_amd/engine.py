@@ -54,7 +54,7 @@ PROP_AUTO, PROP_GAUSSIAN, PROP_LOGSPACE, PROP_REFLECT, PROP_PRIOR_RESAMPLE = ran
 TOK = {"const": 0, "site": 1, "data": 2, "neg": 3, "exp": 4, "ln": 5, "sqrt": 6, "abs": 7, "floor": 8, "sin": 9,
        "cos": 10, "tanh": 11, "add": 12, "sub": 13, "mul": 14, "div": 15, "pow": 16, "min": 17, "max": 18,
        "clamp": 19, "select": 20}
-GRAD_FD_DENSE, GRAD_FD_SPARSE = 0, 1
+GRAD_FD_DENSE, GRAD_FD_SPARSE, GRAD_ANALYTIC = 0, 1, 2
 # engine error codes (include/fugue_amd.h)
 FG_E_NO_DEVICE, FG_E_HIP, FG_E_BAD_ARG, FG_E_NOT_FINALIZED, FG_E_STATE, FG_E_UNSUPPORTED, FG_E_LIMIT = -1, -2, -3, -4, -5, -6, -7
 

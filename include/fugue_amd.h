@@ -157,8 +157,14 @@ int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp);
 /* ------------------------------------------------------------------ HMC
  * Replaces hmc_chain / HmcSession (src/inference/hmc.rs:566-583, 643-920). */
 enum { FG_GRAD_FD_DENSE = 0,   /* hmc.rs:304-329 verbatim: 2d full model runs per gradient */
-       FG_GRAD_FD_SPARSE = 1   /* same central difference, re-evaluating only the terms that
-                                  depend on the perturbed coordinate */ };
+       FG_GRAD_FD_SPARSE = 1,  /* same central difference, re-evaluating only the terms that
+                                  depend on the perturbed coordinate */
+       FG_GRAD_ANALYTIC = 2    /* closed-form derivative where the model allows it (every force term a Normal with
+                                  constant sigma whose mean is a site, a constant or a linear predictor):
+                                  d/dq_i sum of -(x - mu)^2 / (2 sigma^2).  NOT the reference's arithmetic (it has
+                                  no analytic mode): agrees with the finite difference to its O(h^2) + rounding
+                                  error; the step-size search still uses FG_GRAD_FD_SPARSE.  fg_hmc_init returns
+                                  FG_E_UNSUPPORTED for other programs. */ };
 typedef struct fg_hmc_config {      /* HMCConfig, hmc.rs:106-135 (same defaults) */
     int32_t n_leapfrog;             /* 16 */
     double  target_accept;          /* 0.8 */

@@ -230,7 +230,7 @@ template <class T, class F> auto traverse_vec(const std::vector<T> &items, F f) 
 template <class F> auto plate(int n, F f) { std::vector<int> idx(n); for (int i = 0; i < n; ++i) idx[i] = i; return traverse_vec(idx, f); }
 
 // ---- engine handle + many-chain drivers ---------------------------------------------------------------
-enum class GradMode { FdDense = FG_GRAD_FD_DENSE, FdSparse = FG_GRAD_FD_SPARSE };
+enum class GradMode { FdDense = FG_GRAD_FD_DENSE, FdSparse = FG_GRAD_FD_SPARSE, Analytic = FG_GRAD_ANALYTIC };
 struct HMCConfig {                       // hmc.rs:106-135, same defaults
     size_t n_leapfrog = 16; double target_accept = 0.8; std::optional<double> init_step_size; double finite_diff_eps = 1e-5;
     bool adapt_mass = false; GradMode grad_mode = GradMode::FdSparse;

@@ -365,3 +365,68 @@ def test_hmc_config_is_validated_and_tiny_engines_run():
         d2 = ref.device_alloc(5 * cp.d * 130 * 8)
         ref.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE), 5, 10, d2)
         assert np.array_equal(ref.download(d2, (5, cp.d, 130))[:, :, :C], x)
+
+
+@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "hier", "ridge", "ridge7", "linreg"])
+def test_analytic_gradient_matches_finite_difference(oracle, name):
+    """FG_GRAD_ANALYTIC (closed form for Normal / linear-predictor force terms) against the oracle's central difference
+    (hmc.rs:304-329): they differ by the finite difference's own O(h^2) + rounding error -- the same 5e-6 * (1 + |lj|)
+    bound the FD parity test uses -- and against a numpy derivative of the same density where that is easy."""
+    cp, om = _pair(oracle, name)
+    C = 70
+    cells = f64_values_for(om, np.random.default_rng(11), C)
+    eng = E.Engine(cp, C, seed=1)
+    eng.set_values(cells)
+    g_an, ok = eng.hmc_grad(1e-5, E.GRAD_ANALYTIC)
+    g_fd, _ = eng.hmc_grad(1e-5, E.GRAD_FD_SPARSE)
+    assert ok.all() and np.isfinite(g_an).all()
+    for c in range(0, C, 3):
+        q = _f64(cells[om.f64_sites, c])
+        og, _ = om.grad_log_joint(cells[:, c], q)
+        tol = 5e-6 * (1.0 + abs(om.log_joint_at(cells[:, c], q)))
+        _close(g_an[:, c], og, 1e-7, tol)
+    _close(g_an, g_fd, 1e-6, 1e-4)
+    if name == "normal32":                                # d/dx [-x^2/2 - (y - x)^2 / (2 * 0.25)]
+        x = _f64(cells)
+        y = np.array([0.2 * int(n.split("#")[1]) - 1.0 for n in cp.site_names])[:, None]
+        _close(g_an, -x + (y - x) / 0.25, 1e-13, 1e-13)
+
+
+def test_analytic_mode_is_refused_where_unavailable():
+    for name in ("hier_scale", "mixture", "alldists"):
+        eng = E.Engine(E.compile_model(ZOO[name]()), 64, seed=1)
+        with pytest.raises(E.EngineError) as ei:
+            eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_ANALYTIC), 10)
+        assert ei.value.code == E.FG_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["normal32", "ridge"])
+def test_hmc_analytic_mode_posterior_and_wave_invariance(name, monkeypatch):
+    """hmc_chain with FG_GRAD_ANALYTIC: bit-identical for 1, 2, 4 waves per tile, close to the finite-difference chain
+    for a few fixed-step transitions, and the closed-form posterior mean is recovered."""
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 256, 60, 60
+    out = []
+    for W_ in (1, 2, 4):
+        monkeypatch.setenv("FG_HMC_WAVES", str(W_))
+        eng = E.Engine(cp, C, seed=8)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_ANALYTIC, n_leapfrog=8, adapt_mass=True), ns, nw, d)
+        out.append((eng.download(d, (ns, cp.d, C)), eng.hmc_step_sizes(), st.accept_rate))
+        eng.device_free(d)
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+    assert 0.6 < out[0][2] <= 1.0
+    monkeypatch.delenv("FG_HMC_WAVES")
+    res = {}
+    for mode in (E.GRAD_ANALYTIC, E.GRAD_FD_SPARSE):      # fixed step size: no chaotic step-size feedback
+        eng = E.Engine(cp, C, seed=8)
+        d = eng.device_alloc(4 * cp.d * C * 8)
+        eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=8, init_step_size=0.05), 4, 0, d)
+        res[mode] = eng.download(d, (4, cp.d, C))
+        eng.device_free(d)
+    same = np.isclose(res[E.GRAD_ANALYTIC], res[E.GRAD_FD_SPARSE], rtol=1e-5, atol=1e-6).all(axis=(0, 1))
+    assert same.sum() >= C - 2                             # an accept on a knife edge may flip a chain
+    if name == "normal32":
+        _, tm, _ = W.normal_sites_truth(32)
+        assert np.abs(out[0][0].mean(axis=(0, 2)) - tm).max() < 0.02
