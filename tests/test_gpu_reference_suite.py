@@ -78,3 +78,25 @@ def test_smc_reference_targets():
     prog, bmean = R.beta_bernoulli()
     r = E.Engine(E.compile_model(prog), 65536, seed=3).smc_run(rejuvenation_steps=0)
     assert abs(float((r["weights"] * r["values"].view(np.float64)[0]).sum()) - bmean) < 5e-3
+
+
+def test_fg31_hmc_beats_mh_on_ess_per_model_eval():
+    """tests/f_hmc_efficiency.rs:25-80: on a rho = 0.99 Gaussian, hmc_chain (L = 12, reference arithmetic: dense FD) must be at
+    least 2x more efficient than adaptive_mcmc_chain PER MODEL EVALUATION for s = x + y.  Model evaluations are counted the
+    way the reference counts model_fn calls: (L + 1) * 2d + 1 per HMC transition (hmc.rs:304-329, 353-407, 283-299; the
+    Alg. 4 step-size search adds at most 100 * (2 * 2d + 1) once), one per MH step (mh.rs:1186-1202).  ESS is the mean
+    over chains of effective_sample_size_mcmc."""
+    from fugue_amd import validation as V
+    prog = R.correlated_gaussian(0.99)
+    C, L, d = 64, 12, 2
+    cp, eng, st, draws, _ = _hmc(prog, C, 600, 1500, seed=20260711, n_leapfrog=L, grad_mode=E.GRAD_FD_DENSE)
+    s = draws[:, 0, :] + draws[:, 1, :]
+    hmc_ess = np.mean([V.effective_sample_size_mcmc(s[:, c]) for c in range(C)])
+    hmc_evals = (1500 + 600) * ((L + 1) * 2 * d + 1) + 100 * (2 * 2 * d + 1)
+    cp, st2, cells = _mh(prog, C, 2000, 12000, seed=20260711)
+    xy = cells.view(np.float64)
+    s2 = xy[:, 0, :] + xy[:, 1, :]
+    mh_ess = np.mean([V.effective_sample_size_mcmc(s2[:, c]) for c in range(C)])
+    mh_evals = 12000 + 2000
+    ratio = (hmc_ess / hmc_evals) / (mh_ess / mh_evals)
+    assert ratio >= 2.0, (hmc_ess, hmc_evals, mh_ess, mh_evals, ratio)
