@@ -46,13 +46,17 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
         extra = list(extra) + ["-D" + d for d in os.environ["FG_EXTRA_DEFS"].split(",")]
     if os.environ.get("FG_MIN_WAVES"):
         extra = list(extra) + ["-DFG_MIN_WAVES=" + os.environ["FG_MIN_WAVES"]]
-    cmd = [hipcc()] + FLAGS + list(extra) + srcs + ["-o", LIB]
+    tmp = f"{LIB}.tmp.{os.getpid()}"                      # several ranks may build at once: write aside, then rename atomically
+    cmd = [hipcc()] + FLAGS + list(extra) + srcs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed building libfugue_amd.so")
+    os.replace(tmp, LIB)
     if verbose and r.stderr:
         sys.stderr.write(r.stderr)
     return LIB
