@@ -943,12 +943,14 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         const int nrec = e->prog->n_gstream;
         std::vector<int> cstart(e->d + 1, nrec);                 // first record of each coordinate
         for (int k = nrec - 1; k >= 0; --k) cstart[gs[k].coord] = k;
+        std::vector<long long> cum(nrec + 1, 0);                 // work before record k: a linear predictor costs its terms
+        for (int k = 0; k < nrec; ++k) cum[k + 1] = cum[k] + ((gs[k].flags & FG_G_LIN) ? 1 + gs[k].maskm / 2 : 1);
         for (int w = 0; w <= FG_MW_MAX; ++w) { seg.c[w] = e->d; seg.g[w] = nrec; }
         seg.c[0] = 0; seg.g[0] = 0;
         for (int w = 1, k = 0; w < W; ++w) {
             if (dense_stream) { seg.c[w] = (int)((long long)e->d * w / W); seg.g[w] = 0; continue; }   // every coordinate costs one whole-program pass
-            const long long target = (long long)nrec * w / W;     // cut at the coordinate boundary nearest to w/W of the records
-            while (k < e->d && cstart[k] < target) ++k;
+            const long long target = cum[nrec] * w / W;           // cut at the coordinate boundary nearest to w/W of the work
+            while (k < e->d && cum[cstart[k]] < target) ++k;
             seg.c[w] = k; seg.g[w] = cstart[k];
         }
         // do the waves interact inside a trajectory?  Not when every record only reads coordinates of its own wave.

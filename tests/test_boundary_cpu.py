@@ -94,3 +94,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "fugue_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_stream_records_report_what_the_compiler_could_build():
+    """fg_program_stream_records: (gradient records, score records, record kinds) -- 0 means the interpreter kernels."""
+    from tests.models import ZOO
+    want = {"readme": (2, 2, 0), "normal32": (64, 64, 0), "refmodel8": (22, 15, 0), "ridge": (100, 28, 1), "hier_scale": (29, 20, 2),
+            "mixture": (44, 24, 2), "alldists": (0, 0, 0), "coin": (0, 0, 0)}
+    for name, rec in want.items():
+        assert E.compile_model(ZOO[name]()).stream_records == rec, name
