@@ -267,3 +267,34 @@ def geweke_diagnostic(chain: np.ndarray) -> float:
     if se == 0.0:
         return 0.0
     return float((a.sum() / len(a) - b.sum() / len(b)) / se)
+
+
+def format_diagnostics(names, cd: "ChainDiagnostics", draws: Optional[np.ndarray] = None) -> str:
+    """`print_diagnostics` (diagnostics.rs:394-456) for many chains: the same table and convergence verdict.  `draws`
+    [n][d][C] (host) supplies the 2.5 % / 50 % / 97.5 % quantiles (`quantiles_f64` rule); without it they print as NaN."""
+    s = cd.summary()
+    lines = ["MCMC Diagnostics:",
+             "{:<15} {:>8} {:>8} {:>8} {:>8} {:>8} {:>8} {:>8}".format("Parameter", "Mean", "Std", "2.5%", "50%", "97.5%", "R-hat", "ESS"),
+             "-" * 80]
+    for i, name in enumerate(names):
+        q = quantiles_f64(draws[:, i, :], (0.025, 0.5, 0.975)) if draws is not None else {}
+        vals = [q.get(k, float("nan")) for k in ("2.5%", "50%", "97.5%")]
+        lines.append("{:<15} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.0f}".format(
+            str(name), s["mean"][i], s["std"][i], vals[0], vals[1], vals[2], s["r_hat"][i], s["ess"][i]))
+    fin = s["r_hat"][np.isfinite(s["r_hat"])]
+    if fin.size:
+        mx, avg = float(fin.max()), float(fin.mean())
+        lines.append("")
+        lines.append("Convergence Assessment:")
+        if mx < 1.01:
+            lines.append("✓ Excellent convergence (max R-hat = {:.3f})".format(mx))
+        elif mx < 1.1:
+            lines.append("⚠ Good convergence (max R-hat = {:.3f})".format(mx))
+        else:
+            lines.append("✗ Poor convergence (max R-hat = {:.3f}) - consider more samples".format(mx))
+        lines.append("  Average R-hat: {:.3f}".format(avg))
+    return "\n".join(lines)
+
+
+def print_diagnostics(names, cd: "ChainDiagnostics", draws: Optional[np.ndarray] = None) -> None:
+    print(format_diagnostics(names, cd, draws))

@@ -98,3 +98,18 @@ dist.destroy_process_group()
         assert out["classic"][i] == pytest.approx(oracle.classic_rhat(ch), rel=1e-11)
         assert out["ess"][i] == pytest.approx(oracle.ess_multichain(ch), rel=1e-9)
         assert out["ess"][i] == pytest.approx(single.ess()[i], rel=1e-12)
+
+
+def test_print_diagnostics_table():
+    """print_diagnostics (diagnostics.rs:394-456): header, one row per parameter, convergence verdict by max R-hat."""
+    from fugue_amd import diagnostics as D
+    rng = np.random.default_rng(0)
+    draws = rng.standard_normal((200, 2, 8)) + np.array([0.0, 3.0])[None, :, None]
+    cd = D.ChainDiagnostics(D.HostMoments(draws))
+    txt = D.format_diagnostics(["mu", "tau"], cd, draws)
+    lines = txt.split("\n")
+    assert lines[0] == "MCMC Diagnostics:" and lines[2] == "-" * 80 and lines[1].startswith("Parameter")
+    assert lines[3].startswith("mu ") and lines[4].startswith("tau ") and " 3.0" in lines[4]
+    assert "Excellent convergence" in txt and "Average R-hat" in txt
+    bad = draws.copy(); bad[:, 0, :4] += 5.0                     # half of the chains elsewhere
+    assert "Poor convergence" in D.format_diagnostics(["mu", "tau"], D.ChainDiagnostics(D.HostMoments(bad)), bad)
