@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the MH / SMC / dense-FD side measurements")
     ap.add_argument("--cpu-chains", type=int, default=4096)
-    ap.add_argument("--cpu-transitions", type=int, default=24)
+    ap.add_argument("--cpu-transitions", type=int, default=64)
     return ap.parse_args()
 
 
@@ -63,6 +63,12 @@ def cpu_baseline(args):
     from oracle import oracle as orc
     om = orc.OracleModel(W.normal_sites(N_SITES))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                   # a container's CPU quota, when it is tighter than the affinity mask
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
     nw = args.cpu_transitions // 2
     ns = args.cpu_transitions - nw
     t0 = time.perf_counter()
