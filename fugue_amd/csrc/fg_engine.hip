@@ -51,6 +51,27 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint(FgProgramDe
     }
 }
 
+// ---- the same scoring run over the SCORE STREAM (one 64-byte record per statement, program order): what the HMC
+// endpoint, the MH pre-run proposal path and SMC rejuvenation evaluate.  rec_lp (optional) [n_sstream][C] receives every
+// record's log-density, so each record kind can be checked against the reference's known-answer values.
+__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint_stream(FgProgramDev P, FgChainCtx X, double *acc_out, double *rec_lp) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + threadIdx.x;
+    fg_load_values(P, X, c, slots, tw);
+    FgAcc3 A = {0.0, 0.0, 0.0};
+    for (int k = 0; k < P.n_sstream; ++k) {
+        const fg_u32x16 r = fg_fetch_grec(P.sstream, k);
+        const double xs = slots[r[0] * tw], ms = slots[r[1] * tw];
+        const double lp = fg_score_one<2>(r, xs, ms, P.pool, slots, tw, A);
+        if (live && rec_lp) rec_lp[(long long)k * X.C + c] = lp;
+    }
+    if (live && acc_out) { acc_out[c] = A.prior; acc_out[X.C + c] = A.lik; acc_out[2 * X.C + c] = A.fac; }
+}
+
 // ---- HMC building blocks ---------------------------------------------------------------
 
 // leapfrog (hmc.rs:353-407) followed by the endpoint score (score_full, hmc.rs:283-299), as
@@ -744,7 +765,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
-    if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) ||
+    if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) || set_lds(k_log_joint_stream, e->lds_score) ||
         set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false>, lds_hmc) ||
         set_lds(k_hmc_stream_steps<0, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
         set_lds(k_hmc_grad, lds_hmc) || set_lds(k_hmc_find_eps, lds_hmc) ||
@@ -842,6 +863,22 @@ int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp) {
     if (h_logp)     // the kernel indexes rows by LDS slot; hand them back in site order
         for (int j = 0; j < e->S; j++)
             HIPCHK(hipMemcpy(h_logp + (size_t)j * e->C, e->d_logp + (size_t)e->prog->site_slot[j] * e->C, (size_t)e->C * 8, hipMemcpyDeviceToHost));
+    return FG_OK;
+}
+
+int fg_log_joint_stream(fg_engine *e, double *h_acc, double *h_rec_lp) {
+    NEED_ENGINE(e);
+    if (!e->P.sstream) { fg_set_error("fg_log_joint_stream: the program has no score stream (some statement needs the interpreter)"); return FG_E_UNSUPPORTED; }
+    double *d_rec = nullptr;
+    const size_t nrec = (size_t)e->P.n_sstream * e->C;
+    if (h_rec_lp) { int rc = dev_alloc(&d_rec, nrec); if (rc) return rc; }
+    hipLaunchKernelGGL(k_log_joint_stream, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc, d_rec);
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess && h_acc) he = hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess && h_rec_lp) he = hipMemcpyAsync(h_rec_lp, d_rec, nrec * 8, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (d_rec) (void)hipFree(d_rec);
+    if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
     return FG_OK;
 }
 

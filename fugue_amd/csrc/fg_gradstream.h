@@ -279,7 +279,7 @@ __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, 
 // the same additions as FG_OP_NORMAL_FAST in the interpreter (operand = slot or immediate; z != z -> -inf guard;
 // log_prior and log_likelihood accumulated separately).  Records are fetched two ahead, operands one ahead.
 template <int RK>
-__device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
+__device__ __forceinline__ double fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     const uint32_t fl = r[2];
     double lp;
     if (RK >= 2 && __builtin_expect((fl & FG_G_GEN) != 0u, 0)) {
@@ -305,6 +305,7 @@ __device__ __forceinline__ void fg_score_one(const fg_u32x16 &r, double xs, doub
         lp = (z != z) ? FG_NEG_INF : lp;
     }
     if (fl & FG_S_OBS) A.lik += lp; else A.prior += lp;
+    return lp;
 }
 template <int RK>
 __device__ __forceinline__ void fg_score_stream(const FgGradRec *g, const int n, const double *pool, const double *slots, int tw, FgAcc3 &A) {

@@ -682,6 +682,16 @@ static int add_dist_stmt(fg_program *p, int kind, const char *addr, int dist, co
 int fg_program_sample(fg_program *p, const char *addr, int dist, const fg_tok *toks, const int32_t *plen, int n_params) {
     return add_dist_stmt(p, 0, addr, dist, toks, plen, n_params, nullptr, 0);
 }
+int fg_program_sample_discrete_uniform(fg_program *p, const char *addr, int64_t lo, int64_t hi) {
+    if (!p || !addr) { fg_set_error("bad argument"); return FG_E_BAD_ARG; }
+    fg_tok t[2] = { { FG_T_CONST, 0, 0, 0, (double)lo }, { FG_T_CONST, 0, 0, 0, (double)hi } };
+    const int32_t plen[2] = { 1, 1 };
+    const int h = add_dist_stmt(p, 0, addr, FG_DISCRETEUNIFORM, t, plen, 2, nullptr, 0);
+    if (h < 0) return h;
+    FgStmt &s = p->stmts.back();
+    s.exact_bounds = true; s.lo = (long long)lo; s.hi = (long long)hi;
+    return h;
+}
 int fg_program_observe(fg_program *p, const char *addr, int dist, const fg_tok *toks, const int32_t *plen, int n_params,
                        const fg_tok *value, int n_value) {
     if (!value || n_value <= 0) { fg_set_error("observe needs a value expression"); return FG_E_BAD_ARG; }

@@ -65,7 +65,8 @@ ABI_SYMBOLS = [
     "fg_program_n_instructions", "fg_program_n_slots", "fg_program_site_name", "fg_program_site_vtype",
     "fg_program_site_of_handle", "fg_program_f64_site", "fg_program_dep_count", "fg_program_stream_records", "fg_last_error", "fg_abi_version",
     "fg_engine_new", "fg_engine_free", "fg_engine_synchronize", "fg_engine_stream", "fg_engine_set_stream", "fg_engine_n_chains",
-    "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint",
+    "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint", "fg_log_joint_stream",
+    "fg_program_sample_discrete_uniform",
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
@@ -105,6 +106,7 @@ def lib():
     L.fg_program_sample.argtypes = [vp, C.c_char_p, C.c_int, tp, ip, C.c_int]
     L.fg_program_observe.argtypes = [vp, C.c_char_p, C.c_int, tp, ip, C.c_int, tp, C.c_int]
     L.fg_program_factor.argtypes = [vp, tp, C.c_int]
+    L.fg_program_sample_discrete_uniform.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64]
     for f in ("fg_program_finalize", "fg_program_n_sites", "fg_program_n_f64", "fg_program_n_observe",
               "fg_program_n_instructions", "fg_program_n_slots"):
         getattr(L, f).argtypes = [vp]
@@ -126,6 +128,7 @@ def lib():
     L.fg_engine_values_device.argtypes = [vp]
     L.fg_prior_init.argtypes = [vp, C.c_uint32, dp]
     L.fg_log_joint.argtypes = [vp, dp, dp]
+    L.fg_log_joint_stream.argtypes = [vp, dp, dp]
     L.fg_hmc_config_default.argtypes = [C.POINTER(fg_hmc_config)]
     L.fg_hmc_init.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_int]
     L.fg_hmc_step.argtypes = [vp, C.c_int, vp]
@@ -241,7 +244,11 @@ class CompiledProgram:
                 _postfix(p, toks)
                 lens.append(len(toks) - n0)
             plen = (C.c_int32 * max(1, len(lens)))(*lens)
-            if st.kind == M.SAMPLE:
+            if st.kind == M.SAMPLE and st.dist.i64_bounds is not None:
+                rc = L.fg_program_sample_discrete_uniform(self.h, st.addr.encode("utf-8"), *st.dist.i64_bounds)
+                if rc < 0 or rc != st.handle:
+                    raise EngineError(rc, last_error())
+            elif st.kind == M.SAMPLE:
                 rc = L.fg_program_sample(self.h, st.addr.encode("utf-8"), st.dist.kind, _tok_array(toks), plen, len(lens))
                 if rc < 0 or rc != st.handle:
                     raise EngineError(rc, last_error())
@@ -365,6 +372,13 @@ class Engine:
         logp = np.zeros((max(1, self.S), self.C)) if want_logp else None
         _check(lib().fg_log_joint(self.h, _dp(acc), _dp(logp) if want_logp else None))
         return (acc, logp[:self.S]) if want_logp else acc
+
+    def log_joint_stream(self, want_records: bool = False):
+        """ScoreGivenTrace over the score stream: acc [3][C] (and every statement's log-density [n_records][C])."""
+        acc = np.zeros((3, self.C))
+        rec = np.zeros((max(1, self.cp.stream_records[1]), self.C)) if want_records else None
+        _check(lib().fg_log_joint_stream(self.h, _dp(acc), _dp(rec) if want_records else None))
+        return (acc, rec[:self.cp.stream_records[1]]) if want_records else acc
 
     # ---- HMC ----------------------------------------------------------------------------
     def hmc_init(self, cfg: fg_hmc_config, n_warmup: int):

@@ -190,6 +190,7 @@ def _cval(e: Expr) -> Optional[float]:
 class Dist:
     name: str
     params: List[Expr]
+    i64_bounds: Optional[tuple] = None     # DiscreteUniform::new(lo: i64, hi: i64) with exact integer bounds
 
     @property
     def kind(self) -> int:
@@ -332,10 +333,13 @@ def InverseGamma(shape, rate) -> Dist:
 
 
 def DiscreteUniform(low, high) -> Dist:
+    exact = (int(low), int(high)) if all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in (low, high)) else None
     low, high = as_expr(low), as_expr(high)
+    if exact is not None and exact[1] < exact[0]:
+        raise FugueError("DiscreteUniform: high < low", ErrorCode.InvalidRange)
     if _cval(low) is not None and _cval(high) is not None and _cval(high) < _cval(low):
         raise FugueError("DiscreteUniform: high < low", ErrorCode.InvalidRange)
-    return Dist("DiscreteUniform", [low, high])
+    return Dist("DiscreteUniform", [low, high], exact)
 
 
 # --------------------------------------------------------------------------------------

@@ -93,6 +93,9 @@ int fg_program_sample(fg_program *p, const char *addr_utf8, int dist, const fg_t
 /* `observe(addr, dist, value)` (model.rs:381-424) */
 int fg_program_observe(fg_program *p, const char *addr_utf8, int dist, const fg_tok *toks,
                        const int32_t *param_len, int n_params, const fg_tok *value, int n_value);
+/* `sample(addr, DiscreteUniform::new(lo, hi))` with exact i64 bounds (src/core/distribution.rs:1842-1853 takes i64;
+ * the token form above carries them as f64, exact only up to 2^53). */
+int fg_program_sample_discrete_uniform(fg_program *p, const char *addr_utf8, int64_t lo, int64_t hi);
 /* `factor(logw)` (model.rs:426-431) */
 int fg_program_factor(fg_program *p, const fg_tok *toks, int n);
 /* sorts sites by address, rejects duplicate addresses (AddressConflict = 301, the panic of
@@ -153,6 +156,13 @@ int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc);
 /* `run(ScoreGivenTrace, model)` per chain (interpreters.rs:138-163) on the engine's current
  * values; h_acc [3][C]; h_logp (optional) [S][C] fresh per-site log-densities. */
 int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp);
+/* The same scoring run evaluated over the SCORE STREAM (one 64-byte record per statement in program order) -- the
+ * evaluator of the HMC endpoint score_full (src/inference/hmc.rs:283-299), of single_site_mh_step's model run
+ * (src/inference/mh.rs:698-744) and of SMC rejuvenation (src/inference/smc.rs:662-675) for programs whose statements
+ * all have a record form.  h_acc [3][C]; h_rec_lp (optional) [n_records][C], n_records =
+ * fg_program_stream_records(p, 1): the log-density of every statement.  FG_E_UNSUPPORTED when the program has no
+ * score stream. */
+int fg_log_joint_stream(fg_engine *e, double *h_acc, double *h_rec_lp);
 
 /* ------------------------------------------------------------------ HMC
  * Replaces hmc_chain / HmcSession (src/inference/hmc.rs:566-583, 643-920). */

@@ -33,6 +33,7 @@ def _compare(cp, draws, odraws, max_bad_chains=0):
         else:
             bad |= (draws[:, j, :] != odraws[:, j, :]).any(axis=0)
     assert bad.sum() <= max_bad_chains, np.nonzero(bad)[0][:10]
+    return bad
 
 
 @pytest.mark.parametrize("name", ["readme", "coin", "refmodel8", "mixture", "alldists", "normal32", "hier_scale", "ridge7", "linreg"])
@@ -40,11 +41,18 @@ def test_mh_chain_matches_oracle(oracle, name):
     prog = ZOO[name]()
     cp, eng, st, draws, odraws, ofinal, oscales, ost = _run_both(oracle, prog, C=96, nw=150, ns=60, seed=13, chain0=3)
     # a proposal whose acceptance sits on a 1e-13 knife edge may flip on one chain
-    _compare(cp, draws, odraws, max_bad_chains=1)
+    bad = _compare(cp, draws, odraws, max_bad_chains=1)
     assert abs(st.accept_rate - ost.accept_rate) < 2e-3
     same = np.isclose(eng.mh_scales(), oscales, rtol=1e-10).all(axis=0)
     assert same.sum() >= 95                                    # frozen after warmup: mh.rs:989-1001
-    assert np.array_equal(eng.get_values()[:, same], ofinal[:, same]) or True
+    # final state of every chain whose recorded draws matched: discrete cells exact, f64 cells to the draws' tolerance
+    good = ~bad
+    final = eng.get_values()
+    for j in range(cp.S):
+        if cp.site_vtypes[j] == 0:
+            assert np.allclose(final[j, good].view(np.float64), ofinal[j, good].view(np.float64), rtol=1e-9, atol=1e-12), cp.site_names[j]
+        else:
+            assert np.array_equal(final[j, good], ofinal[j, good]), cp.site_names[j]
 
 
 def test_mh_positive_support_uses_log_space_walk(oracle):
