@@ -732,7 +732,8 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->S = (int)p->sorted_stmt.size(); e->d = (int)p->f64_slot.size(); e->n_slots = p->n_slots;
     e->tw = tile_width_for(e->C);
     e->n_simd = 4 * prop.multiProcessorCount;
-    if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4) e->mw_override = w; }
+    if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) e->mw_override = w; }
+    if (const char *sp = std::getenv("FG_HMC_SEP")) e->sep_disabled = std::atoi(sp) == 0;
     // LDS tile of 64 chains: the score / prior / MH / SMC kernels need the slot rows only, the HMC kernels also the
     // momentum and the multi-wave exchange rows.  A model whose slots alone exceed the 160 KB of a CU cannot run at all;
     // one that only fits without the momentum is refused by fg_hmc_init.
@@ -750,6 +751,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_upload(&e->d_coord, p->coord)) return fail("upload coord");
     if (dev_upload(&e->d_gstream, p->gstream)) return fail("upload gstream");
     if (dev_upload(&e->d_sstream, p->sstream)) return fail("upload sstream");
+    if (dev_upload(&e->d_sep, p->sep) || dev_upload(&e->d_sep_coord, p->sep_coord) || dev_upload(&e->d_sobs, p->sobs)) return fail("upload sep");
     if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
     if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
@@ -761,6 +763,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_alloc(&e->d_tmp, (size_t)e->C)) return fail("alloc tmp");
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
     e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream;
+    e->P.sep = p->sep_coord.empty() ? nullptr : e->d_sep; e->P.sep_coord = e->d_sep_coord; e->P.sobs = e->d_sobs;
     e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_kinds = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0); e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
@@ -781,7 +784,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->hmc_allocs) hipFree(q);
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
-    void *ptrs[] = { e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_sep, e->d_sep_coord, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -965,11 +968,15 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
     const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr && e->P.sstream_kinds == 0;
     const bool analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
+    {   // independent-sites programs: whole trajectories in registers (fg_hmc_sep.hip)
+        const int rc = fg_hmc_sep_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+        if (rc != FG_E_UNSUPPORTED) return rc;
+    }
     if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
         // a tile, whatever the chain count; each wave should still own at least 2 coordinates
-        int W = e->mw_override > 0 ? e->mw_override : 1;
+        int W = e->mw_override > 0 ? std::min(e->mw_override, FG_MW_MAX) : 1;
         if (e->mw_override <= 0) {
             const long long n_cu = std::max(1, e->n_simd / 4);
             const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)e->lds_bytes, ((long long)tiles + n_cu - 1) / n_cu));

@@ -74,6 +74,8 @@ struct fg_engine {
     FgIns *d_ins = nullptr, *d_ins_fast = nullptr, *d_sub = nullptr;
     FgCoord *d_coord = nullptr;
     FgGradRec *d_gstream = nullptr, *d_sstream = nullptr;
+    FgSepRec *d_sep = nullptr; FgSepCoord *d_sep_coord = nullptr; uint32_t *d_sobs = nullptr;
+    bool sep_disabled = false;   // FG_HMC_SEP=0: keep independent-sites programs on the gradient-stream kernel (A/B tests)
     int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr, *d_site_cat = nullptr;
     double *d_pool = nullptr;
     FgProgramDev P{};
@@ -134,5 +136,8 @@ int dev_upload(T **p, const std::vector<T> &v) {
 
 #define NEED_ENGINE(e) do { if (!(e)) { fg_set_error("null engine"); return FG_E_BAD_ARG; } \
     if (hipSetDevice((e)->device) != hipSuccess) { fg_set_error("hipSetDevice failed"); return FG_E_HIP; } } while (0)
+
+// fg_hmc_sep.hip: register-resident trajectories for independent-sites programs (FG_E_UNSUPPORTED: not applicable)
+int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
 
 extern "C" int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj);

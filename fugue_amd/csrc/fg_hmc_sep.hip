@@ -1,0 +1,273 @@
+// fg_hmc_sep.hip -- HmcSession::step x n (hmc.rs:819-919) for INDEPENDENT-SITES programs: every force term is a Normal with
+// constant sigma that reads ONE coordinate and constants (the north-star model: x#i ~ N(0,1); y#i ~ N(x#i, 0.5)).
+//
+// Inside a trajectory such a coordinate never sees another one: its L leapfrog steps (hmc.rs:353-407) are a closed
+// recurrence on (q_i, p_i).  So a wave runs the WHOLE trajectory of a coordinate with q_i, p_i in registers and the
+// coordinate's <= FG_SEP_MAXREC records in SGPRs (loaded once per trajectory, not once per gradient): no LDS access, no
+// record fetch, no address arithmetic inside the L-step loop -- just the f64 instructions of the reference's arithmetic
+// (the same additions and multiplications in the same order as fg_grad_stream / two sparse evaluations of log_prob, hence
+// bit-identical draws: tests/test_gpu_parity.py::test_hmc_sep_kernel_is_bit_identical) and a handful of scalar branches.
+// A 64-chain tile is shared by W = 1..16 waves, wave w owning an even-aligned run of coordinates (Box-Muller pairs are not
+// split); with few tiles per CU (small chain counts) W grows so that every SIMD still holds 4 waves.
+//
+// Per transition:  momentum of the own coordinates -> p rows | barrier | wave 0: H0 (in-order kinetic sum) | barrier |
+// trajectories in registers -> q, p rows | barrier | wave 0: K1 (in-order) | barrier | endpoint score: every wave
+// evaluates its share of the statements' log-densities (TERMS) into the p rows, wave 0 adds them in program order into
+// log_prior / log_likelihood -- the same sums in the same order as score_full (hmc.rs:283-299), without one wave doing all
+// the arithmetic | accept, dual averaging (cold, out of line) | barrier | commit / roll back the own coordinates.
+#include "fg_engine_internal.h"
+#include "fg_gradstream.h"
+#include "fg_cold.h"
+
+#define FG_SEP_WMAX 16
+struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
+
+// in-order kinetic energy 0.5 * sum p_i^2 m_inv_i (hmc.rs:442-443)
+__device__ __forceinline__ double fg_sep_kinetic(int d, const double *pl, int tw, const double *m_inv, long long C) {
+    double s = 0.0;
+    if (m_inv) { for (int i = 0; i < d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; } }
+    else {
+#pragma unroll 8
+        for (int i = 0; i < d; ++i) { const double p = pl[i * tw]; s += p * p; }
+    }
+    return 0.5 * s;
+}
+
+#define FG_SEP_LOAD(k) \
+    const fg_u32x8 a##k = *(const FG_AS4 fg_u32x8 *)(rb + 64 * k); \
+    const fg_u32x4 b##k = *(const FG_AS4 fg_u32x4 *)(rb + 64 * k + 32);
+
+// one record at q + h and q - h: the arithmetic of fg_grec_math (fg_gradstream.h) with both operands resolved to
+// "the coordinate" or "the record's constant"
+#define FG_SEP_EVAL(k)                                                                                              \
+    if (n_rec > k) {                                                                                                \
+        const uint32_t fl = a##k[0];                                                                                \
+        const double c = fg_dbl(a##k[2], a##k[3]), inv = fg_dbl(a##k[4], a##k[5]), lns = fg_dbl(a##k[6], a##k[7]); \
+        double dlp, dlm;                                                                                            \
+        if (fl & FG_G_PERT_X) {                                                                                     \
+            if (__builtin_expect((fl & FG_G_PERT_M) != 0u, 0)) { dlp = qp - qp; dlm = qm - qm; }                    \
+            else { dlp = qp - c; dlm = qm - c; }                                                                    \
+        } else { dlp = c - qp; dlm = c - qm; }                                                                      \
+        double zp = dlp * inv, zm = dlm * inv;                                                                      \
+        if (__builtin_expect(!(fl & FG_G_POW2), 0)) {                                                               \
+            const double sg = fg_dbl(b##k[0], b##k[1]);                                                             \
+            if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; }                                                    \
+            else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }                              \
+        }                                                                                                           \
+        const double lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;                                                  \
+        const double lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;                                                  \
+        if (fl & FG_G_SWITCH) { prip = sp; prim = sm; sp = 0.0; sm = 0.0; }                                         \
+        sp += lpp; sm += lpm;                                                                                       \
+    }
+
+// The whole trajectory of coordinate i: (q, p) -> (q', p') after L leapfrog steps with step size e; returns "some force
+// component was non-finite".  emi = e * m_inv_i (hmc.rs:391-393: eps * m_inv[i] * p[i], left to right) or e.
+__device__ __forceinline__ bool fg_sep_trajectory(const FgSepRec *recs, int off, int n_rec, double &q_io, double &p_io, double emi, double hk,
+                                                  int L, double h, double two_h, double rcp_2h) {
+    const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(recs + off);
+    FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
+    double q = q_io, p = p_io;
+    bool bad = false;
+    for (int gs = 0; gs <= L; ++gs) {
+        const double qp = q + h, qm = q - h;                     // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
+        double sp = 0.0, sm = 0.0, prip = 0.0, prim = 0.0;
+        FG_SEP_EVAL(0) FG_SEP_EVAL(1) FG_SEP_EVAL(2) FG_SEP_EVAL(3)
+        const double tp = prip + sp, tm = prim + sm;             // total_log_weight (trace.rs:198-200)
+        const double n = tp - tm;
+        double g = fg_div_const(n, two_h, rcp_2h);               // (lp - lm) / (2h), hmc.rs:322
+        const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
+        if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953]
+        bad = bad || !fg_finite(g);
+        const double kick = hk * g;
+        p = p + kick;                                            // hmc.rs:389 / :400
+        if (gs > 0 && gs < L) p = p + kick;                      // trailing kick of this step + leading kick of the next
+        if (gs < L) q = q + emi * p;                             // hmc.rs:391-393
+    }
+    q_io = q; p_io = p;
+    return bad;
+}
+
+template <bool MASS>
+__global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSegSep seg, int iter0, int n_steps,
+                                                                             int n_warmup, int welford_on, double *draws, int first_sample_t,
+                                                                             double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const long long chain = (long long)blockIdx.x * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    const int d = P.d, L = H.L, n_s = P.n_sstream;
+    double *slots = lds + lane;
+    double *pl = lds + (long long)P.n_slots * tw + lane;               // p rows; the endpoint score reuses them for its terms
+    double *xch = lds + (long long)(P.n_slots + d) * tw + lane;        // rows: 0 step size, 1 accepted, 2 divergence bits
+    const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
+    const double *mi = MASS ? H.m_inv + c : nullptr;
+    const double *ms = MASS ? H.mass_sqrt + c : nullptr;
+    const double h = fg_uniform(H.h), two_h = fg_uniform(2.0 * H.h), rcp_2h = fg_uniform(1.0 / (2.0 * H.h));
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    // wave 0 owns the per-chain sampler state
+    double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
+    unsigned long long da_m = 0, ndiv = 0;
+    if (wv == 0) {
+        fg_load_values(P, X, c, slots, tw);
+        lj = H.lj[c]; eps = H.eps[c]; frozen = H.frozen[c];
+        da_mu = H.da_mu[c]; da_leb = H.da_leb[c]; da_hbar = H.da_hbar[c]; da_m = H.da_m[c];
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const int iter = iter0 + t;
+        const bool warming = iter < n_warmup;
+        double h0 = 0.0, u = 0.0, e_cur = 0.0;
+        // ---- p0 ~ N(0, M) for the own coordinates (hmc.rs:436-441): pair j of the chain's (iteration) stream is Philox block j
+        for (int i = k0; i < k1; i += 2) {
+            const FgD2 z = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC);
+            pl[i * tw] = MASS ? z.a * ms[(long long)i * X.C] : z.a;
+            if (i + 1 < k1) pl[(i + 1) * tw] = MASS ? z.b * ms[(long long)(i + 1) * X.C] : z.b;
+        }
+        if (wv == 0) {
+            if (warming) e_cur = eps;
+            else {                                             // frozen_or_current: hmc.rs:789-798
+                if (frozen == frozen) e_cur = frozen;
+                else if (n_warmup > 0) e_cur = fg_cold_exp(da_leb);
+                else e_cur = eps;
+                frozen = e_cur;
+            }
+            u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)((d + 1) >> 1), (uint32_t)iter, FG_RNG_HMC).a;
+            xch[0] = e_cur;
+            xch[2 * tw] = 0.0;
+        }
+        __syncthreads();                                         // p rows, step size, cleared divergence bits
+        if (wv == 0) h0 = -lj + fg_sep_kinetic(d, pl, tw, mi, X.C);      // hmc.rs:442-443 (all of p0, before any kick)
+        __syncthreads();                                         // the p rows may be overwritten from here on
+        const double e = xch[0], hk = 0.5 * e;
+        // ---- leapfrog (hmc.rs:353-407): the whole trajectory of each own coordinate, in registers
+        bool bad = false;
+        for (int i = k0; i < k1; ++i) {
+            const FgSepCoord cd = P.sep_coord[i];
+            double q = slots[i * tw], p = pl[i * tw];
+            const double emi = MASS ? e * mi[(long long)i * X.C] : e;
+            bad = fg_sep_trajectory(P.sep, cd.off, cd.n, q, p, emi, hk, L, h, two_h, rcp_2h) || bad;
+            slots[i * tw] = q; pl[i * tw] = p;
+        }
+        if (bad) atomicOr((unsigned long long *)(xch + 2 * tw), 1ull);
+        __syncthreads();                                         // endpoint q, p of every coordinate
+        double k1e = 0.0;
+        if (wv == 0) k1e = fg_sep_kinetic(d, pl, tw, mi, X.C);
+        __syncthreads();                                         // the p rows now carry score terms
+        // ---- endpoint score_full (hmc.rs:283-299): terms in parallel, sums in program order on wave 0
+        FgAcc3 A = {0.0, 0.0, 0.0};
+        for (int base = 0; base < n_s; base += d) {
+            const int cn = n_s - base < d ? n_s - base : d;
+            const int per = (cn + W - 1) / W;
+            const int r0 = base + wv * per, r1 = (r0 + per < base + cn) ? r0 + per : base + cn;
+            for (int k = r0; k < r1; ++k) {
+                const fg_u32x16 r = fg_fetch_grec(P.sstream, k);
+                const double xs = slots[r[0] * tw], mv = slots[r[1] * tw];
+                FgAcc3 dummy = {0.0, 0.0, 0.0};
+                pl[(k - base) * tw] = fg_score_one<0>(r, xs, mv, P.pool, slots, tw, dummy);
+            }
+            __syncthreads();
+            if (wv == 0) {
+                for (int k = 0; k < cn; ++k) {
+                    const uint32_t ob = (P.sobs[(base + k) >> 5] >> ((base + k) & 31)) & 1u;     // scalar: observe statement?
+                    const double lp = pl[k * tw];
+                    if (ob) A.lik += lp; else A.prior += lp;
+                }
+            }
+            if (base + d < n_s) __syncthreads();
+        }
+        if (wv == 0) {
+            bool div = fg_as_i64(xch[2 * tw]) != 0;
+            const double lj_new = fg_total(A);
+            div = div || !fg_finite(lj_new);
+            double ap = 0.0; bool acc = false;
+            if (!div) {
+                const double h_new = -lj_new + k1e;
+                ap = fg_cold_accept_prob(h0, h_new);             // hmc.rs:460
+                acc = u < ap;                                    // hmc.rs:461
+            }
+            if (acc) lj = lj_new;
+            xch[tw] = acc ? 1.0 : 0.0;
+            asum += ap; ndiv += div ? 1ull : 0ull;
+            if (live && info) {                                  // HmcStepInfo: hmc.rs:587-602
+                double *r = info + (long long)t * 4 * X.C + c;
+                r[0] = acc ? 1.0 : 0.0; r[X.C] = div ? 1.0 : 0.0; r[2 * X.C] = ap; r[3 * X.C] = e_cur;
+            }
+            if (warming) {                                       // DualAveraging::update: hmc.rs:168-178
+                da_m += 1ull;
+                const FgD3 r = fg_cold_da_update(da_hbar, da_leb, (double)da_m, da_mu, H.target, ap);
+                eps = r.a; da_hbar = r.b; da_leb = r.c;
+            }
+        }
+        __syncthreads();
+        const bool acc = xch[tw] != 0.0;
+        unsigned long long wn = 0;
+        if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
+        for (int i = k0; i < k1; ++i) {                           // commit or roll back the own f64 sites
+            const long long g = (long long)P.f64_site[i] * X.C + c;
+            if (acc) { if (live) X.values[g] = fg_as_i64(slots[i * tw]); }
+            else slots[i * tw] = fg_as_double(X.values[g]);
+            const double x = slots[i * tw];
+            if (live && pos_all) pos_all[((long long)t * d + i) * X.C + c] = x;
+            if (warming) {
+                if (welford_on) {                                 // Welford::push: hmc.rs:202-211
+                    const long long gi = (long long)i * X.C + c;
+                    const double n = (double)wn;
+                    double mean = H.w_mean[gi];
+                    const double delta = x - mean;
+                    mean += delta / n;
+                    const double delta2 = x - mean;
+                    if (live) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
+                }
+            } else if (draws && live) draws[((long long)(t - first_sample_t) * d + i) * X.C + c] = x;   // hmc.rs:577-582
+        }
+        if (warming && welford_on) {
+            __syncthreads();                                      // all waves hold the old count
+            if (wv == 0 && live) H.w_n[c] = wn;
+        }
+    }
+    if (wv == 0 && live) {
+        H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
+        H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
+        H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
+    }
+}
+
+// Launch for `n` transitions from iteration `iter0`; returns FG_E_UNSUPPORTED when the program / configuration is not an
+// independent-sites FD-sparse run (the caller then takes the gradient-stream kernel).
+int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
+    if (!e->P.sep || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
+    const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
+    const size_t lds = (size_t)(e->n_slots + e->d + 3) * FG_WAVE * sizeof(double);
+    if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
+    // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
+    // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates.
+    int W = e->mw_override > 0 ? e->mw_override : 1;
+    if (e->mw_override <= 0) {
+        const long long n_cu = std::max(1, e->n_simd / 4);
+        const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
+        while (W < FG_SEP_WMAX && resident * W < 16 && e->d >= 4 * W) W *= 2;
+    }
+    while (W > 1 && 2 * (W - 1) >= e->d + 1) W /= 2;             // no empty waves
+    FgSegSep seg;
+    const int pairs = (e->d + 1) / 2;
+    for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
+    for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, 2 * (int)((long long)pairs * w / W));
+    static bool attr_set_dev[64][2];
+    const int mass = e->H.use_mass ? 1 : 0;
+    bool &attr_set = attr_set_dev[e->device & 63][mass];
+    if (!attr_set) {
+        const hipError_t he = mass ? hipFuncSetAttribute((const void *)k_hmc_sep_steps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                                   : hipFuncSetAttribute((const void *)k_hmc_sep_steps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
+        attr_set = true;
+    }
+    if (mass) hipLaunchKernelGGL(k_hmc_sep_steps<true>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, e->n_warmup, welford_on,
+                                 draws, first_sample_t, pos_all, info);
+    else hipLaunchKernelGGL(k_hmc_sep_steps<false>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, e->n_warmup, welford_on,
+                            draws, first_sample_t, pos_all, info);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}

@@ -91,6 +91,17 @@ struct FgGenRec { uint32_t xi, mi, flags, coord; double x; double p[3]; double h
 static_assert(sizeof(FgGenRec) == 64, "FgGenRec must be 64 bytes");
 static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
 
+// Register-resident trajectories (fg_hmc_sep.hip): when every record of the gradient stream reads only its OWN coordinate
+// and constants (an independent-sites model: no coordinate ever sees another one inside a trajectory), the whole L-step
+// trajectory of a coordinate runs with q_i, p_i in registers and its <= FG_SEP_MAXREC records in SGPRs.  One compact
+// record per (coordinate, dependent statement), in gradient-stream order:
+//   flags: FG_G_POW2 / FG_G_DIV / FG_G_SWITCH / FG_G_END as in the gradient stream; FG_G_PERT_X: x is the coordinate
+//   (else x = c); FG_G_PERT_M: mu is the coordinate (else mu = c).
+#define FG_SEP_MAXREC 4
+struct FgSepRec { uint32_t flags, pad0; double c, inv, lns, sigma; double pad1[3]; };   // dwords 0..7 = one s_load_dwordx8, sigma = dwords 8..9
+static_assert(sizeof(FgSepRec) == 64, "FgSepRec must be 64 bytes");
+struct FgSepCoord { int off, n; };     // records of coordinate k: sep[off .. off + n)
+
 struct FgProgramDev {
     const FgIns  *ins;       // full program (generic opcodes only: PRIOR / MH / SCORE), n_ins
     const FgIns  *ins_fast;  // the same program with score-only fast opcodes substituted (HMC / SMC / log-joint)
@@ -104,6 +115,9 @@ struct FgProgramDev {
     const int    *site_cat;  // [S][2] {pool base, K} of Categorical sites with a valid constant probability table, else -1
     const FgGradRec *gstream;  // fused gradient stream or null
     const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
+    const FgSepRec *sep;       // compact per-coordinate records or null (see FgSepRec)
+    const FgSepCoord *sep_coord;   // [d]
+    const uint32_t *sobs;      // bit k = record k of the score stream is an observe statement ((n_sstream + 31) / 32 words)
     int n_gstream, n_sstream;
     int sstream_kinds;         // record kinds in the score stream: 0 fast Normals, 1 + linear predictors, 2 + general records
     int n_ins, n_slots, S, d;

@@ -625,6 +625,34 @@ int fg_program::finalize() {
             for (int q = 0; q < 4; q++) sstream.push_back(pad);
         }
     }
+    // observe bits of the score stream (the parallel-terms endpoint score sums prior and likelihood terms apart)
+    sobs.assign((size_t)(n_sstream + 31) / 32 + 1, 0u);
+    for (int k = 0; k < n_sstream; k++) if (sstream[k].flags & FG_S_OBS) sobs[k >> 5] |= 1u << (k & 31);
+    // independent-sites programs: compact per-coordinate records for the register-resident trajectories
+    sep.clear(); sep_coord.clear();
+    if (n_gstream > 0 && n_sstream > 0 && !sstream_has_lin && !sstream_has_gen) {
+        bool ok = true;
+        std::vector<FgSepRec> recs; std::vector<FgSepCoord> cds(f64_slot.size(), FgSepCoord{0, 0});
+        for (int k = 0; k < n_gstream && ok; k++) {
+            const FgGradRec &r = gstream[k];
+            const uint32_t ck = r.coord;
+            if (r.flags & (FG_G_LIN | FG_G_GEN | FG_G_NSEL | FG_G_CATC)) { ok = false; break; }
+            const bool x_own = (r.flags & FG_G_PERT_X) != 0u, m_own = (r.flags & FG_G_PERT_M) != 0u;
+            if (!x_own && !(r.flags & FG_G_X_CONST)) ok = false;        // x is another site
+            if (!m_own && !(r.flags & FG_G_M_CONST)) ok = false;        // mu is another site
+            if (!ok) break;
+            FgSepRec q; std::memset(&q, 0, sizeof(q));
+            q.flags = r.flags & (FG_G_POW2 | FG_G_DIV | FG_G_SWITCH | FG_G_END | FG_G_PERT_X | FG_G_PERT_M);
+            q.c = x_own ? r.mimm : r.ximm;                                // the constant operand (unused when both are the coordinate)
+            q.inv = r.inv; q.lns = r.lns; q.sigma = r.sigma;
+            if (cds[ck].n == 0) cds[ck].off = (int)recs.size();
+            cds[ck].n += 1;
+            if (cds[ck].n > FG_SEP_MAXREC) ok = false;
+            recs.push_back(q);
+        }
+        for (const FgSepCoord &c : cds) ok = ok && c.n > 0;
+        if (ok) { sep = recs; sep_coord = cds; for (int q = 0; q < FG_SEP_MAXREC; q++) { FgSepRec z; std::memset(&z, 0, sizeof(z)); sep.push_back(z); } }
+    }
     if (pool.empty()) pool.push_back(0.0);
     // the kernels prefetch two instructions ahead: keep two readable no-ops past each array
     n_ins = (int)ins.size();
@@ -726,6 +754,7 @@ int fg_program_stream_records(const fg_program *p, int which) {
     if (!p || !p->finalized) return FG_E_STATE;
     if (which == 0) return p->n_gstream;
     if (which == 1) return p->n_sstream;
+    if (which == 3) return (int)p->sep_coord.size() > 0 ? (int)p->sep.size() - FG_SEP_MAXREC : 0;   // records of the register-resident trajectories
     int k = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0);
     for (int i = 0; i < p->n_gstream; i++) k = std::max(k, (p->gstream[i].flags & FG_G_GEN) ? 2 : ((p->gstream[i].flags & FG_G_LIN) ? 1 : 0));
     return k;

@@ -38,6 +38,9 @@ struct fg_program {
     int n_sstream = 0;
     bool sstream_has_lin = false;       // some record is a linear-predictor Normal (FG_G_LIN)
     bool sstream_has_gen = false;       // some record is a general distribution record (FG_G_GEN)
+    std::vector<FgSepRec> sep;        // empty unless the program is an independent-sites model (fg_ir.h)
+    std::vector<FgSepCoord> sep_coord;
+    std::vector<uint32_t> sobs;       // observe bits of the score stream
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
     std::vector<int> site_cat;               // [S][2] {pool base, K} of Categorical sites with a valid constant table, else -1

@@ -115,7 +115,9 @@ int fg_program_f64_site(const fg_program *p, int k);
 int fg_program_dep_count(const fg_program *p, int k);
 /* record streams the compiler could build for the stream kernels (0 = the interpreter kernels are used):
  * which = 0: records of the fused finite-difference gradient stream; 1: records of the score stream;
- * 2: record kinds present (0 fast Normals only, 1 + linear predictors, 2 + general distribution records) */
+ * 2: record kinds present (0 fast Normals only, 1 + linear predictors, 2 + general distribution records);
+ * 3: records of the register-resident trajectory kernel (> 0 only for independent-sites programs: every force term reads
+ *    one coordinate and constants) */
 int fg_program_stream_records(const fg_program *p, int which);
 
 const char *fg_last_error(void);

@@ -136,3 +136,24 @@ def linreg_forms() -> M.Program:
 
 
 ZOO["linreg"] = linreg_forms
+
+
+def indep_mixed() -> M.Program:
+    """Independent sites with every shape the register-resident trajectory kernel handles: 1 to 4 force terms per
+    coordinate, sigma a power of two / not / outside the exact-reciprocal range, the coordinate as x or as mu, a
+    constant-only statement (no coordinate), an odd number of coordinates."""
+    P = M.Program()
+    rng = np.random.default_rng(17)
+    sig = [1.0, 0.7, 2.0, 0.3, 1.5, 0.25, 1e-3]
+    P.observe(M.addr("const_obs"), M.Normal(0.2, 1.3), 0.9)                  # reads no coordinate
+    for i in range(7):
+        x = P.sample(M.addr("x", i), M.Normal(0.1 * i - 0.2, sig[i]))
+        for j in range(i % 4):                                               # 0..3 observes -> 1..4 records
+            if j % 2 == 0:
+                P.observe(M.addr(f"y{j}", i), M.Normal(x, 0.5 + 0.35 * j), float(rng.normal(0.1 * i, 0.5)))
+            else:
+                P.observe(M.addr(f"y{j}", i), M.Normal(0.3 * j, sig[(i + j) % 6]), x)      # the coordinate is the VALUE of the observe
+    return P
+
+
+ZOO["indep_mixed"] = indep_mixed

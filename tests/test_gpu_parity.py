@@ -345,6 +345,37 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
 
 
+@pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("readme", False), ("indep_mixed", True), ("indep_mixed", False)])
+def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
+    """Independent-sites programs run whole trajectories in registers (k_hmc_sep_steps, 1..16 waves per tile) and evaluate
+    the endpoint score as parallel terms summed in program order; the arithmetic per coordinate and per accumulator is the
+    gradient-stream kernel's, so draws, step sizes, mass matrix, log-joint and statistics agree BIT FOR BIT with it."""
+    cp = E.compile_model(ZOO[name]())
+    assert cp.stream_records[0] > 0 and lib_sep_records(cp) > 0
+    C, nw, ns = 150, 40, 25
+    out = []
+    for sep, W in ((0, 1), (1, 1), (1, 2), (1, 4), (1, 8), (1, 16)):
+        monkeypatch.setenv("FG_HMC_SEP", str(sep))
+        monkeypatch.setenv("FG_HMC_WAVES", str(W))
+        eng = E.Engine(cp, C, seed=21, chain_offset=5)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        pos, info = eng.hmc_step_info(3)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
+                    eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
+        eng.close()
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
+
+
+def lib_sep_records(cp):
+    return E.lib().fg_program_stream_records(cp.h, 3)
+
+
 def test_hmc_config_is_validated_and_tiny_engines_run():
     """n_leapfrog = 0 (the reference's loop then never moves, hmc.rs:385) and a non-positive finite-difference step are
     refused at the boundary; one chain, and a chain count that leaves most lanes of the last tile empty, run."""
