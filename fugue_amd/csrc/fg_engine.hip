@@ -751,7 +751,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_upload(&e->d_coord, p->coord)) return fail("upload coord");
     if (dev_upload(&e->d_gstream, p->gstream)) return fail("upload gstream");
     if (dev_upload(&e->d_sstream, p->sstream)) return fail("upload sstream");
-    if (dev_upload(&e->d_sep, p->sep) || dev_upload(&e->d_sep_coord, p->sep_coord) || dev_upload(&e->d_sobs, p->sobs)) return fail("upload sep");
+    if (dev_upload(&e->d_sep, p->sep) || dev_upload(&e->d_sep_coord, p->sep_coord) || dev_upload(&e->d_sep_free, p->sep_free) || dev_upload(&e->d_sobs, p->sobs)) return fail("upload sep");
     if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
     if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
@@ -764,6 +764,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
     e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream;
     e->P.sep = p->sep_coord.empty() ? nullptr : e->d_sep; e->P.sep_coord = e->d_sep_coord; e->P.sobs = e->d_sobs;
+    e->P.sep_free = e->d_sep_free; e->P.n_sep_free = (int)p->sep_free.size(); e->P.n_prior_terms = p->n_prior_terms;
     e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_kinds = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0); e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
@@ -784,7 +785,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->hmc_allocs) hipFree(q);
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
-    void *ptrs[] = { e->d_sep, e->d_sep_coord, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);

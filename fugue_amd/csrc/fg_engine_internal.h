@@ -74,7 +74,7 @@ struct fg_engine {
     FgIns *d_ins = nullptr, *d_ins_fast = nullptr, *d_sub = nullptr;
     FgCoord *d_coord = nullptr;
     FgGradRec *d_gstream = nullptr, *d_sstream = nullptr;
-    FgSepRec *d_sep = nullptr; FgSepCoord *d_sep_coord = nullptr; uint32_t *d_sobs = nullptr;
+    FgSepRec *d_sep = nullptr; FgSepCoord *d_sep_coord = nullptr; FgSepFree *d_sep_free = nullptr; uint32_t *d_sobs = nullptr;
     bool sep_disabled = false;   // FG_HMC_SEP=0: keep independent-sites programs on the gradient-stream kernel (A/B tests)
     int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr, *d_site_cat = nullptr;
     double *d_pool = nullptr;

@@ -10,11 +10,11 @@
 // A 64-chain tile is shared by W = 1..16 waves, wave w owning an even-aligned run of coordinates (Box-Muller pairs are not
 // split); with few tiles per CU (small chain counts) W grows so that every SIMD still holds 4 waves.
 //
-// Per transition:  momentum of the own coordinates -> p rows | barrier | wave 0: H0 (in-order kinetic sum) | barrier |
-// trajectories in registers -> q, p rows | barrier | wave 0: K1 (in-order) | barrier | endpoint score: every wave
-// evaluates its share of the statements' log-densities (TERMS) into the p rows, wave 0 adds them in program order into
-// log_prior / log_likelihood -- the same sums in the same order as score_full (hmc.rs:283-299), without one wave doing all
-// the arithmetic | accept, dual averaging (cold, out of line) | barrier | commit / roll back the own coordinates.
+// Per transition (two workgroup barriers): every wave, for each own coordinate: draw p0, emit its kinetic term, run the
+// trajectory in registers, emit the endpoint's kinetic term and the endpoint-score TERMS of the coordinate's statements
+// (LDS rows) | barrier | wave 0 adds the terms IN ORDER -- kinetic terms in coordinate order (hmc.rs:442-443), log_prior and
+// log_likelihood terms in program order (score_full, hmc.rs:283-299): the same sums in the same order as one wave doing all
+// the arithmetic -- then accept and dual averaging (cold code, out of line) | barrier | commit / roll back the own coordinates.
 #include "fg_engine_internal.h"
 #include "fg_gradstream.h"
 #include "fg_cold.h"
@@ -22,57 +22,50 @@
 #define FG_SEP_WMAX 16
 struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 
-// in-order kinetic energy 0.5 * sum p_i^2 m_inv_i (hmc.rs:442-443)
-__device__ __forceinline__ double fg_sep_kinetic(int d, const double *pl, int tw, const double *m_inv, long long C) {
-    double s = 0.0;
-    if (m_inv) { for (int i = 0; i < d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; } }
-    else {
-#pragma unroll 8
-        for (int i = 0; i < d; ++i) { const double p = pl[i * tw]; s += p * p; }
-    }
-    return 0.5 * s;
-}
-
 #define FG_SEP_LOAD(k) \
     const fg_u32x8 a##k = *(const FG_AS4 fg_u32x8 *)(rb + 64 * k); \
     const fg_u32x4 b##k = *(const FG_AS4 fg_u32x4 *)(rb + 64 * k + 32);
 
-// one record at q + h and q - h: the arithmetic of fg_grec_math (fg_gradstream.h) with both operands resolved to
-// "the coordinate" or "the record's constant"
-#define FG_SEP_EVAL(k)                                                                                              \
-    if (n_rec > k) {                                                                                                \
-        const uint32_t fl = a##k[0];                                                                                \
-        const double c = fg_dbl(a##k[2], a##k[3]), inv = fg_dbl(a##k[4], a##k[5]), lns = fg_dbl(a##k[6], a##k[7]); \
-        double dlp, dlm;                                                                                            \
-        if (fl & FG_G_PERT_X) {                                                                                     \
-            if (__builtin_expect((fl & FG_G_PERT_M) != 0u, 0)) { dlp = qp - qp; dlm = qm - qm; }                    \
-            else { dlp = qp - c; dlm = qm - c; }                                                                    \
-        } else { dlp = c - qp; dlm = c - qm; }                                                                      \
-        double zp = dlp * inv, zm = dlm * inv;                                                                      \
-        if (__builtin_expect(!(fl & FG_G_POW2), 0)) {                                                               \
-            const double sg = fg_dbl(b##k[0], b##k[1]);                                                             \
-            if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; }                                                    \
-            else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }                              \
-        }                                                                                                           \
-        const double lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;                                                  \
-        const double lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;                                                  \
-        if (fl & FG_G_SWITCH) { prip = sp; prim = sm; sp = 0.0; sm = 0.0; }                                         \
-        sp += lpp; sm += lpm;                                                                                       \
-    }
+// (x - mu) / sigma of record k for the operand difference dl = q - c (x - mu is +dl or -dl: the quotient's sign flips with
+// it exactly -- multiplication, the FMA sequence of fg_div_const and IEEE division are odd functions under round-to-nearest
+// -- and z only enters the density as z * z)
+#define FG_SEP_Z(k, dl) (P2 ? (dl) * fg_dbl(a##k[4], a##k[5])                                                                   \
+                            : ((a##k[0] & FG_G_POW2) ? (dl) * fg_dbl(a##k[4], a##k[5])                                           \
+                                                     : ((a##k[0] & FG_G_DIV) ? (dl) / fg_dbl(b##k[0], b##k[1])                    \
+                                                                             : fg_div_const((dl), fg_dbl(b##k[0], b##k[1]), fg_dbl(a##k[4], a##k[5])))))
+// Normal log-density of record k at z: distribution.rs:207
+#define FG_SEP_LP(k, z) (-0.5 * (z) * (z) - fg_dbl(a##k[6], a##k[7]) - 0.5 * FG_LN_2PI)
+// record k at q + h and q - h
+#define FG_SEP_DUAL(k, outp, outm)                                                                     \
+    double outp, outm;                                                                                 \
+    { const double c = fg_dbl(a##k[2], a##k[3]); const double zp = FG_SEP_Z(k, qp - c), zm = FG_SEP_Z(k, qm - c); \
+      outp = FG_SEP_LP(k, zp); outm = FG_SEP_LP(k, zm); }
+// record k at q (endpoint score term; NaN z -> -inf like FG_OP_NORMAL_FAST)
+#define FG_SEP_TERM(k)                                                                                 \
+    { const double z = FG_SEP_Z(k, q - fg_dbl(a##k[2], a##k[3])); const double lp = FG_SEP_LP(k, z); \
+      terms[a##k[1] * tw] = (z != z) ? FG_NEG_INF : lp; }
 
-// The whole trajectory of coordinate i: (q, p) -> (q', p') after L leapfrog steps with step size e; returns "some force
-// component was non-finite".  emi = e * m_inv_i (hmc.rs:391-393: eps * m_inv[i] * p[i], left to right) or e.
-__device__ __forceinline__ bool fg_sep_trajectory(const FgSepRec *recs, int off, int n_rec, double &q_io, double &p_io, double emi, double hk,
-                                                  int L, double h, double two_h, double rcp_2h) {
-    const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(recs + off);
+// The whole trajectory of one coordinate: (q, p) -> (q', p') after L leapfrog steps (hmc.rs:353-407) with step size e, then
+// the endpoint-score terms of its statements.  NOBS observe records follow the coordinate's own sample record; P2: every
+// sigma is a power of two (no quotient branch at all).  The sums are fg_grec_math's: log_prior = the sample record,
+// log_likelihood = the observe records in order, total = prior + likelihood (trace.rs:198-200), g = (lp - lm) / (2h).
+// emi = e * m_inv_i (hmc.rs:391-393: eps * m_inv[i] * p[i], left to right) or e.  Returns "a force component was non-finite".
+template <int NOBS, bool P2>
+__device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double &q_io, double &p_io, double emi, double hk, int L, double h, double two_h,
+                                                  double rcp_2h, double *terms, int tw) {
     FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
     double q = q_io, p = p_io;
     bool bad = false;
     for (int gs = 0; gs <= L; ++gs) {
         const double qp = q + h, qm = q - h;                     // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
-        double sp = 0.0, sm = 0.0, prip = 0.0, prim = 0.0;
-        FG_SEP_EVAL(0) FG_SEP_EVAL(1) FG_SEP_EVAL(2) FG_SEP_EVAL(3)
-        const double tp = prip + sp, tm = prim + sm;             // total_log_weight (trace.rs:198-200)
+        FG_SEP_DUAL(0, tp, tm)
+        if (NOBS >= 1) {
+            FG_SEP_DUAL(1, lp1, lm1)
+            double sp = lp1, sm = lm1;
+            if (NOBS >= 2) { FG_SEP_DUAL(2, lp2, lm2) sp += lp2; sm += lm2; }
+            if (NOBS >= 3) { FG_SEP_DUAL(3, lp3, lm3) sp += lp3; sm += lm3; }
+            tp = tp + sp; tm = tm + sm;                          // log_prior + log_likelihood
+        }
         const double n = tp - tm;
         double g = fg_div_const(n, two_h, rcp_2h);               // (lp - lm) / (2h), hmc.rs:322
         const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
@@ -83,6 +76,10 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FgSepRec *recs, int off,
         if (gs > 0 && gs < L) p = p + kick;                      // trailing kick of this step + leading kick of the next
         if (gs < L) q = q + emi * p;                             // hmc.rs:391-393
     }
+    FG_SEP_TERM(0)
+    if (NOBS >= 1) FG_SEP_TERM(1)
+    if (NOBS >= 2) FG_SEP_TERM(2)
+    if (NOBS >= 3) FG_SEP_TERM(3)
     q_io = q; p_io = p;
     return bad;
 }
@@ -95,97 +92,95 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = (int)(blockDim.x >> 6);
     const long long chain = (long long)blockIdx.x * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
-    const int d = P.d, L = H.L, n_s = P.n_sstream;
+    const int d = P.d, L = H.L, n_s = P.n_sstream, n_pri = P.n_prior_terms;
+    // LDS tile [rows][64]: site values | kinetic terms of p0 | kinetic terms of the endpoint p | score terms | exchange
     double *slots = lds + lane;
-    double *pl = lds + (long long)P.n_slots * tw + lane;               // p rows; the endpoint score reuses them for its terms
-    double *xch = lds + (long long)(P.n_slots + d) * tw + lane;        // rows: 0 step size, 1 accepted, 2 divergence bits
+    double *kin0 = lds + (long long)P.n_slots * tw + lane;
+    double *kin1 = kin0 + (long long)d * tw;
+    double *terms = kin1 + (long long)d * tw;
+    double *xch = terms + (long long)n_s * tw;                     // rows: 0 step size, 1 accepted, 2 divergence bits
     const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
     const double *mi = MASS ? H.m_inv + c : nullptr;
     const double *ms = MASS ? H.mass_sqrt + c : nullptr;
     const double h = fg_uniform(H.h), two_h = fg_uniform(2.0 * H.h), rcp_2h = fg_uniform(1.0 / (2.0 * H.h));
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     // wave 0 owns the per-chain sampler state
-    double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
+    double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0, e_cur = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
     if (wv == 0) {
         fg_load_values(P, X, c, slots, tw);
         lj = H.lj[c]; eps = H.eps[c]; frozen = H.frozen[c];
         da_mu = H.da_mu[c]; da_leb = H.da_leb[c]; da_hbar = H.da_hbar[c]; da_m = H.da_m[c];
+        for (int k = 0; k < P.n_sep_free; ++k) {                    // statements that read no coordinate: their terms never change
+            const FgSepFree f = P.sep_free[k];
+            const fg_u32x16 r = fg_fetch_grec(P.sstream, (int)f.sidx);
+            FgAcc3 dummy = {0.0, 0.0, 0.0};
+            terms[f.trow * tw] = fg_score_one<0>(r, slots[r[0] * tw], slots[r[1] * tw], P.pool, slots, tw, dummy);
+        }
+        if (iter0 < n_warmup) e_cur = eps;
+        else {                                                 // frozen_or_current: hmc.rs:789-798
+            if (frozen == frozen) e_cur = frozen;
+            else if (n_warmup > 0) e_cur = fg_cold_exp(da_leb);
+            else e_cur = eps;
+            frozen = e_cur;
+        }
+        xch[0] = e_cur;
+        xch[2 * tw] = 0.0;
     }
+    __syncthreads();
     for (int t = 0; t < n_steps; ++t) {
         const int iter = iter0 + t;
         const bool warming = iter < n_warmup;
-        double h0 = 0.0, u = 0.0, e_cur = 0.0;
-        // ---- p0 ~ N(0, M) for the own coordinates (hmc.rs:436-441): pair j of the chain's (iteration) stream is Philox block j
-        for (int i = k0; i < k1; i += 2) {
-            const FgD2 z = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC);
-            pl[i * tw] = MASS ? z.a * ms[(long long)i * X.C] : z.a;
-            if (i + 1 < k1) pl[(i + 1) * tw] = MASS ? z.b * ms[(long long)(i + 1) * X.C] : z.b;
-        }
-        if (wv == 0) {
-            if (warming) e_cur = eps;
-            else {                                             // frozen_or_current: hmc.rs:789-798
-                if (frozen == frozen) e_cur = frozen;
-                else if (n_warmup > 0) e_cur = fg_cold_exp(da_leb);
-                else e_cur = eps;
-                frozen = e_cur;
-            }
-            u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)((d + 1) >> 1), (uint32_t)iter, FG_RNG_HMC).a;
-            xch[0] = e_cur;
-            xch[2 * tw] = 0.0;
-        }
-        __syncthreads();                                         // p rows, step size, cleared divergence bits
-        if (wv == 0) h0 = -lj + fg_sep_kinetic(d, pl, tw, mi, X.C);      // hmc.rs:442-443 (all of p0, before any kick)
-        __syncthreads();                                         // the p rows may be overwritten from here on
         const double e = xch[0], hk = 0.5 * e;
-        // ---- leapfrog (hmc.rs:353-407): the whole trajectory of each own coordinate, in registers
+        // ---- the own coordinates: p0 ~ N(0, M) (hmc.rs:436-441; pair j of the chain's (iteration) stream is Philox block j),
+        // its kinetic term, the whole trajectory in registers, the endpoint's kinetic and score terms
         bool bad = false;
+        double zb = 0.0;
         for (int i = k0; i < k1; ++i) {
+            double z;
+            if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
+            else z = zb;
+            double p = MASS ? z * ms[(long long)i * X.C] : z;
+            const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
+            kin0[i * tw] = MASS ? p * p * mii : p * p;                  // hmc.rs:442-443, summed in coordinate order by wave 0
+            double q = slots[i * tw];
+            const double emi = MASS ? e * mii : e;
             const FgSepCoord cd = P.sep_coord[i];
-            double q = slots[i * tw], p = pl[i * tw];
-            const double emi = MASS ? e * mi[(long long)i * X.C] : e;
-            bad = fg_sep_trajectory(P.sep, cd.off, cd.n, q, p, emi, hk, L, h, two_h, rcp_2h) || bad;
-            slots[i * tw] = q; pl[i * tw] = p;
+            const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
+            const int nobs = (cd.n & 7) - 1;
+            bool b;
+#define FG_SEP_CALL(NO, PP) b = fg_sep_trajectory<NO, PP>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw)
+            if (cd.n & 256) { if (nobs == 1) FG_SEP_CALL(1, true); else if (nobs == 0) FG_SEP_CALL(0, true); else if (nobs == 2) FG_SEP_CALL(2, true); else FG_SEP_CALL(3, true); }
+            else { if (nobs == 1) FG_SEP_CALL(1, false); else if (nobs == 0) FG_SEP_CALL(0, false); else if (nobs == 2) FG_SEP_CALL(2, false); else FG_SEP_CALL(3, false); }
+#undef FG_SEP_CALL
+            bad = bad || b;
+            slots[i * tw] = q;
+            kin1[i * tw] = MASS ? p * p * mii : p * p;
         }
         if (bad) atomicOr((unsigned long long *)(xch + 2 * tw), 1ull);
-        __syncthreads();                                         // endpoint q, p of every coordinate
-        double k1e = 0.0;
-        if (wv == 0) k1e = fg_sep_kinetic(d, pl, tw, mi, X.C);
-        __syncthreads();                                         // the p rows now carry score terms
-        // ---- endpoint score_full (hmc.rs:283-299): terms in parallel, sums in program order on wave 0
-        FgAcc3 A = {0.0, 0.0, 0.0};
-        for (int base = 0; base < n_s; base += d) {
-            const int cn = n_s - base < d ? n_s - base : d;
-            const int per = (cn + W - 1) / W;
-            const int r0 = base + wv * per, r1 = (r0 + per < base + cn) ? r0 + per : base + cn;
-            for (int k = r0; k < r1; ++k) {
-                const fg_u32x16 r = fg_fetch_grec(P.sstream, k);
-                const double xs = slots[r[0] * tw], mv = slots[r[1] * tw];
-                FgAcc3 dummy = {0.0, 0.0, 0.0};
-                pl[(k - base) * tw] = fg_score_one<0>(r, xs, mv, P.pool, slots, tw, dummy);
-            }
-            __syncthreads();
-            if (wv == 0) {
-                for (int k = 0; k < cn; ++k) {
-                    const uint32_t ob = (P.sobs[(base + k) >> 5] >> ((base + k) & 31)) & 1u;     // scalar: observe statement?
-                    const double lp = pl[k * tw];
-                    if (ob) A.lik += lp; else A.prior += lp;
-                }
-            }
-            if (base + d < n_s) __syncthreads();
-        }
+        __syncthreads();                                         // every coordinate's endpoint and terms
         if (wv == 0) {
+            // four in-order sums, interleaved (independent chains): H0's and the endpoint's kinetic energy in coordinate
+            // order, log_prior and log_likelihood in program order (score_full, hmc.rs:283-299)
+            double s0 = 0.0, s1 = 0.0;
+            for (int i = 0; i < d; ++i) { s0 += kin0[i * tw]; s1 += kin1[i * tw]; }
+            double pri = 0.0, lik = 0.0;
+            const int n_lik = n_s - n_pri, nb = n_pri < n_lik ? n_pri : n_lik;
+            for (int k = 0; k < nb; ++k) { pri += terms[k * tw]; lik += terms[(n_pri + k) * tw]; }
+            for (int k = nb; k < n_pri; ++k) pri += terms[k * tw];
+            for (int k = nb; k < n_lik; ++k) lik += terms[(n_pri + k) * tw];
+            const double h0 = -lj + 0.5 * s0;                        // hmc.rs:442-443
+            const double lj_new = pri + lik + 0.0;                   // total_log_weight (log_factors = 0: no factor statement has a record)
             bool div = fg_as_i64(xch[2 * tw]) != 0;
-            const double lj_new = fg_total(A);
             div = div || !fg_finite(lj_new);
             double ap = 0.0; bool acc = false;
             if (!div) {
-                const double h_new = -lj_new + k1e;
+                const double h_new = -lj_new + 0.5 * s1;
                 ap = fg_cold_accept_prob(h0, h_new);             // hmc.rs:460
+                const double u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)((d + 1) >> 1), (uint32_t)iter, FG_RNG_HMC).a;
                 acc = u < ap;                                    // hmc.rs:461
             }
             if (acc) lj = lj_new;
@@ -200,6 +195,16 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                 const FgD3 r = fg_cold_da_update(da_hbar, da_leb, (double)da_m, da_mu, H.target, ap);
                 eps = r.a; da_hbar = r.b; da_leb = r.c;
             }
+            // the next transition's step size
+            if (iter + 1 < n_warmup) e_cur = eps;
+            else {                                               // frozen_or_current: hmc.rs:789-798
+                if (frozen == frozen) e_cur = frozen;
+                else if (n_warmup > 0) e_cur = fg_cold_exp(da_leb);
+                else e_cur = eps;
+                if (t + 1 < n_steps) frozen = e_cur;
+            }
+            if (t + 1 < n_steps) xch[0] = e_cur;
+            xch[2 * tw] = 0.0;
         }
         __syncthreads();
         const bool acc = xch[tw] != 0.0;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
     if (!e->P.sep || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
     const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
-    const size_t lds = (size_t)(e->n_slots + e->d + 3) * FG_WAVE * sizeof(double);
+    const size_t lds = (size_t)(e->n_slots + 2 * e->d + e->P.n_sstream + 3) * FG_WAVE * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
     // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates.

@@ -94,13 +94,16 @@ static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
 // Register-resident trajectories (fg_hmc_sep.hip): when every record of the gradient stream reads only its OWN coordinate
 // and constants (an independent-sites model: no coordinate ever sees another one inside a trajectory), the whole L-step
 // trajectory of a coordinate runs with q_i, p_i in registers and its <= FG_SEP_MAXREC records in SGPRs.  One compact
-// record per (coordinate, dependent statement), in gradient-stream order:
-//   flags: FG_G_POW2 / FG_G_DIV / FG_G_SWITCH / FG_G_END as in the gradient stream; FG_G_PERT_X: x is the coordinate
-//   (else x = c); FG_G_PERT_M: mu is the coordinate (else mu = c).
+// record per (coordinate, dependent statement), in gradient-stream order: record 0 is the coordinate's own sample
+// statement (the only prior term such a coordinate can have), the others are observe statements.
+//   c = the statement's constant operand (x - mu is +-(q - c): the sign changes no bit of the log-density);
+//   flags: FG_G_POW2 / FG_G_DIV as in the gradient stream;  trow = LDS row of the statement's endpoint-score term
+//   (prior terms first, then likelihood terms, each in program order).
 #define FG_SEP_MAXREC 4
-struct FgSepRec { uint32_t flags, pad0; double c, inv, lns, sigma; double pad1[3]; };   // dwords 0..7 = one s_load_dwordx8, sigma = dwords 8..9
+struct FgSepRec { uint32_t flags, trow; double c, inv, lns, sigma; double pad1[3]; };   // dwords 0..7 = one s_load_dwordx8, sigma = dwords 8..9
 static_assert(sizeof(FgSepRec) == 64, "FgSepRec must be 64 bytes");
-struct FgSepCoord { int off, n; };     // records of coordinate k: sep[off .. off + n)
+struct FgSepCoord { int off, n; };     // records of coordinate k: sep[off .. off + (n & 7)); bit 8 of n: every sigma is a power of two
+struct FgSepFree { uint32_t sidx, trow; };   // score-stream statements that read no coordinate: evaluated once per launch
 
 struct FgProgramDev {
     const FgIns  *ins;       // full program (generic opcodes only: PRIOR / MH / SCORE), n_ins
@@ -117,6 +120,8 @@ struct FgProgramDev {
     const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
     const FgSepRec *sep;       // compact per-coordinate records or null (see FgSepRec)
     const FgSepCoord *sep_coord;   // [d]
+    const FgSepFree *sep_free;     // [n_sep_free]
+    int n_sep_free, n_prior_terms; // term rows [0, n_prior_terms) are log_prior terms, [n_prior_terms, n_sstream) log_likelihood terms
     const uint32_t *sobs;      // bit k = record k of the score stream is an observe statement ((n_sstream + 31) / 32 words)
     int n_gstream, n_sstream;
     int sstream_kinds;         // record kinds in the score stream: 0 fast Normals, 1 + linear predictors, 2 + general records

@@ -598,6 +598,7 @@ int fg_program::finalize() {
                     FgGradRec r = make_rec(shape[order[q]], (int)k);
                     if (obs && !seen_obs) r.flags |= FG_G_SWITCH;
                     if (q + 1 == order.size()) r.flags |= FG_G_END;
+                    if (shape[order[q]].kind == 1) r.maskx = (uint32_t)order[q];    // fast Normal: its statement index (= score-stream index)
                     seen_obs = seen_obs || obs;
                     gstream.push_back(r);
                 }
@@ -629,29 +630,54 @@ int fg_program::finalize() {
     sobs.assign((size_t)(n_sstream + 31) / 32 + 1, 0u);
     for (int k = 0; k < n_sstream; k++) if (sstream[k].flags & FG_S_OBS) sobs[k >> 5] |= 1u << (k & 31);
     // independent-sites programs: compact per-coordinate records for the register-resident trajectories
-    sep.clear(); sep_coord.clear();
+    sep.clear(); sep_coord.clear(); sep_free.clear(); n_prior_terms = 0;
     if (n_gstream > 0 && n_sstream > 0 && !sstream_has_lin && !sstream_has_gen) {
         bool ok = true;
+        // LDS row of every statement's score term: prior terms first, then likelihood terms, each in program order
+        std::vector<uint32_t> trow((size_t)n_sstream, 0u);
+        int n_pri = 0, n_lik = 0;
+        for (int k = 0; k < n_sstream; k++) if (!(sstream[k].flags & FG_S_OBS)) trow[k] = (uint32_t)n_pri++;
+        for (int k = 0; k < n_sstream; k++) if (sstream[k].flags & FG_S_OBS) trow[k] = (uint32_t)(n_pri + n_lik++);
+        std::vector<char> covered((size_t)n_sstream, 0);
         std::vector<FgSepRec> recs; std::vector<FgSepCoord> cds(f64_slot.size(), FgSepCoord{0, 0});
         for (int k = 0; k < n_gstream && ok; k++) {
             const FgGradRec &r = gstream[k];
             const uint32_t ck = r.coord;
             if (r.flags & (FG_G_LIN | FG_G_GEN | FG_G_NSEL | FG_G_CATC)) { ok = false; break; }
             const bool x_own = (r.flags & FG_G_PERT_X) != 0u, m_own = (r.flags & FG_G_PERT_M) != 0u;
-            if (!x_own && !(r.flags & FG_G_X_CONST)) ok = false;        // x is another site
-            if (!m_own && !(r.flags & FG_G_M_CONST)) ok = false;        // mu is another site
+            if (x_own == m_own) ok = false;                              // exactly one operand is the coordinate ...
+            if (!x_own && !(r.flags & FG_G_X_CONST)) ok = false;        // ... and the other one a constant
+            if (!m_own && !(r.flags & FG_G_M_CONST)) ok = false;
+            const int si = (int)r.maskx;                                 // statement index (set when the stream was built)
+            if (si < 0 || si >= n_sstream || covered[si]) ok = false;
             if (!ok) break;
+            covered[si] = 1;
+            const bool first = cds[ck].n == 0, obs = (sstream[si].flags & FG_S_OBS) != 0u;
+            if (first == obs) ok = false;                                // record 0 = the coordinate's own sample statement, the rest observes
+            if (first && !x_own) ok = false;
             FgSepRec q; std::memset(&q, 0, sizeof(q));
-            q.flags = r.flags & (FG_G_POW2 | FG_G_DIV | FG_G_SWITCH | FG_G_END | FG_G_PERT_X | FG_G_PERT_M);
-            q.c = x_own ? r.mimm : r.ximm;                                // the constant operand (unused when both are the coordinate)
+            q.flags = r.flags & (FG_G_POW2 | FG_G_DIV);
+            q.trow = trow[si];
+            q.c = x_own ? r.mimm : r.ximm;
             q.inv = r.inv; q.lns = r.lns; q.sigma = r.sigma;
-            if (cds[ck].n == 0) cds[ck].off = (int)recs.size();
+            if (first) cds[ck].off = (int)recs.size();
             cds[ck].n += 1;
             if (cds[ck].n > FG_SEP_MAXREC) ok = false;
             recs.push_back(q);
         }
-        for (const FgSepCoord &c : cds) ok = ok && c.n > 0;
-        if (ok) { sep = recs; sep_coord = cds; for (int q = 0; q < FG_SEP_MAXREC; q++) { FgSepRec z; std::memset(&z, 0, sizeof(z)); sep.push_back(z); } }
+        for (size_t k = 0; k < cds.size() && ok; k++) {
+            ok = cds[k].n > 0;
+            bool p2 = true;
+            for (int q = 0; q < cds[k].n && ok; q++) p2 = p2 && (recs[cds[k].off + q].flags & FG_G_POW2);
+            if (ok && p2) cds[k].n |= 256;
+        }
+        if ((size_t)n_slots + 2 * f64_slot.size() + (size_t)n_sstream + 3 > 320) ok = false;     // q, kinetic and term rows of a tile in 160 KB of LDS
+        if (ok) {
+            for (int k = 0; k < n_sstream; k++) if (!covered[k]) sep_free.push_back(FgSepFree{(uint32_t)k, trow[k]});
+            n_prior_terms = n_pri;
+            sep = recs; sep_coord = cds;
+            for (int q = 0; q < FG_SEP_MAXREC; q++) { FgSepRec z; std::memset(&z, 0, sizeof(z)); sep.push_back(z); }
+        }
     }
     if (pool.empty()) pool.push_back(0.0);
     // the kernels prefetch two instructions ahead: keep two readable no-ops past each array

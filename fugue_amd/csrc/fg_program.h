@@ -40,6 +40,7 @@ struct fg_program {
     bool sstream_has_gen = false;       // some record is a general distribution record (FG_G_GEN)
     std::vector<FgSepRec> sep;        // empty unless the program is an independent-sites model (fg_ir.h)
     std::vector<FgSepCoord> sep_coord;
+    std::vector<FgSepFree> sep_free; int n_prior_terms = 0;
     std::vector<uint32_t> sobs;       // observe bits of the score stream
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
