@@ -734,6 +734,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->n_simd = 4 * prop.multiProcessorCount;
     if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) e->mw_override = w; }
     if (const char *sp = std::getenv("FG_HMC_SEP")) e->sep_disabled = std::atoi(sp) == 0;
+    if (const char *sp = std::getenv("FG_MH_MW")) e->mh_mw_disabled = std::atoi(sp) == 0;
     // LDS tile of 64 chains: the score / prior / MH / SMC kernels need the slot rows only, the HMC kernels also the
     // momentum and the multi-wave exchange rows.  A model whose slots alone exceed the 160 KB of a CU cannot run at all;
     // one that only fits without the momentum is refused by fg_hmc_init.
@@ -751,7 +752,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_upload(&e->d_coord, p->coord)) return fail("upload coord");
     if (dev_upload(&e->d_gstream, p->gstream)) return fail("upload gstream");
     if (dev_upload(&e->d_sstream, p->sstream)) return fail("upload sstream");
-    if (dev_upload(&e->d_sep, p->sep) || dev_upload(&e->d_sep_coord, p->sep_coord) || dev_upload(&e->d_sep_free, p->sep_free) || dev_upload(&e->d_sobs, p->sobs)) return fail("upload sep");
+    if (dev_upload(&e->d_sep, p->sep) || dev_upload(&e->d_sep_coord, p->sep_coord) || dev_upload(&e->d_sep_free, p->sep_free) || dev_upload(&e->d_site_rec, p->site_rec) || dev_upload(&e->d_sobs, p->sobs)) return fail("upload sep");
     if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
     if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
@@ -764,8 +765,8 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_alloc(&e->d_itmp, (size_t)3 * e->C)) return fail("alloc itmp");
     e->P.ins = e->d_ins; e->P.ins_fast = e->d_ins_fast; e->P.coord = e->d_coord; e->P.gstream = p->n_gstream > 0 ? e->d_gstream : nullptr; e->P.n_gstream = p->n_gstream;
     e->P.sep = p->sep_coord.empty() ? nullptr : e->d_sep; e->P.sep_coord = e->d_sep_coord; e->P.sobs = e->d_sobs;
-    e->P.sep_free = e->d_sep_free; e->P.n_sep_free = (int)p->sep_free.size(); e->P.n_prior_terms = p->n_prior_terms;
-    e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_kinds = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0); e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
+    e->P.sep_free = e->d_sep_free; e->P.n_sep_free = (int)p->sep_free.size(); e->P.n_prior_terms = p->n_prior_terms; e->P.site_rec = e->d_site_rec;
+    e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_kinds = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0); e->P.sstream_gen = p->sstream_has_genrec ? 1 : 0; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
@@ -785,7 +786,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->hmc_allocs) hipFree(q);
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
-    void *ptrs[] = { e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -1239,7 +1240,9 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
     const int TB = 256;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((S * C + TB - 1) / TB)), dim3(TB), 0, e->stream, e->M.scale, (long long)(S * C), 1.0);
     e->M.ov_kind = nullptr; e->M.ov_lo = nullptr; e->M.ov_hi = nullptr;
+    e->mh_has_prior_resample = false;
     if (overrides) {
+        for (int j = 0; j < e->S; j++) if (overrides[j].kind == FG_PROP_PRIOR_RESAMPLE) e->mh_has_prior_resample = true;
         std::vector<int> k(S); std::vector<double> lo(S), hi(S);
         for (int j = 0; j < e->S; j++) {            // device tables are indexed by LDS slot
             const int sl = e->prog->site_slot[j];
@@ -1276,6 +1279,11 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
     e->M.rec = e->d_rec; e->M.n_rec = n_rec;
     const int iter = e->mh_iter;
     const int first_sample_t = std::max(iter, e->mh_warmup) - iter;
+    if (n_steps > 0) {                                                  // multi-wave tiles when every statement has a score-stream record
+        const int rc = fg_mh_mw_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
+        if (rc == FG_OK) { e->mh_iter += n_steps; return FG_OK; }
+        if (rc != FG_E_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL(k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->M,
                        iter, n_steps, e->mh_warmup, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
     HIPCHK(hipGetLastError());

@@ -74,7 +74,9 @@ struct fg_engine {
     FgIns *d_ins = nullptr, *d_ins_fast = nullptr, *d_sub = nullptr;
     FgCoord *d_coord = nullptr;
     FgGradRec *d_gstream = nullptr, *d_sstream = nullptr;
-    FgSepRec *d_sep = nullptr; FgSepCoord *d_sep_coord = nullptr; FgSepFree *d_sep_free = nullptr; uint32_t *d_sobs = nullptr;
+    FgSepRec *d_sep = nullptr; FgSepCoord *d_sep_coord = nullptr; FgSepFree *d_sep_free = nullptr; uint32_t *d_sobs = nullptr; int *d_site_rec = nullptr;
+    bool mh_mw_disabled = false;  // FG_MH_MW=0: keep every program on the one-wave-per-tile MH kernel (A/B tests)
+    bool mh_has_prior_resample = false;   // an override asks for PriorResample on some site (needs the model-driven proposal path)
     bool sep_disabled = false;   // FG_HMC_SEP=0: keep independent-sites programs on the gradient-stream kernel (A/B tests)
     int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr, *d_site_cat = nullptr;
     double *d_pool = nullptr;
@@ -139,5 +141,8 @@ int dev_upload(T **p, const std::vector<T> &v) {
 
 // fg_hmc_sep.hip: register-resident trajectories for independent-sites programs (FG_E_UNSUPPORTED: not applicable)
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
+
+// fg_mh.hip: multi-wave single-site MH for programs with a score stream (FG_E_UNSUPPORTED: not applicable)
+int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t);
 
 extern "C" int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj);

@@ -282,7 +282,7 @@ template <int RK>
 __device__ __forceinline__ double fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
     const uint32_t fl = r[2];
     double lp;
-    if (RK >= 2 && __builtin_expect((fl & FG_G_GEN) != 0u, 0)) {
+    if (RK == 2 && __builtin_expect((fl & FG_G_GEN) != 0u, 0)) {      // RK = 3: linear predictors, option selects and Categorical tables, but no general records
         double lp2[2];
         fg_gen_lp(r, xs, slots, tw, 0.0, 1, lp2);
         lp = lp2[0];

@@ -120,10 +120,12 @@ struct FgProgramDev {
     const FgGradRec *sstream;  // score stream (the whole program as records, program order) or null: every statement is a fast Normal
     const FgSepRec *sep;       // compact per-coordinate records or null (see FgSepRec)
     const FgSepCoord *sep_coord;   // [d]
+    const int *site_rec;           // [S] score-stream record of each site's own sample statement (or null without a score stream)
     const FgSepFree *sep_free;     // [n_sep_free]
     int n_sep_free, n_prior_terms; // term rows [0, n_prior_terms) are log_prior terms, [n_prior_terms, n_sstream) log_likelihood terms
     const uint32_t *sobs;      // bit k = record k of the score stream is an observe statement ((n_sstream + 31) / 32 words)
     int n_gstream, n_sstream;
+    int sstream_gen;           // the score stream holds general distribution records (FG_G_GEN)
     int sstream_kinds;         // record kinds in the score stream: 0 fast Normals, 1 + linear predictors, 2 + general records
     int n_ins, n_slots, S, d;
 };

@@ -1,0 +1,223 @@
+// fg_mh.hip -- adaptive single-site Metropolis-Hastings (single_site_mh_step x n, src/inference/mh.rs:698-744, 938-1014) with a
+// 64-chain tile shared by W waves, for programs whose statements all have a score-stream record.
+//
+// One MH step of a chain is a short serial recipe -- pick a site, propose, re-run the model (S + O log-densities), accept,
+// adapt -- and at 65 536 chains a one-wave-per-tile kernel puts ONE wave on every SIMD: in-order issue, nothing hides the
+// random-number generation, the transcendental functions or the gathers of the adaptation state (round 1: 0.03 of the f64
+// peak, 390 spilled VGPRs).  Here the step is software-pipelined over the waves of a workgroup:
+//
+//   phase A   wave 0 (control): finishes step t-1 -- adds the statements' log-density TERMS in program order (log_prior
+//             terms, then log_likelihood terms: the same sums in the same order as one scoring run, interpreters.rs:76-163),
+//             accept (mh.rs:731-733), DiminishingAdaptation::update (mcmc_utils.rs:88-150), commit / roll back -- and
+//             makes the proposal of step t (mh.rs:183-294, 516-530, 557-567) from the random numbers published two
+//             barriers earlier;
+//             wave W-1 (random numbers), at the same time: Philox blocks 0..2 of step t+1 -> target site, gaussian_z
+//             (mh.rs:128-132) and both candidate accept uniforms, into the other half of a double buffer;
+//   barrier
+//   phase B   every wave: its share of the statements' log-densities at the proposed state -> term rows in LDS;
+//   barrier
+//
+// Two barriers per step; the scalar record fetches, LDS reads and arithmetic of a term are independent of the other
+// terms'.  All proposals here are model-independent (random walks on f64 / u64 / i64 sites, the bool flip, prior resampling
+// of Categorical sites with a constant table): the engine keeps programs with other needs on k_mh_steps (fg_engine.hip).
+// Values and decisions are those of k_mh_steps: the same random numbers, the same operations in the same order.
+#include "fg_engine_internal.h"
+#include "fg_gradstream.h"
+#include "fg_cold.h"
+
+#define FG_MH_WMAX 16
+
+// records [r0, r1) of the score stream at the current tile state -> term rows (row = the record's `coord` field)
+template <int RK>
+__device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, const double *pool, const double *slots, int tw, double *terms) {
+    if (r0 >= r1) return;
+    fg_u32x16 ra = fg_fetch_grec(g, r0), rb = fg_fetch_grec(g, r0 + 1), rc;
+    double xa = slots[ra[0] * tw], ma = slots[ra[1] * tw], xb, mb;
+    for (int k = r0; k < r1; ++k) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        rc = fg_fetch_grec(g, k + 2);
+        xb = slots[rb[0] * tw]; mb = slots[rb[1] * tw];
+        __builtin_amdgcn_sched_barrier(0);
+        FgAcc3 dummy = {0.0, 0.0, 0.0};
+        terms[ra[3] * tw] = fg_score_one<RK>(ra, xa, ma, pool, slots, tw, dummy);
+        ra = rb; rb = rc; xa = xb; ma = mb;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
+struct FgMhSeg { int r[FG_MH_WMAX + 1]; };     // records [r[w], r[w + 1]) are wave w's share
+
+template <int RK>
+__global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
+                                                                           long long *draws, int first_sample_t) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const long long chain = (long long)blockIdx.x * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    const int n_s = P.n_sstream, n_pri = P.n_prior_terms, n_lik = n_s - n_pri;
+    double *slots = lds + lane;
+    double *terms = lds + (long long)P.n_slots * tw + lane;
+    double *xch = terms + (long long)n_s * tw;                   // rows 4 b .. 4 b + 3: target, z, u(block 1), u(block 2) of buffer b = step & 1
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    const int rng_wave = W - 1;
+
+    // random numbers of step `it` -> buffer (it & 1): gen_range target (mh.rs:716), gaussian_z, the accept uniform candidates
+    auto publish_rng = [&](int it) {
+        double *b = xch + (long long)(4 * (it & 1)) * tw;
+        FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c1 = 0; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
+        unsigned long long ra, rb;
+        fg_rng_block(rng, ra, rb);
+        b[0] = fg_as_double((long long)fg_pick(ra, (uint32_t)P.S));
+        fg_rng_block(rng, ra, rb);
+        b[tw] = fg_cold_gaussian_z(ra, rb);
+        b[2 * tw] = fg_u01_of(ra);
+        fg_rng_block(rng, ra, rb);
+        b[3 * tw] = fg_u01_of(ra);
+    };
+
+    // ---- control-wave state
+    double lw = 0.0, old_cell = 0.0, lqf = 0.0, lqr = 0.0, scale = 1.0, u_acc = 0.0;
+    int target = 0, tslot = 0, kind0 = 0, kind_new = 0;
+    long long g = 0;
+    unsigned long long nacc = 0;
+    // proposal of step `it` (control wave): reads the published random numbers, writes the proposed value into the tile
+    auto propose = [&](int it) {
+        const double *b = xch + (long long)(4 * (it & 1)) * tw;
+        target = (int)fg_as_i64(b[0]);
+        FgMhCtx mh;
+        mh.z = b[tw];
+        const double u1 = b[2 * tw], u2 = b[3 * tw];
+        g = (long long)target * X.C + c;
+        tslot = P.site_slot[target];                                       // per-lane gather (site -> LDS slot)
+        mh.target = tslot;
+        mh.scale = M.scale[g];                                             // get_scale  mcmc_utils.rs:70-77
+        mh.kind = M.kind[g];
+        kind0 = mh.kind;
+        mh.next_block = 2;
+        mh.lqf = 0.0; mh.lqr = 0.0;
+        mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
+        mh.old_cell = slots[tslot * tw];
+        const uint32_t tv = (uint32_t)P.site_vtype[target];
+        int kind_eff = FG_PROP_AUTO;
+        if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
+        // f64_kind (mh.rs:339-358): an undecided site is LogSpace iff its current value is positive and its prior density at
+        // -1.0 is -inf.  Lanes hold different sites: one pass per distinct undecided site in the wave (transient -- a kind is
+        // decided once per (site, chain)).
+        bool undecided = tv == 0u && kind_eff == FG_PROP_AUTO;
+        unsigned long long todo = __ballot(undecided);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int tl = __builtin_amdgcn_readlane(target, leader);
+            const unsigned long long same = __ballot(undecided && target == tl);
+            const fg_u32x16 r = fg_fetch_grec(P.sstream, P.site_rec[tl]);
+            FgAcc3 dummy = {0.0, 0.0, 0.0};
+            const double probe = fg_score_one<RK>(r, -1.0, slots[r[1] * tw], P.pool, slots, tw, dummy);
+            if (undecided && target == tl) { kind_eff = (mh.old_cell > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN; mh.kind = kind_eff; }
+            todo &= ~same;
+        }
+        if (tv == 3u) {                                   // usize target: resample from the constant prior table (mh.rs:516-530)
+            const int cat_base = P.site_cat[2 * target], cat_K = P.site_cat[2 * target + 1];
+            double cum = 0.0; int idx = cat_K;
+            for (int i = 0; i < cat_K; ++i) { cum += P.pool[cat_base + i]; if (idx == cat_K && !(cum < u1)) idx = i; }
+            const long long prop = idx < cat_K - 1 ? idx : cat_K - 1;
+            const long long cur = fg_as_i64(mh.old_cell);
+            const double pp = P.pool[cat_base + (int)prop];
+            const double pc = (cur < 0 || cur >= (long long)cat_K) ? 0.0 : P.pool[cat_base + (int)cur];
+            mh.lqf += !(pp > 0.0) ? FG_NEG_INF : fg_cold_log(pp);
+            mh.lqr += !(pc > 0.0) ? FG_NEG_INF : fg_cold_log(pc);
+            mh.next_block = 2;
+            slots[tslot * tw] = fg_as_double(prop);
+        } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+        old_cell = mh.old_cell; lqf = mh.lqf; lqr = mh.lqr; scale = mh.scale; kind_new = mh.kind;
+        u_acc = mh.next_block == 1 ? u1 : u2;                              // the accept uniform's block (mh.rs:733)
+    };
+
+    if (wv == 0) {
+        fg_load_values(P, X, c, slots, tw);
+        lw = M.lw[c];
+    }
+    if (wv == rng_wave) { publish_rng(iter0); if (n_steps > 1) publish_rng(iter0 + 1); }
+    __syncthreads();
+    for (int t = 0; t <= n_steps; ++t) {
+        const int iter = iter0 + t;
+        // ---- phase A
+        if (wv == 0) {
+            if (t > 0) {                                                   // finish step t - 1
+                const int itp = iter - 1;
+                const bool adapt = itp < n_warmup;
+                double pri = 0.0, lik = 0.0;
+                const int nb = n_pri < n_lik ? n_pri : n_lik;
+                for (int k = 0; k < nb; ++k) { pri += terms[k * tw]; lik += terms[(n_pri + k) * tw]; }
+                for (int k = nb; k < n_pri; ++k) pri += terms[k * tw];
+                for (int k = nb; k < n_lik; ++k) lik += terms[(n_pri + k) * tw];
+                const double prop_lw = pri + lik + 0.0;                    // total_log_weight (no factor statement has a record)
+                const double log_alpha = prop_lw - lw + (lqr - lqf);       // + dim_term == 0 (fixed structure)  mh.rs:731-732
+                const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
+                if (adapt) {                                               // DiminishingAdaptation::update  mcmc_utils.rs:88-150
+                    const uint32_t tot = M.tot[g] + 1u;
+                    const uint32_t acn = M.acc[g] + (accept ? 1u : 0u);
+                    double sc = scale, ls = M.log_scale[g];
+                    if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
+                    if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
+                }
+                if (live && kind_new != kind0) M.kind[g] = kind_new;
+                if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
+                else slots[tslot * tw] = old_cell;
+                if (!adapt && draws && live) {                             // recorded cells of the CURRENT state (mh.rs:1010)
+                    long long *row = draws + (long long)(t - 1 - first_sample_t) * M.n_rec * X.C + c;
+                    for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
+                }
+            }
+            if (t < n_steps) propose(iter);
+        } else if (wv == rng_wave) {
+            if (t > 0 && t + 1 < n_steps) publish_rng(iter + 1);            // buffer (iter + 1) & 1 was last read in phase A of step t - 1
+        }
+        if (t == n_steps) break;
+        __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
+        // ---- phase B: every wave scores its share of the statements
+        fg_mh_terms<RK>(P.sstream, seg.r[wv], seg.r[wv + 1], P.pool, slots, tw, terms);
+        __syncthreads();
+    }
+    if (wv == 0 && live) { M.lw[c] = lw; M.n_acc[c] += nacc; }
+}
+
+int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
+    if (!e->P.sstream || e->S < 1 || n_steps < 1 || e->mh_mw_disabled) return FG_E_UNSUPPORTED;
+    const fg_program *p = e->prog;
+    // every site must take a model-independent proposal: Categorical sites need a constant table, no PriorResample override
+    if (e->mh_has_prior_resample) return FG_E_UNSUPPORTED;
+    for (int j = 0; j < e->S; j++) if (p->site_vtype[j] == FG_USIZE && p->site_cat[2 * j + 1] <= 0) return FG_E_UNSUPPORTED;
+    const int n_s = e->P.n_sstream;
+    const size_t lds = (size_t)(e->n_slots + n_s + 8) * FG_WAVE * sizeof(double);
+    if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
+    const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
+    int W = e->mw_override > 0 ? e->mw_override : 2;
+    if (e->mw_override <= 0) {
+        const long long n_cu = std::max(1, e->n_simd / 4);
+        const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
+        while (W < FG_MH_WMAX && resident * W < 16 && n_s >= 4 * W) W *= 2;
+    }
+    if (W < 2) W = 2;                                                       // control wave + random-number wave
+    FgMhSeg seg;
+    // the random-number wave has its own work in phase A; in phase B all waves share the records evenly
+    for (int w = 0; w <= FG_MH_WMAX; ++w) seg.r[w] = n_s;
+    for (int w = 0; w < W; ++w) seg.r[w] = (int)((long long)n_s * w / W);
+    const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
+    static bool attr_set_dev[64][4];
+    bool &attr_set = attr_set_dev[e->device & 63][rk];
+    if (!attr_set) {
+        const void *fn = rk == 0 ? (const void *)k_mh_mw_steps<0> : (rk == 2 ? (const void *)k_mh_mw_steps<2> : (const void *)k_mh_mw_steps<3>);
+        const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
+        attr_set = true;
+    }
+    if (rk == 2) hipLaunchKernelGGL(k_mh_mw_steps<2>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t);
+    else if (rk == 3) hipLaunchKernelGGL(k_mh_mw_steps<3>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t);
+    else hipLaunchKernelGGL(k_mh_mw_steps<0>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}

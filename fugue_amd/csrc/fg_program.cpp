@@ -610,7 +610,7 @@ int fg_program::finalize() {
     // score stream: when the WHOLE program is FAST / LIN statements its endpoint score (score_full, hmc.rs:283-299)
     // is a lean pass over one 64-byte record per statement, in program order (the accumulation order of
     // PriorHandler / ScoreGivenTrace), instead of a pass of the general interpreter
-    sstream.clear(); n_sstream = 0; sstream_has_lin = false; sstream_has_gen = false;
+    sstream.clear(); n_sstream = 0; sstream_has_lin = false; sstream_has_gen = false; sstream_has_genrec = false;
     {
         bool ok = !stmts.empty();
         for (const Shape &sh : shape) ok = ok && sh.kind != 0;
@@ -620,6 +620,7 @@ int fg_program::finalize() {
                 if (sh.F.op & FG_F_OBSERVE) r.flags |= FG_S_OBS;
                 sstream_has_lin = sstream_has_lin || sh.kind == 2;
                 sstream_has_gen = sstream_has_gen || sh.kind >= 3;
+                sstream_has_genrec = sstream_has_genrec || sh.kind == 3;
                 sstream.push_back(r);
             }
             n_sstream = (int)sstream.size();
@@ -629,15 +630,25 @@ int fg_program::finalize() {
     // observe bits of the score stream (the parallel-terms endpoint score sums prior and likelihood terms apart)
     sobs.assign((size_t)(n_sstream + 31) / 32 + 1, 0u);
     for (int k = 0; k < n_sstream; k++) if (sstream[k].flags & FG_S_OBS) sobs[k >> 5] |= 1u << (k & 31);
+    // term rows of the score stream (multi-wave kernels: every wave evaluates a share of the statements' log-densities into
+    // LDS rows, one wave adds them in program order): log_prior terms first, then log_likelihood terms, each in program
+    // order; the row sits in the record's (otherwise unused) `coord` field.  site_rec: record of each site's sample statement.
+    n_prior_terms = 0;
+    site_rec.assign((size_t)std::max(1, S), -1);
+    {
+        int n_pri = 0, n_lik = 0;
+        for (int k = 0; k < n_sstream; k++) if (!(sstream[k].flags & FG_S_OBS)) sstream[k].coord = (uint32_t)n_pri++;
+        for (int k = 0; k < n_sstream; k++) if (sstream[k].flags & FG_S_OBS) sstream[k].coord = (uint32_t)(n_pri + n_lik++);
+        n_prior_terms = n_pri;
+        if (n_sstream > 0) for (size_t i = 0; i < stmts.size(); i++) if (stmts[i].kind == 0) site_rec[stmts[i].sorted] = (int)i;
+    }
     // independent-sites programs: compact per-coordinate records for the register-resident trajectories
-    sep.clear(); sep_coord.clear(); sep_free.clear(); n_prior_terms = 0;
+    sep.clear(); sep_coord.clear(); sep_free.clear();
     if (n_gstream > 0 && n_sstream > 0 && !sstream_has_lin && !sstream_has_gen) {
         bool ok = true;
         // LDS row of every statement's score term: prior terms first, then likelihood terms, each in program order
         std::vector<uint32_t> trow((size_t)n_sstream, 0u);
-        int n_pri = 0, n_lik = 0;
-        for (int k = 0; k < n_sstream; k++) if (!(sstream[k].flags & FG_S_OBS)) trow[k] = (uint32_t)n_pri++;
-        for (int k = 0; k < n_sstream; k++) if (sstream[k].flags & FG_S_OBS) trow[k] = (uint32_t)(n_pri + n_lik++);
+        for (int k = 0; k < n_sstream; k++) trow[k] = sstream[k].coord;
         std::vector<char> covered((size_t)n_sstream, 0);
         std::vector<FgSepRec> recs; std::vector<FgSepCoord> cds(f64_slot.size(), FgSepCoord{0, 0});
         for (int k = 0; k < n_gstream && ok; k++) {
@@ -674,7 +685,6 @@ int fg_program::finalize() {
         if ((size_t)n_slots + 2 * f64_slot.size() + (size_t)n_sstream + 3 > 320) ok = false;     // q, kinetic and term rows of a tile in 160 KB of LDS
         if (ok) {
             for (int k = 0; k < n_sstream; k++) if (!covered[k]) sep_free.push_back(FgSepFree{(uint32_t)k, trow[k]});
-            n_prior_terms = n_pri;
             sep = recs; sep_coord = cds;
             for (int q = 0; q < FG_SEP_MAXREC; q++) { FgSepRec z; std::memset(&z, 0, sizeof(z)); sep.push_back(z); }
         }

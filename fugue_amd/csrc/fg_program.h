@@ -37,11 +37,13 @@ struct fg_program {
     std::vector<FgGradRec> sstream;   // empty unless the whole program is fast Normals
     int n_sstream = 0;
     bool sstream_has_lin = false;       // some record is a linear-predictor Normal (FG_G_LIN)
+    bool sstream_has_genrec = false;    // ... a FG_G_GEN record proper (sstream_has_gen also counts option selects / Categorical tables)
     bool sstream_has_gen = false;       // some record is a general distribution record (FG_G_GEN)
     std::vector<FgSepRec> sep;        // empty unless the program is an independent-sites model (fg_ir.h)
     std::vector<FgSepCoord> sep_coord;
     std::vector<FgSepFree> sep_free; int n_prior_terms = 0;
     std::vector<uint32_t> sobs;       // observe bits of the score stream
+    std::vector<int> site_rec;        // [S] score-stream record of each site's sample statement
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;
     std::vector<int> site_cat;               // [S][2] {pool base, K} of Categorical sites with a valid constant table, else -1

@@ -111,3 +111,27 @@ def test_mh_mixture_recovers_component_means():
     srt = np.sort(mu, axis=1)
     med = np.median(srt.mean(axis=0), axis=1)                     # robust to a few label-merged chains
     assert np.abs(med - np.array([-6.0, -2.0, 2.0, 6.0])).max() < 1.0
+
+
+@pytest.mark.parametrize("name", ["refmodel8", "normal32", "mixture", "hier_scale", "linreg", "readme", "coin"])
+def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypatch):
+    """k_mh_mw_steps (W waves per tile: parallel log-density terms, in-order sums, pipelined random numbers) reproduces
+    k_mh_steps exactly: recorded draws, final state, adapted scales, log-weights and accept counts, for every W."""
+    prog = ZOO[name]()
+    cp = E.compile_model(prog)
+    C, nw, ns = 150, 120, 40
+    rec = list(range(cp.S))
+    out = []
+    for mw, W in ((0, 1), (1, 2), (1, 4), (1, 8), (1, 16)):
+        monkeypatch.setenv("FG_MH_MW", str(mw))
+        monkeypatch.setenv("FG_HMC_WAVES", str(W))
+        eng = E.Engine(cp, C, seed=13, chain_offset=3)
+        d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
+        st = eng.mh_run(ns, nw, None, rec, d)
+        draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
+        eng.device_free(d)
+        out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
+        eng.close()
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
