@@ -291,8 +291,10 @@ __device__ __forceinline__ double fg_score_one(const fg_u32x16 &r, double xs, do
         const uint32_t base = r[6], K = r[7];
         lp = (zi < 0 || zi >= (long long)K) ? FG_NEG_INF : pool[base + K + (zi < 0 || zi >= (long long)K ? 0 : (int)zi)];
     } else {
-        const double x = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
-        double m = (fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms;
+        // operand = slot + immediate, as FG_OP_NORMAL_FAST forms it (fg_interp.h): a constant operand reads the always-zero
+        // slot, a site operand has the immediate 0.0 -- one f64 add per operand instead of a flag test and a select
+        const double x = xs + fg_dbl(r[4], r[5]);
+        double m = (RK == 0) ? ms + fg_dbl(r[6], r[7]) : ((fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms);
         if (RK >= 2 && __builtin_expect((fl & FG_G_NSEL) != 0u, 0)) { double mm_; fg_nsel_mu(r, ms, pool, slots, tw, ~0u, 0.0, m, mm_); }
         if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
         const double dl = x - m, inv = fg_dbl(r[10], r[11]);

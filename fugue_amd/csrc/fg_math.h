@@ -243,8 +243,9 @@ FG_HD uint32_t fg_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned
 FG_HD void fg_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *o) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t h0 = fg_mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = fg_mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32 on gfx950) instead of a mul_hi / mul_lo pair
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0, h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

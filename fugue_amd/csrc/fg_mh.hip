@@ -27,20 +27,26 @@
 
 #define FG_MH_WMAX 16
 
-// records [r0, r1) of the score stream at the current tile state -> term rows (row = the record's `coord` field)
+// records [r0, r1) of the score stream at the current tile state -> term rows (row = the record's `coord` field).  Records
+// are fetched two ahead into three rotating 16-SGPR buffers (the loop is unrolled by three so that no buffer is ever
+// copied), operands one ahead; s_waitcnt by hand (SMEM returns out of order).
+#define FG_MH_TSTAGE(RA, XA, MA, RB, XB, MB, RC)                                                  \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                                           \
+    RC = fg_fetch_grec(g, k + 2);                                                                 \
+    XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw];                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy); } \
+    if (++k >= r1) break;
 template <int RK>
 __device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, const double *pool, const double *slots, int tw, double *terms) {
     if (r0 >= r1) return;
     fg_u32x16 ra = fg_fetch_grec(g, r0), rb = fg_fetch_grec(g, r0 + 1), rc;
-    double xa = slots[ra[0] * tw], ma = slots[ra[1] * tw], xb, mb;
-    for (int k = r0; k < r1; ++k) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        rc = fg_fetch_grec(g, k + 2);
-        xb = slots[rb[0] * tw]; mb = slots[rb[1] * tw];
-        __builtin_amdgcn_sched_barrier(0);
-        FgAcc3 dummy = {0.0, 0.0, 0.0};
-        terms[ra[3] * tw] = fg_score_one<RK>(ra, xa, ma, pool, slots, tw, dummy);
-        ra = rb; rb = rc; xa = xb; ma = mb;
+    double xa = slots[ra[0] * tw], ma = slots[ra[1] * tw], xb, mb, xc, mc;
+    int k = r0;
+    for (;;) {
+        FG_MH_TSTAGE(ra, xa, ma, rb, xb, mb, rc)
+        FG_MH_TSTAGE(rb, xb, mb, rc, xc, mc, ra)
+        FG_MH_TSTAGE(rc, xc, mc, ra, xa, ma, rb)
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
@@ -65,19 +71,24 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     const int rng_wave = W - 1;
 
-    // random numbers of step `it` -> buffer (it & 1): gen_range target (mh.rs:716), gaussian_z, the accept uniform candidates
-    auto publish_rng = [&](int it) {
+    // random numbers of step `it` -> buffer (it & 1): gen_range target (mh.rs:716) and the accept uniform of block 2 (part 0);
+    // gaussian_z (mh.rs:128-132) and the uniform of block 1 (part 1).  With W >= 3 the two parts run on two waves.
+    auto publish_rng = [&](int it, int part) {
         double *b = xch + (long long)(4 * (it & 1)) * tw;
-        FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c1 = 0; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
+        FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
         unsigned long long ra, rb;
-        fg_rng_block(rng, ra, rb);
-        b[0] = fg_as_double((long long)fg_pick(ra, (uint32_t)P.S));
-        fg_rng_block(rng, ra, rb);
-        b[tw] = fg_cold_gaussian_z(ra, rb);
-        b[2 * tw] = fg_u01_of(ra);
-        fg_rng_block(rng, ra, rb);
-        b[3 * tw] = fg_u01_of(ra);
+        if (part == 0) {
+            rng.c1 = 0; fg_rng_block(rng, ra, rb);
+            b[0] = fg_as_double((long long)fg_pick(ra, (uint32_t)P.S));
+            rng.c1 = 2; fg_rng_block(rng, ra, rb);
+            b[3 * tw] = fg_u01_of(ra);
+        } else {
+            rng.c1 = 1; fg_rng_block(rng, ra, rb);
+            b[tw] = fg_cold_gaussian_z(ra, rb);
+            b[2 * tw] = fg_u01_of(ra);
+        }
     };
+    const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
 
     // ---- control-wave state
     double lw = 0.0, old_cell = 0.0, lqf = 0.0, lqr = 0.0, scale = 1.0, u_acc = 0.0;
@@ -140,7 +151,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
         fg_load_values(P, X, c, slots, tw);
         lw = M.lw[c];
     }
-    if (wv == rng_wave) { publish_rng(iter0); if (n_steps > 1) publish_rng(iter0 + 1); }
+    if (wv == rng_wave) { publish_rng(iter0, 0); if (n_steps > 1) publish_rng(iter0 + 1, 0); }
+    if (wv == rng_wave1) { publish_rng(iter0, 1); if (n_steps > 1) publish_rng(iter0 + 1, 1); }
     __syncthreads();
     for (int t = 0; t <= n_steps; ++t) {
         const int iter = iter0 + t;
@@ -173,8 +185,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 }
             }
             if (t < n_steps) propose(iter);
-        } else if (wv == rng_wave) {
-            if (t > 0 && t + 1 < n_steps) publish_rng(iter + 1);            // buffer (iter + 1) & 1 was last read in phase A of step t - 1
+        } else if (t > 0 && t + 1 < n_steps) {                             // buffer (iter + 1) & 1 was last read in phase A of step t - 1
+            if (wv == rng_wave) publish_rng(iter + 1, 0);
+            if (wv == rng_wave1) publish_rng(iter + 1, 1);
         }
         if (t == n_steps) break;
         __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
