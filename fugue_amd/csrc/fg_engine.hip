@@ -660,10 +660,9 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
                 for (int i = 0; i < cat_K; ++i) { cum += P.pool[cat_base + i]; if (idx == cat_K && !(cum < uu)) idx = i; }
                 const long long prop = idx < cat_K - 1 ? idx : cat_K - 1;
                 const long long cur = fg_as_i64(mh.old_cell);
-                const double pp = P.pool[cat_base + (int)prop];
-                const double pc = (cur < 0 || cur >= (long long)cat_K) ? 0.0 : P.pool[cat_base + (int)cur];
-                mh.lqf += !(pp > 0.0) ? FG_NEG_INF : log(pp);
-                mh.lqr += !(pc > 0.0) ? FG_NEG_INF : log(pc);
+                // prior log-probabilities of the proposed and the current index: the table's precomputed ln p (-inf for p <= 0)
+                mh.lqf += P.pool[cat_base + cat_K + (int)prop];
+                mh.lqr += (cur < 0 || cur >= (long long)cat_K) ? FG_NEG_INF : P.pool[cat_base + cat_K + (int)cur];
                 mh.next_block = (int)s1.c1;
                 slots[tslot * tw] = fg_as_double(prop);
             } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);

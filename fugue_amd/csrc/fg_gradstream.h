@@ -108,6 +108,21 @@ __device__ __forceinline__ void fg_nsel_mu(const fg_u32x16 &r, double zs, const 
     mup = mp; mum = mm;
 }
 
+// The same option select for a SCORING run (no perturbation): every lane fetches the pool entry its own z names (one
+// 16-byte gather, the table is L1-resident) and then the slot that entry names -- one round trip instead of K scalar
+// fetches, LDS reads and selects.  The value is the one fg_nsel_mu / FG_OP_GATHER return (NaN when z is outside 0..K-1).
+__device__ __forceinline__ double fg_nsel_mu_lane(const fg_u32x16 &r, double zs, const double *pool, const double *slots, int tw) {
+    const uint32_t off = r[6], K = r[7];
+    const long long zi = fg_as_i64(zs);
+    const bool ok = zi >= 0 && zi < (long long)K;
+    const double *ent = pool + off + 2 * (ok ? (int)zi : 0);
+    const long long hdr = fg_as_i64(ent[0]);                 // {u32 slot, u32 is_const}
+    const double cst = ent[1];
+    const uint32_t slot = (uint32_t)hdr, is_const = (uint32_t)(hdr >> 32);
+    const double v = is_const ? cst : slots[slot * tw];
+    return ok ? v : NAN;
+}
+
 struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
 struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
 
@@ -279,7 +294,11 @@ __device__ __forceinline__ bool fg_grad_stream(const FgGradRec *g, const int n, 
 // the same additions as FG_OP_NORMAL_FAST in the interpreter (operand = slot or immediate; z != z -> -inf guard;
 // log_prior and log_likelihood accumulated separately).  Records are fetched two ahead, operands one ahead.
 template <int RK>
-__device__ __forceinline__ double fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A) {
+// lane_pool: where the per-lane table lookups (Categorical ln p, option lists) read the constant pool -- a kernel may stage a
+// small pool into LDS; linear-predictor terms always come from `pool` by scalar loads.
+__device__ __forceinline__ double fg_score_one(const fg_u32x16 &r, double xs, double ms, const double *pool, const double *slots, int tw, FgAcc3 &A,
+                                               const double *lane_pool = nullptr) {
+    const double *lp_tab = lane_pool ? lane_pool : pool;
     const uint32_t fl = r[2];
     double lp;
     if (RK == 2 && __builtin_expect((fl & FG_G_GEN) != 0u, 0)) {      // RK = 3: linear predictors, option selects and Categorical tables, but no general records
@@ -289,13 +308,13 @@ __device__ __forceinline__ double fg_score_one(const fg_u32x16 &r, double xs, do
     } else if (RK >= 2 && __builtin_expect((fl & FG_G_CATC) != 0u, 0)) {   // Categorical site, constant table: ln p[z] precomputed
         const long long zi = fg_as_i64(xs);
         const uint32_t base = r[6], K = r[7];
-        lp = (zi < 0 || zi >= (long long)K) ? FG_NEG_INF : pool[base + K + (zi < 0 || zi >= (long long)K ? 0 : (int)zi)];
+        lp = (zi < 0 || zi >= (long long)K) ? FG_NEG_INF : lp_tab[base + K + (zi < 0 || zi >= (long long)K ? 0 : (int)zi)];
     } else {
         // operand = slot + immediate, as FG_OP_NORMAL_FAST forms it (fg_interp.h): a constant operand reads the always-zero
         // slot, a site operand has the immediate 0.0 -- one f64 add per operand instead of a flag test and a select
         const double x = xs + fg_dbl(r[4], r[5]);
         double m = (RK == 0) ? ms + fg_dbl(r[6], r[7]) : ((fl & FG_G_M_CONST) ? fg_dbl(r[6], r[7]) : ms);
-        if (RK >= 2 && __builtin_expect((fl & FG_G_NSEL) != 0u, 0)) { double mm_; fg_nsel_mu(r, ms, pool, slots, tw, ~0u, 0.0, m, mm_); }
+        if (RK >= 2 && __builtin_expect((fl & FG_G_NSEL) != 0u, 0)) m = fg_nsel_mu_lane(r, ms, lp_tab, slots, tw);
         if (RK >= 1 && __builtin_expect((fl & FG_G_LIN) != 0u, 0)) m = fg_lin_mu(r, pool, slots, tw);
         const double dl = x - m, inv = fg_dbl(r[10], r[11]);
         double z = dl * inv;

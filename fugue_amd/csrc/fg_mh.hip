@@ -35,10 +35,10 @@
     RC = fg_fetch_grec(g, k + 2);                                                                 \
     XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw];                                               \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy); } \
+    { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy, lane_pool); } \
     if (++k >= r1) break;
 template <int RK>
-__device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, const double *pool, const double *slots, int tw, double *terms) {
+__device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, const double *pool, const double *lane_pool, const double *slots, int tw, double *terms) {
     if (r0 >= r1) return;
     fg_u32x16 ra = fg_fetch_grec(g, r0), rb = fg_fetch_grec(g, r0 + 1), rc;
     double xa = slots[ra[0] * tw], ma = slots[ra[1] * tw], xb, mb, xc, mc;
@@ -55,7 +55,8 @@ struct FgMhSeg { int r[FG_MH_WMAX + 1]; };     // records [r[w], r[w + 1]) are w
 
 template <int RK>
 __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
-                                                                           long long *draws, int first_sample_t) {
+                                                                           long long *draws, int first_sample_t, int exp_mask /* timing experiments only (FG_MH_EXP): results are wrong when non-zero */,
+                                                                           int pool_n /* > 0: the constant pool (pool_n doubles) is staged into LDS behind the exchange rows */) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1);
@@ -67,90 +68,69 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     const int n_s = P.n_sstream, n_pri = P.n_prior_terms, n_lik = n_s - n_pri;
     double *slots = lds + lane;
     double *terms = lds + (long long)P.n_slots * tw + lane;
-    double *xch = terms + (long long)n_s * tw;                   // rows 4 b .. 4 b + 3: target, z, u(block 1), u(block 2) of buffer b = step & 1
+    // exchange rows, double-buffered by step parity (8 rows each): 0 target site, 1 gaussian_z, 2 u(block 1), 3 u(block 2),
+    // 4 {LDS slot, value type} of the target, 5 Categorical targets: {pool base, K} of the constant table, 6 their proposed
+    // index, 7 its prior log-probability
+    double *xch = terms + (long long)n_s * tw;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     const int rng_wave = W - 1;
+    const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
 
-    // random numbers of step `it` -> buffer (it & 1): gen_range target (mh.rs:716) and the accept uniform of block 2 (part 0);
-    // gaussian_z (mh.rs:128-132) and the uniform of block 1 (part 1).  With W >= 3 the two parts run on two waves.
+    // Everything of step `it` that does not depend on the chain's state -> buffer (it & 1).
+    //   part 0: gen_range target (mh.rs:716) with its site-table entries, the uniform of block 1 and -- for a Categorical
+    //           target -- the index resampled from the constant prior table with its prior log-probability (mh.rs:516-530);
+    //   part 1: gaussian_z (mh.rs:128-132) from block 1 and the accept uniform of block 2.
+    // With W >= 3 the two parts run on two waves (block 1 is then generated twice: the parts stay independent).
     auto publish_rng = [&](int it, int part) {
-        double *b = xch + (long long)(4 * (it & 1)) * tw;
+        double *b = xch + (long long)(8 * (it & 1)) * tw;
         FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
         unsigned long long ra, rb;
         if (part == 0) {
             rng.c1 = 0; fg_rng_block(rng, ra, rb);
-            b[0] = fg_as_double((long long)fg_pick(ra, (uint32_t)P.S));
-            rng.c1 = 2; fg_rng_block(rng, ra, rb);
-            b[3 * tw] = fg_u01_of(ra);
+            const int tg = (int)fg_pick(ra, (uint32_t)P.S);
+            const int ts = P.site_slot[tg], tvv = P.site_vtype[tg];               // per-lane gathers of small tables
+            const int cb = P.site_cat[2 * tg], cK = P.site_cat[2 * tg + 1];
+            rng.c1 = 1; fg_rng_block(rng, ra, rb);
+            const double u1 = fg_u01_of(ra);
+            b[0] = fg_as_double((long long)tg);
+            b[2 * tw] = u1;
+            b[4 * tw] = fg_as_double((long long)(uint32_t)ts | ((long long)tvv << 32));
+            b[5 * tw] = fg_as_double((long long)(uint32_t)cb | ((long long)cK << 32));
+            if (tvv == 3 && cK > 0) {                                  // first index whose cumulative probability reaches u, clamped (distribution.rs:771-784)
+                double cum = 0.0; int idx = cK;
+                for (int i0 = 0; i0 < cK; i0 += 4) {                  // four table entries in flight
+                    double pv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pv[q] = (i0 + q < cK) ? P.pool[cb + i0 + q] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (i0 + q < cK) { cum += pv[q]; if (idx == cK && !(cum < u1)) idx = i0 + q; }
+                }
+                const int prop = idx < cK - 1 ? idx : cK - 1;
+                b[6 * tw] = fg_as_double((long long)prop);
+                b[7 * tw] = P.pool[cb + cK + prop];                   // the table's precomputed ln p (-inf for p <= 0)
+            }
         } else {
             rng.c1 = 1; fg_rng_block(rng, ra, rb);
             b[tw] = fg_cold_gaussian_z(ra, rb);
-            b[2 * tw] = fg_u01_of(ra);
+            rng.c1 = 2; fg_rng_block(rng, ra, rb);
+            b[3 * tw] = fg_u01_of(ra);
         }
     };
-    const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
 
     // ---- control-wave state
     double lw = 0.0, old_cell = 0.0, lqf = 0.0, lqr = 0.0, scale = 1.0, u_acc = 0.0;
-    int target = 0, tslot = 0, kind0 = 0, kind_new = 0;
+    int tslot = 0, kind0 = 0, kind_new = 0;
     long long g = 0;
     unsigned long long nacc = 0;
-    // proposal of step `it` (control wave): reads the published random numbers, writes the proposed value into the tile
-    auto propose = [&](int it) {
-        const double *b = xch + (long long)(4 * (it & 1)) * tw;
-        target = (int)fg_as_i64(b[0]);
-        FgMhCtx mh;
-        mh.z = b[tw];
-        const double u1 = b[2 * tw], u2 = b[3 * tw];
-        g = (long long)target * X.C + c;
-        tslot = P.site_slot[target];                                       // per-lane gather (site -> LDS slot)
-        mh.target = tslot;
-        mh.scale = M.scale[g];                                             // get_scale  mcmc_utils.rs:70-77
-        mh.kind = M.kind[g];
-        kind0 = mh.kind;
-        mh.next_block = 2;
-        mh.lqf = 0.0; mh.lqr = 0.0;
-        mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
-        mh.old_cell = slots[tslot * tw];
-        const uint32_t tv = (uint32_t)P.site_vtype[target];
-        int kind_eff = FG_PROP_AUTO;
-        if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
-        // f64_kind (mh.rs:339-358): an undecided site is LogSpace iff its current value is positive and its prior density at
-        // -1.0 is -inf.  Lanes hold different sites: one pass per distinct undecided site in the wave (transient -- a kind is
-        // decided once per (site, chain)).
-        bool undecided = tv == 0u && kind_eff == FG_PROP_AUTO;
-        unsigned long long todo = __ballot(undecided);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int tl = __builtin_amdgcn_readlane(target, leader);
-            const unsigned long long same = __ballot(undecided && target == tl);
-            const fg_u32x16 r = fg_fetch_grec(P.sstream, P.site_rec[tl]);
-            FgAcc3 dummy = {0.0, 0.0, 0.0};
-            const double probe = fg_score_one<RK>(r, -1.0, slots[r[1] * tw], P.pool, slots, tw, dummy);
-            if (undecided && target == tl) { kind_eff = (mh.old_cell > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN; mh.kind = kind_eff; }
-            todo &= ~same;
-        }
-        if (tv == 3u) {                                   // usize target: resample from the constant prior table (mh.rs:516-530)
-            const int cat_base = P.site_cat[2 * target], cat_K = P.site_cat[2 * target + 1];
-            double cum = 0.0; int idx = cat_K;
-            for (int i = 0; i < cat_K; ++i) { cum += P.pool[cat_base + i]; if (idx == cat_K && !(cum < u1)) idx = i; }
-            const long long prop = idx < cat_K - 1 ? idx : cat_K - 1;
-            const long long cur = fg_as_i64(mh.old_cell);
-            const double pp = P.pool[cat_base + (int)prop];
-            const double pc = (cur < 0 || cur >= (long long)cat_K) ? 0.0 : P.pool[cat_base + (int)cur];
-            mh.lqf += !(pp > 0.0) ? FG_NEG_INF : fg_cold_log(pp);
-            mh.lqr += !(pc > 0.0) ? FG_NEG_INF : fg_cold_log(pc);
-            mh.next_block = 2;
-            slots[tslot * tw] = fg_as_double(prop);
-        } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
-        old_cell = mh.old_cell; lqf = mh.lqf; lqr = mh.lqr; scale = mh.scale; kind_new = mh.kind;
-        u_acc = mh.next_block == 1 ? u1 : u2;                              // the accept uniform's block (mh.rs:733)
-    };
 
     if (wv == 0) {
         fg_load_values(P, X, c, slots, tw);
         lw = M.lw[c];
     }
+    // small constant pools (Categorical tables, option lists) are read per lane by the record evaluators: from LDS a lookup
+    // costs an LDS round trip instead of a vector-memory one
+    double *pool_l = lds + (long long)(P.n_slots + n_s + 16) * tw;
+    for (int k = (int)threadIdx.x; k < pool_n; k += (int)blockDim.x) pool_l[k] = P.pool[k];
     if (wv == rng_wave) { publish_rng(iter0, 0); if (n_steps > 1) publish_rng(iter0 + 1, 0); }
     if (wv == rng_wave1) { publish_rng(iter0, 1); if (n_steps > 1) publish_rng(iter0 + 1, 1); }
     __syncthreads();
@@ -158,21 +138,44 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
         const int iter = iter0 + t;
         // ---- phase A
         if (wv == 0) {
-            if (t > 0) {                                                   // finish step t - 1
+            // the next proposal's inputs first: its adaptation state comes from HBM / L2 while step t - 1 is being finished
+            const double *b = xch + (long long)(8 * (iter & 1)) * tw;
+            int n_target = 0, n_tslot = 0; uint32_t n_tv = 0u; long long n_g = 0;
+            double n_scale = 1.0; int n_kind = 0;
+            const bool do_prop = t < n_steps && !(exp_mask & 4);
+            if (do_prop) {
+                n_target = (int)fg_as_i64(b[0]);
+                const long long st = fg_as_i64(b[4 * tw]);
+                n_tslot = (int)(uint32_t)st; n_tv = (uint32_t)(st >> 32);
+                n_g = (long long)n_target * X.C + c;
+                n_scale = M.scale[n_g];                                    // get_scale  mcmc_utils.rs:70-77
+                n_kind = M.kind[n_g];
+            }
+            if (t > 0 && !(exp_mask & 2)) {                                // finish step t - 1
                 const int itp = iter - 1;
                 const bool adapt = itp < n_warmup;
+                // log_prior and log_likelihood: the terms in program order (two independent chains), eight rows of each in flight
                 double pri = 0.0, lik = 0.0;
                 const int nb = n_pri < n_lik ? n_pri : n_lik;
-                for (int k = 0; k < nb; ++k) { pri += terms[k * tw]; lik += terms[(n_pri + k) * tw]; }
-                for (int k = nb; k < n_pri; ++k) pri += terms[k * tw];
-                for (int k = nb; k < n_lik; ++k) lik += terms[(n_pri + k) * tw];
+                int k = 0;
+                for (; k + 8 <= nb; k += 8) {
+                    double a[8], l[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { a[q] = terms[(k + q) * tw]; l[q] = terms[(n_pri + k + q) * tw]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { pri += a[q]; lik += l[q]; }
+                }
+                for (; k < nb; ++k) { pri += terms[k * tw]; lik += terms[(n_pri + k) * tw]; }
+                for (int q = nb; q < n_pri; ++q) pri += terms[q * tw];
+                for (int q = nb; q < n_lik; ++q) lik += terms[(n_pri + q) * tw];
                 const double prop_lw = pri + lik + 0.0;                    // total_log_weight (no factor statement has a record)
                 const double log_alpha = prop_lw - lw + (lqr - lqf);       // + dim_term == 0 (fixed structure)  mh.rs:731-732
                 const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
+                double sc = scale;
                 if (adapt) {                                               // DiminishingAdaptation::update  mcmc_utils.rs:88-150
                     const uint32_t tot = M.tot[g] + 1u;
                     const uint32_t acn = M.acc[g] + (accept ? 1u : 0u);
-                    double sc = scale, ls = M.log_scale[g];
+                    double ls = M.log_scale[g];
                     if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
                     if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
                 }
@@ -183,16 +186,62 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                     long long *row = draws + (long long)(t - 1 - first_sample_t) * M.n_rec * X.C + c;
                     for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
                 }
+                // the state fetched above is stale where the next proposal hits the site just updated
+                if (do_prop && n_g == g) { n_scale = sc; n_kind = kind_new; }
             }
-            if (t < n_steps) propose(iter);
-        } else if (t > 0 && t + 1 < n_steps) {                             // buffer (iter + 1) & 1 was last read in phase A of step t - 1
+            if (do_prop) {                                                 // proposal of step t (mh.rs:183-294, 516-530, 557-567)
+                FgMhCtx mh;
+                mh.z = b[tw];
+                const double u1 = b[2 * tw], u2 = b[3 * tw];
+                g = n_g; tslot = n_tslot;
+                mh.target = tslot; mh.scale = n_scale; mh.kind = n_kind;
+                kind0 = n_kind;
+                mh.next_block = 2;
+                mh.lqf = 0.0; mh.lqr = 0.0;
+                mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
+                mh.old_cell = slots[tslot * tw];
+                const uint32_t tv = n_tv;
+                int kind_eff = FG_PROP_AUTO;
+                if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
+                // f64_kind (mh.rs:339-358): an undecided site is LogSpace iff its current value is positive and its prior density
+                // at -1.0 is -inf.  Lanes hold different sites: one pass per distinct undecided site in the wave (transient -- a
+                // kind is decided once per (site, chain)).
+                const bool undecided = tv == 0u && kind_eff == FG_PROP_AUTO;
+                unsigned long long todo = __ballot(undecided);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int tl = __builtin_amdgcn_readlane(n_target, leader);
+                    const unsigned long long same = __ballot(undecided && n_target == tl);
+                    const fg_u32x16 r = fg_fetch_grec(P.sstream, P.site_rec[tl]);
+                    FgAcc3 dummy = {0.0, 0.0, 0.0};
+                    const double probe = fg_score_one<RK>(r, -1.0, slots[r[1] * tw], P.pool, slots, tw, dummy);
+                    if (undecided && n_target == tl) { kind_eff = (mh.old_cell > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN; mh.kind = kind_eff; }
+                    todo &= ~same;
+                }
+                if (tv == 3u) {                               // usize target: the index resampled from the constant prior table (mh.rs:516-530)
+                    const long long ct = fg_as_i64(b[5 * tw]);
+                    const int cat_base = (int)(uint32_t)ct, cat_K = (int)(ct >> 32);
+                    const long long prop = fg_as_i64(b[6 * tw]);
+                    const long long cur = fg_as_i64(mh.old_cell);
+                    mh.lqf += b[7 * tw];                                   // prior log-probabilities of the proposed and the current index
+                    mh.lqr += (cur < 0 || cur >= (long long)cat_K) ? FG_NEG_INF : P.pool[cat_base + cat_K + (int)cur];
+                    mh.next_block = 2;
+                    slots[tslot * tw] = fg_as_double(prop);
+                } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+                old_cell = mh.old_cell; lqf = mh.lqf; lqr = mh.lqr; scale = mh.scale; kind_new = mh.kind;
+                u_acc = mh.next_block == 1 ? u1 : u2;                      // the accept uniform's block (mh.rs:733)
+            }
+        } else if (t > 0 && t + 1 < n_steps && !(exp_mask & 8)) {          // buffer (iter + 1) & 1 was last read in phase A of step t - 1
             if (wv == rng_wave) publish_rng(iter + 1, 0);
             if (wv == rng_wave1) publish_rng(iter + 1, 1);
         }
         if (t == n_steps) break;
         __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
         // ---- phase B: every wave scores its share of the statements
-        fg_mh_terms<RK>(P.sstream, seg.r[wv], seg.r[wv + 1], P.pool, slots, tw, terms);
+        if (!(exp_mask & 1)) {
+            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(P.sstream, seg.r[wv], seg.r[wv + 1], P.pool, pool_l, slots, tw, terms);
+            else fg_mh_terms<RK>(P.sstream, seg.r[wv], seg.r[wv + 1], P.pool, nullptr, slots, tw, terms);
+        }
         __syncthreads();
     }
     if (wv == 0 && live) { M.lw[c] = lw; M.n_acc[c] += nacc; }
@@ -205,8 +254,11 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     if (e->mh_has_prior_resample) return FG_E_UNSUPPORTED;
     for (int j = 0; j < e->S; j++) if (p->site_vtype[j] == FG_USIZE && p->site_cat[2 * j + 1] <= 0) return FG_E_UNSUPPORTED;
     const int n_s = e->P.n_sstream;
-    const size_t lds = (size_t)(e->n_slots + n_s + 8) * FG_WAVE * sizeof(double);
+    size_t lds = (size_t)(e->n_slots + n_s + 16) * FG_WAVE * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
+    int pool_n = 0;                                                          // stage the constant pool into LDS when it is small and the tile leaves room
+    if (e->P.sstream_kinds != 0 && p->pool.size() * 8 <= 24 * 1024 && lds + p->pool.size() * 8 <= 160 * 1024 &&
+        (160 * 1024) / lds == (160 * 1024) / (lds + p->pool.size() * 8)) { pool_n = (int)p->pool.size(); lds += p->pool.size() * 8; }
     const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
     int W = e->mw_override > 0 ? e->mw_override : 2;
     if (e->mw_override <= 0) {
@@ -219,6 +271,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     // the random-number wave has its own work in phase A; in phase B all waves share the records evenly
     for (int w = 0; w <= FG_MH_WMAX; ++w) seg.r[w] = n_s;
     for (int w = 0; w < W; ++w) seg.r[w] = (int)((long long)n_s * w / W);
+    const int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
     static bool attr_set_dev[64][4];
     bool &attr_set = attr_set_dev[e->device & 63][rk];
@@ -228,9 +281,9 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-    if (rk == 2) hipLaunchKernelGGL(k_mh_mw_steps<2>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t);
-    else if (rk == 3) hipLaunchKernelGGL(k_mh_mw_steps<3>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t);
-    else hipLaunchKernelGGL(k_mh_mw_steps<0>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t);
+    if (rk == 2) hipLaunchKernelGGL(k_mh_mw_steps<2>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
+    else if (rk == 3) hipLaunchKernelGGL(k_mh_mw_steps<3>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
+    else hipLaunchKernelGGL(k_mh_mw_steps<0>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
     HIPCHK(hipGetLastError());
     return FG_OK;
 }
