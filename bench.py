@@ -404,9 +404,9 @@ def leg_smc(args, E, W, torch, clock, stream, world, rank, dev):
     cp = E.compile_model(W.smc_normal())
     eng = E.Engine(cp, N, seed=42 + rank, device=dev)
     eng.set_stream(stream.cuda_stream)
-    eng.smc_run(rejuvenation_steps=3)                      # untimed: allocations, first-launch effects
+    eng.smc_run(rejuvenation_steps=3, download=False)      # untimed: allocations, first-launch effects
     res = {}
-    dt = clock.region(lambda: res.update(eng.smc_run(rejuvenation_steps=3)))
+    dt = clock.region(lambda: res.update(eng.smc_run(rejuvenation_steps=3, download=False)))   # particles and weights stay in HBM
     eng.close()
     n_steps = len(res["betas"])
     moves = (res["n_model_runs"] - N) / 2

@@ -96,6 +96,7 @@ struct fg_engine {
     std::vector<void *> mh_allocs;
     int mh_warmup = 0, mh_iter = 0;
     int *d_rec = nullptr; int rec_cap = 0;
+    void *smc_arena = nullptr; size_t smc_arena_bytes = 0;   // scratch of fg_smc_run, allocated once per engine (fg_smc.hip)
     double *d_tmp = nullptr;     // [C] scratch
     int *d_itmp = nullptr;       // [3][C] scratch
     size_t lds_bytes = 0;        // LDS tile of the HMC kernels (slots + momentum + exchange rows)

@@ -18,6 +18,7 @@
 // scales from the start of the sweep and the per-site counts are folded in once per sweep.
 #include "fg_engine_internal.h"
 #include "fg_gradstream.h"
+#include "fg_cold.h"
 
 #define RED_BLOCKS 512
 #define RED_THREADS 256
@@ -29,7 +30,14 @@ struct FgSmcScalars {      // device-resident scalars of one SMC run
     double beta, bnew, lo, hi, mid, one, target_ess;
     double log_evidence, log_norm, lse1, lse2, ess;
     int done, force_one;
+    // lookahead bisection (k_smc_ess_pass): candidates of the current pass, bisection steps taken, arrival ticket
+    double cand[8];
+    int n_cand, iters, first;
+    unsigned int ticket;
 };
+#define ESS_BLOCKS 512
+#define ESS_THREADS 256
+#define ESS_MAXC 8
 
 // ---------------------------------------------------------------------------------------
 // reductions:  v_i = lw_i + (b - beta) * ll_i     (smc.rs:590-594 / :512-516)
@@ -126,6 +134,269 @@ __global__ __launch_bounds__(RED_THREADS) void k_smc_finish(FgSmcScalars *st, co
         st->mid = 0.5 * (st->lo + st->hi);
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// next_beta (smc.rs:588-622) without a launch per reduction: ONE kernel per pass evaluates ESS(b) for every candidate of
+// the next THREE bisection levels (the 7 midpoints of the depth-3 decision tree over [lo, hi]; the first pass also
+// b = 1), the last block to arrive walks the tree -- the same comparisons `ess_at(mid) < target` on the same midpoints
+// 0.5 * (lo + hi) as 3 consecutive iterations of the reference's loop -- and writes the next pass's candidates.  64
+// bisections = 22 passes instead of 195 launches.
+// Each ESS(b) = exp(2 lse(v) - lse(2 v)), v_i = lw_i + (b - beta) ll_i, is accumulated as (max, sum exp(v - max),
+// sum exp(v - max)^2) per thread, then combined by a fixed tree (lanes, waves, blocks in index order) with the usual
+// rescaling, so the result does not depend on scheduling.  It differs from the reference's two-pass log_sum_exp in the last
+// bits only (a partial maximum instead of the global one); these values DECIDE comparisons, they are never stored -- the
+// reweight that follows uses the exact two-pass form (k_smc_red_max / k_smc_red_sum).
+// The last block's single-thread epilogue of a pass: walk the decision tree with the candidates' ESS values and set up the
+// next pass.
+__device__ __forceinline__ void fg_ess_decide(FgSmcScalars *st, const double *ess_c, int nc) {
+    int c0 = 0;
+    if (st->first) {                                               // candidate 0 of the first pass is b = 1: smc.rs:604-607
+        st->first = 0; c0 = 1;
+        st->lo = st->beta; st->hi = 1.0;
+        if (ess_c[0] >= st->target_ess) { st->done = 1; st->bnew = 1.0; st->ticket = 0u; return; }
+    }
+    // the remaining candidates are the midpoint tree of [lo, hi] in heap order: node j has children 2j + 1, 2j + 2
+    const int ntree = nc - c0;
+    int node = 0, depth = 0;
+    double lo = st->lo, hi = st->hi;
+    while (node < ntree && st->iters + depth < 64) {               // smc.rs:612-619, one level = one iteration
+        const double mid = st->cand[c0 + node];
+        if (ess_c[c0 + node] < st->target_ess) { hi = mid; node = 2 * node + 1; } else { lo = mid; node = 2 * node + 2; }
+        ++depth;
+    }
+    st->lo = lo; st->hi = hi; st->iters += depth;
+    if (st->iters >= 64) {                                          // smc.rs:620-621
+        st->bnew = fmin(fmax(hi, st->beta + 1e-9), 1.0);
+        st->done = 1;
+    } else {                                                        // next pass: the midpoint tree of the new bracket
+        const int left = 64 - st->iters, lv = left < 3 ? left : 3;
+        double blo[7], bhi[7];
+        blo[0] = lo; bhi[0] = hi;
+        const int nn = (1 << lv) - 1;
+        for (int j = 0; j < nn; ++j) {
+            const double mid = 0.5 * (blo[j] + bhi[j]);             // smc.rs:613
+            st->cand[j] = mid;
+            if (2 * j + 2 < 7) { blo[2 * j + 1] = blo[j]; bhi[2 * j + 1] = mid; blo[2 * j + 2] = mid; bhi[2 * j + 2] = bhi[j]; }
+        }
+        st->n_cand = nn;
+    }
+    st->ticket = 0u;
+}
+struct EssAcc { double m, s1, s2; };
+__device__ __forceinline__ EssAcc ess_combine(const EssAcc &a, const EssAcc &b) {
+    EssAcc r;
+    r.m = fmax(a.m, b.m);
+    if (isinf(r.m) && r.m < 0.0) { r.s1 = 0.0; r.s2 = 0.0; return r; }
+    const double ea = exp(a.m - r.m), eb = exp(b.m - r.m);           // one of them is exp(0) = 1
+    r.s1 = a.s1 * ea + b.s1 * eb;
+    r.s2 = a.s2 * (ea * ea) + b.s2 * (eb * eb);
+    return r;
+}
+__device__ __forceinline__ EssAcc ess_shfl(const EssAcc &a, int o) {
+    EssAcc r; r.m = __shfl_down(a.m, o, 64); r.s1 = __shfl_down(a.s1, o, 64); r.s2 = __shfl_down(a.s2, o, 64); return r;
+}
+__global__ __launch_bounds__(ESS_THREADS) void k_smc_ess_pass(const double *lw, const double *ll, long long n, FgSmcScalars *st, double *part /*[gridDim.x][ESS_MAXC][3]*/) {
+    __shared__ double sh[ESS_THREADS / 64][ESS_MAXC][3];
+    __shared__ int is_last;
+    if (st->done) return;
+    const int nc = st->n_cand;
+    const double beta = st->beta;
+    double bc[ESS_MAXC];
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) bc[q] = st->cand[q < nc ? q : 0] - beta;
+    EssAcc A[ESS_MAXC];
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) { A[q].m = -INFINITY; A[q].s1 = 0.0; A[q].s2 = 0.0; }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double w = lw[i], l = ll[i];
+#pragma unroll
+        for (int q = 0; q < ESS_MAXC; ++q) {
+            if (q < nc) {
+                const double v = w + bc[q] * l;                    // smc.rs:593
+                if (v > A[q].m) {                                   // a new running maximum: rescale what has been summed
+                    const double e = exp(A[q].m - v);               // exp(-inf) = 0 on the first element
+                    A[q].s1 = A[q].s1 * e + 1.0; A[q].s2 = A[q].s2 * (e * e) + 1.0; A[q].m = v;
+                } else {                                            // NaN propagates like the reference's sum; -inf adds nothing
+                    const double e = (isinf(v) && v < 0.0) ? 0.0 : exp(v - A[q].m);
+                    A[q].s1 += e; A[q].s2 += e * e;
+                }
+            }
+        }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) {
+        if (q < nc) {
+            for (int o = 32; o > 0; o >>= 1) A[q] = ess_combine(A[q], ess_shfl(A[q], o));
+            if (lane == 0) { sh[wv][q][0] = A[q].m; sh[wv][q][1] = A[q].s1; sh[wv][q][2] = A[q].s2; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nc) {
+        const int q = threadIdx.x;
+        EssAcc r = { sh[0][q][0], sh[0][q][1], sh[0][q][2] };
+        for (int k = 1; k < ESS_THREADS / 64; ++k) { const EssAcc o = { sh[k][q][0], sh[k][q][1], sh[k][q][2] }; r = ess_combine(r, o); }
+        double *p = part + ((long long)blockIdx.x * ESS_MAXC + q) * 3;
+        p[0] = r.m; p[1] = r.s1; p[2] = r.s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                            // release the partials ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = atomicAdd(&st->ticket, 1u);         // ... before the arrival ticket
+        is_last = tk == gridDim.x - 1;
+        if (is_last) __threadfence();                               // acquire: every block's partials are visible
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- last block: combine the blocks' partials in index order (fixed tree), then walk the decision tree
+    __shared__ double ess_c[ESS_MAXC];
+    for (int q = 0; q < nc; ++q) {
+        EssAcc r = { -INFINITY, 0.0, 0.0 };
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+            const double *p = part + ((long long)b * ESS_MAXC + q) * 3;
+            const EssAcc o = { __builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2) };
+            r = ess_combine(r, o);
+        }
+        for (int o = 32; o > 0; o >>= 1) r = ess_combine(r, ess_shfl(r, o));
+        __syncthreads();
+        if (lane == 0) { sh[wv][0][0] = r.m; sh[wv][0][1] = r.s1; sh[wv][0][2] = r.s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            EssAcc t = { sh[0][0][0], sh[0][0][1], sh[0][0][2] };
+            for (int k = 1; k < ESS_THREADS / 64; ++k) { const EssAcc o = { sh[k][0][0], sh[k][0][1], sh[k][0][2] }; t = ess_combine(t, o); }
+            const bool empty = isinf(t.m) && t.m < 0.0;
+            const double lse1 = (empty || t.s1 == 0.0) ? -INFINITY : t.m + log(t.s1);          // numerical.rs:33-37
+            const double lse2 = (empty || t.s2 == 0.0) ? -INFINITY : 2.0 * t.m + log(t.s2);
+            ess_c[q] = (!isfinite(lse1) || !isfinite(lse2)) ? (double)n : exp(2.0 * lse1 - lse2);   // smc.rs:598-601
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) fg_ess_decide(st, ess_c, nc);
+}
+
+// The same pass when the incoming log-weights are UNIFORM (every next_beta call of adaptive_smc: log_w = -ln N after the
+// previous step's resample, smc.rs:476,538-540): ESS(b) = (sum t_i)^2 / sum t_i^2 with t_i = exp((b - beta)(ll_i - L)),
+// L = max ll (the common factor of the weights cancels).  The 7 midpoints of the depth-3 tree are equally spaced,
+// b_k = lo + k delta, so t_ik = E_i R_i^k with E_i = exp((lo - beta)(ll_i - L)), R_i = exp(delta (ll_i - L)): two exps
+// and seven multiplications per particle instead of seven exps.  The particle with ll_i = L contributes exactly 1 to every
+// sum (no underflow of the whole sum); like k_smc_ess_pass these values only decide comparisons.
+__global__ __launch_bounds__(ESS_THREADS) void k_smc_ess_pass_uniform(const double *ll, long long n, FgSmcScalars *st, const double *ll_max, double *part /*[gridDim.x][ESS_MAXC][3]*/) {
+    __shared__ double sh[ESS_THREADS / 64][ESS_MAXC][2];
+    __shared__ int is_last;
+    if (st->done) return;
+    const int nc = st->n_cand, first = st->first;
+    const double beta = st->beta, L = *ll_max;
+    const int nt = nc - first;                                       // tree candidates: 1, 3 or 7, heap order over [lo, hi]
+    const int lv = nt >= 7 ? 3 : (nt >= 3 ? 2 : 1);
+    const double lo = first ? beta : st->lo, hi = first ? 1.0 : st->hi;
+    // heap node j of the tree sits at grid position k(j) of lo + k (hi - lo) / 2^lv:  lv = 3: 4, 2, 6, 1, 3, 5, 7;  lv = 2: 2, 1, 3;
+    // lv = 1: 1.  (The candidates the decision walk RECORDS are the reference's 0.5 * (lo + hi) chains in st->cand; the grid
+    // points used here agree with them to the last bit or two.)
+    const double d0 = lo - beta, d1 = 1.0 - beta, dl = (hi - lo) / (double)(1 << lv);
+    double s1[ESS_MAXC], s2[ESS_MAXC];
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+    const bool allneg = isinf(L) && L < 0.0;
+#define ESS_ADD(q, tv) { const double tv_ = (tv); s1[q] += tv_; s2[q] += tv_ * tv_; }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n && !allneg; i += (long long)gridDim.x * blockDim.x) {
+        const double x = ll[i] - L;                                  // <= 0; -inf: the particle has no weight at any b > beta
+        if (isinf(x) && x < 0.0) continue;
+        const double E = exp(d0 * x), R = exp(dl * x);
+        const double p1 = E * R, p2 = p1 * R, p3 = p2 * R;
+        if (first) {                                                 // candidate 0 = b = 1, then the depth-3 tree over [beta, 1]
+            ESS_ADD(0, exp(d1 * x))
+            const double p4 = p3 * R, p5 = p4 * R, p6 = p5 * R, p7 = p6 * R;
+            ESS_ADD(1, p4) ESS_ADD(2, p2) ESS_ADD(3, p6) ESS_ADD(4, p1) ESS_ADD(5, p3) ESS_ADD(6, p5) ESS_ADD(7, p7)
+        } else if (lv == 3) {
+            const double p4 = p3 * R, p5 = p4 * R, p6 = p5 * R, p7 = p6 * R;
+            ESS_ADD(0, p4) ESS_ADD(1, p2) ESS_ADD(2, p6) ESS_ADD(3, p1) ESS_ADD(4, p3) ESS_ADD(5, p5) ESS_ADD(6, p7)
+        } else if (lv == 2) { ESS_ADD(0, p2) ESS_ADD(1, p1) ESS_ADD(2, p3) }
+        else ESS_ADD(0, p1)
+    }
+#undef ESS_ADD
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) {
+        if (q < nc) {
+            for (int o = 32; o > 0; o >>= 1) { s1[q] += __shfl_down(s1[q], o, 64); s2[q] += __shfl_down(s2[q], o, 64); }
+            if (lane == 0) { sh[wv][q][0] = s1[q]; sh[wv][q][1] = s2[q]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nc) {
+        const int q = threadIdx.x;
+        double a = sh[0][q][0], b = sh[0][q][1];
+        for (int k = 1; k < ESS_THREADS / 64; ++k) { a += sh[k][q][0]; b += sh[k][q][1]; }
+        double *p = part + ((long long)blockIdx.x * ESS_MAXC + q) * 3;
+        p[0] = 0.0; p[1] = a; p[2] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int tk = atomicAdd(&st->ticket, 1u);
+        is_last = tk == gridDim.x - 1;
+        if (is_last) __threadfence();
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // last block: every candidate's sums over the blocks in ONE sweep (thread t takes blocks t, t + 256, ...; lanes, then waves,
+    // in index order: a fixed tree)
+    __shared__ double ess_c[ESS_MAXC];
+    __shared__ double shl[ESS_THREADS / 64][ESS_MAXC][2];
+    double a[ESS_MAXC], b[ESS_MAXC];
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) { a[q] = 0.0; b[q] = 0.0; }
+    for (int bk = threadIdx.x; bk < (int)gridDim.x; bk += blockDim.x) {
+        const double *p = part + (long long)bk * ESS_MAXC * 3;
+#pragma unroll
+        for (int q = 0; q < ESS_MAXC; ++q) if (q < nc) { a[q] += __builtin_nontemporal_load(p + 3 * q + 1); b[q] += __builtin_nontemporal_load(p + 3 * q + 2); }
+    }
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) {
+        if (q < nc) {
+            for (int o = 32; o > 0; o >>= 1) { a[q] += __shfl_down(a[q], o, 64); b[q] += __shfl_down(b[q], o, 64); }
+            if (lane == 0) { shl[wv][q][0] = a[q]; shl[wv][q][1] = b[q]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nc) {
+        const int q = threadIdx.x;
+        double ta = shl[0][q][0], tb = shl[0][q][1];
+        for (int k = 1; k < ESS_THREADS / 64; ++k) { ta += shl[k][q][0]; tb += shl[k][q][1]; }
+        const double e = ta * ta / tb;
+        ess_c[q] = (allneg || !(ta > 0.0) || !isfinite(e)) ? (double)n : e;                       // smc.rs:598-601
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) fg_ess_decide(st, ess_c, nc);
+}
+__global__ __launch_bounds__(RED_THREADS) void k_smc_max_finish(const double *part_max, int nb, double *out) {   // max of the block maxima
+    __shared__ double sh[RED_THREADS / 64];
+    double m = -INFINITY;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) m = fmax(m, part_max[k]);
+    m = block_reduce_max(m, sh);
+    if (threadIdx.x == 0) *out = m;
+}
+// arms the lookahead search for the current beta: first pass = {b = 1} + the midpoint tree of [beta, 1]
+__global__ void k_smc_ess_begin(FgSmcScalars *st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->done = 0; st->iters = 0; st->first = 1; st->ticket = 0u;
+    const double lo = st->beta, hi = 1.0;
+    double blo[7], bhi[7];
+    blo[0] = lo; bhi[0] = hi;
+    st->cand[0] = 1.0;
+    for (int j = 0; j < 7; ++j) {
+        const double mid = 0.5 * (blo[j] + bhi[j]);
+        st->cand[1 + j] = mid;
+        if (2 * j + 2 < 7) { blo[2 * j + 1] = blo[j]; bhi[2 * j + 1] = mid; blo[2 * j + 2] = mid; bhi[2 * j + 2] = bhi[j]; }
+    }
+    st->n_cand = 8;
+}
+__global__ void k_smc_ess_end(FgSmcScalars *st) {                   // smc.rs:504-506: the step cap forces beta = 1
+    if (threadIdx.x == 0 && blockIdx.x == 0 && st->force_one) st->bnew = 1.0;
+}
+
 // lw <- combined - log_norm (or uniform), w <- exp(lw)      smc.rs:520-528,535
 __global__ void k_smc_apply(double *lw, const double *ll, double *w, long long n, const FgSmcScalars *st) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,10 +436,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_chunk_sums(const double *
     s = block_reduce_sum(s, sh);
     if (threadIdx.x == 0) chunk_sum[blockIdx.x] = s;
 }
-__global__ void k_scan_chunk_offsets(double *chunk_sum, int n_chunks) {   // exclusive scan, sequential (n_chunks is small)
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double run = 0.0;
-    for (int k = 0; k < n_chunks; ++k) { const double t = chunk_sum[k]; chunk_sum[k] = run; run += t; }
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_chunk_offsets(double *chunk_sum, int n_chunks) {   // exclusive scan of the chunk totals, one block
+    __shared__ double sh[SCAN_THREADS];
+    if (blockIdx.x != 0) return;
+    const int per = (n_chunks + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int k0 = threadIdx.x * per, k1 = k0 + per < n_chunks ? k0 + per : n_chunks;
+    double tot = 0.0;
+    for (int k = k0; k < k1; ++k) tot += chunk_sum[k];
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = 1; o < SCAN_THREADS; o <<= 1) {             // Hillis-Steele inclusive scan of the thread totals (fixed order)
+        const double t = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    double run = threadIdx.x ? sh[threadIdx.x - 1] : 0.0;
+    for (int k = k0; k < k1; ++k) { const double t = chunk_sum[k]; chunk_sum[k] = run; run += t; }
 }
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_cumsum(const double *w, long long n, const double *chunk_off, double *cum) {
     __shared__ double sh[SCAN_THREADS];
@@ -222,65 +506,86 @@ struct FgSmcDev {
     double *scale, *log_scale;        // [S] shared DiminishingAdaptation (smc.rs:482)
     long long *acc, *tot;             // [S]
     unsigned int *sw_n, *sw_a;        // [S] per-sweep proposal / accept counts
+    unsigned int *blk;                // [n_blocks][2][S] per-block proposal / accept counts of the sweep in flight
+    int S;
 };
-__global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_smc_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st,
-                                                                      uint32_t move_id) {
+#define FG_SMC_HIST 320               /* sites of a program (LDS bounds a tile to 320 cells) */
+#define FG_SMC_WPB(SCORE) ((SCORE) < 0 ? 1 : ((SCORE) == 2 ? 4 : 16))   /* tiles (waves) per block of k_smc_rejuv<SCORE> */
+// SCORE: 0 = score stream of fast Normals, 3 = + linear predictors / option selects / Categorical tables, 2 = + general
+// distribution records, -1 = the interpreter (programs without a score stream).  The stream variants carry no interpreter
+// code and run 4 tiles per 256-thread block.
+template <int SCORE>
+__global__ __launch_bounds__(FG_SMC_WPB(SCORE) * FG_WAVE, SCORE == 2 ? 1 : (SCORE < 0 ? FG_MIN_WAVES : 4)) void k_smc_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st,
+                                                                                                              uint32_t move_id) {
     extern __shared__ double lds[];
+    __shared__ unsigned int hist[2][FG_SMC_HIST];                   // the block's proposal / accept counts per site
     constexpr int tw = FG_WAVE;
-    const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
+    const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
+    for (int j = (int)threadIdx.x; j < 2 * FG_SMC_HIST; j += (int)blockDim.x) (&hist[0][0])[j] = 0u;
+    __syncthreads();
+    const long long chain = ((long long)blockIdx.x * (blockDim.x >> 6) + wv) * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
-    double *slots = lds + threadIdx.x;
+    double *slots = lds + (long long)wv * P.n_slots * tw + lane;          // one tile per wave
     fg_load_values(P, X, c, slots, tw);
     const double beta = st->beta;
-    FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, move_id, FG_RNG_SMC_REJUV);
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    FgStream rng = fg_stream(X.seed, gchain, move_id, FG_RNG_SMC_REJUV);
     unsigned long long ra, rb;
     fg_rng_block(rng, ra, rb);
     const int k = (int)fg_pick(ra, (uint32_t)P.d);            // f64_sites[rng.gen_range(0..len)]  smc.rs:650
     const int site = P.f64_site[k];                           // sorted site index (adaptation / values row)
     const double scale = M.scale[site];                       // get_scale  smc.rs:651
-    const double z = fg_rng_normal(rng);                      // Normal(0,1).sample  smc.rs:655
+    const double z = fg_cold_normal_pair(sk0, sk1, gchain, 1u, move_id, FG_RNG_SMC_REJUV).a;      // Normal(0,1).sample  smc.rs:655 (block 1)
     const double cur = slots[k * tw];                         // LDS slot of coordinate k is k
     const double prop = cur + scale * z;
     double pri[2], lik[2];
     for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed: two model runs  smc.rs:662-675
         slots[k * tw] = pass ? prop : cur;
         FgAcc3 A = {0.0, 0.0, 0.0};
-        if (P.sstream && P.sstream_kinds == 0) fg_score_stream<0>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
-        else if (P.sstream) fg_score_stream<2>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
+        if (SCORE >= 0) fg_score_stream<(SCORE < 0 ? 0 : SCORE)>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
         else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         pri[pass] = A.prior; lik[pass] = A.lik + A.fac;
     }
     const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
-    const double u = fg_rng_u01(rng);
-    const bool accept = (log_alpha >= 0.0) || (u < exp(log_alpha));                          // smc.rs:680
+    const double u = fg_cold_u01_pair(sk0, sk1, gchain, 2u, move_id, FG_RNG_SMC_REJUV).a;     // block 2
+    const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));                  // smc.rs:680
     if (live) {
         if (accept) X.values[(long long)site * X.C + c] = fg_as_i64(prop);
         M.lprior[c] = accept ? pri[1] : pri[0];               // the freshly scored trace is returned either way
         M.ll[c] = accept ? lik[1] : lik[0];
     }
-    // per-sweep proposal / accept counts, one pair of atomics per distinct site in the wave (a one-site model would
-    // otherwise send a million atomics to one address)
+    // per-sweep proposal / accept counts: one LDS add per distinct site in the wave, one row of counts per block in HBM
+    // (k_smc_adapt adds the rows) -- a one-site model would otherwise send a million global atomics to one address
     unsigned long long todo = __ballot(live);
     const unsigned long long acc_mask = __ballot(live && accept);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int s_lead = __builtin_amdgcn_readlane(site, leader);
         const unsigned long long same = __ballot(live && site == s_lead);
-        if ((int)threadIdx.x == leader) {
-            atomicAdd(&M.sw_n[s_lead], (unsigned int)__popcll(same));
+        if (lane == leader) {
+            atomicAdd(&hist[0][s_lead], (unsigned int)__popcll(same));
             const unsigned int na = (unsigned int)__popcll(same & acc_mask);
-            if (na) atomicAdd(&M.sw_a[s_lead], na);
+            if (na) atomicAdd(&hist[1][s_lead], na);
         }
         todo &= ~same;
     }
+    __syncthreads();
+    unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
+    for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
 }
-// per-sweep batched DiminishingAdaptation update (see file header; oracle: adapt_update_batched)
-__global__ void k_smc_adapt(FgSmcDev M, int S) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= S) return;
-    const long long n = M.sw_n[j], a = M.sw_a[j];
-    M.sw_n[j] = 0; M.sw_a[j] = 0;
+// per-sweep batched DiminishingAdaptation update (see file header; oracle: adapt_update_batched): block j adds site j's
+// per-block counts, thread 0 applies the update
+__global__ __launch_bounds__(256) void k_smc_adapt(FgSmcDev M, int S, int n_blk) {
+    __shared__ unsigned int shn[4], sha[4];
+    const int j = blockIdx.x;
+    unsigned int cn = 0, ca = 0;
+    for (int b = threadIdx.x; b < n_blk; b += blockDim.x) { cn += M.blk[(long long)b * 2 * S + j]; ca += M.blk[(long long)b * 2 * S + S + j]; }
+    for (int o = 32; o > 0; o >>= 1) { cn += __shfl_down(cn, o, 64); ca += __shfl_down(ca, o, 64); }
+    if ((threadIdx.x & 63) == 0) { shn[threadIdx.x >> 6] = cn; sha[threadIdx.x >> 6] = ca; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const long long n = (long long)shn[0] + shn[1] + shn[2] + shn[3], a = (long long)sha[0] + sha[1] + sha[2] + sha[3];
     if (n <= 0) return;
     const long long T0 = M.tot[j];
     const long long tot = T0 + n, acc = M.acc[j] + a;
@@ -305,12 +610,29 @@ __global__ void k_smc_adapt(FgSmcDev M, int S) {
 namespace {
 
 struct Reducer {     // scratch for the two-pass reductions
-    double *part_max = nullptr, *part_sum = nullptr;
+    double *part_max = nullptr, *part_sum = nullptr, *ess_part = nullptr;
     int init() {
-        if (dev_alloc(&part_max, RED_BLOCKS) || dev_alloc(&part_sum, 2 * RED_BLOCKS)) return FG_E_HIP;
+        if (dev_alloc(&part_max, RED_BLOCKS) || dev_alloc(&part_sum, 2 * RED_BLOCKS) || dev_alloc(&ess_part, (size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8)) return FG_E_HIP;
         return FG_OK;
     }
-    void free_all() { if (part_max) (void)hipFree(part_max); if (part_sum) (void)hipFree(part_sum); part_max = part_sum = nullptr; }
+    void free_all() { if (part_max) (void)hipFree(part_max); if (part_sum) (void)hipFree(part_sum); if (ess_part) (void)hipFree(ess_part); part_max = part_sum = ess_part = nullptr; }
+    // next_beta (smc.rs:588-622) -> st->bnew: ESS at b = 1, then 64 bisections, three levels per pass (k_smc_ess_pass)
+    // uniform_lw: the caller guarantees that every lw_i is the same number (adaptive_smc: always) -> the two-exp pass
+    int next_beta(hipStream_t s, const double *lw, const double *ll, long long n, FgSmcScalars *st, bool uniform_lw = false) {
+        hipLaunchKernelGGL(k_smc_ess_begin, dim3(1), dim3(1), 0, s, st);
+        const int nb = (int)std::min<long long>(ESS_BLOCKS, (n + ESS_THREADS - 1) / ESS_THREADS);
+        if (uniform_lw) {
+            hipLaunchKernelGGL(k_smc_red_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, ll, (const double *)nullptr, n, (const double *)&st->one, (const double *)&st->beta, part_max);
+            hipLaunchKernelGGL(k_smc_max_finish, dim3(1), dim3(RED_THREADS), 0, s, (const double *)part_max, RED_BLOCKS, ess_part + (size_t)ESS_BLOCKS * ESS_MAXC * 3);
+        }
+        for (int pass = 0; pass < 23; ++pass) {      // pass 0: b = 1 and levels 1-3; passes 1..20: three levels each; pass 21: the 64th; one spare (a no-op once done)
+            if (uniform_lw) hipLaunchKernelGGL(k_smc_ess_pass_uniform, dim3(nb), dim3(ESS_THREADS), 0, s, ll, n, st, (const double *)(ess_part + (size_t)ESS_BLOCKS * ESS_MAXC * 3), ess_part);
+            else hipLaunchKernelGGL(k_smc_ess_pass, dim3(nb), dim3(ESS_THREADS), 0, s, lw, ll, n, st, ess_part);
+        }
+        hipLaunchKernelGGL(k_smc_ess_end, dim3(1), dim3(1), 0, s, st);
+        HIPCHK(hipGetLastError());
+        return FG_OK;
+    }
     // lse / ESS of v = lw + (b - beta) ll, then k_smc_finish(phase)
     int run(hipStream_t s, const double *lw, const double *ll, long long n, FgSmcScalars *st, const double *b_ptr, int phase) {
         hipLaunchKernelGGL(k_smc_red_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, lw, ll, n, b_ptr, (const double *)&st->beta, part_max);
@@ -324,22 +646,24 @@ struct Reducer {     // scratch for the two-pass reductions
 
 struct Scanner {     // scratch for the prefix sum
     double *chunk = nullptr, *cum = nullptr; long long cap = 0;
+    bool external = false;      // buffers belong to the caller's arena
     int ensure(long long n) {
         if (n <= cap) return FG_OK;
+        if (external) { fg_set_error("scan scratch too small"); return FG_E_BAD_ARG; }
         free_all();
         const long long nc = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
         if (dev_alloc(&chunk, (size_t)nc) || dev_alloc(&cum, (size_t)n)) return FG_E_HIP;
         cap = n;
         return FG_OK;
     }
-    void free_all() { if (chunk) (void)hipFree(chunk); if (cum) (void)hipFree(cum); chunk = cum = nullptr; cap = 0; }
+    void free_all() { if (!external) { if (chunk) (void)hipFree(chunk); if (cum) (void)hipFree(cum); } chunk = cum = nullptr; cap = 0; }
     int indices(hipStream_t s, const double *w, long long n, int method, double U, const double *d_u, unsigned long long seed,
                 uint32_t step, long long *d_idx) {
         int rc = ensure(n);
         if (rc) return rc;
         const int nc = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
         hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nc), dim3(SCAN_THREADS), 0, s, w, n, chunk);
-        hipLaunchKernelGGL(k_scan_chunk_offsets, dim3(1), dim3(1), 0, s, chunk, nc);
+        hipLaunchKernelGGL(k_scan_chunk_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, chunk, nc);
         hipLaunchKernelGGL(k_scan_cumsum, dim3(nc), dim3(SCAN_THREADS), 0, s, w, n, (const double *)chunk, cum);
         hipLaunchKernelGGL(k_resample_search, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double *)cum, n, method, U, d_u, seed,
                            step, d_idx);
@@ -393,9 +717,7 @@ int fg_device_next_beta(int device, double beta, const double *h_log_w, const do
     HIPCHK(hipMemcpy(st, &h, sizeof(h), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_lw, h_log_w, (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_ll, h_ll, (size_t)n * 8, hipMemcpyHostToDevice));
-    rc = R.run(nullptr, d_lw, d_ll, n, st, (const double *)&st->one, 0);
-    for (int it = 0; it < 64 && !rc; ++it) rc = R.run(nullptr, d_lw, d_ll, n, st, (const double *)&st->mid, 1);
-    if (!rc) hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(RED_THREADS), 0, nullptr, st, (const double *)R.part_max, (const double *)R.part_sum, RED_BLOCKS, (long long)n, 2);
+    rc = R.next_beta(nullptr, d_lw, d_ll, n, st);
     if (!rc) { hipError_t e_ = hipMemcpy(&h, st, sizeof(h), hipMemcpyDeviceToHost); if (e_ != hipSuccess) rc = FG_E_HIP; else *out_beta = h.bnew; }
     (void)hipFree(d_lw); (void)hipFree(d_ll); (void)hipFree(st); R.free_all();
     return rc;
@@ -425,17 +747,33 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
     const long long N = e->C;
     const int S = e->S, TB = 256, NB = (int)((N + TB - 1) / TB);
     hipStream_t s = e->stream;
-    std::vector<void *> allocs;
-    auto A = [&](auto **p, size_t n) { int rc = dev_alloc(p, n); if (!rc) allocs.push_back((void *)*p); return rc; };
-    auto cleanup = [&]() { (void)hipStreamSynchronize(s); for (void *q : allocs) (void)hipFree(q); };
-    FgSmcDev M{}; FgSmcScalars *st = nullptr; Reducer R; Scanner SC;
-    double *d_lw = nullptr, *d_w = nullptr, *d_ll2 = nullptr, *d_lp2 = nullptr;
-    long long *d_vals2 = nullptr, *d_idx = nullptr;
+    // scratch: one arena per engine, allocated on the first run and reused (hipMalloc / hipFree per run cost more than the run)
     const size_t Sn = (size_t)std::max(1, S);
-    if (A(&M.ll, N) || A(&M.lprior, N) || A(&M.scale, Sn) || A(&M.log_scale, Sn) || A(&M.acc, Sn) || A(&M.tot, Sn) || A(&M.sw_n, Sn) ||
-        A(&M.sw_a, Sn) || A(&st, 1) || A(&d_lw, N) || A(&d_w, N) || A(&d_ll2, N) || A(&d_lp2, N) || A(&d_vals2, Sn * N) || A(&d_idx, N) ||
-        R.init()) { cleanup(); return FG_E_HIP; }
-    allocs.push_back(R.part_max); allocs.push_back(R.part_sum);
+    const long long n_chunks = (N + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const size_t max_blk = (size_t)((N + FG_WAVE - 1) / FG_WAVE);          // k_smc_rejuv blocks at one tile per block
+    size_t arena_off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = arena_off; arena_off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_ll = carve(N * 8), o_lp = carve(N * 8), o_scale = carve(Sn * 8), o_ls = carve(Sn * 8), o_acc = carve(Sn * 8), o_tot = carve(Sn * 8),
+                 o_st = carve(sizeof(FgSmcScalars)), o_lw = carve(N * 8), o_w = carve(N * 8), o_ll2 = carve(N * 8), o_lp2 = carve(N * 8), o_vals2 = carve(Sn * N * 8),
+                 o_idx = carve(N * 8), o_pmax = carve(RED_BLOCKS * 8), o_psum = carve(2 * RED_BLOCKS * 8), o_ess = carve(((size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) * 8),
+                 o_chunk = carve((size_t)n_chunks * 8), o_cum = carve(N * 8), o_blk = carve(max_blk * 2 * Sn * 4);
+    if (e->smc_arena_bytes < arena_off) {
+        if (e->smc_arena) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(e->smc_arena)); e->smc_arena = nullptr; e->smc_arena_bytes = 0; }
+        HIPCHK(hipMalloc(&e->smc_arena, arena_off));
+        e->smc_arena_bytes = arena_off;
+    }
+    char *ar = (char *)e->smc_arena;
+    auto cleanup = [&]() { (void)hipStreamSynchronize(s); };
+    FgSmcDev M{}; Reducer R; Scanner SC;
+    M.ll = (double *)(ar + o_ll); M.lprior = (double *)(ar + o_lp); M.scale = (double *)(ar + o_scale); M.log_scale = (double *)(ar + o_ls);
+    M.acc = (long long *)(ar + o_acc); M.tot = (long long *)(ar + o_tot); M.sw_n = nullptr; M.sw_a = nullptr;
+    M.blk = (unsigned int *)(ar + o_blk); M.S = S;
+    FgSmcScalars *st = (FgSmcScalars *)(ar + o_st);
+    double *d_lw = (double *)(ar + o_lw), *d_w = (double *)(ar + o_w), *d_ll2 = (double *)(ar + o_ll2), *d_lp2 = (double *)(ar + o_lp2);
+    long long *d_vals2 = (long long *)(ar + o_vals2), *d_idx = (long long *)(ar + o_idx);
+    R.part_max = (double *)(ar + o_pmax); R.part_sum = (double *)(ar + o_psum); R.ess_part = (double *)(ar + o_ess);
+    SC.chunk = (double *)(ar + o_chunk); SC.cum = (double *)(ar + o_cum); SC.cap = N; SC.external = true;
+    HIPCHK(hipMemsetAsync(ar + o_ls, 0, o_st - o_ls, s));                   // log_scale, acc, tot start at zero (DiminishingAdaptation::new)
     int rc = FG_OK;
 #define SMC_TRY(x) do { rc = (x); if (rc) { cleanup(); SC.free_all(); return rc; } } while (0)
 #define SMC_HIP(x) do { if ((x) != hipSuccess) { fg_set_error(#x); cleanup(); SC.free_all(); return FG_E_HIP; } } while (0)
@@ -461,10 +799,8 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
         while (beta < 1.0) {                                 // smc.rs:501-560
             steps += 1;
             // next_beta: ESS at b = 1, then 64 bisections on the device (smc.rs:588-622)
-            SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->one, 0));
-            for (int it = 0; it < 64; ++it) SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->mid, 1));
             if (steps >= 10000) { int one = 1; SMC_HIP(hipMemcpyAsync(&st->force_one, &one, sizeof(int), hipMemcpyHostToDevice, s)); }
-            hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(RED_THREADS), 0, s, st, (const double *)R.part_max, (const double *)R.part_sum, RED_BLOCKS, N, 2);
+            SMC_TRY(R.next_beta(s, d_lw, M.ll, N, st, /*uniform_lw=*/true));      // log_w = -ln N at every step's start (smc.rs:476,538-540)
             // reweight + evidence (smc.rs:512-529)
             SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
             hipLaunchKernelGGL(k_smc_apply, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, d_w, N, (const FgSmcScalars *)st);
@@ -483,11 +819,18 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
                 std::swap(M.ll, d_ll2); std::swap(M.lprior, d_lp2);
                 hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, -std::log((double)N));
                 if (e->d > 0) {
-                    SMC_TRY(set_lds(k_smc_rejuv, e->lds_score));
+                    const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
+                    const int wpb = FG_SMC_WPB(score);                                  // tiles (waves) per block
+                    const size_t lds_r = e->lds_score * wpb;
+                    if (lds_r > 150 * 1024 || S > FG_SMC_HIST) { fg_set_error("SMC rejuvenation: tile does not fit LDS"); cleanup(); SC.free_all(); return FG_E_LIMIT; }
+                    const unsigned nblk = (unsigned)((N + (long long)e->tw * wpb - 1) / ((long long)e->tw * wpb));
                     for (int r = 0; r < cfg->rejuvenation_steps; ++r) {
-                        hipLaunchKernelGGL(k_smc_rejuv, dim3((unsigned)((N + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, s, e->P, e->X, M,
-                                           (const FgSmcScalars *)st, (uint32_t)((steps - 1) * cfg->rejuvenation_steps + r));
-                        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, s, M, S);
+                        const uint32_t mv = (uint32_t)((steps - 1) * cfg->rejuvenation_steps + r);
+#define SMC_REJUV(SC_) do { SMC_TRY(set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))); \
+                            hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); } while (0)
+                        if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2); else SMC_REJUV(-1);
+#undef SMC_REJUV
+                        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, M, S, (int)nblk);
                         n_runs += 2 * N;
                     }
                 }

@@ -492,13 +492,16 @@ class Engine:
         return a
 
     # ---- SMC ----------------------------------------------------------------------------
-    def smc_run(self, resampling_method=RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=0, max_betas=10000):
-        """`adaptive_smc` (/root/reference/src/inference/smc.rs:455-581) over this engine's chains as particles."""
+    def smc_run(self, resampling_method=RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=0, max_betas=10000, download=True):
+        """`adaptive_smc` (/root/reference/src/inference/smc.rs:455-581) over this engine's chains as particles.
+        download=False leaves particles and weights in HBM (engine values / fg_smc_run's device state): only the
+        evidence, the ladder and the counters come back."""
         cfg = fg_smc_config(int(resampling_method), float(ess_threshold), int(rejuvenation_steps))
         res = fg_smc_result()
-        log_w, w, betas = np.zeros(self.C), np.zeros(self.C), np.zeros(max_betas)
-        _check(lib().fg_smc_run(self.h, C.byref(cfg), _dp(log_w), _dp(w), C.byref(res), _dp(betas), max_betas))
-        return dict(values=self.get_values(), log_w=log_w, weights=w, log_evidence=res.log_evidence,
+        betas = np.zeros(max_betas)
+        log_w, w = (np.zeros(self.C), np.zeros(self.C)) if download else (None, None)
+        _check(lib().fg_smc_run(self.h, C.byref(cfg), _dp(log_w) if download else None, _dp(w) if download else None, C.byref(res), _dp(betas), max_betas))
+        return dict(values=self.get_values() if download else None, log_w=log_w, weights=w, log_evidence=res.log_evidence,
                     betas=betas[:res.n_steps], n_model_runs=res.n_model_runs)
 
     # ---- diagnostics kernels -----------------------------------------------------------------
