@@ -155,28 +155,6 @@ __device__ __forceinline__ bool fg_trajectory(const FgProgramDev &P, double *slo
     return bad || !fg_finite(lj_end);
 }
 
-__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, int tw, const double *m_inv, long long C) {
-    double s = 0.0;
-    if (m_inv) {
-        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; }
-    } else {                                              // identity mass: p*p*1.0 == p*p exactly
-#pragma unroll 8
-        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p; }
-    }
-    return 0.5 * s;
-}
-
-// p0 ~ N(0, M): hmc.rs:436-441.  Box-Muller pairs from the chain's (iteration) stream.
-__device__ __forceinline__ void fg_draw_momentum(const FgProgramDev &P, FgStream &rng, double *pl, int tw, const double *mass_sqrt,
-                                                 long long C) {
-    for (int i = 0; i < P.d; i += 2) {
-        double z0, z1;
-        fg_rng_normal_pair(rng, z0, z1);
-        pl[i * tw] = z0 * (mass_sqrt ? mass_sqrt[(long long)i * C] : 1.0);
-        if (i + 1 < P.d) pl[(i + 1) * tw] = z1 * (mass_sqrt ? mass_sqrt[(long long)(i + 1) * C] : 1.0);
-    }
-}
-
 struct FgTransOut { bool accepted, divergent; double alpha, lj; };
 
 // hmc_transition (hmc.rs:419-473).  On entry: slots = current q (and discrete sites),
@@ -888,7 +866,7 @@ int fg_log_joint_stream(fg_engine *e, double *h_acc, double *h_rec_lp) {
 }
 
 // ------------------------------------------------------------------ HMC host side
-static int hmc_alloc(fg_engine *e, bool mass) {
+int fg_internal_hmc_alloc(fg_engine *e, bool mass) {
     auto A = [&](auto **p, size_t n) { int rc = dev_alloc(p, n); if (!rc) e->hmc_allocs.push_back((void *)*p); return rc; };
     size_t C = (size_t)e->C, d = (size_t)std::max(1, e->d);
     if (!e->H.lj) {
@@ -903,7 +881,7 @@ static int hmc_alloc(fg_engine *e, bool mass) {
     return FG_OK;
 }
 
-static void hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg) {
+void fg_internal_hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg) {
     e->cfg = *cfg;
     e->H.L = cfg->n_leapfrog > 1 ? cfg->n_leapfrog : 1;        // hmc.rs:684
     e->H.h = cfg->finite_diff_eps; e->H.target = cfg->target_accept;
@@ -935,9 +913,9 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
     if (cfg->n_leapfrog < 1 || cfg->n_leapfrog > 100000) { fg_set_error("n_leapfrog must be in [1, 100000] (a trajectory of 0 steps never moves: hmc.rs:385)"); return FG_E_BAD_ARG; }
     if (!(cfg->finite_diff_eps > 0.0) || !std::isfinite(cfg->finite_diff_eps)) { fg_set_error("finite_diff_eps must be positive and finite"); return FG_E_BAD_ARG; }
     const bool mass = cfg->adapt_mass && n_warmup >= 4;                 // hmc.rs:704-708
-    int rc = hmc_alloc(e, mass);
+    int rc = fg_internal_hmc_alloc(e, mass);
     if (rc) return rc;
-    hmc_set_cfg(e, cfg);
+    fg_internal_hmc_set_cfg(e, cfg);
     e->H.use_mass = mass ? 1 : 0;
     e->n_warmup = n_warmup; e->iter = 0; e->mass_adapt_at = mass ? n_warmup / 2 : -1;
     const int TB = 256, NB = (int)((e->C + TB - 1) / TB);
@@ -1028,7 +1006,7 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
     return FG_OK;
 }
 
-static int hmc_step_impl(fg_engine *e, int n_transitions, double *d_draws, double *d_pos_all, double *d_info) {
+int fg_internal_hmc_step(fg_engine *e, int n_transitions, double *d_draws, double *d_pos_all, double *d_info) {
     NEED_ENGINE(e);
     if (!e->hmc_ready) { fg_set_error("fg_hmc_step before fg_hmc_init"); return FG_E_STATE; }
     if (n_transitions < 0) return FG_E_BAD_ARG;
@@ -1068,9 +1046,9 @@ static int hmc_step_impl(fg_engine *e, int n_transitions, double *d_draws, doubl
     return FG_OK;
 }
 
-int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) { return hmc_step_impl(e, n_transitions, d_draws, nullptr, nullptr); }
+int fg_hmc_step(fg_engine *e, int n_transitions, double *d_draws) { return fg_internal_hmc_step(e, n_transitions, d_draws, nullptr, nullptr); }
 int fg_hmc_step_info(fg_engine *e, int n_transitions, double *d_positions, double *d_info) {
-    return hmc_step_impl(e, n_transitions, nullptr, d_positions, d_info);
+    return fg_internal_hmc_step(e, n_transitions, nullptr, d_positions, d_info);
 }
 
 int fg_hmc_get_stats(fg_engine *e, fg_hmc_stats *st) {
@@ -1146,8 +1124,19 @@ int fg_hmc_set_step_size(fg_engine *e, double eps) {    // hmc.rs:741-747
     hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, e->stream, e->H.frozen, e->C, eps);
     HIPCHK(hipGetLastError());
     e->n_warmup = std::min(e->n_warmup, e->iter);
+    // leaving warmup also ends mass adaptation: the reference only adapts the mass while `warming` (hmc.rs:877-908)
+    if (e->mass_adapt_at >= e->iter) e->mass_adapt_at = -1;
     return FG_OK;
 }
+int fg_hmc_set_n_leapfrog(fg_engine *e, int n_leapfrog) {     // hmc.rs:751-753
+    NEED_ENGINE(e);
+    if (!e->hmc_ready) return FG_E_STATE;
+    e->cfg.n_leapfrog = n_leapfrog > 1 ? n_leapfrog : 1;
+    e->H.L = e->cfg.n_leapfrog;
+    return FG_OK;
+}
+int fg_hmc_is_warming_up(const fg_engine *e) { return (e && e->hmc_ready && e->iter < e->n_warmup) ? 1 : 0; }   // hmc.rs:780-782
+int64_t fg_hmc_iterations(const fg_engine *e) { return (e && e->hmc_ready) ? (int64_t)e->iter : 0; }             // hmc.rs:785-787
 
 int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *h_ok) {
     NEED_ENGINE(e);
@@ -1172,7 +1161,7 @@ int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *
 static int hmc_prepare_injected(fg_engine *e, const fg_hmc_config *cfg) {
     if (!cfg) return FG_E_BAD_ARG;
     if (int rc0 = hmc_lds_ok(e)) return rc0;
-    int rc = hmc_alloc(e, false);
+    int rc = fg_internal_hmc_alloc(e, false);
     if (rc) return rc;
     if (!e->hmc_ready) {      // standalone use: lj of the current values, identity mass
         e->H.use_mass = 0;
@@ -1180,7 +1169,7 @@ static int hmc_prepare_injected(fg_engine *e, const fg_hmc_config *cfg) {
                            (double *)nullptr, e->H.lj);
         HIPCHK(hipGetLastError());
     }
-    hmc_set_cfg(e, cfg);
+    fg_internal_hmc_set_cfg(e, cfg);
     return FG_OK;
 }
 
@@ -1222,9 +1211,7 @@ int fg_hmc_find_eps_injected(fg_engine *e, const fg_hmc_config *cfg, const doubl
 
 
 // ------------------------------------------------------------------ MH host side
-int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
-    NEED_ENGINE(e);
-    if (n_warmup < 0) return FG_E_BAD_ARG;
+int fg_internal_mh_alloc(fg_engine *e) {
     size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S);
     auto A = [&](auto **p, size_t n) { int rc = dev_alloc(p, n); if (!rc) e->mh_allocs.push_back((void *)*p); return rc; };
     if (!e->M.lw) {
@@ -1232,6 +1219,33 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
             A(&e->M.kind, S * C) || A(&e->M.n_acc, C))
             return FG_E_HIP;
     }
+    return FG_OK;
+}
+int fg_internal_mh_set_overrides(fg_engine *e, const fg_site_proposal *overrides) {
+    const size_t S = (size_t)std::max(1, e->S);
+    e->M.ov_kind = nullptr; e->M.ov_lo = nullptr; e->M.ov_hi = nullptr;
+    e->mh_has_prior_resample = false;
+    e->mh_overrides.clear();
+    if (!overrides) return FG_OK;
+    e->mh_overrides.assign(overrides, overrides + e->S);
+    for (int j = 0; j < e->S; j++) if (overrides[j].kind == FG_PROP_PRIOR_RESAMPLE) e->mh_has_prior_resample = true;
+    std::vector<int> k(S); std::vector<double> lo(S), hi(S);
+    for (int j = 0; j < e->S; j++) {            // device tables are indexed by LDS slot
+        const int sl = e->prog->site_slot[j];
+        k[sl] = overrides[j].kind; lo[sl] = overrides[j].lower; hi[sl] = overrides[j].upper;
+        if (k[sl] < 0 || k[sl] > 4) { fg_set_error("fg_mh_init: unknown proposal kind"); return FG_E_BAD_ARG; }
+    }
+    int *dk = nullptr; double *dlo = nullptr, *dhi = nullptr;
+    if (dev_upload(&dk, k) || dev_upload(&dlo, lo) || dev_upload(&dhi, hi)) return FG_E_HIP;
+    e->mh_allocs.push_back(dk); e->mh_allocs.push_back(dlo); e->mh_allocs.push_back(dhi);
+    e->M.ov_kind = dk; e->M.ov_lo = dlo; e->M.ov_hi = dhi;
+    return FG_OK;
+}
+int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
+    NEED_ENGINE(e);
+    if (n_warmup < 0) return FG_E_BAD_ARG;
+    size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S);
+    if (int rc0 = fg_internal_mh_alloc(e)) return rc0;
     HIPCHK(hipMemsetAsync(e->M.log_scale, 0, S * C * 8, e->stream));
     HIPCHK(hipMemsetAsync(e->M.acc, 0, S * C * 4, e->stream));
     HIPCHK(hipMemsetAsync(e->M.tot, 0, S * C * 4, e->stream));
@@ -1239,21 +1253,7 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
     HIPCHK(hipMemsetAsync(e->M.n_acc, 0, C * 8, e->stream));
     const int TB = 256;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((S * C + TB - 1) / TB)), dim3(TB), 0, e->stream, e->M.scale, (long long)(S * C), 1.0);
-    e->M.ov_kind = nullptr; e->M.ov_lo = nullptr; e->M.ov_hi = nullptr;
-    e->mh_has_prior_resample = false;
-    if (overrides) {
-        for (int j = 0; j < e->S; j++) if (overrides[j].kind == FG_PROP_PRIOR_RESAMPLE) e->mh_has_prior_resample = true;
-        std::vector<int> k(S); std::vector<double> lo(S), hi(S);
-        for (int j = 0; j < e->S; j++) {            // device tables are indexed by LDS slot
-            const int sl = e->prog->site_slot[j];
-            k[sl] = overrides[j].kind; lo[sl] = overrides[j].lower; hi[sl] = overrides[j].upper;
-            if (k[sl] < 0 || k[sl] > 4) { fg_set_error("fg_mh_init: unknown proposal kind"); return FG_E_BAD_ARG; }
-        }
-        int *dk = nullptr; double *dlo = nullptr, *dhi = nullptr;
-        if (dev_upload(&dk, k) || dev_upload(&dlo, lo) || dev_upload(&dhi, hi)) return FG_E_HIP;
-        e->mh_allocs.push_back(dk); e->mh_allocs.push_back(dlo); e->mh_allocs.push_back(dhi);
-        e->M.ov_kind = dk; e->M.ov_lo = dlo; e->M.ov_hi = dhi;
-    }
+    if (int rc1 = fg_internal_mh_set_overrides(e, overrides)) return rc1;
     int rc = fg_launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->M.lw);       // mh.rs:950-957
     if (rc) return rc;
     e->mh_warmup = n_warmup; e->mh_iter = 0; e->mh_ready = true;

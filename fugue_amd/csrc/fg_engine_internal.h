@@ -95,6 +95,7 @@ struct fg_engine {
     FgMhDev M{};
     std::vector<void *> mh_allocs;
     int mh_warmup = 0, mh_iter = 0;
+    std::vector<fg_site_proposal> mh_overrides;   // as given to fg_mh_init (site order), for fg_state_export
     int *d_rec = nullptr; int rec_cap = 0;
     void *smc_arena = nullptr; size_t smc_arena_bytes = 0;   // scratch of fg_smc_run, allocated once per engine (fg_smc.hip)
     double *d_tmp = nullptr;     // [C] scratch
@@ -105,6 +106,30 @@ struct fg_engine {
     int n_simd = 1024;         // SIMDs on the device (4 per CU)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
+
+// in-order kinetic energy and momentum draw shared by the HMC kernels
+__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, int tw, const double *m_inv, long long C) {
+    double s = 0.0;
+    if (m_inv) {
+        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; }
+    } else {                                              // identity mass: p*p*1.0 == p*p exactly
+#pragma unroll 8
+        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p; }
+    }
+    return 0.5 * s;
+}
+
+// p0 ~ N(0, M): hmc.rs:436-441.  Box-Muller pairs from the chain's (iteration) stream.
+__device__ __forceinline__ void fg_draw_momentum(const FgProgramDev &P, FgStream &rng, double *pl, int tw, const double *mass_sqrt,
+                                                 long long C) {
+    for (int i = 0; i < P.d; i += 2) {
+        double z0, z1;
+        fg_rng_normal_pair(rng, z0, z1);
+        pl[i * tw] = z0 * (mass_sqrt ? mass_sqrt[(long long)i * C] : 1.0);
+        if (i + 1 < P.d) pl[(i + 1) * tw] = z1 * (mass_sqrt ? mass_sqrt[(long long)(i + 1) * C] : 1.0);
+    }
+}
+
 
 namespace {
 
@@ -142,6 +167,15 @@ int dev_upload(T **p, const std::vector<T> &v) {
 
 // fg_hmc_sep.hip: register-resident trajectories for independent-sites programs (FG_E_UNSUPPORTED: not applicable)
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
+
+// fg_engine.hip internals used by fg_state.hip
+extern "C" {
+int fg_internal_hmc_alloc(fg_engine *e, bool mass);
+void fg_internal_hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg);
+int fg_internal_hmc_step(fg_engine *e, int n_transitions, double *d_draws, double *d_pos_all, double *d_info);
+int fg_internal_mh_alloc(fg_engine *e);
+int fg_internal_mh_set_overrides(fg_engine *e, const fg_site_proposal *overrides);
+}
 
 // fg_mh.hip: multi-wave single-site MH for programs with a score stream (FG_E_UNSUPPORTED: not applicable)
 int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t);

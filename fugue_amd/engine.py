@@ -68,7 +68,8 @@ ABI_SYMBOLS = [
     "fg_engine_set_values", "fg_engine_get_values", "fg_engine_values_device", "fg_prior_init", "fg_log_joint", "fg_log_joint_stream",
     "fg_program_sample_discrete_uniform",
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
-    "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_grad", "fg_hmc_transition_injected",
+    "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_set_n_leapfrog", "fg_hmc_is_warming_up", "fg_hmc_iterations", "fg_hmc_step_recorded",
+    "fg_state_size", "fg_state_export", "fg_state_import", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
@@ -139,6 +140,15 @@ def lib():
     L.fg_hmc_get_step_sizes.argtypes = [vp, dp]
     L.fg_hmc_get_log_joint.argtypes = [vp, dp]
     L.fg_hmc_set_step_size.argtypes = [vp, C.c_double]
+    L.fg_hmc_set_n_leapfrog.argtypes = [vp, C.c_int]
+    L.fg_hmc_is_warming_up.argtypes = [vp]
+    L.fg_hmc_iterations.restype = C.c_int64
+    L.fg_hmc_iterations.argtypes = [vp]
+    L.fg_hmc_step_recorded.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), dp, dp, ip, vp]
+    L.fg_state_size.restype = C.c_int64
+    L.fg_state_size.argtypes = [vp]
+    L.fg_state_export.argtypes = [vp, vp, C.c_size_t]
+    L.fg_state_import.argtypes = [vp, vp, C.c_size_t]
     L.fg_hmc_grad.argtypes = [vp, C.c_double, C.c_int, dp, ip]
     L.fg_hmc_transition_injected.argtypes = [vp, C.POINTER(fg_hmc_config), C.c_double, dp, dp, ip, dp, ip, dp]
     L.fg_hmc_find_eps_injected.argtypes = [vp, C.POINTER(fg_hmc_config), dp, dp]
@@ -428,6 +438,35 @@ class Engine:
 
     def hmc_set_step_size(self, eps: float):
         _check(lib().fg_hmc_set_step_size(self.h, float(eps)))
+
+    def hmc_set_n_leapfrog(self, n: int):
+        _check(lib().fg_hmc_set_n_leapfrog(self.h, int(n)))
+
+    def hmc_is_warming_up(self) -> bool:
+        return bool(lib().fg_hmc_is_warming_up(self.h))
+
+    def hmc_iterations(self) -> int:
+        return int(lib().fg_hmc_iterations(self.h))
+
+    def hmc_step_recorded(self, chain_ids: Sequence[int], n_leapfrog: int):
+        """`HmcSession::step_recorded` for every chain; returns (trajectories [K][L+1][d], Hamiltonians [K][L+1],
+        points recorded [K]) of the chosen chains."""
+        ids = np.ascontiguousarray(chain_ids, dtype=np.int64)
+        K, L = ids.size, int(n_leapfrog)
+        traj, ham = np.zeros((max(1, K), L + 1, max(1, self.d))), np.zeros((max(1, K), L + 1))
+        npts = np.zeros(max(1, K), dtype=np.int32)
+        _check(lib().fg_hmc_step_recorded(self.h, K, ids.ctypes.data_as(C.POINTER(C.c_int64)), _dp(traj), _dp(ham),
+                                          npts.ctypes.data_as(C.POINTER(C.c_int32)), None))
+        return traj[:K, :, :self.d], ham[:K], npts[:K]
+
+    def state_export(self) -> bytes:
+        n = lib().fg_state_size(self.h)
+        buf = C.create_string_buffer(n)
+        _check(lib().fg_state_export(self.h, buf, n))
+        return buf.raw
+
+    def state_import(self, blob: bytes):
+        _check(lib().fg_state_import(self.h, blob, len(blob)))
 
     def hmc_grad(self, h: float = 1e-5, grad_mode: int = GRAD_FD_DENSE):
         g = np.zeros((max(1, self.d), self.C))

@@ -211,6 +211,17 @@ int fg_hmc_get_log_joint(fg_engine *e, double *h_lj /*[C]*/);
 int fg_hmc_get_mass(fg_engine *e, double *h_m_inv);
 /* set_step_size (hmc.rs:741-747) for every chain */
 int fg_hmc_set_step_size(fg_engine *e, double eps);
+/* HmcSession::set_n_leapfrog / is_warming_up / iterations (hmc.rs:751-753, 780-782, 785-787) */
+int     fg_hmc_set_n_leapfrog(fg_engine *e, int n_leapfrog);
+int     fg_hmc_is_warming_up(const fg_engine *e);
+int64_t fg_hmc_iterations(const fg_engine *e);
+/* HmcSession::step_recorded (hmc.rs:811-817) for every chain: ONE transition, and for the n_recorded chains h_chain_ids
+ * the leapfrog trajectory with the Hamiltonian at each integration point (LeapfrogPoint, hmc.rs:338-343):
+ * h_traj [n_recorded][L+1][d] positions, h_ham [n_recorded][L+1], h_n_points [n_recorded] (L + 1, fewer when the
+ * trajectory left the support: recording stops at the last finite point).  d_info (optional) [4][C] as fg_hmc_step_info.
+ * Recording consumes no randomness: the chains advance exactly as under fg_hmc_step (hmc.rs:1058-1087). */
+int fg_hmc_step_recorded(fg_engine *e, int n_recorded, const int64_t *h_chain_ids, double *h_traj, double *h_ham,
+                         int32_t *h_n_points, double *d_info);
 /* test / diagnostics hooks under injected randomness -------------------------------- */
 /* grad_log_joint (hmc.rs:304-329) at the engine's current values; h_grad [d][C], h_ok [C] */
 int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *h_ok);
@@ -285,6 +296,16 @@ int fg_diag_chain_moments(fg_engine *e, const double *d_draws, int n, int d, dou
  * (mcmc_utils.rs:231-244) for t in [lag0, lag0 + n_lags). */
 int fg_diag_autocov_sums(fg_engine *e, const double *d_draws, int n, int d, const double *d_moments,
                          int lag0, int n_lags, double *h_sums);
+
+/* ------------------------------------------------------------------ checkpoint / resume
+ * The per-chain sampler state as one flat host blob: the fields of HmcSession (hmc.rs:643-661) for every chain, the MH
+ * chain state (current trace, log-weight, DiminishingAdaptation per site, decided proposal kinds, overrides) and the
+ * iteration counters that position the counter-based random streams (cf. the wasm samplers' step(n) protocol,
+ * crates/fugue-wasm/src/mh.rs:92-168).  run(a); export; [new engine of the same program and chain count] import;
+ * run(b) reproduces run(a + b) bit for bit. */
+int64_t fg_state_size(fg_engine *e);
+int     fg_state_export(fg_engine *e, void *h_buf, size_t capacity);
+int     fg_state_import(fg_engine *e, const void *h_buf, size_t size);
 
 /* raw device memory helpers so a host without a HIP binding can own draw buffers */
 void *fg_device_alloc(fg_engine *e, size_t bytes);
