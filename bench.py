@@ -148,7 +148,7 @@ def cpu_baseline_mh():
     cal = {}
     for n_sites, published_us in ((20, 15.3), (50, 73.1)):
         om = orc.OracleModel(W.reference_model(n_sites))
-        chains = 4000 if n_sites == 20 else 1500
+        chains = 20000 if n_sites == 20 else 8000
         t0 = time.perf_counter()
         om.mh_run(1, chains, 50, 50, None, [0], n_threads=1, want_draws=False)
         dt = time.perf_counter() - t0
@@ -156,16 +156,16 @@ def cpu_baseline_mh():
                                               "sample": f"{chains} chains x (50 + 50) transitions, 1 thread"}
     cores = host_cores()
     om = orc.OracleModel(W.reference_model(20))
-    chains = 4096 * max(1, cores // 4)
+    chains = 8192 * max(1, cores // 4)
     t0 = time.perf_counter()
-    om.mh_run(1, chains, 100, 100, None, [0], n_threads=cores, want_draws=False)
+    om.mh_run(1, chains, 1000, 1000, None, [0], n_threads=cores, want_draws=False)
     dt = time.perf_counter() - t0
-    return {"value": chains * 200 / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{chains} chains x (100 + 100) steps of reference_model(20), {dt:.1f} s wall; C restatement, not the Rust binary",
+    return {"value": chains * 2000 / dt, "unit": "chain-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{chains} chains x (1000 + 1000) steps of reference_model(20), {dt:.1f} s wall; C restatement, not the Rust binary",
             "calibration": cal}
 
 
-def cpu_baseline_smc(n=65536):
+def cpu_baseline_smc(n=1 << 20):
     from fugue_amd import workloads as W
     from oracle import oracle as orc
     om = orc.OracleModel(W.smc_normal())
@@ -285,14 +285,37 @@ def run_rank(args):
     dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n, draws[done].data_ptr()), K, args.launch)))
     launch_ms, n_launch = full_launch_ms(events)
 
-    # ---- after the timed region: the ONLY cross-chain step -- split R-hat / multichain ESS.  Each rank reduces its own
-    # draws to per-chain moments on its GPU; ranks all-gather those over RCCL/xGMI.
+    # ---- after the timed region: the ONLY cross-chain step -- split R-hat / multichain ESS.  Each rank reduces its own draws
+    # to per-chain moments on its GPU; the library all-gathers those and all-reduces the pooled lag sums over RCCL / xGMI
+    # (fg_diag_rhat_ess, communicator created from an id that rank 0 obtains and torch.distributed's store hands out).
     t_diag = time.perf_counter()
-    prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
-    cd = D.ChainDiagnostics(prov, device=coll_dev if (world > 1 and not one_device) else None)
-    rhat = cd.split_rhat()
-    ess = cd.ess() if K >= 4 else np.full(d, float("nan"))
-    prov.close()
+    diag_path, comm = "library (single GPU)", None
+    if world > 1 and not one_device:
+        ok = 1
+        try:
+            ids = [E.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = eng.comm_init(world, rank, ids[0])
+        except Exception as ex:                                  # every rank must take the same path
+            sys.stderr.write(f"rank {rank}: RCCL communicator in the library failed ({ex}); falling back to torch.distributed\n")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            E.comm_destroy(comm); comm = None
+        diag_path = "library: ncclAllGather + ncclAllReduce" if comm is not None else "torch.distributed collectives + library combination"
+    if world == 1 or comm is not None:
+        r = eng.diag_rhat_ess(draws.data_ptr(), K, d, comm)
+        rhat, ess, n_chains_diag = r["r_hat"], (r["ess"] if K >= 4 else np.full(d, float("nan"))), r["chains"]
+        if comm is not None:
+            E.comm_destroy(comm)
+    else:
+        prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
+        cd = D.ChainDiagnostics(prov, device=None if one_device else coll_dev)
+        rhat = cd.split_rhat()
+        ess = cd.ess() if K >= 4 else np.full(d, float("nan"))
+        n_chains_diag = cd.m
+        prov.close()
     t_diag = time.perf_counter() - t_diag
 
     st = eng.hmc_stats()
@@ -322,7 +345,7 @@ def run_rank(args):
                    "transitions_per_launch": n_launch, "sharding": f"chains x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS, "traffic": measured_traffic(C, n_launch, args.grad),
-                     "kernel": "k_hmc_stream_steps", "avg_launch_ms": launch_ms,
+                     "kernel": "k_hmc_sep_steps" if args.grad == "fd_sparse" else "k_hmc_stream_steps", "avg_launch_ms": launch_ms,
                      "logpdf_evals_per_transition": evals, "flops_per_logpdf": FLOPS_PER_NORMAL_LOGPDF,
                      "note": "achieved = log-pdf evaluations the launch performs x 8 flops / HIP-event time; peak = f64 vector FMA peak "
                              "(2 flops/instr at 2.4 GHz) -- the arithmetic is unfused add/mul (reference rounding, 1 flop/instr) and the clock "
@@ -339,8 +362,8 @@ def run_rank(args):
                                                           "sampling transitions after W untimed warmup transitions)"},
         "check": {"posterior_mean_max_abs_err": mean_err, "posterior_var_max_abs_err": var_err,
                   "accept_rate": st.accept_rate, "mean_step_size": st.mean_step_size, "n_divergent": int(st.n_divergent),
-                  "split_rhat_max": float(np.max(rhat)), "ess_min": float(np.min(ess)), "chains_in_rhat": int(cd.m),
-                  "diagnostics_seconds": t_diag,
+                  "split_rhat_max": float(np.max(rhat)), "ess_min": float(np.min(ess)), "chains_in_rhat": int(n_chains_diag),
+                  "diagnostics_seconds": t_diag, "diagnostics_path": diag_path,
                   "note": "statistics of the K timed draws themselves: with few steps / a short warmup they are NOT the 1e-3 evidence (a chain of "
                           "20 draws after 5 warmup transitions has not mixed) -- see `validity`"},
     }
@@ -389,7 +412,7 @@ def leg_mh(args, E, W, torch, clock, stream, world, rank, dev):
             "config": {"workload": f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91: S=20, O=19), {C} chains/GPU, "
                                    f"{nw} adapting + {ns} sampling steps, all timed", "steps_per_launch": n_launch},
             "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "k_mh_steps", "avg_launch_ms": launch_ms,
+                         "traffic": None, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
                          "note": "(S + O) log-pdfs x 8 flops per chain step / HIP-event time",
                          "hbm_nominal": {"achieved": C * n_launch * bytes_per_step / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "note": "SURVEY 8d: 8 S + 40 B per chain step; the value row lives in LDS across a launch"}},

@@ -1,15 +1,19 @@
-// fg_diag.hip -- per-chain statistics for the cross-chain diagnostics (split R-hat:
-// src/inference/diagnostics.rs:240-304; multi-chain ESS: src/inference/mcmc_utils.rs:231-339).
+// fg_diag.hip -- cross-chain diagnostics behind the C ABI: split R-hat (src/inference/diagnostics.rs:240-304), multi-chain ESS
+// (src/inference/mcmc_utils.rs:231-339), pooled mean / std (diagnostics.rs:331-352).
 //
-// Draws stay on the GPU that produced them, laid out [n][d][C] (chain fastest): each thread owns
-// one (coordinate, chain) column and walks the n draws with stride d*C -- coalesced across the 64
-// lanes of a wave.  Only O(d*C) moments (for R-hat) and O(d*lags) pooled autocovariance sums
-// (for ESS) leave the GPU; with several GPUs those are what the RCCL all-gather / all-reduce
-// moves (fugue_amd/diagnostics.py).
+// Draws stay on the GPU that produced them, laid out [n][d][C] (chain fastest): a thread owns one (coordinate, chain)
+// column and walks its n draws with stride d*C -- coalesced across the 64 lanes of a wave.  Per chain only moments leave
+// the kernel ([d][6][C]); per lag only the sum over chains of the lag's autocovariance ([d][lags]).  With several GPUs
+// (one process per GPU, chains sharded) the ONLY exchange of the whole engine happens here, inside the library, over
+// RCCL: an all-gather of the per-chain moments and an all-reduce of the pooled lag sums; the Geyer / R-hat combination
+// is C++ (fg_diag_host.cpp).  RCCL is bound at run time (dlopen): the copy that sits next to the HIP runtime this library runs on.
 #include "fg_engine_internal.h"
 
-// moments [d][6][C]: full-chain mean, sum of squared deviations; then the same for the first and
-// second half (half = n/2, the middle draw dropped when n is odd: split_f64_chains :240-253).
+#include <dlfcn.h>
+
+// moments [d][6][C]: full-chain mean, sum of squared deviations; then the same for the first and second half (half = n/2,
+// the middle draw dropped when n is odd: split_f64_chains :240-253).  Two sweeps over the column: the three sums (each
+// the in-order sum the reference forms, values.iter().sum() :275-278), then the three sums of squared deviations (:292-296).
 __global__ void k_diag_moments(const double *draws, int n, int d, long long C, double *out) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
@@ -17,43 +21,177 @@ __global__ void k_diag_moments(const double *draws, int n, int d, long long C, d
     const double *x = draws + (long long)i * C + c;
     const long long st = (long long)d * C;
     const int half = n / 2;
-    const int lo[3] = { 0, 0, half }, hi[3] = { n, half, 2 * half };
-    for (int part = 0; part < 3; ++part) {
-        const int a = lo[part], b = hi[part], len = b - a;
-        double s = 0.0;
-        for (int t = a; t < b; ++t) s += x[t * st];
-        const double mean = len > 0 ? s / (double)len : NAN;            // values.iter().sum() / len  :275-278
-        double ssd = 0.0;
-        for (int t = a; t < b; ++t) { const double dv = x[t * st] - mean; ssd += dv * dv; }   // :292-296
-        out[((long long)i * 6 + 2 * part) * C + c] = mean;
-        out[((long long)i * 6 + 2 * part + 1) * C + c] = ssd;
+    double s_full = 0.0, s_h1 = 0.0, s_h2 = 0.0;
+    for (int t = 0; t < n; ++t) {
+        const double v = x[t * st];
+        s_full += v;
+        if (t == half - 1) s_h1 = s_full;                      // the in-order sum of the first half IS the running sum there
+        if (t >= half && t < 2 * half) s_h2 += v;
     }
+    const double m_full = n > 0 ? s_full / (double)n : NAN, m_h1 = half > 0 ? s_h1 / (double)half : NAN, m_h2 = half > 0 ? s_h2 / (double)half : NAN;
+    double q_full = 0.0, q_h1 = 0.0, q_h2 = 0.0;
+    for (int t = 0; t < n; ++t) {
+        const double v = x[t * st];
+        const double a = v - m_full; q_full += a * a;
+        if (t < half) { const double b = v - m_h1; q_h1 += b * b; }
+        else if (t < 2 * half) { const double b = v - m_h2; q_h2 += b * b; }
+    }
+    double *o = out + (long long)i * 6 * C + c;
+    o[0] = m_full; o[C] = q_full; o[2 * C] = m_h1; o[3 * C] = q_h1; o[4 * C] = m_h2; o[5 * C] = q_h2;
 }
 
-// Sum over chains of the biased autocovariances acov_t = (1/n) sum_i c_i c_{i+t}
-// (autocovariances, mcmc_utils.rs:231-244) for lags [lag0, lag0 + n_lags).
-// grid = (chain blocks, lags, d); per-block partial sums are written out and added on the host in
-// block order, so the result does not depend on scheduling.
+// Sum over chains of the biased autocovariances acov_t = (1/n) sum_i c_i c_{i+t} (autocovariances, mcmc_utils.rs:231-244) for
+// the FG_ACOV_LAGS lags [lag0, lag0 + FG_ACOV_LAGS): ONE sweep over the column with the last FG_ACOV_LAGS centred values of
+// the trailing stream in registers (each draw is read twice per chunk, not twice per lag); per chain the products are
+// added in the reference's order (ascending i).  Block partials go to `partial`, k_diag_acov_finish adds them in block
+// order: the result does not depend on scheduling.
+#define FG_ACOV_LAGS 32
 __global__ __launch_bounds__(256) void k_diag_autocov(const double *draws, int n, int d, long long C, const double *moments, int lag0,
-                                                       double *partial /*[d][n_lags][gridDim.x]*/) {
-    __shared__ double sh[4];
+                                                       double *partial /*[d][FG_ACOV_LAGS][gridDim.x]*/) {
+    __shared__ double sh[4][FG_ACOV_LAGS];
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lag = lag0 + blockIdx.y, i = blockIdx.z;
-    double s = 0.0;
-    if (c < C && lag < n) {
+    const int i = blockIdx.y;
+    double acc[FG_ACOV_LAGS], win[FG_ACOV_LAGS];
+#pragma unroll
+    for (int k = 0; k < FG_ACOV_LAGS; ++k) { acc[k] = 0.0; win[k] = 0.0; }
+    if (c < C) {
         const double *x = draws + (long long)i * C + c;
         const long long st = (long long)d * C;
         const double mean = moments[((long long)i * 6) * C + c];
-        for (int t = 0; t + lag < n; ++t) s += (x[t * st] - mean) * (x[(t + lag) * st] - mean);
-        s /= (double)n;
+        // u = the later index of a product c_{u - lag} c_u; win[k] = c_{u - lag0 - k} (0 before the chain starts)
+        for (int u = lag0; u < n; ++u) {
+            const double cur = x[u * st] - mean;
+#pragma unroll
+            for (int k = FG_ACOV_LAGS - 1; k > 0; --k) win[k] = win[k - 1];
+            win[0] = x[(u - lag0) * st] - mean;
+#pragma unroll
+            for (int k = 0; k < FG_ACOV_LAGS; ++k) acc[k] += win[k] * cur;      // win[k] = 0 before the chain starts: adds +-0
+        }
+#pragma unroll
+        for (int k = 0; k < FG_ACOV_LAGS; ++k) acc[k] /= (double)n;
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+#pragma unroll
+    for (int k = 0; k < FG_ACOV_LAGS; ++k) {
+        double s = acc[k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = s;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partial[((long long)i * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x < FG_ACOV_LAGS) {
+        const int k = threadIdx.x;
+        partial[((long long)i * FG_ACOV_LAGS + k) * gridDim.x + blockIdx.x] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+    }
+}
+__global__ void k_diag_acov_finish(const double *partial, int nblk, int n_lags, int d, double *out /*[d][n_lags]*/) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d * n_lags) return;
+    const int i = j / n_lags, k = j % n_lags;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[((long long)i * FG_ACOV_LAGS + k) * nblk + b];
+    out[j] = s;
 }
 
+// geweke_diagnostic (mcmc_utils.rs:354-421) of every (coordinate, chain) column: z = (mean of the first 10 % - mean of the
+// last 50 %) / sqrt of the two segments' spectral variances of the mean (spectral_variance_of_mean :392-421: s^2 tau / n with
+// tau summed over the initial positive autocorrelations).  One thread per column; the lag loop stops per chain.
+__device__ double fg_spectral_var_of_mean(const double *x, long long st, int a, int b) {
+    const int k = b - a;
+    if (k < 2) return 0.0;
+    double s = 0.0;
+    for (int t = a; t < b; ++t) s += x[t * st];
+    const double mean = s / (double)k;
+    double q = 0.0;
+    for (int t = a; t < b; ++t) { const double dv = x[t * st] - mean; q += dv * dv; }
+    const double s2 = q / ((double)k - 1.0);
+    if (s2 == 0.0) return 0.0;
+    const int max_lag = k - 1 < 1024 ? k - 1 : 1024;
+    const double var0 = q / (double)k;                         // acov[0]: the same sum of squares / n (mcmc_utils.rs:231-244)
+    if (var0 <= 0.0) return 0.0;
+    double tau = 1.0;
+    for (int lag = 1; lag <= max_lag; ++lag) {
+        double c = 0.0;
+        for (int t = a; t + lag < b; ++t) c += (x[t * st] - mean) * (x[(t + lag) * st] - mean);
+        const double rho = (c / (double)k) / var0;
+        if (rho <= 0.0) break;
+        tau += 2.0 * rho;
+    }
+    return s2 * tau / (double)k;
+}
+__global__ void k_diag_geweke(const double *draws, int n, int d, long long C, double *out /*[d][C]*/) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (c >= C) return;
+    const double *x = draws + (long long)i * C + c;
+    const long long st = (long long)d * C;
+    double z = NAN;
+    const int first_end = n / 10, last_start = n / 2;
+    if (n >= 20 && first_end >= 2 && n - last_start >= 2) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = 0; t < first_end; ++t) s1 += x[t * st];
+        for (int t = last_start; t < n; ++t) s2 += x[t * st];
+        const double mean1 = s1 / (double)first_end, mean2 = s2 / (double)(n - last_start);
+        const double se = sqrt(fg_spectral_var_of_mean(x, st, 0, first_end) + fg_spectral_var_of_mean(x, st, last_start, n));
+        z = se == 0.0 ? 0.0 : (mean1 - mean2) / se;
+    }
+    out[(long long)i * C + c] = z;
+}
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------------
+struct FgUniqueId { char b[128]; };
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, struct FgUniqueId, int) = nullptr;   // ncclUniqueId is passed BY VALUE: a 128-byte struct
+    int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*CommUserRank)(void *, int *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl R;
+    static bool tried = false;
+    if (tried) return R.h ? &R : nullptr;
+    tried = true;
+    // The RCCL that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm stacks (the system's and
+    // the one bundled with PyTorch), and a communicator must run on the runtime that owns the engine's device state.  So:
+    // the librccl next to the loaded libamdhip64 first, then the usual names.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr((void *)(hipError_t (*)(void **, size_t))&hipMalloc, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t sl = dir.rfind('/');
+        if (sl != std::string::npos) { dir.resize(sl); names.push_back(dir + "/librccl.so.1"); names.push_back(dir + "/librccl.so"); }
+    }
+    for (const char *nm : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) names.push_back(nm);
+    for (const std::string &nm : names) { R.h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
+    if (!R.h) return nullptr;
+    *(void **)&R.GetUniqueId = dlsym(R.h, "ncclGetUniqueId");
+    *(void **)&R.CommInitRank = dlsym(R.h, "ncclCommInitRank");
+    *(void **)&R.CommDestroy = dlsym(R.h, "ncclCommDestroy");
+    *(void **)&R.CommCount = dlsym(R.h, "ncclCommCount");
+    *(void **)&R.CommUserRank = dlsym(R.h, "ncclCommUserRank");
+    *(void **)&R.AllGather = dlsym(R.h, "ncclAllGather");
+    *(void **)&R.AllReduce = dlsym(R.h, "ncclAllReduce");
+    *(void **)&R.GetErrorString = dlsym(R.h, "ncclGetErrorString");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.CommCount || !R.AllGather || !R.AllReduce) { R.h = nullptr; return nullptr; }
+    return &R;
+}
+int rccl_fail(Rccl *R, const char *what, int rc) {
+    fg_set_error(std::string(what) + ": " + ((R && R->GetErrorString) ? R->GetErrorString(rc) : "RCCL error"));
+    return FG_E_HIP;
+}
+const int kNcclFloat64 = 8, kNcclSum = 0;
+
+struct AcovCtx { fg_engine *e; const double *d_draws; int n, d; const double *d_mom; void *comm; };
+}  // namespace
+
 extern "C" {
+
+typedef int (*fg_acov_fn)(void *user, int lag0, int n_lags, double *h_sums);
+int fg_diag_combine(const double *h_moments, int64_t m, int n, int d, fg_acov_fn acov, void *user, double *h_rhat, double *h_ess, double *h_mean, double *h_std);
 
 int fg_diag_chain_moments(fg_engine *e, const double *d_draws, int n, int d, double *d_moments) {
     NEED_ENGINE(e);
@@ -63,26 +201,139 @@ int fg_diag_chain_moments(fg_engine *e, const double *d_draws, int n, int d, dou
     return FG_OK;
 }
 
-int fg_diag_autocov_sums(fg_engine *e, const double *d_draws, int n, int d, const double *d_moments, int lag0, int n_lags, double *h_sums) {
+int fg_diag_geweke(fg_engine *e, const double *d_draws, int n, int d, double *d_z) {
     NEED_ENGINE(e);
-    if (!d_draws || !d_moments || !h_sums || n <= 0 || d <= 0 || lag0 < 0 || n_lags <= 0) return FG_E_BAD_ARG;
+    if (!d_draws || !d_z || n <= 0 || d <= 0) return FG_E_BAD_ARG;
+    hipLaunchKernelGGL(k_diag_geweke, dim3((unsigned)((e->C + 255) / 256), (unsigned)d), dim3(256), 0, e->stream, d_draws, n, d, e->C, d_z);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}
+
+// device result: d_sums [d][n_lags] (this engine's chains only)
+static int acov_sums_device(fg_engine *e, const double *d_draws, int n, int d, const double *d_moments, int lag0, int n_lags, double *d_sums) {
+    if (n_lags > FG_ACOV_LAGS) { fg_set_error("fg_diag_autocov_sums: at most 32 lags per call"); return FG_E_BAD_ARG; }
     const unsigned nb = (unsigned)((e->C + 255) / 256);
     double *d_part = nullptr;
-    int rc = dev_alloc(&d_part, (size_t)d * n_lags * nb);
+    int rc = dev_alloc(&d_part, (size_t)d * FG_ACOV_LAGS * nb);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_diag_autocov, dim3(nb, (unsigned)n_lags, (unsigned)d), dim3(256), 0, e->stream, d_draws, n, d, e->C, d_moments, lag0, d_part);
-    std::vector<double> part((size_t)d * n_lags * nb);
+    hipLaunchKernelGGL(k_diag_autocov, dim3(nb, (unsigned)d), dim3(256), 0, e->stream, d_draws, n, d, e->C, d_moments, lag0, d_part);
+    hipLaunchKernelGGL(k_diag_acov_finish, dim3((unsigned)((d * n_lags + 127) / 128)), dim3(128), 0, e->stream, (const double *)d_part, (int)nb, n_lags, d, d_sums);
     hipError_t he = hipGetLastError();
-    if (he == hipSuccess) he = hipMemcpyAsync(part.data(), d_part, part.size() * 8, hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     (void)hipFree(d_part);
     if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
-    for (size_t k = 0; k < (size_t)d * n_lags; ++k) {
-        double s = 0.0;
-        for (unsigned b = 0; b < nb; ++b) s += part[k * nb + b];
-        h_sums[k] = s;
-    }
     return FG_OK;
+}
+
+int fg_diag_autocov_sums(fg_engine *e, const double *d_draws, int n, int d, const double *d_moments, int lag0, int n_lags, double *h_sums) {
+    NEED_ENGINE(e);
+    if (!d_draws || !d_moments || !h_sums || n <= 0 || d <= 0 || lag0 < 0 || n_lags <= 0) return FG_E_BAD_ARG;
+    std::vector<double> out((size_t)d * n_lags, 0.0);
+    double *d_sums = nullptr;
+    int rc = dev_alloc(&d_sums, (size_t)d * FG_ACOV_LAGS);
+    if (rc) return rc;
+    for (int l0 = 0; l0 < n_lags && !rc; l0 += FG_ACOV_LAGS) {       // chunks of 32 lags
+        const int nl = std::min(FG_ACOV_LAGS, n_lags - l0);
+        rc = acov_sums_device(e, d_draws, n, d, d_moments, lag0 + l0, nl, d_sums);
+        std::vector<double> tmp((size_t)d * nl);
+        if (!rc && hipMemcpy(tmp.data(), d_sums, tmp.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = FG_E_HIP;
+        for (int i = 0; i < d && !rc; ++i) for (int k = 0; k < nl; ++k) out[(size_t)i * n_lags + l0 + k] = tmp[(size_t)i * nl + k];
+    }
+    (void)hipFree(d_sums);
+    if (rc) return rc;
+    std::memcpy(h_sums, out.data(), out.size() * 8);
+    return FG_OK;
+}
+
+// ---- communicator helpers: the ranks of one run share an RCCL communicator created from a 128-byte unique id that rank 0
+// obtains and the host distributes (any transport: a file, MPI, torch.distributed's store)
+int fg_comm_unique_id(void *out_128_bytes) {
+    Rccl *R = rccl();
+    if (!R) { fg_set_error("RCCL is not available (librccl.so not found)"); return FG_E_UNSUPPORTED; }
+    if (!out_128_bytes) return FG_E_BAD_ARG;
+    const int rc = R->GetUniqueId(out_128_bytes);
+    return rc ? rccl_fail(R, "ncclGetUniqueId", rc) : FG_OK;
+}
+int fg_comm_init(fg_engine *e, int world_size, int rank, const void *unique_id_128_bytes, void **out_comm) {
+    NEED_ENGINE(e);
+    Rccl *R = rccl();
+    if (!R) { fg_set_error("RCCL is not available (librccl.so not found)"); return FG_E_UNSUPPORTED; }
+    if (!unique_id_128_bytes || !out_comm || world_size < 1 || rank < 0 || rank >= world_size) return FG_E_BAD_ARG;
+    FgUniqueId id; std::memcpy(id.b, unique_id_128_bytes, 128);
+    const int rc = R->CommInitRank(out_comm, world_size, id, rank);
+    return rc ? rccl_fail(R, "ncclCommInitRank", rc) : FG_OK;
+}
+int fg_comm_destroy(void *comm) {
+    Rccl *R = rccl();
+    if (!R || !comm) return FG_E_BAD_ARG;
+    const int rc = R->CommDestroy(comm);
+    return rc ? rccl_fail(R, "ncclCommDestroy", rc) : FG_OK;
+}
+
+static int acov_cb(void *user, int lag0, int n_lags, double *h_sums) {
+    AcovCtx *A = (AcovCtx *)user;
+    fg_engine *e = A->e;
+    double *d_sums = nullptr;
+    int rc = dev_alloc(&d_sums, (size_t)A->d * FG_ACOV_LAGS);
+    if (rc) return rc;
+    rc = acov_sums_device(e, A->d_draws, A->n, A->d, A->d_mom, lag0, n_lags, d_sums);
+    if (!rc && A->comm) {                                          // pooled over every rank's chains: all-reduce over RCCL / xGMI
+        Rccl *R = rccl();
+        const int nr = R->AllReduce(d_sums, d_sums, (size_t)A->d * n_lags, kNcclFloat64, kNcclSum, A->comm, e->stream);
+        if (nr) rc = rccl_fail(R, "ncclAllReduce", nr);
+    }
+    if (!rc) {
+        hipError_t he = hipMemcpyAsync(h_sums, d_sums, (size_t)A->d * n_lags * 8, hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); rc = FG_E_HIP; }
+    }
+    (void)hipFree(d_sums);
+    return rc;
+}
+
+// r_hat_f64 + effective_sample_size_multichain + summarize_f64_parameter for every coordinate of d_draws [n][d][C] over the
+// chains of EVERY rank of `comm` (NULL: this engine's chains).  All ranks call it with equal n, d and C and get the same
+// numbers.  h_* [d], any may be NULL.
+int fg_diag_rhat_ess(fg_engine *e, const double *d_draws, int n, int d, void *comm, double *h_rhat, double *h_ess, double *h_mean, double *h_std,
+                     int64_t *out_total_chains) {
+    NEED_ENGINE(e);
+    if (!d_draws || n <= 0 || d <= 0) return FG_E_BAD_ARG;
+    Rccl *R = comm ? rccl() : nullptr;
+    if (comm && !R) { fg_set_error("RCCL is not available (librccl.so not found)"); return FG_E_UNSUPPORTED; }
+    int world = 1;
+    if (comm) { const int rc = R->CommCount(comm, &world); if (rc) return rccl_fail(R, "ncclCommCount", rc); }
+    const size_t per = (size_t)d * 6 * e->C;
+    double *d_mom = nullptr, *d_all = nullptr;
+    int rc = dev_alloc(&d_mom, per);
+    if (rc) return rc;
+    rc = fg_diag_chain_moments(e, d_draws, n, d, d_mom);
+    std::vector<double> mom;
+    const int64_t m = (int64_t)world * e->C;
+    if (!rc && comm) {                                              // every rank needs every chain's moments: all-gather over RCCL / xGMI
+        rc = dev_alloc(&d_all, per * world);
+        if (!rc) { const int nr = R->AllGather(d_mom, d_all, per, kNcclFloat64, comm, e->stream); if (nr) rc = rccl_fail(R, "ncclAllGather", nr); }
+    }
+    if (!rc) {
+        std::vector<double> raw(per * world);
+        hipError_t he = hipMemcpyAsync(raw.data(), comm ? d_all : d_mom, raw.size() * 8, hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); rc = FG_E_HIP; }
+        else if (world == 1) mom.swap(raw);
+        else {                                                      // [rank][d][6][C] -> [d][6][rank * C + c]: global chain order
+            mom.resize(per * world);
+            for (int r = 0; r < world; ++r)
+                for (int i = 0; i < d * 6; ++i)
+                    std::memcpy(&mom[((size_t)i * world + r) * e->C], &raw[((size_t)r * d * 6 + i) * e->C], (size_t)e->C * 8);
+        }
+    }
+    if (!rc) {
+        AcovCtx A{ e, d_draws, n, d, d_mom, comm };
+        rc = fg_diag_combine(mom.data(), m, n, d, acov_cb, &A, h_rhat, h_ess, h_mean, h_std);
+    }
+    if (out_total_chains) *out_total_chains = m;
+    (void)hipFree(d_mom);
+    if (d_all) (void)hipFree(d_all);
+    return rc;
 }
 
 }  // extern "C"

@@ -109,118 +109,61 @@ def _all_reduce_sum(x: np.ndarray, group=None, device=None) -> np.ndarray:
     return t.cpu().numpy()
 
 
-# ---- formulas ------------------------------------------------------------------------------
-def _rhat(means: np.ndarray, ssds: np.ndarray, n: int) -> float:
-    """r_hat_from_f64_chains (diagnostics.rs:262-304) from per-chain means and sums of squared deviations."""
-    m = means.shape[0]
-    if m < 2:
-        return 1.0
-    if n == 0:
-        return float("nan")
-    overall = means.sum() / m
-    b = n / (m - 1.0) * ((means - overall) ** 2).sum()
-    with np.errstate(divide="ignore", invalid="ignore"):
-        w = (ssds / (n - 1.0)).sum() / m
-        var_plus = ((n - 1.0) / n) * w + (1.0 / n) * b
-        return float(np.sqrt(var_plus / w))
-
-
+# ---- the combination: C++ (fg_diag_combine, fugue_amd/csrc/fg_diag_host.cpp) ------------------------------------------
 class ChainDiagnostics:
-    """Diagnostics of `C_total` chains x `n` draws x `d` coordinates, sharded over the ranks of `group`."""
+    """Diagnostics of `C_total` chains x `n` draws x `d` coordinates, sharded over the ranks of `group`: every rank's
+    moments are all-gathered, pooled lag sums all-reduced (torch.distributed: RCCL on GPUs, gloo in the CPU tests), and the
+    R-hat / Geyer-ESS formulas run in the library.  (A process that owns an RCCL communicator can skip this class and call
+    `Engine.diag_rhat_ess(..., comm)`: the same computation with the collectives inside the library.)"""
 
     def __init__(self, provider: MomentProvider, group=None, device=None):
+        from . import engine as E
         self.p, self.group, self.device = provider, group, device
         self.n, self.d = provider.n, provider.d
         self._mom = _all_gather_concat(provider.moments(), group, device)        # [d][6][C_total]
         self.m = self._mom.shape[2]
-        self._acov_cache = {}
+        self._res = None
+        self._E = E
 
-    # r_hat_f64: split-R-hat over 2m half-chains (diagnostics.rs:218-224, 240-260)
-    def split_rhat(self) -> np.ndarray:
-        half = self.n // 2
-        if half == 0:
-            return self.classic_rhat()
+    def _acov(self, lag0: int, n_lags: int) -> np.ndarray:
+        return _all_reduce_sum(self.p.autocov_sums(lag0, n_lags), self.group, self.device)
+
+    def _combine(self):
+        if self._res is None:
+            self._res = self._E.diag_combine(self._mom, self.n, self._acov)
+        return self._res
+
+    def split_rhat(self) -> np.ndarray:                 # r_hat_f64 (diagnostics.rs:218-224, 240-260)
+        return self._combine()["r_hat"]
+
+    def classic_rhat(self) -> np.ndarray:               # classic_r_hat_f64 (diagnostics.rs:226-238): whole chains, no split
+        whole = np.concatenate([self._mom[:, 0:2], self._mom[:, 0:2], self._mom[:, 0:2]], axis=1)     # halves := whole chain
+        m = self.m
         out = np.empty(self.d)
         for i in range(self.d):
-            means = np.stack([self._mom[i, 2], self._mom[i, 4]], axis=1).ravel()   # c0h0, c0h1, c1h0, ...
-            ssds = np.stack([self._mom[i, 3], self._mom[i, 5]], axis=1).ravel()
-            out[i] = _rhat(means, ssds, half)
+            means, ssds, n = self._mom[i, 0], self._mom[i, 1], float(self.n)
+            if m < 2:
+                out[i] = 1.0
+                continue
+            overall = means.sum() / m
+            b = n / (m - 1.0) * ((means - overall) ** 2).sum()
+            w = (ssds / (n - 1.0)).sum() / m
+            out[i] = math.sqrt((((n - 1.0) / n) * w + b / n) / w) if w > 0 else float("nan")
+        del whole
         return out
-
-    # classic_r_hat_f64 (diagnostics.rs:226-238)
-    def classic_rhat(self) -> np.ndarray:
-        return np.array([_rhat(self._mom[i, 0], self._mom[i, 1], self.n) for i in range(self.d)])
 
     def pooled_mean(self) -> np.ndarray:
-        return self._mom[:, 0].mean(axis=1)
+        return self._combine()["mean"]
 
     def pooled_std(self) -> np.ndarray:
-        """sample std of all m*n values (summarize_f64_parameter, diagnostics.rs:348-352)."""
-        gm = self.pooled_mean()
-        ss = self._mom[:, 1].sum(axis=1) + self.n * ((self._mom[:, 0] - gm[:, None]) ** 2).sum(axis=1)
-        return np.sqrt(ss / (self.m * self.n - 1.0))
+        return self._combine()["std"]
 
-    def _acov_mean(self, t: int) -> np.ndarray:
-        """mean over ALL chains of the lag-t autocovariance, fetched in chunks of 32 lags."""
-        chunk = 32
-        k = t // chunk
-        if k not in self._acov_cache:
-            lag0 = k * chunk
-            n_l = min(chunk, self.n - lag0)
-            sums = self.p.autocov_sums(lag0, n_l)
-            self._acov_cache[k] = _all_reduce_sum(sums, self.group, self.device) / self.m
-        return self._acov_cache[k][:, t - k * chunk]
-
-    # effective_sample_size_multichain / ess_from_chains (mcmc_utils.rs:214-224, 253-339)
-    def ess(self) -> np.ndarray:
-        n, m, d = self.n, self.m, self.d
-        if m == 0:
-            return np.zeros(d)
-        if n < 4:
-            return np.full(d, float(max(m * n, 1)))
-        max_lag = min(n - 1, 2048)
-        nf, mf = float(n), float(m)
-        out = np.empty(d)
-        chain_means = self._mom[:, 0]                          # [d][m]
-        chain_vars = (self._mom[:, 1] / nf) * nf / (nf - 1.0)  # acov0 * n/(n-1)
-        for i in range(d):
-            mean_var = chain_vars[i].sum() / mf
-            if mean_var <= 0.0:
-                out[i] = float(m * n)
-                continue
-            var_plus = mean_var * (nf - 1.0) / nf
-            if m > 1:
-                overall = chain_means[i].sum() / mf
-                var_plus += ((chain_means[i] - overall) ** 2).sum() / (mf - 1.0)
-
-            def rho(t, i=i, mean_var=mean_var, var_plus=var_plus):
-                return 1.0 - (mean_var - self._acov_mean(t)[i]) / var_plus
-
-            rho_hat = np.zeros(max_lag + 1)
-            rho_hat[0] = 1.0
-            if max_lag >= 1:
-                rho_hat[1] = rho(1)
-            t, max_t = 1, min(1, max_lag)
-            while t + 2 <= max_lag:                             # Geyer initial positive sequence
-                re, ro = rho(t + 1), rho(t + 2)
-                if re + ro < 0.0:
-                    break
-                rho_hat[t + 1], rho_hat[t + 2] = re, ro
-                max_t = t + 2
-                t += 2
-            k = 1
-            while k + 2 <= max_t:                               # monotone pair sums
-                prev = rho_hat[k - 1] + rho_hat[k]
-                cur = rho_hat[k + 1] + rho_hat[k + 2]
-                if cur > prev:
-                    rho_hat[k + 1] = rho_hat[k + 2] = prev / 2.0
-                k += 2
-            tau = max(-1.0 + 2.0 * rho_hat[:max_t + 1].sum(), 1.0)
-            out[i] = m * n / tau
-        return out
+    def ess(self) -> np.ndarray:                        # effective_sample_size_multichain (mcmc_utils.rs:214-339)
+        return self._combine()["ess"]
 
     def summary(self) -> dict:
-        return dict(mean=self.pooled_mean(), std=self.pooled_std(), r_hat=self.split_rhat(), ess=self.ess())
+        r = self._combine()
+        return dict(mean=r["mean"], std=r["std"], r_hat=r["r_hat"], ess=r["ess"])
 
 
 def quantiles_f64(values: np.ndarray, ps=(0.025, 0.25, 0.5, 0.75, 0.975)) -> dict:
@@ -267,34 +210,3 @@ def geweke_diagnostic(chain: np.ndarray) -> float:
     if se == 0.0:
         return 0.0
     return float((a.sum() / len(a) - b.sum() / len(b)) / se)
-
-
-def format_diagnostics(names, cd: "ChainDiagnostics", draws: Optional[np.ndarray] = None) -> str:
-    """`print_diagnostics` (diagnostics.rs:394-456) for many chains: the same table and convergence verdict.  `draws`
-    [n][d][C] (host) supplies the 2.5 % / 50 % / 97.5 % quantiles (`quantiles_f64` rule); without it they print as NaN."""
-    s = cd.summary()
-    lines = ["MCMC Diagnostics:",
-             "{:<15} {:>8} {:>8} {:>8} {:>8} {:>8} {:>8} {:>8}".format("Parameter", "Mean", "Std", "2.5%", "50%", "97.5%", "R-hat", "ESS"),
-             "-" * 80]
-    for i, name in enumerate(names):
-        q = quantiles_f64(draws[:, i, :], (0.025, 0.5, 0.975)) if draws is not None else {}
-        vals = [q.get(k, float("nan")) for k in ("2.5%", "50%", "97.5%")]
-        lines.append("{:<15} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.3f} {:>8.0f}".format(
-            str(name), s["mean"][i], s["std"][i], vals[0], vals[1], vals[2], s["r_hat"][i], s["ess"][i]))
-    fin = s["r_hat"][np.isfinite(s["r_hat"])]
-    if fin.size:
-        mx, avg = float(fin.max()), float(fin.mean())
-        lines.append("")
-        lines.append("Convergence Assessment:")
-        if mx < 1.01:
-            lines.append("✓ Excellent convergence (max R-hat = {:.3f})".format(mx))
-        elif mx < 1.1:
-            lines.append("⚠ Good convergence (max R-hat = {:.3f})".format(mx))
-        else:
-            lines.append("✗ Poor convergence (max R-hat = {:.3f}) - consider more samples".format(mx))
-        lines.append("  Average R-hat: {:.3f}".format(avg))
-    return "\n".join(lines)
-
-
-def print_diagnostics(names, cd: "ChainDiagnostics", draws: Optional[np.ndarray] = None) -> None:
-    print(format_diagnostics(names, cd, draws))

@@ -72,11 +72,13 @@ ABI_SYMBOLS = [
     "fg_state_size", "fg_state_export", "fg_state_import", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_device_log_sum_exp", "fg_device_next_beta",
-    "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
+    "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_diag_rhat_ess", "fg_diag_combine", "fg_diag_geweke",
+    "fg_comm_unique_id", "fg_comm_init", "fg_comm_destroy", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
     "fg_dsl_compile", "fg_dsl_warning_count", "fg_dsl_warning",
 ]
 
 _lib = None
+ACOV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double))     # fg_acov_fn
 
 
 class DslError(ValueError):
@@ -165,6 +167,12 @@ def lib():
     L.fg_device_resample_indices.argtypes = [C.c_int, C.c_int, dp, C.c_int64, dp, C.POINTER(C.c_int64)]
     L.fg_diag_chain_moments.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.fg_diag_autocov_sums.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, dp]
+    L.fg_diag_geweke.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.fg_diag_rhat_ess.argtypes = [vp, vp, C.c_int, C.c_int, vp, dp, dp, dp, dp, C.POINTER(C.c_int64)]
+    L.fg_diag_combine.argtypes = [dp, C.c_int64, C.c_int, C.c_int, ACOV_FN, vp, dp, dp, dp, dp]
+    L.fg_comm_unique_id.argtypes = [vp]
+    L.fg_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.fg_comm_destroy.argtypes = [vp]
     L.fg_device_alloc.restype = vp
     L.fg_device_alloc.argtypes = [vp, C.c_size_t]
     L.fg_device_free.argtypes = [vp, vp]
@@ -552,6 +560,28 @@ class Engine:
         _check(lib().fg_diag_autocov_sums(self.h, d_draws, int(n), int(d), d_moments, int(lag0), int(n_lags), _dp(out)))
         return out
 
+    def diag_geweke(self, d_draws: int, n: int, d: int) -> np.ndarray:
+        """`geweke_diagnostic` of every (coordinate, chain) on the device: [d][C]."""
+        d_z = self.device_alloc(max(1, d * self.C) * 8)
+        try:
+            _check(lib().fg_diag_geweke(self.h, d_draws, int(n), int(d), d_z))
+            return self.download(d_z, (d, self.C))
+        finally:
+            self.device_free(d_z)
+
+    def diag_rhat_ess(self, d_draws: int, n: int, d: int, comm: Optional[int] = None):
+        """Split R-hat, multi-chain ESS, pooled mean / std of d_draws [n][d][C] over the chains of every rank of `comm`
+        (an RCCL communicator from `comm_init`; None = this engine's chains): computed inside the library."""
+        rhat, ess, mean, std = (np.zeros(d) for _ in range(4))
+        tot = C.c_int64()
+        _check(lib().fg_diag_rhat_ess(self.h, d_draws, int(n), int(d), comm, _dp(rhat), _dp(ess), _dp(mean), _dp(std), C.byref(tot)))
+        return dict(r_hat=rhat, ess=ess, mean=mean, std=std, chains=tot.value)
+
+    def comm_init(self, world_size: int, rank: int, unique_id: bytes) -> int:
+        out = C.c_void_p()
+        _check(lib().fg_comm_init(self.h, int(world_size), int(rank), unique_id, C.byref(out)))
+        return out.value
+
     # ---- raw device buffers ---------------------------------------------------------------
     def device_alloc(self, nbytes: int) -> int:
         p = lib().fg_device_alloc(self.h, int(nbytes))
@@ -590,3 +620,38 @@ def device_resample_indices(method: int, weights, u, device: int = 0) -> np.ndar
     idx = np.zeros(w.size, dtype=np.int64)
     _check(lib().fg_device_resample_indices(device, int(method), _dp(w), w.size, _dp(uu), idx.ctypes.data_as(C.POINTER(C.c_int64))))
     return idx
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls it; the host distributes the 128 bytes)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().fg_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_destroy(comm: int):
+    _check(lib().fg_comm_destroy(comm))
+
+
+def diag_combine(moments: np.ndarray, n: int, acov_sums):
+    """`fg_diag_combine`: the C++ R-hat / ESS combination over host moments [d][6][m] of all chains; `acov_sums(lag0, n_lags)`
+    returns the pooled lag sums [d][n_lags] (e.g. all-reduced over gloo)."""
+    mom = np.ascontiguousarray(moments, dtype=np.float64)
+    d, _, m = mom.shape
+    err = []
+
+    def cb(_user, lag0, n_lags, out):
+        try:
+            a = np.ascontiguousarray(acov_sums(int(lag0), int(n_lags)), dtype=np.float64)
+            C.memmove(out, a.ctypes.data, d * n_lags * 8)
+            return 0
+        except Exception as ex:      # pragma: no cover
+            err.append(ex)
+            return FG_E_BAD_ARG
+    fn = ACOV_FN(cb)
+    rhat, ess, mean, std = (np.zeros(d) for _ in range(4))
+    rc = lib().fg_diag_combine(_dp(mom), m, int(n), d, fn, None, _dp(rhat), _dp(ess), _dp(mean), _dp(std))
+    if err:
+        raise err[0]
+    _check(rc)
+    return dict(r_hat=rhat, ess=ess, mean=mean, std=std)

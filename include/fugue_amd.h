@@ -307,6 +307,27 @@ int64_t fg_state_size(fg_engine *e);
 int     fg_state_export(fg_engine *e, void *h_buf, size_t capacity);
 int     fg_state_import(fg_engine *e, const void *h_buf, size_t size);
 
+/* geweke_diagnostic (src/inference/mcmc_utils.rs:354-421) of every (coordinate, chain): d_draws [n][d][C] -> d_z [d][C] */
+int fg_diag_geweke(fg_engine *e, const double *d_draws, int n, int d, double *d_z);
+/* r_hat_f64 (split R-hat, diagnostics.rs:218-224,240-304), effective_sample_size_multichain (mcmc_utils.rs:214-339) and the
+ * pooled mean / sample std of summarize_f64_parameter (diagnostics.rs:331-352) for every coordinate of d_draws [n][d][C],
+ * over the chains of EVERY rank of `rccl_comm` (an ncclComm_t; NULL = this engine's chains only).  With a communicator the
+ * per-chain moments are all-gathered and the pooled lag sums all-reduced over RCCL / xGMI inside the call; all ranks call
+ * it with equal n, d and chain count and receive the same numbers.  h_* are [d]; any may be NULL. */
+int fg_diag_rhat_ess(fg_engine *e, const double *d_draws, int n, int d, void *rccl_comm, double *h_rhat, double *h_ess,
+                     double *h_mean, double *h_std, int64_t *out_total_chains);
+/* The combination alone, on host buffers (no GPU needed): h_moments [d][6][m] of ALL chains in global chain order;
+ * `acov` returns h_sums [d][n_lags] = sum over all chains of the biased lag-t autocovariances for t in
+ * [lag0, lag0 + n_lags) (it is asked for 32 lags at a time, only as far as Geyer's sequence runs). */
+typedef int (*fg_acov_fn)(void *user, int lag0, int n_lags, double *h_sums);
+int fg_diag_combine(const double *h_moments, int64_t m, int n, int d, fg_acov_fn acov, void *user, double *h_rhat,
+                    double *h_ess, double *h_mean, double *h_std);
+/* RCCL communicator of the ranks of one run (one process per GPU): rank 0 obtains a 128-byte id (ncclGetUniqueId), the
+ * host distributes it by any means, every rank calls fg_comm_init.  RCCL is bound at run time (librccl.so). */
+int fg_comm_unique_id(void *out_128_bytes);
+int fg_comm_init(fg_engine *e, int world_size, int rank, const void *unique_id_128_bytes, void **out_comm);
+int fg_comm_destroy(void *comm);
+
 /* raw device memory helpers so a host without a HIP binding can own draw buffers */
 void *fg_device_alloc(fg_engine *e, size_t bytes);
 int   fg_device_free(fg_engine *e, void *d_ptr);

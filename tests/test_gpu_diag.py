@@ -31,3 +31,35 @@ def test_chain_diagnostics_on_hmc_draws(oracle, ns):
         assert cd.ess()[i] == pytest.approx(oracle.ess_multichain(ch), rel=1e-8)
     assert (cd.split_rhat() < 1.05).all()
     prov.close()
+
+
+def test_native_rhat_ess_entry_point_and_geweke(oracle):
+    """fg_diag_rhat_ess (moments + lag sums on the device, combination in C++) and fg_diag_geweke against the oracle;
+    with a one-rank RCCL communicator the same call goes through ncclAllGather / ncclAllReduce and must not change a bit."""
+    cp = E.compile_model(W.normal_sites(4))
+    C, ns, nw = 150, 240, 60
+    eng = E.Engine(cp, C, seed=6)
+    d_draws = eng.device_alloc(ns * cp.d * C * 8)
+    eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=3), ns, nw, d_draws)
+    draws = eng.download(d_draws, (ns, cp.d, C))
+    r = eng.diag_rhat_ess(d_draws, ns, cp.d)
+    assert r["chains"] == C
+    for i in range(cp.d):
+        ch = np.ascontiguousarray(draws[:, i, :].T)
+        assert r["r_hat"][i] == pytest.approx(oracle.split_rhat(ch), rel=1e-10)
+        assert r["ess"][i] == pytest.approx(oracle.ess_multichain(ch), rel=1e-8)
+        s = oracle.summarize(ch)
+        assert r["mean"][i] == pytest.approx(s["mean"], rel=1e-11, abs=1e-12) and r["std"][i] == pytest.approx(s["std"], rel=1e-10)
+    z = eng.diag_geweke(d_draws, ns, cp.d)
+    for i in range(cp.d):
+        for c in (0, 7, 149):
+            assert z[i, c] == pytest.approx(oracle.geweke(np.ascontiguousarray(draws[:, i, c])), rel=1e-9, abs=1e-12, nan_ok=True)
+    assert np.isnan(eng.diag_geweke(d_draws, 15, cp.d)).all()                 # n < 20 (mcmc_utils.rs:356-358)
+    comm = eng.comm_init(1, 0, E.comm_unique_id())
+    try:
+        r1 = eng.diag_rhat_ess(d_draws, ns, cp.d, comm)
+    finally:
+        E.comm_destroy(comm)
+    for k in ("r_hat", "ess", "mean", "std"):
+        assert np.array_equal(r[k], r1[k])
+    eng.device_free(d_draws)
