@@ -97,6 +97,7 @@ struct fg_engine {
     int mh_warmup = 0, mh_iter = 0;
     std::vector<fg_site_proposal> mh_overrides;   // as given to fg_mh_init (site order), for fg_state_export
     int *d_rec = nullptr; int rec_cap = 0;
+    bool smc_pop_ready = false;   // the arena holds a particle population (log-weights, weights, log-likelihoods) for the standalone SMC calls
     void *smc_arena = nullptr; size_t smc_arena_bytes = 0;   // scratch of fg_smc_run, allocated once per engine (fg_smc.hip)
     double *d_tmp = nullptr;     // [C] scratch
     int *d_itmp = nullptr;       // [3][C] scratch

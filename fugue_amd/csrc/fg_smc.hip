@@ -604,6 +604,42 @@ __global__ __launch_bounds__(256) void k_smc_adapt(FgSmcDev M, int S, int n_blk)
     M.log_scale[j] = (sc == 1.0) ? 0.0 : log(sc);
 }
 
+
+// ---- standalone population primitives (smc.rs:230-233, 326-349, 698-790) ----
+// in-order-by-construction plain sums: block partials (fixed tree), then one block adds the partials in index order
+__global__ __launch_bounds__(RED_THREADS) void k_sum_partials(const double *x, long long n, int square, double *part) {
+    __shared__ double sh[RED_THREADS / 64];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { const double v = x[i]; s += square ? v * v : v; }
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(RED_THREADS) void k_sum_finish(const double *part, int nb, double *out) {
+    __shared__ double sh[RED_THREADS / 64];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) s += part[k];
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) *out = s;
+}
+// normalize_particles (smc.rs:719-755): weight = exp(log_weight - lse) (uniform when every log-weight is -inf), then / sum
+__global__ void k_smc_norm_exp(const double *lw, double *w, long long n, const FgSmcScalars *st) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lse = st->lse1;
+    w[i] = (isinf(lse) && lse < 0.0) ? 1.0 / (double)n : exp(lw[i] - lse);
+}
+__global__ void k_smc_norm_div(double *w, long long n, const FgSmcScalars *st, const double *sum) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lse = st->lse1;
+    if ((isinf(lse) && lse < 0.0) || !(*sum > 0.0)) return;        // the uniform fallback returns before the renormalisation
+    w[i] = w[i] / *sum;
+}
+__global__ void k_copy_f64(double *dst, const double *src, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // ======================================================================================
 // host side
 // ======================================================================================
@@ -671,6 +707,48 @@ struct Scanner {     // scratch for the prefix sum
         return FG_OK;
     }
 };
+
+
+// The population state and scratch of an engine's particles: one arena, allocated on first use and kept (hipMalloc / hipFree
+// per run cost more than a run).  fg_smc_run and the standalone entry points share it.
+struct SmcWs {
+    FgSmcDev M{}; FgSmcScalars *st = nullptr; Reducer R; Scanner SC;
+    double *d_lw = nullptr, *d_w = nullptr, *d_ll2 = nullptr, *d_lp2 = nullptr, *d_red = nullptr;
+    long long *d_vals2 = nullptr, *d_idx = nullptr;
+    size_t o_ls = 0, o_st = 0;
+    char *base = nullptr;
+};
+int smc_workspace(fg_engine *e, SmcWs &W) {
+    const long long N = e->C;
+    const int S = e->S;
+    const size_t Sn = (size_t)std::max(1, S);
+    const long long n_chunks = (N + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const size_t max_blk = (size_t)((N + FG_WAVE - 1) / FG_WAVE);          // k_smc_rejuv blocks at one tile per block
+    size_t arena_off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = arena_off; arena_off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_ll = carve(N * 8), o_lp = carve(N * 8), o_scale = carve(Sn * 8), o_ls = carve(Sn * 8), o_acc = carve(Sn * 8), o_tot = carve(Sn * 8),
+                 o_st = carve(sizeof(FgSmcScalars)), o_lw = carve(N * 8), o_w = carve(N * 8), o_ll2 = carve(N * 8), o_lp2 = carve(N * 8), o_vals2 = carve(Sn * N * 8),
+                 o_idx = carve(N * 8), o_pmax = carve(RED_BLOCKS * 8), o_psum = carve(2 * RED_BLOCKS * 8), o_ess = carve(((size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) * 8),
+                 o_chunk = carve((size_t)n_chunks * 8), o_cum = carve(N * 8), o_blk = carve(max_blk * 2 * Sn * 4), o_red = carve(64);
+    if (e->smc_arena_bytes < arena_off) {
+        if (e->smc_arena) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->smc_arena)); e->smc_arena = nullptr; e->smc_arena_bytes = 0; }
+        HIPCHK(hipMalloc(&e->smc_arena, arena_off));
+        e->smc_arena_bytes = arena_off;
+        e->smc_pop_ready = false;
+    }
+    char *ar = (char *)e->smc_arena;
+    W.base = ar; W.o_ls = o_ls; W.o_st = o_st;
+    FgSmcDev &M = W.M;
+    M.ll = (double *)(ar + o_ll); M.lprior = (double *)(ar + o_lp); M.scale = (double *)(ar + o_scale); M.log_scale = (double *)(ar + o_ls);
+    M.acc = (long long *)(ar + o_acc); M.tot = (long long *)(ar + o_tot); M.sw_n = nullptr; M.sw_a = nullptr;
+    M.blk = (unsigned int *)(ar + o_blk); M.S = S;
+    W.st = (FgSmcScalars *)(ar + o_st);
+    W.d_lw = (double *)(ar + o_lw); W.d_w = (double *)(ar + o_w); W.d_ll2 = (double *)(ar + o_ll2); W.d_lp2 = (double *)(ar + o_lp2);
+    W.d_vals2 = (long long *)(ar + o_vals2); W.d_idx = (long long *)(ar + o_idx); W.d_red = (double *)(ar + o_red);
+    W.R.part_max = (double *)(ar + o_pmax); W.R.part_sum = (double *)(ar + o_psum); W.R.ess_part = (double *)(ar + o_ess);
+    W.SC.chunk = (double *)(ar + o_chunk); W.SC.cum = (double *)(ar + o_cum); W.SC.cap = N; W.SC.external = true;
+    return FG_OK;
+}
 
 int set_device_or_fail(int device) {
     int ndev = 0;
@@ -747,32 +825,15 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
     const long long N = e->C;
     const int S = e->S, TB = 256, NB = (int)((N + TB - 1) / TB);
     hipStream_t s = e->stream;
-    // scratch: one arena per engine, allocated on the first run and reused (hipMalloc / hipFree per run cost more than the run)
+    SmcWs WS;
+    if (int rc0 = smc_workspace(e, WS)) return rc0;
     const size_t Sn = (size_t)std::max(1, S);
-    const long long n_chunks = (N + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    const size_t max_blk = (size_t)((N + FG_WAVE - 1) / FG_WAVE);          // k_smc_rejuv blocks at one tile per block
-    size_t arena_off = 0;
-    auto carve = [&](size_t bytes) { const size_t o = arena_off; arena_off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_ll = carve(N * 8), o_lp = carve(N * 8), o_scale = carve(Sn * 8), o_ls = carve(Sn * 8), o_acc = carve(Sn * 8), o_tot = carve(Sn * 8),
-                 o_st = carve(sizeof(FgSmcScalars)), o_lw = carve(N * 8), o_w = carve(N * 8), o_ll2 = carve(N * 8), o_lp2 = carve(N * 8), o_vals2 = carve(Sn * N * 8),
-                 o_idx = carve(N * 8), o_pmax = carve(RED_BLOCKS * 8), o_psum = carve(2 * RED_BLOCKS * 8), o_ess = carve(((size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) * 8),
-                 o_chunk = carve((size_t)n_chunks * 8), o_cum = carve(N * 8), o_blk = carve(max_blk * 2 * Sn * 4);
-    if (e->smc_arena_bytes < arena_off) {
-        if (e->smc_arena) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipFree(e->smc_arena)); e->smc_arena = nullptr; e->smc_arena_bytes = 0; }
-        HIPCHK(hipMalloc(&e->smc_arena, arena_off));
-        e->smc_arena_bytes = arena_off;
-    }
-    char *ar = (char *)e->smc_arena;
     auto cleanup = [&]() { (void)hipStreamSynchronize(s); };
-    FgSmcDev M{}; Reducer R; Scanner SC;
-    M.ll = (double *)(ar + o_ll); M.lprior = (double *)(ar + o_lp); M.scale = (double *)(ar + o_scale); M.log_scale = (double *)(ar + o_ls);
-    M.acc = (long long *)(ar + o_acc); M.tot = (long long *)(ar + o_tot); M.sw_n = nullptr; M.sw_a = nullptr;
-    M.blk = (unsigned int *)(ar + o_blk); M.S = S;
-    FgSmcScalars *st = (FgSmcScalars *)(ar + o_st);
-    double *d_lw = (double *)(ar + o_lw), *d_w = (double *)(ar + o_w), *d_ll2 = (double *)(ar + o_ll2), *d_lp2 = (double *)(ar + o_lp2);
-    long long *d_vals2 = (long long *)(ar + o_vals2), *d_idx = (long long *)(ar + o_idx);
-    R.part_max = (double *)(ar + o_pmax); R.part_sum = (double *)(ar + o_psum); R.ess_part = (double *)(ar + o_ess);
-    SC.chunk = (double *)(ar + o_chunk); SC.cum = (double *)(ar + o_cum); SC.cap = N; SC.external = true;
+    FgSmcDev &M = WS.M; Reducer &R = WS.R; Scanner &SC = WS.SC;
+    FgSmcScalars *st = WS.st;
+    double *d_lw = WS.d_lw, *d_w = WS.d_w, *d_ll2 = WS.d_ll2, *d_lp2 = WS.d_lp2;
+    long long *d_vals2 = WS.d_vals2, *d_idx = WS.d_idx;
+    char *ar = WS.base; const size_t o_ls = WS.o_ls, o_st = WS.o_st;
     HIPCHK(hipMemsetAsync(ar + o_ls, 0, o_st - o_ls, s));                   // log_scale, acc, tot start at zero (DiminishingAdaptation::new)
     int rc = FG_OK;
 #define SMC_TRY(x) do { rc = (x); if (rc) { cleanup(); SC.free_all(); return rc; } } while (0)
@@ -816,7 +877,8 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
                 hipLaunchKernelGGL(k_smc_gather, dim3(NB), dim3(TB), 0, s, (const long long *)e->d_values, d_vals2, (const double *)M.ll, d_ll2,
                                    (const double *)M.lprior, d_lp2, (const long long *)d_idx, S, N);
                 SMC_HIP(hipMemcpyAsync(e->d_values, d_vals2, (size_t)S * N * 8, hipMemcpyDeviceToDevice, s));
-                std::swap(M.ll, d_ll2); std::swap(M.lprior, d_lp2);
+                SMC_HIP(hipMemcpyAsync(M.ll, d_ll2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+                SMC_HIP(hipMemcpyAsync(M.lprior, d_lp2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
                 hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, -std::log((double)N));
                 if (e->d > 0) {
                     const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
@@ -845,6 +907,7 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
     if (h_log_w) SMC_HIP(hipMemcpyAsync(h_log_w, d_lw, (size_t)N * 8, hipMemcpyDeviceToHost, s));
     if (h_weights) SMC_HIP(hipMemcpyAsync(h_weights, d_w, (size_t)N * 8, hipMemcpyDeviceToHost, s));
     SMC_HIP(hipStreamSynchronize(s));
+    e->smc_pop_ready = true;
     res->log_evidence = h.log_evidence; res->n_steps = n_steps; res->n_model_runs = n_runs;
     if (h_betas) for (int i = 0; i < (int)betas.size() && i < max_betas; ++i) h_betas[i] = betas[i];
     cleanup();
@@ -852,6 +915,151 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
     return FG_OK;
 #undef SMC_TRY
 #undef SMC_HIP
+}
+
+
+// ---- the reference's standalone SMC building blocks over the engine's population (values [S][N] in the engine, log-weights /
+// weights / log-likelihoods in the engine's SMC arena) -------------------------------------------------------------------
+static int smc_pop(fg_engine *e, SmcWs &W, bool need_ready) {
+    if (int rc = smc_workspace(e, W)) return rc;
+    if (need_ready && !e->smc_pop_ready) { fg_set_error("no particle population: call fg_smc_prior_particles (or fg_smc_run) first"); return FG_E_STATE; }
+    return FG_OK;
+}
+static int smc_normalize_impl(fg_engine *e, SmcWs &W) {                  // normalize_particles (smc.rs:719-755)
+    const long long N = e->C;
+    const int TB = 256, NB = (int)((N + TB - 1) / TB);
+    hipStream_t s = e->stream;
+    FgSmcScalars h; std::memset(&h, 0, sizeof(h)); h.one = 1.0;
+    HIPCHK(hipMemcpyAsync(W.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    if (int rc = W.R.run(s, W.d_lw, nullptr, N, W.st, (const double *)&W.st->one, 4)) return rc;      // lse1 = log_sum_exp(log_weights)
+    hipLaunchKernelGGL(k_smc_norm_exp, dim3(NB), dim3(TB), 0, s, (const double *)W.d_lw, W.d_w, N, (const FgSmcScalars *)W.st);
+    hipLaunchKernelGGL(k_sum_partials, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, (const double *)W.d_w, N, 0, W.R.part_sum);
+    hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(RED_THREADS), 0, s, (const double *)W.R.part_sum, RED_BLOCKS, W.d_red);
+    hipLaunchKernelGGL(k_smc_norm_div, dim3(NB), dim3(TB), 0, s, W.d_w, N, (const FgSmcScalars *)W.st, (const double *)W.d_red);
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}
+
+int fg_smc_prior_particles(fg_engine *e, uint32_t iteration) {           // smc_prior_particles (smc.rs:764-790)
+    NEED_ENGINE(e);
+    SmcWs W;
+    if (int rc = smc_pop(e, W, false)) return rc;
+    const long long N = e->C;
+    const int TB = 256, NB = (int)((N + TB - 1) / TB);
+    if (int rc = fg_launch_prior(e, iteration, FG_RNG_SMC_PRIOR, e->d_acc, nullptr)) return rc;
+    hipLaunchKernelGGL(k_smc_split_acc, dim3(NB), dim3(TB), 0, e->stream, (const double *)e->d_acc, W.M.lprior, W.M.ll, N);
+    hipLaunchKernelGGL(k_copy_f64, dim3(NB), dim3(TB), 0, e->stream, W.d_lw, (const double *)W.M.ll, N);      // log_weight = log_likelihood + log_factors (FG-03)
+    if (int rc = smc_normalize_impl(e, W)) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->smc_pop_ready = true;
+    return FG_OK;
+}
+int fg_smc_normalize(fg_engine *e) {
+    NEED_ENGINE(e);
+    SmcWs W;
+    if (int rc = smc_pop(e, W, true)) return rc;
+    if (int rc = smc_normalize_impl(e, W)) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+int fg_smc_ess(fg_engine *e, double *out_ess) {                         // effective_sample_size (smc.rs:230-233): 1 / sum w^2
+    NEED_ENGINE(e);
+    if (!out_ess) return FG_E_BAD_ARG;
+    SmcWs W;
+    if (int rc = smc_pop(e, W, true)) return rc;
+    hipLaunchKernelGGL(k_sum_partials, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, e->stream, (const double *)W.d_w, e->C, 1, W.R.part_sum);
+    hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(RED_THREADS), 0, e->stream, (const double *)W.R.part_sum, RED_BLOCKS, W.d_red);
+    double s2 = 0.0;
+    HIPCHK(hipMemcpyAsync(&s2, W.d_red, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out_ess = 1.0 / s2;
+    return FG_OK;
+}
+int fg_smc_get_weights(fg_engine *e, double *h_log_w, double *h_w) {
+    NEED_ENGINE(e);
+    SmcWs W;
+    if (int rc = smc_pop(e, W, true)) return rc;
+    if (h_log_w) HIPCHK(hipMemcpyAsync(h_log_w, W.d_lw, (size_t)e->C * 8, hipMemcpyDeviceToHost, e->stream));
+    if (h_w) HIPCHK(hipMemcpyAsync(h_w, W.d_w, (size_t)e->C * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+int fg_smc_set_log_weights(fg_engine *e, const double *h_log_w) {       // a caller's own reweighting step; follow with fg_smc_normalize
+    NEED_ENGINE(e);
+    if (!h_log_w) return FG_E_BAD_ARG;
+    SmcWs W;
+    if (int rc = smc_pop(e, W, true)) return rc;
+    HIPCHK(hipMemcpyAsync(W.d_lw, h_log_w, (size_t)e->C * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return FG_OK;
+}
+// resample_particles (smc.rs:326-349): ancestors by `method` from the current weights, particles cloned, weight = 1/N and
+// log_weight = ln(1/N).  `step` selects the random sub-stream (as fg_smc_run's tempering step does).
+int fg_smc_resample(fg_engine *e, int method, uint32_t step, int64_t *h_indices) {
+    NEED_ENGINE(e);
+    if (method < 0 || method > 2) return FG_E_BAD_ARG;
+    SmcWs W;
+    if (int rc = smc_pop(e, W, true)) return rc;
+    const long long N = e->C;
+    const int S = e->S, TB = 256, NB = (int)((N + TB - 1) / TB);
+    hipStream_t s = e->stream;
+    double U = 0.0;
+    if (method == FG_RESAMPLE_SYSTEMATIC) { FgStream rs = fg_stream(e->seed, 0, step, FG_RNG_SMC_RESAMPLE); U = fg_rng_u01(rs); }
+    if (int rc = W.SC.indices(s, W.d_w, N, method, U, nullptr, e->seed, step, W.d_idx)) return rc;
+    hipLaunchKernelGGL(k_smc_gather, dim3(NB), dim3(TB), 0, s, (const long long *)e->d_values, W.d_vals2, (const double *)W.M.ll, W.d_ll2,
+                       (const double *)W.M.lprior, W.d_lp2, (const long long *)W.d_idx, S, N);
+    HIPCHK(hipMemcpyAsync(e->d_values, W.d_vals2, (size_t)S * N * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.M.ll, W.d_ll2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.M.lprior, W.d_lp2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+    const double uw = 1.0 / (double)N;
+    hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, W.d_w, N, uw);
+    hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, W.d_lw, N, std::log(uw));
+    HIPCHK(hipGetLastError());
+    if (h_indices) HIPCHK(hipMemcpyAsync(h_indices, W.d_idx, (size_t)N * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return FG_OK;
+}
+// rejuvenate_particles (smc.rs:698-713): `steps` pi_beta-invariant single-site MH moves per particle with a fresh
+// DiminishingAdaptation (batched per sweep, as in fg_smc_run); weights are NOT touched (FG-13).
+int fg_smc_rejuvenate(fg_engine *e, double beta, int steps, uint32_t first_move_id, double *h_accept_rate) {
+    NEED_ENGINE(e);
+    if (steps < 0) return FG_E_BAD_ARG;
+    SmcWs W;
+    if (int rc = smc_pop(e, W, true)) return rc;
+    const long long N = e->C;
+    const int S = e->S, TB = 256;
+    const size_t Sn = (size_t)std::max(1, S);
+    hipStream_t s = e->stream;
+    if (e->d == 0 || steps == 0) { if (h_accept_rate) *h_accept_rate = 0.0; return FG_OK; }
+    FgSmcScalars h; std::memset(&h, 0, sizeof(h)); h.one = 1.0; h.beta = beta;
+    HIPCHK(hipMemcpyAsync(W.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(W.base + W.o_ls, 0, W.o_st - W.o_ls, s));            // log_scale, acc, tot = 0; scale = 1
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((Sn + TB - 1) / TB)), dim3(TB), 0, s, W.M.scale, (long long)Sn, 1.0);
+    const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
+    const int wpb = FG_SMC_WPB(score);
+    const size_t lds_r = e->lds_score * wpb;
+    if (lds_r > 150 * 1024 || S > FG_SMC_HIST) { fg_set_error("SMC rejuvenation: tile does not fit LDS"); return FG_E_LIMIT; }
+    const unsigned nblk = (unsigned)((N + (long long)e->tw * wpb - 1) / ((long long)e->tw * wpb));
+    for (int r = 0; r < steps; ++r) {
+        const uint32_t mv = first_move_id + (uint32_t)r;
+#define SMC_REJUV(SC_) do { if (int rc_ = set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))) return rc_; \
+                            hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); } while (0)
+        if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2); else SMC_REJUV(-1);
+#undef SMC_REJUV
+        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, W.M, S, (int)nblk);
+    }
+    HIPCHK(hipGetLastError());
+    if (h_accept_rate) {
+        std::vector<long long> acc(Sn), tot(Sn);
+        HIPCHK(hipMemcpyAsync(acc.data(), W.M.acc, Sn * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tot.data(), W.M.tot, Sn * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        long long a = 0, t = 0;
+        for (size_t j = 0; j < Sn; j++) { a += acc[j]; t += tot[j]; }
+        *h_accept_rate = t > 0 ? (double)a / (double)t : 0.0;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return FG_OK;
 }
 
 }  // extern "C"

@@ -71,7 +71,8 @@ ABI_SYMBOLS = [
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_set_n_leapfrog", "fg_hmc_is_warming_up", "fg_hmc_iterations", "fg_hmc_step_recorded",
     "fg_state_size", "fg_state_export", "fg_state_import", "fg_hmc_grad", "fg_hmc_transition_injected",
     "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
-    "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_device_log_sum_exp", "fg_device_next_beta",
+    "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_smc_prior_particles", "fg_smc_normalize", "fg_smc_ess", "fg_smc_resample", "fg_smc_rejuvenate",
+    "fg_smc_get_weights", "fg_smc_set_log_weights", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_diag_rhat_ess", "fg_diag_combine", "fg_diag_geweke",
     "fg_comm_unique_id", "fg_comm_init", "fg_comm_destroy", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
     "fg_dsl_compile", "fg_dsl_warning_count", "fg_dsl_warning",
@@ -162,6 +163,13 @@ def lib():
     L.fg_mh_get_log_weight.argtypes = [vp, dp]
     L.fg_smc_config_default.argtypes = [C.POINTER(fg_smc_config)]
     L.fg_smc_run.argtypes = [vp, C.POINTER(fg_smc_config), dp, dp, C.POINTER(fg_smc_result), dp, C.c_int]
+    L.fg_smc_prior_particles.argtypes = [vp, C.c_uint32]
+    L.fg_smc_normalize.argtypes = [vp]
+    L.fg_smc_ess.argtypes = [vp, dp]
+    L.fg_smc_resample.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_int64)]
+    L.fg_smc_rejuvenate.argtypes = [vp, C.c_double, C.c_int, C.c_uint32, dp]
+    L.fg_smc_get_weights.argtypes = [vp, dp, dp]
+    L.fg_smc_set_log_weights.argtypes = [vp, dp]
     L.fg_device_log_sum_exp.argtypes = [C.c_int, dp, C.c_int64, dp]
     L.fg_device_next_beta.argtypes = [C.c_int, C.c_double, dp, dp, C.c_int64, C.c_double, dp]
     L.fg_device_resample_indices.argtypes = [C.c_int, C.c_int, dp, C.c_int64, dp, C.POINTER(C.c_int64)]
@@ -550,6 +558,38 @@ class Engine:
         _check(lib().fg_smc_run(self.h, C.byref(cfg), _dp(log_w) if download else None, _dp(w) if download else None, C.byref(res), _dp(betas), max_betas))
         return dict(values=self.get_values() if download else None, log_w=log_w, weights=w, log_evidence=res.log_evidence,
                     betas=betas[:res.n_steps], n_model_runs=res.n_model_runs)
+
+    # standalone building blocks (smc.rs:230-349, 698-790) over the engine's particle population
+    def smc_prior_particles(self, iteration: int = 0):
+        _check(lib().fg_smc_prior_particles(self.h, int(iteration)))
+
+    def smc_normalize(self):
+        _check(lib().fg_smc_normalize(self.h))
+
+    def smc_ess(self) -> float:
+        out = C.c_double()
+        _check(lib().fg_smc_ess(self.h, C.byref(out)))
+        return out.value
+
+    def smc_resample(self, method: int = RESAMPLE_SYSTEMATIC, step: int = 1) -> np.ndarray:
+        idx = np.zeros(self.C, dtype=np.int64)
+        _check(lib().fg_smc_resample(self.h, int(method), int(step), idx.ctypes.data_as(C.POINTER(C.c_int64))))
+        return idx
+
+    def smc_rejuvenate(self, beta: float, steps: int, first_move_id: int = 0) -> float:
+        out = C.c_double()
+        _check(lib().fg_smc_rejuvenate(self.h, float(beta), int(steps), int(first_move_id), C.byref(out)))
+        return out.value
+
+    def smc_weights(self):
+        lw, w = np.zeros(self.C), np.zeros(self.C)
+        _check(lib().fg_smc_get_weights(self.h, _dp(lw), _dp(w)))
+        return lw, w
+
+    def smc_set_log_weights(self, log_w):
+        a = np.ascontiguousarray(log_w, dtype=np.float64)
+        assert a.shape == (self.C,)
+        _check(lib().fg_smc_set_log_weights(self.h, _dp(a)))
 
     # ---- diagnostics kernels -----------------------------------------------------------------
     def diag_chain_moments(self, d_draws: int, n: int, d: int, d_moments: int):

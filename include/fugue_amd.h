@@ -275,6 +275,21 @@ void fg_smc_config_default(fg_smc_config *cfg);
  * h_betas (optional) the inverse-temperature ladder. */
 int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *h_weights,
                fg_smc_result *h_result, double *h_betas, int max_betas);
+/* The reference's standalone SMC building blocks over the engine's particles (values [S][N] in the engine; log-weights,
+ * weights and log-likelihoods in HBM beside them):
+ *   fg_smc_prior_particles  smc_prior_particles (smc.rs:764-790): prior draws, log_weight = log_likelihood + log_factors, normalised
+ *   fg_smc_normalize        normalize_particles (smc.rs:719-755): weight = exp(log_weight - lse) / sum; uniform if all -inf
+ *   fg_smc_ess              effective_sample_size (smc.rs:230-233): 1 / sum w^2
+ *   fg_smc_resample         resample_particles (smc.rs:326-349): ancestors (h_indices, optional), clones, weight = 1/N
+ *   fg_smc_rejuvenate       rejuvenate_particles (smc.rs:698-713): pi_beta-invariant MH moves, weights untouched
+ *   fg_smc_get_weights / fg_smc_set_log_weights: the population's log-weights and weights (a caller's own reweighting) */
+int fg_smc_prior_particles(fg_engine *e, uint32_t iteration);
+int fg_smc_normalize(fg_engine *e);
+int fg_smc_ess(fg_engine *e, double *out_ess);
+int fg_smc_resample(fg_engine *e, int method, uint32_t step, int64_t *h_indices /*[N] or NULL*/);
+int fg_smc_rejuvenate(fg_engine *e, double beta, int steps, uint32_t first_move_id, double *h_accept_rate /*or NULL*/);
+int fg_smc_get_weights(fg_engine *e, double *h_log_w, double *h_weights);
+int fg_smc_set_log_weights(fg_engine *e, const double *h_log_w);
 /* population-wide primitives on device `device_ordinal`, usable without a program:
  * log_sum_exp (src/core/numerical.rs:15-38), next_beta (smc.rs:588-622) and
  * {multinomial,systematic,stratified}_indices (smc.rs:255-314) with the uniforms injected

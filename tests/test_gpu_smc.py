@@ -125,3 +125,48 @@ def test_smc_million_particles_closed_form():
     assert abs(r["log_evidence"] - (-1.9305103088617774)) < 5e-3
     assert abs(mean - 1.2) < 5e-3 and abs(var - 0.2) < 5e-3
     assert abs(r["weights"].sum() - 1.0) < 1e-9 and len(r["betas"]) >= 2 and r["betas"][-1] == 1.0
+
+
+def test_standalone_smc_building_blocks(oracle):
+    """smc_prior_particles / normalize_particles / effective_sample_size / resample_particles / rejuvenate_particles
+    (smc.rs:230-233, 326-349, 698-790) as separate calls over the engine's population."""
+    N = 5000
+    cp = E.compile_model(W.smc_normal())
+    eng = E.Engine(cp, N, seed=42)
+    with pytest.raises(E.EngineError):
+        eng.smc_ess()                                               # no population yet
+    eng.smc_prior_particles()
+    lw, w = eng.smc_weights()
+    mu = eng.get_values()[0].view(np.float64)
+    ll = -0.5 * ((1.5 - mu) / 0.5) ** 2 - np.log(0.5) - 0.5 * np.log(2 * np.pi)
+    assert np.allclose(lw, ll, rtol=1e-12)                          # log_weight = log-likelihood only (FG-03)
+    ref = np.exp(lw - oracle.log_sum_exp(lw)); ref /= ref.sum()
+    assert np.allclose(w, ref, rtol=1e-12) and abs(w.sum() - 1.0) < 1e-12
+    assert eng.smc_ess() == pytest.approx(1.0 / np.sum(w * w), rel=1e-12)
+    assert eng.smc_ess() == pytest.approx(oracle.ess_particles(w), rel=1e-12)
+    assert abs(np.sum(w * mu) - 1.2) < 0.05                         # importance-sampling posterior mean of C4
+    # all log-weights -inf -> uniform fallback (smc.rs:735-741)
+    eng.smc_set_log_weights(np.full(N, -np.inf)); eng.smc_normalize()
+    assert np.array_equal(eng.smc_weights()[1], np.full(N, 1.0 / N))
+    eng.smc_set_log_weights(lw); eng.smc_normalize()
+    assert np.allclose(eng.smc_weights()[1], ref, rtol=1e-12)
+    # resample: the ancestors are those of the tested index primitive for the same uniform; clones; weights exactly 1/N
+    before = eng.get_values().copy()
+    idx = eng.smc_resample(E.RESAMPLE_SYSTEMATIC, step=3)
+    import ctypes
+    st = oracle.stream(42, 0, 3, 5)                                 # (seed, chain 0, step, FG_RNG_SMC_RESAMPLE)
+    oracle.lib().orc_stream_u01.restype = ctypes.c_double
+    U = oracle.lib().orc_stream_u01(ctypes.byref(st))
+    assert np.array_equal(idx, E.device_resample_indices(E.RESAMPLE_SYSTEMATIC, w, U))
+    assert idx.min() >= 0 and idx.max() < N and (np.diff(idx) >= 0).all()
+    assert np.array_equal(eng.get_values(), before[:, idx])
+    lw2, w2 = eng.smc_weights()
+    assert np.array_equal(w2, np.full(N, 1.0 / N)) and np.array_equal(lw2, np.full(N, np.log(1.0 / N)))
+    assert eng.smc_ess() == pytest.approx(N, rel=1e-9)
+    # rejuvenation moves particles, leaves the weights exactly uniform (tests/f_smc_smc.rs:45-205) and targets pi_1
+    acc = eng.smc_rejuvenate(1.0, 5)
+    assert 0.1 < acc < 0.95
+    assert np.array_equal(eng.smc_weights()[1], np.full(N, 1.0 / N))
+    mu2 = eng.get_values()[0].view(np.float64)
+    assert (mu2 != before[0, idx].view(np.float64)).mean() > 0.3
+    assert abs(mu2.mean() - 1.2) < 0.05 and abs(mu2.var() - 0.2) < 0.05
