@@ -116,7 +116,7 @@ const struct { const char *name; int kind, lo, hi; } DISTS[] = {    // dist_arit
 EP parse_expr(Lexer &lx);
 EP mk(Expr::K k) { auto e = std::make_shared<Expr>(); e->k = k; return e; }
 struct Depth { int &d; explicit Depth(int &x) : d(x) { if (++d > 200) throw DslError{"expression or block nesting deeper than 200"}; } ~Depth() { --d; } };
-int g_depth = 0;      // parser recursion guard (single-threaded use under fg_dsl_compile)
+thread_local int g_depth = 0;      // parser recursion guard: per thread, so concurrent fg_dsl_compile calls do not share it
 EP parse_primary(Lexer &lx) {
     Depth guard(g_depth);
     const Tok t = lx.peek();

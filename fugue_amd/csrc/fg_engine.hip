@@ -688,7 +688,7 @@ extern "C" {
 void fg_hmc_config_default(fg_hmc_config *c) {     // HMCConfig::default, hmc.rs:125-135
     if (!c) return;
     c->n_leapfrog = 16; c->target_accept = 0.8; c->init_step_size = NAN; c->finite_diff_eps = 1e-5;
-    c->adapt_mass = 0; c->grad_mode = FG_GRAD_FD_DENSE;
+    c->adapt_mass = 0; c->grad_mode = FG_GRAD_FD_SPARSE;    // the engine's one default (C ABI, Python mirror, bench); FG_GRAD_FD_DENSE = the reference verbatim
 }
 
 fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, uint32_t chain_offset, int device) {

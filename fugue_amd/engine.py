@@ -15,7 +15,7 @@ import numpy as np
 from . import model as M
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfugue_amd.so")
+LIB_PATH = os.environ.get("FG_LIB_PATH") or os.path.join(_HERE, "lib", "libfugue_amd.so")   # FG_LIB_PATH: an experiment build (tools/)
 
 
 class fg_tok(C.Structure):
@@ -97,9 +97,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _b
+    from . import build as _b
+    try:                                  # a no-op when the library is fresh; rebuilds a stale one where hipcc exists
         _b.build()
+    except Exception:
+        if not os.path.exists(LIB_PATH):
+            raise
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
     tp = C.POINTER(fg_tok)
@@ -209,8 +212,9 @@ def _dp(a: np.ndarray):
 
 
 def hmc_config(n_leapfrog=16, target_accept=0.8, init_step_size=None, finite_diff_eps=1e-5, adapt_mass=False,
-               grad_mode=GRAD_FD_DENSE) -> fg_hmc_config:
-    """`HMCConfig` (/root/reference/src/inference/hmc.rs:106-135), same defaults."""
+               grad_mode=GRAD_FD_SPARSE) -> fg_hmc_config:
+    """`HMCConfig` (/root/reference/src/inference/hmc.rs:106-135), same defaults; grad_mode: the engine's one default is
+    FG_GRAD_FD_SPARSE (C ABI, Python, bench) -- GRAD_FD_DENSE is the reference's arithmetic verbatim."""
     return fg_hmc_config(int(n_leapfrog), float(target_accept),
                          float("nan") if init_step_size is None else float(init_step_size),
                          float(finite_diff_eps), int(bool(adapt_mass)), int(grad_mode))

@@ -110,12 +110,22 @@ def hmc_chain(seed: int, model_fn, n_samples: int, n_warmup: int, config: Option
     cp = _compile(model_fn)
     cfg = config or HMCConfig()
     eng = E.Engine(cp, n_chains, seed=seed, device=device)
-    buf = eng.device_alloc(max(1, n_samples * cp.d * n_chains) * 8)
-    st = eng.hmc_run(cfg.raw(), n_samples, n_warmup, buf)
-    draws = eng.download(buf, (n_samples, cp.d, n_chains), dtype=np.int64)
-    eng.device_free(buf)
-    sites = [cp.site_names[j] for j in cp.f64_sites]            # hmc_chain moves the f64 sites; discrete sites stay at their prior draw
-    out = ChainBatch(sites, [0] * cp.d, draws, st.accept_rate, st.mean_step_size, int(st.n_divergent))
+    cells = np.zeros((n_samples, cp.S, n_chains), dtype=np.int64)
+    if cp.d == 0:                                               # no continuous site: every step is a fresh prior draw (hmc.rs:826-845)
+        eng.hmc_init(cfg.raw(), n_warmup)
+        eng.hmc_step(n_warmup)
+        for t in range(n_samples):
+            eng.hmc_step(1)
+            cells[t] = eng.get_values()
+        st = eng.hmc_stats()
+    else:
+        buf = eng.device_alloc(max(1, n_samples * cp.d * n_chains) * 8)
+        st = eng.hmc_run(cfg.raw(), n_samples, n_warmup, buf)
+        draws = eng.download(buf, (n_samples, cp.d, n_chains), dtype=np.int64)
+        eng.device_free(buf)
+        cells[:] = eng.get_values()[None]                       # HMC moves the f64 sites; discrete sites keep their prior draw (hmc.rs:238-260)
+        cells[:, cp.f64_sites, :] = draws
+    out = ChainBatch(list(cp.site_names), list(cp.site_vtypes), cells, st.accept_rate, st.mean_step_size, int(st.n_divergent))
     eng.close()
     return out
 
@@ -149,7 +159,7 @@ def adaptive_smc(seed: int, num_particles: int, model_fn, config: Optional[SMCCo
     cp = _compile(model_fn)
     cfg = config or SMCConfig()
     if num_particles == 0:                                         # smc.rs:462-467
-        return SMCResult(list(cp.site_names), list(cp.site_vtypes), np.zeros((cp.S, 0), dtype=np.int64), np.zeros(0), np.zeros(0), float("-inf"))
+        return SMCResult(list(cp.site_names), list(cp.site_vtypes), np.zeros((cp.S, 0), dtype=np.int64), np.zeros(0), np.zeros(0), 0.0)   # empty population: log_evidence 0.0
     eng = E.Engine(cp, num_particles, seed=seed, device=device)
     r = eng.smc_run(cfg.resampling_method, cfg.ess_threshold, cfg.rejuvenation_steps)
     out = SMCResult(list(cp.site_names), list(cp.site_vtypes), r["values"], r["weights"], r["log_w"], r["log_evidence"], r["betas"])

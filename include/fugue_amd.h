@@ -183,7 +183,7 @@ typedef struct fg_hmc_config {      /* HMCConfig, hmc.rs:106-135 (same defaults)
     double  init_step_size;         /* NaN = None: Hoffman-Gelman Alg. 4 (hmc.rs:479-535) */
     double  finite_diff_eps;        /* 1e-5 */
     int32_t adapt_mass;             /* 0 */
-    int32_t grad_mode;              /* FG_GRAD_FD_* (engine extension; 0 = reference) */
+    int32_t grad_mode;              /* FG_GRAD_* (engine extension): default FG_GRAD_FD_SPARSE; FG_GRAD_FD_DENSE = the reference verbatim */
 } fg_hmc_config;
 typedef struct fg_hmc_stats {
     double  accept_rate;            /* mean acceptance probability over chains x transitions */

@@ -50,4 +50,20 @@ def test_adaptive_smc_evidence():
     assert abs(w.sum() - 1.0) < 1e-9 and abs((w * r.get_f64(F.addr("mu"))).sum() - 1.2) < 0.02
     assert len(r.betas) >= 1 and r.betas[-1] == 1.0
     empty = F.adaptive_smc(1, 0, model, F.SMCConfig())
-    assert empty.weights.size == 0
+    assert empty.weights.size == 0 and empty.log_evidence == 0.0      # smc.rs:462-467
+
+
+def test_hmc_chain_returns_every_site():
+    """hmc_chain's states carry the whole trace: a discrete site keeps its prior draw next to the moving f64 site, and a
+    model without continuous sites yields a fresh prior draw per step (hmc.rs:826-845)."""
+    mixed = lambda: F.sample(F.addr("k"), F.Poisson(3.0)).bind(
+        lambda k: F.sample(F.addr("mu"), F.Normal(0.0, 2.0)).bind(lambda mu: F.observe(F.addr("y"), F.Normal(mu, 1.0), 3.0).map(lambda _: mu)))
+    ch = F.hmc_chain(11, mixed, 50, 50, F.HMCConfig(), n_chains=256)
+    k, mu = ch.get_int(F.addr("k")), ch.get_f64(F.addr("mu"))
+    assert k.shape == mu.shape == (50, 256)
+    assert (k == k[0]).all() and k.min() >= 0 and 2.0 < k[0].mean() < 4.0
+    assert abs(mu.mean() - 2.4) < 0.1
+    coin = lambda: F.sample(F.addr("k"), F.Poisson(3.0)).map(lambda k: k)
+    ch = F.hmc_chain(5, coin, 40, 10, F.HMCConfig(), n_chains=1024)
+    k = ch.get_int(F.addr("k"))
+    assert k.shape == (40, 1024) and (k[0] != k[1]).any() and abs(k.mean() - 3.0) < 0.1 and ch.accept_rate == 1.0
