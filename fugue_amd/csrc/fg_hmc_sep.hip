@@ -50,38 +50,53 @@ struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 // sigma is a power of two (no quotient branch at all).  The sums are fg_grec_math's: log_prior = the sample record,
 // log_likelihood = the observe records in order, total = prior + likelihood (trace.rs:198-200), g = (lp - lm) / (2h).
 // emi = e * m_inv_i (hmc.rs:391-393: eps * m_inv[i] * p[i], left to right) or e.  Returns "a force component was non-finite".
-template <int NOBS, bool P2>
+// CHECK = false leaves the per-step "force component non-finite" test (hmc.rs:395-399) to the caller: a non-finite g makes
+// hk * g non-finite, p only ever changes by adding kicks, and inf / NaN never add back to a finite number -- so a finite
+// endpoint p proves every g was finite; a non-finite one sends the coordinate through the CHECK = true instance again.
+// The uniform conditions on gs are real scalar branches (the empty asm keeps the compiler from turning them into selects:
+// two v_cndmask per f64 and a compare in a loop that is bound by VALU issue).
+template <int NOBS, bool P2, bool CHECK>
 __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double &q_io, double &p_io, double emi, double hk, int L, double h, double two_h,
-                                                  double rcp_2h, double *terms, int tw) {
+                                                  double rcp_2h, double *terms, int tw, int nobs_rt) {
+#define FG_SEP_HAS(k) (NOBS >= 0 ? NOBS >= (k) : nobs_rt >= (k))
     FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
     double q = q_io, p = p_io;
     bool bad = false;
     for (int gs = 0; gs <= L; ++gs) {
         const double qp = q + h, qm = q - h;                     // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
         FG_SEP_DUAL(0, tp, tm)
-        if (NOBS >= 1) {
+        if (FG_SEP_HAS(1)) {
             FG_SEP_DUAL(1, lp1, lm1)
             double sp = lp1, sm = lm1;
-            if (NOBS >= 2) { FG_SEP_DUAL(2, lp2, lm2) sp += lp2; sm += lm2; }
-            if (NOBS >= 3) { FG_SEP_DUAL(3, lp3, lm3) sp += lp3; sm += lm3; }
+            if (FG_SEP_HAS(2)) { FG_SEP_DUAL(2, lp2, lm2) sp += lp2; sm += lm2; }
+            if (FG_SEP_HAS(3)) { FG_SEP_DUAL(3, lp3, lm3) sp += lp3; sm += lm3; }
             tp = tp + sp; tm = tm + sm;                          // log_prior + log_likelihood
         }
         const double n = tp - tm;
         double g = fg_div_const(n, two_h, rcp_2h);               // (lp - lm) / (2h), hmc.rs:322
         const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
-        if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953]
-        bad = bad || !fg_finite(g);
+        if (__builtin_expect(__any(!((ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953] (n = 0 too: a true division is always right)
+        if (CHECK) bad = bad || !fg_finite(g);
         const double kick = hk * g;
         p = p + kick;                                            // hmc.rs:389 / :400
-        if (gs > 0 && gs < L) p = p + kick;                      // trailing kick of this step + leading kick of the next
-        if (gs < L) q = q + emi * p;                             // hmc.rs:391-393
+        if (gs > 0 && gs < L) { asm volatile(""); p = p + kick; }   // trailing kick of this step + leading kick of the next
+        if (gs < L) { asm volatile(""); q = q + emi * p; }       // hmc.rs:391-393
     }
     FG_SEP_TERM(0)
-    if (NOBS >= 1) FG_SEP_TERM(1)
-    if (NOBS >= 2) FG_SEP_TERM(2)
-    if (NOBS >= 3) FG_SEP_TERM(3)
+    if (FG_SEP_HAS(1)) FG_SEP_TERM(1)
+    if (FG_SEP_HAS(2)) FG_SEP_TERM(2)
+    if (FG_SEP_HAS(3)) FG_SEP_TERM(3)
     q_io = q; p_io = p;
     return bad;
+#undef FG_SEP_HAS
+}
+
+// the checked re-run of a coordinate whose endpoint momentum came out non-finite: any record mix, out of line
+__device__ __noinline__ FgD3 fg_sep_trajectory_checked(const FG_AS4 char *rb, double q, double p, double emi, double hk, int L, double h,
+                                                       double two_h, double rcp_2h, double *terms, int tw, int nobs) {
+    const bool bad = fg_sep_trajectory<-1, false, true>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+    FgD3 r; r.a = q; r.b = p; r.c = bad ? 1.0 : 0.0;
+    return r;
 }
 
 template <bool MASS>
@@ -96,9 +111,14 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     const int d = P.d, L = H.L, n_s = P.n_sstream, n_pri = P.n_prior_terms;
-    // LDS tile [rows][64]: site values | kinetic terms of p0 | kinetic terms of the endpoint p | score terms | exchange
+    // LDS tile [rows][64]: (site values, only when a statement reads no coordinate) | kinetic terms of p0 | kinetic terms of
+    // the endpoint p | score terms | exchange.  The coordinates themselves are NOT in LDS: a trajectory starts from the chain's
+    // committed value row in HBM (L2-resident: d * C * 8 B split over 8 XCDs) and parks its endpoint in the proposal rows
+    // (H.p0_scratch) until the accept decision -- 32 rows less per tile, which is what lets TWO tiles share a CU's 160 KB at
+    // d = 32, so one tile's in-order sums / accept step overlap the other tile's trajectories.
+    const int srows = P.n_sep_free > 0 ? P.n_slots : 0;
     double *slots = lds + lane;
-    double *kin0 = lds + (long long)P.n_slots * tw + lane;
+    double *kin0 = lds + (long long)srows * tw + lane;
     double *kin1 = kin0 + (long long)d * tw;
     double *terms = kin1 + (long long)d * tw;
     double *xch = terms + (long long)n_s * tw;                     // rows: 0 step size, 1 accepted, 2 divergence bits
@@ -111,7 +131,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0, e_cur = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
     if (wv == 0) {
-        fg_load_values(P, X, c, slots, tw);
+        if (srows) fg_load_values(P, X, c, slots, tw);
         lj = H.lj[c]; eps = H.eps[c]; frozen = H.frozen[c];
         da_mu = H.da_mu[c]; da_leb = H.da_leb[c]; da_hbar = H.da_hbar[c]; da_m = H.da_m[c];
         for (int k = 0; k < P.n_sep_free; ++k) {                    // statements that read no coordinate: their terms never change
@@ -146,18 +166,22 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             double p = MASS ? z * ms[(long long)i * X.C] : z;
             const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
             kin0[i * tw] = MASS ? p * p * mii : p * p;                  // hmc.rs:442-443, summed in coordinate order by wave 0
-            double q = slots[i * tw];
+            const long long gq = (long long)P.f64_site[i] * X.C + c;
+            double q = fg_as_double(X.values[gq]);
             const double emi = MASS ? e * mii : e;
             const FgSepCoord cd = P.sep_coord[i];
             const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
             const int nobs = (cd.n & 7) - 1;
-            bool b;
-#define FG_SEP_CALL(NO, PP) b = fg_sep_trajectory<NO, PP>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw)
+            const double q0 = q, p0 = p;
+#define FG_SEP_CALL(NO, PP) fg_sep_trajectory<NO, PP, false>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, NO)
             if (cd.n & 256) { if (nobs == 1) FG_SEP_CALL(1, true); else if (nobs == 0) FG_SEP_CALL(0, true); else if (nobs == 2) FG_SEP_CALL(2, true); else FG_SEP_CALL(3, true); }
             else { if (nobs == 1) FG_SEP_CALL(1, false); else if (nobs == 0) FG_SEP_CALL(0, false); else if (nobs == 2) FG_SEP_CALL(2, false); else FG_SEP_CALL(3, false); }
 #undef FG_SEP_CALL
-            bad = bad || b;
-            slots[i * tw] = q;
+            if (__builtin_expect(__any(!fg_finite(p)), 0)) {           // some force component may have been non-finite: the exact per-step test
+                const FgD3 r = fg_sep_trajectory_checked(rb, q0, p0, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+                q = r.a; p = r.b; bad = bad || r.c != 0.0;
+            }
+            if (live) H.p0_scratch[(long long)i * X.C + c] = q;       // the proposal row
             kin1[i * tw] = MASS ? p * p * mii : p * p;
         }
         if (bad) atomicOr((unsigned long long *)(xch + 2 * tw), 1ull);
@@ -212,9 +236,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
         for (int i = k0; i < k1; ++i) {                           // commit or roll back the own f64 sites
             const long long g = (long long)P.f64_site[i] * X.C + c;
-            if (acc) { if (live) X.values[g] = fg_as_i64(slots[i * tw]); }
-            else slots[i * tw] = fg_as_double(X.values[g]);
-            const double x = slots[i * tw];
+            const double x = acc ? H.p0_scratch[(long long)i * X.C + c] : fg_as_double(X.values[g]);
+            if (acc && live) X.values[g] = fg_as_i64(x);
             if (live && pos_all) pos_all[((long long)t * d + i) * X.C + c] = x;
             if (warming) {
                 if (welford_on) {                                 // Welford::push: hmc.rs:202-211
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
     if (!e->P.sep || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
     const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
-    const size_t lds = (size_t)(e->n_slots + 2 * e->d + e->P.n_sstream + 3) * FG_WAVE * sizeof(double);
+    const size_t lds = (size_t)((e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * e->d + e->P.n_sstream + 3) * FG_WAVE * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
     // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates.
