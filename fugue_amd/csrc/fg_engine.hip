@@ -12,6 +12,7 @@
 // temporaries + momentum) is a [(n_slots + d)][64] tile of doubles in LDS.
 #include "fg_engine_internal.h"
 #include "fg_gradstream.h"
+#include "fg_cold.h"
 
 // ---- run(PriorHandler, model) per chain: interpreters.rs:88-104 ----
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
@@ -281,7 +282,17 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
 struct FgSeg { int c[FG_MW_MAX + 1]; int g[FG_MW_MAX + 1];
                int separable; };   // every record of a wave reads only that wave's own coordinates (and constants): no barrier inside the leapfrog loop
 
-template <int RK, bool AN>
+// the interpreter's scoring run behind a call: its seventeen inlined log-densities would otherwise take part in the register
+// allocation of the leapfrog loop
+static __device__ __noinline__ FgAcc3 fg_cold_score_exec(const FgIns *ins, int n_ins, const double *pool, double *slots, int tw) {
+    FgAcc3 A = {0.0, 0.0, 0.0};
+    fg_exec<FG_MODE_SCORE, false>(ins, n_ins, pool, slots, tw, A, nullptr, nullptr, 0, false);
+    return A;
+}
+
+// SS: the program has a score stream (endpoint score = one pass over records); without it the endpoint score is the
+// interpreter's scoring run, kept in its own instantiations
+template <int RK, bool AN, bool SS>
 __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSeg seg, int iter0, int n_steps,
                                                                                int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                                double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
@@ -304,6 +315,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
     const bool sep = seg.separable != 0 && !dense;
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     // wave 0 owns the per-chain sampler state
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
@@ -318,13 +330,11 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         double h0 = 0.0, u = 0.0;
         // p0 ~ N(0, M) (hmc.rs:436-441): Box-Muller pair j of the chain's (iteration) Philox stream is block j, so the
         // pairs are drawn by whichever wave gets them -- the values do not depend on who draws
-        FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_HMC);
         const int n_pairs = (d + 1) >> 1;
 #ifndef FG_EXP_NOMOM
         for (int j = wv; j < n_pairs; j += W) {
-            double z0, z1;
-            rng.c1 = (uint32_t)j;
-            fg_rng_normal_pair(rng, z0, z1);
+            const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)j, (uint32_t)iter, FG_RNG_HMC);
+            const double z0 = zz.a, z1 = zz.b;
             const int i = 2 * j;
             pl[i * tw] = z0 * (ms ? ms[(long long)i * X.C] : 1.0);
             if (i + 1 < d) pl[(i + 1) * tw] = z1 * (ms ? ms[(long long)(i + 1) * X.C] : 1.0);
@@ -335,12 +345,11 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
             if (warming) e = eps;
             else {                                             // frozen_or_current: hmc.rs:789-798
                 if (frozen == frozen) e = frozen;
-                else if (n_warmup > 0) e = exp(da_leb);
+                else if (n_warmup > 0) e = fg_cold_exp(da_leb);
                 else e = eps;
                 frozen = e;
             }
-            rng.c1 = (uint32_t)n_pairs;
-            u = fg_rng_u01(rng);
+            u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)n_pairs, (uint32_t)iter, FG_RNG_HMC).a;
             xch[0] = e;
         }
         __syncthreads();
@@ -367,15 +376,15 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
             for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
             FgAcc3 A = {0.0, 0.0, 0.0};
 #ifndef FG_EXP_NOSCORE
-            if (P.sstream) fg_score_stream<RK>(P.sstream, P.n_sstream, P.pool, slots, tw, A);                               // score_full, hmc.rs:283-299
-            else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
+            if (SS) fg_score_stream<RK>(P.sstream, P.n_sstream, P.pool, slots, tw, A);                                       // score_full, hmc.rs:283-299
+            else A = fg_cold_score_exec(P.ins_fast, P.n_ins, P.pool, slots, tw);
 #endif
             const double lj_new = fg_total(A);
             div = div || !fg_finite(lj_new);
             double ap = 0.0; bool acc = false;
             if (!div) {
                 const double h_new = -lj_new + fg_kinetic(P, pl, tw, mi, X.C);
-                ap = fmin(exp(h0 - h_new), 1.0);                 // hmc.rs:460
+                ap = fg_cold_accept_prob(h0, h_new);             // hmc.rs:460
                 acc = u < ap;                                    // hmc.rs:461
             }
             if (acc) lj = lj_new;
@@ -388,14 +397,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
 #ifndef FG_EXP_NODA
             if (warming) {                                       // DualAveraging::update: hmc.rs:168-178
                 da_m += 1ull;
-                const double m = (double)da_m;
-                const double a = ap < 0.0 ? 0.0 : (ap > 1.0 ? 1.0 : ap);
-                const double frac = 1.0 / (m + 10.0);
-                da_hbar = (1.0 - frac) * da_hbar + frac * (H.target - a);
-                const double log_eps = da_mu - (sqrt(m) / 0.05) * da_hbar;
-                const double w = pow(m, -0.75);
-                da_leb = w * log_eps + (1.0 - w) * da_leb;
-                eps = exp(log_eps);
+                const FgD3 r = fg_cold_da_update(da_hbar, da_leb, (double)da_m, da_mu, H.target, ap);
+                eps = r.a; da_hbar = r.b; da_leb = r.c;
             }
 #endif
         }
@@ -748,8 +751,10 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) || set_lds(k_log_joint_stream, e->lds_score) ||
-        set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false>, lds_hmc) ||
-        set_lds(k_hmc_stream_steps<0, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
+        set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false, true>, lds_hmc) ||
+        set_lds(k_hmc_stream_steps<0, true, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true, true>, lds_hmc) ||
+        set_lds(k_hmc_stream_steps<0, false, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false, false>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false, false>, lds_hmc) ||
+        set_lds(k_hmc_stream_steps<0, true, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true, false>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
         set_lds(k_hmc_grad, lds_hmc) || set_lds(k_hmc_find_eps, lds_hmc) ||
         set_lds(k_mh_steps, e->lds_score))
         return fail("hipFuncSetAttribute");
@@ -988,14 +993,16 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
             }
         int rk = e->P.sstream_kinds;                             // record kinds present in either stream
         for (int k = 0; k < nrec && rk < 2; ++k) rk = std::max(rk, (gs[k].flags & FG_G_GEN) ? 2 : ((gs[k].flags & FG_G_LIN) ? 1 : 0));
-#define FG_LAUNCH_STREAM(RK) hipLaunchKernelGGL(k_hmc_stream_steps<RK FG_AN>, dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, \
-                                                iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
-#define FG_AN , false
-        if (!analytic) { if (rk == 2) FG_LAUNCH_STREAM(2); else if (rk == 1) FG_LAUNCH_STREAM(1); else FG_LAUNCH_STREAM(0); }
-#undef FG_AN
-#define FG_AN , true
-        else { if (rk == 1) FG_LAUNCH_STREAM(1); else FG_LAUNCH_STREAM(0); }
-#undef FG_AN
+#define FG_LAUNCH_STREAM(RK, AN, SS) hipLaunchKernelGGL((k_hmc_stream_steps<RK, AN, SS>), dim3(tiles), dim3(FG_WAVE * W), e->lds_bytes, e->stream, e->P, e->X, e->H, seg, \
+                                                        iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
+        const bool ss = e->P.sstream != nullptr;
+        if (!analytic) {
+            if (ss) { if (rk == 2) FG_LAUNCH_STREAM(2, false, true); else if (rk == 1) FG_LAUNCH_STREAM(1, false, true); else FG_LAUNCH_STREAM(0, false, true); }
+            else { if (rk == 2) FG_LAUNCH_STREAM(2, false, false); else if (rk == 1) FG_LAUNCH_STREAM(1, false, false); else FG_LAUNCH_STREAM(0, false, false); }
+        } else {
+            if (ss) { if (rk == 1) FG_LAUNCH_STREAM(1, true, true); else FG_LAUNCH_STREAM(0, true, true); }
+            else { if (rk == 1) FG_LAUNCH_STREAM(1, true, false); else FG_LAUNCH_STREAM(0, true, false); }
+        }
 #undef FG_LAUNCH_STREAM
         HIPCHK(hipGetLastError());
         return FG_OK;

@@ -80,12 +80,17 @@ __device__ __forceinline__ void fg_gen_lp(const fg_u32x16 &r, double xs, const d
         if (fl & (FG_G_GEN_P0SLOT << q)) { const uint32_t idx = r[6 + 2 * q]; p[q] = slots[idx * tw]; pp[q] = dual && idx == ci; }
         else { p[q] = fg_dbl(r[6 + 2 * q], r[7 + 2 * q]); pp[q] = false; }
     }
-    const double hh[5] = { fg_dbl(r[12], r[13]), fg_dbl(r[14], r[15]), 0.0, 0.0, 0.0 };
+    const double hh[2] = { fg_dbl(r[12], r[13]), fg_dbl(r[14], r[15]) };
 #pragma nounroll
     for (int s = 0; s < n_signs; ++s) {                      // the perturbed operand holds orig +- h (hmc.rs:317-319)
         const double hs = dual ? (s == 0 ? h : -h) : 0.0;
-        lp_out[s] = fg_logpdf(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1],
-                              pp[2] ? p[2] + hs : p[2], hh, sh);
+#ifdef FG_GEN_INLINE_LOGPDF
+        const double hh5[5] = { hh[0], hh[1], 0.0, 0.0, 0.0 };
+        lp_out[s] = fg_logpdf(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1], pp[2] ? p[2] + hs : p[2], hh5, sh);
+#else
+        lp_out[s] = fg_logpdf_cold(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1],
+                                   pp[2] ? p[2] + hs : p[2], hh[0], hh[1], 0.0, 0.0, 0.0, sh);   // out of line: the 17 densities stay out of the stream loops' registers
+#endif
     }
 }
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     //           target -- the index resampled from the constant prior table with its prior log-probability (mh.rs:516-530);
     //   part 1: gaussian_z (mh.rs:128-132) from block 1 and the accept uniform of block 2.
     // With W >= 3 the two parts run on two waves (block 1 is then generated twice: the parts stay independent).
-    auto publish_rng = [&](int it, int part) {
+    auto publish_rng = [&](int it, int part) __attribute__((always_inline)) {
         double *b = xch + (long long)(8 * (it & 1)) * tw;
         FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
         unsigned long long ra, rb;

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_record(FgProgramD
     const double hk = 0.5 * e;
     int np = 0;
     bool bad = false;
-    auto record = [&]() {                                      // record_point, hmc.rs:371-381
+    auto record = [&]() __attribute__((always_inline)) {       // record_point, hmc.rs:371-381 (inlined: np / bad stay in registers)
         FgAcc3 A = {0.0, 0.0, 0.0};
         fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
         const double hval = -fg_total(A) + fg_kinetic(P, pl, tw, mi, X.C);
