@@ -30,10 +30,20 @@
 // records [r0, r1) of the score stream at the current tile state -> term rows (row = the record's `coord` field).  Records
 // are fetched two ahead into three rotating 16-SGPR buffers (the loop is unrolled by three so that no buffer is ever
 // copied), operands one ahead; s_waitcnt by hand (SMEM returns out of order).
+#ifdef FG_EXP_MH_NOFETCH      /* timing experiments only (tools/exp_mh_terms.sh): results are wrong */
+#define FG_MH_FETCH(RC) RC = fg_fetch_grec(g, r0 + ((k + 2) & 1));
+#else
+#define FG_MH_FETCH(RC) RC = fg_fetch_grec(g, k + 2);
+#endif
+#ifdef FG_EXP_MH_NOLDS
+#define FG_MH_OPND(RB, XB, MB) XB = xa; MB = ma;
+#else
+#define FG_MH_OPND(RB, XB, MB) XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw];
+#endif
 #define FG_MH_TSTAGE(RA, XA, MA, RB, XB, MB, RC)                                                  \
     __builtin_amdgcn_s_waitcnt(0xc07f);                                                           \
-    RC = fg_fetch_grec(g, k + 2);                                                                 \
-    XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw];                                               \
+    FG_MH_FETCH(RC)                                                                               \
+    FG_MH_OPND(RB, XB, MB)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                            \
     { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy, lane_pool); } \
     if (++k >= r1) break;

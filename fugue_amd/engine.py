@@ -99,7 +99,8 @@ def lib():
         return _lib
     from . import build as _b
     try:                                  # a no-op when the library is fresh; rebuilds a stale one where hipcc exists
-        _b.build()
+        if not (os.environ.get("FG_LIB_PATH") and os.path.exists(LIB_PATH)):   # an experiment library is taken as it is
+            _b.build()
     except Exception:
         if not os.path.exists(LIB_PATH):
             raise

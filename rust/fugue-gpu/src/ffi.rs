@@ -129,6 +129,34 @@ extern "C" {
     pub fn fg_device_alloc(e: *mut fg_engine, bytes: usize) -> *mut c_void;
     pub fn fg_device_free(e: *mut fg_engine, p: *mut c_void) -> c_int;
     pub fn fg_device_download(e: *mut fg_engine, h: *mut c_void, d: *const c_void, bytes: usize) -> c_int;
+    pub fn fg_device_upload(e: *mut fg_engine, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
+    // ---- introspection of programs and engines
+    pub fn fg_program_n_instructions(p: *const fg_program) -> c_int;
+    pub fn fg_program_n_slots(p: *const fg_program) -> c_int;
+    pub fn fg_program_dep_count(p: *const fg_program, k: c_int) -> c_int;
+    pub fn fg_dsl_warning_count(p: *const fg_program) -> c_int;
+    pub fn fg_dsl_warning(p: *const fg_program, i: c_int) -> *const c_char;
+    pub fn fg_engine_stream(e: *mut fg_engine) -> *mut c_void;                       // hipStream_t
+    pub fn fg_engine_set_stream(e: *mut fg_engine, hip_stream: *mut c_void) -> c_int;
+    pub fn fg_engine_n_chains(e: *const fg_engine) -> i64;
+    pub fn fg_engine_values_device(e: *mut fg_engine) -> *mut c_void;                // d_cells [S][C]
+    pub fn fg_log_joint_stream(e: *mut fg_engine, h_acc: *mut f64, h_rec_lp: *mut f64) -> c_int;
+    // ---- pieces of the samplers with their randomness injected (what the reference's unit tests drive: hmc.rs:304-329, 419-535)
+    pub fn fg_hmc_get_log_joint(e: *mut fg_engine, h_lj: *mut f64) -> c_int;
+    pub fn fg_hmc_get_mass(e: *mut fg_engine, h_m_inv: *mut f64) -> c_int;
+    pub fn fg_hmc_grad(e: *mut fg_engine, h: f64, grad_mode: c_int, h_grad: *mut f64, h_ok: *mut i32) -> c_int;
+    pub fn fg_hmc_transition_injected(e: *mut fg_engine, cfg: *const fg_hmc_config, eps: f64, h_p0: *const f64, h_u: *const f64,
+                                      h_accepted: *mut i32, h_alpha: *mut f64, h_divergent: *mut i32, h_lj: *mut f64) -> c_int;
+    pub fn fg_hmc_find_eps_injected(e: *mut fg_engine, cfg: *const fg_hmc_config, h_p0: *const f64, h_eps: *mut f64) -> c_int;
+    pub fn fg_mh_get_stats(e: *mut fg_engine, h_stats: *mut fg_mh_stats) -> c_int;
+    pub fn fg_mh_get_scales(e: *mut fg_engine, h_scales: *mut f64) -> c_int;
+    pub fn fg_mh_get_log_weight(e: *mut fg_engine, h_lw: *mut f64) -> c_int;
+    // ---- population primitives on host arrays (numerical.rs:15-38, smc.rs:255-314, 588-622)
+    pub fn fg_device_log_sum_exp(device_ordinal: c_int, h_x: *const f64, n: i64, out: *mut f64) -> c_int;
+    pub fn fg_device_next_beta(device_ordinal: c_int, beta: f64, h_log_w: *const f64, h_loglik: *const f64, n: i64, target_ess: f64, out_beta: *mut f64) -> c_int;
+    pub fn fg_device_resample_indices(device_ordinal: c_int, method: c_int, h_weights: *const f64, n: i64, h_u: *const f64, h_idx: *mut i64) -> c_int;
+    pub fn fg_diag_chain_moments(e: *mut fg_engine, d_draws: *const f64, n: c_int, d: c_int, d_moments: *mut f64) -> c_int;
+    pub fn fg_diag_autocov_sums(e: *mut fg_engine, d_draws: *const f64, n: c_int, d: c_int, d_moments: *const f64, lag0: c_int, n_lags: c_int, h_sums: *mut f64) -> c_int;
 }
 
 /// The message of the last failed call on this thread.

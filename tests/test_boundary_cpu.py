@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol():
     assert E.lib().fg_abi_version() == 1
 
 
+def test_rust_binding_declares_every_entry_point():
+    """rust/fugue-gpu/src/ffi.rs (the reference-side binding, unverified source) stays in step with include/fugue_amd.h."""
+    ffi = open(os.path.join(ROOT, "rust", "fugue-gpu", "src", "ffi.rs")).read()
+    bound = set(re.findall(r"pub fn (fg_[a-z0-9_]+)\s*\(", ffi))
+    assert bound == set(E.ABI_SYMBOLS), bound ^ set(E.ABI_SYMBOLS)
+
+
 @pytest.mark.parametrize("name", list(ZOO))
 def test_site_order_is_lexicographic_and_matches_oracle(oracle, name):
     prog = ZOO[name]()
