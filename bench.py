@@ -195,6 +195,35 @@ def measured_traffic(chains, n_launch, grad):
     return None
 
 
+NATIVE_RCCL_TIMEOUT_S = 120.0
+
+
+def call_with_timeout(fn, seconds):
+    """fn() on a daemon thread (ctypes calls release the GIL); raises TimeoutError when it has not returned in time -- the
+    thread is then abandoned (the process ends with os._exit in that case, see main)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except BaseException as ex:                              # noqa: BLE001
+            box["e"] = ex
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        ABANDONED.append(th)
+        raise TimeoutError(f"no return within {seconds:.0f} s")
+    if "e" in box:
+        raise box["e"]
+    return box.get("r")
+
+
+ABANDONED = []
+
+
 class Clock:
     """Barrier + synchronize on both sides of a region; MAX over ranks."""
 
@@ -295,20 +324,35 @@ def run_rank(args):
         try:
             ids = [E.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            comm = eng.comm_init(world, rank, ids[0])
-        except Exception as ex:                                  # every rank must take the same path
-            sys.stderr.write(f"rank {rank}: RCCL communicator in the library failed ({ex}); falling back to torch.distributed\n")
+            # under a watchdog: this path has only ever run with one rank (one GPU per development box); a communicator that
+            # cannot form must cost a bounded wait, not the run
+            comm = call_with_timeout(lambda: eng.comm_init(world, rank, ids[0]), NATIVE_RCCL_TIMEOUT_S)
+        except BaseException as ex:                              # every rank must take the same path
+            sys.stderr.write(f"rank {rank}: RCCL communicator in the library failed ({ex!r}); falling back to torch.distributed\n")
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and comm is not None:
             E.comm_destroy(comm); comm = None
         diag_path = "library: ncclAllGather + ncclAllReduce" if comm is not None else "torch.distributed collectives + library combination"
-    if world == 1 or comm is not None:
-        r = eng.diag_rhat_ess(draws.data_ptr(), K, d, comm)
-        rhat, ess, n_chains_diag = r["r_hat"], (r["ess"] if K >= 4 else np.full(d, float("nan"))), r["chains"]
-        if comm is not None:
+    r = None
+    if world == 1:
+        r = eng.diag_rhat_ess(draws.data_ptr(), K, d, None)
+    elif comm is not None:
+        ok = 1
+        try:
+            r = call_with_timeout(lambda: eng.diag_rhat_ess(draws.data_ptr(), K, d, comm), NATIVE_RCCL_TIMEOUT_S)
+        except BaseException as ex:
+            sys.stderr.write(f"rank {rank}: fg_diag_rhat_ess over RCCL failed ({ex!r}); falling back to torch.distributed\n")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            r, diag_path = None, "torch.distributed collectives + library combination (RCCL inside the library did not complete)"
+        else:
             E.comm_destroy(comm)
+    if r is not None:
+        rhat, ess, n_chains_diag = r["r_hat"], (r["ess"] if K >= 4 else np.full(d, float("nan"))), r["chains"]
     else:
         prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
         cd = D.ChainDiagnostics(prov, device=None if one_device else coll_dev)
@@ -507,6 +551,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     run_rank(args)
+    if ABANDONED:                                                # a thread is stuck inside a collective: do not wait for it at interpreter exit
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
