@@ -224,6 +224,26 @@ def call_with_timeout(fn, seconds):
 ABANDONED = []
 
 
+def executed_from_pmc(chains, n_launch, grad, launch_ms):
+    """What the dominant kernel actually issues per launch, from the committed PMC passes (profiles/round2_hmc_pmc.json) and
+    this run's launch time: executed f64 flops (add / mul = 1, fma = 2 per lane) and the share of SIMD cycles that issue a
+    VALU instruction (every wave64 VALU instruction holds its SIMD for 4 cycles).  null when the run is not the profiled
+    configuration."""
+    try:
+        p = json.load(open(os.path.join(ROOT, "profiles", "round2_hmc_pmc.json")))
+        c, m = p["config"], p["per_launch"]
+        if (c["chains"], c["grad"], c["transitions_per_launch"]) != (chains, grad, n_launch):
+            return None
+        flops = 64.0 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2.0 * m["SQ_INSTS_VALU_FMA_F64"])
+        f64 = m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + m["SQ_INSTS_VALU_FMA_F64"]
+        simd_cycles = launch_ms * 1e-3 * 2.1e9 * 1024                          # 256 CUs x 4 SIMDs at the ~2.1 GHz the clock holds under f64 load
+        return {"f64_tflops": flops / (launch_ms * 1e-3) / 1e12, "f64_share_of_valu": f64 / m["SQ_INSTS_VALU"],
+                "valu_issue_share_of_simd_cycles_at_2.1GHz": 4.0 * m["SQ_INSTS_VALU"] / simd_cycles,
+                "note": "instruction counts from profiles/round2_hmc_pmc.json (rocprofv3 --pmc, same configuration) over this run's launch time"}
+    except Exception:                                                          # noqa: BLE001
+        return None
+
+
 class Clock:
     """Barrier + synchronize on both sides of a region; MAX over ranks."""
 
@@ -395,6 +415,7 @@ def run_rank(args):
                              "(2 flops/instr at 2.4 GHz) -- the arithmetic is unfused add/mul (reference rounding, 1 flop/instr) and the clock "
                              "sits near 2.1 GHz under f64 load, so ~34 TFLOP/s is the ceiling of this instruction mix.  traffic = measured "
                              "FETCH_SIZE + WRITE_SIZE per launch (separate rocprofv3 --pmc passes, profiles/)",
+                     "executed": executed_from_pmc(C, n_launch, args.grad, launch_ms),
                      "dense_semantics": {"logpdf_evals_per_transition": evals_dense,
                                          "note": "SURVEY 8d's 2 d (S+O) log-pdfs per gradient is what FG_GRAD_FD_DENSE performs (see hmc_fd_dense); the "
                                                  "sparse default never forms the terms that cancel in the reference's subtraction"},

@@ -73,6 +73,17 @@ for name, d in (("fetch", "smc_fetch"), ("write", "smc_write")):
     doc["smc"][name + "_KiB_by_kernel_4_runs"] = dict(sorted(per.items(), key=lambda kv: -kv[1])[:12])
 json.dump(doc, open(os.path.join(P, "round2_hbm_traffic.json"), "w"), indent=1)
 
+# instruction counts of the headline kernel per launch (bench.py --steps 50 --warmup 25 --launch 25: the last two launches sample)
+mix = {}
+for d in ("hmc_pmc1", "hmc_pmc2", "hmc_pmc3"):
+    for c, v in pick(counters(d), "k_hmc_sep_steps").items():
+        mix[c] = sum(v[-2:]) / max(1, len(v[-2:]))
+if mix:
+    json.dump({"_about": "rocprofv3 --pmc passes over k_hmc_sep_steps (tools/prof_round2.sh), wave-instruction counts per 25-transition sampling launch "
+                         "at 65 536 chains, fd_sparse; read by bench.py for roofline.executed",
+               "config": {"chains": 65536, "grad": "fd_sparse", "transitions_per_launch": 25}, "per_launch": mix},
+              open(os.path.join(P, "round2_hmc_pmc.json"), "w"), indent=1)
+
 # kernel stats of the default bench command + the bench line itself
 ks = first("bench/**/*kernel_stats.csv")
 if ks:
