@@ -195,7 +195,16 @@ def measured_traffic(chains, n_launch, grad):
     return None
 
 
-NATIVE_RCCL_TIMEOUT_S = 120.0
+NATIVE_RCCL_TIMEOUT_S = float(os.environ.get("FG_BENCH_RCCL_TIMEOUT", "120"))
+
+
+def progress(rank, msg):
+    """One stderr line per finished leg (stdout carries the single JSON line)."""
+    sys.stderr.write(f"[bench rank {rank} +{time.perf_counter() - T_START:.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
 
 
 def call_with_timeout(fn, seconds):
@@ -339,7 +348,7 @@ def run_rank(args):
     # (fg_diag_rhat_ess, communicator created from an id that rank 0 obtains and torch.distributed's store hands out).
     t_diag = time.perf_counter()
     diag_path, comm = "library (single GPU)", None
-    if world > 1 and not one_device:
+    if world > 1 and (not one_device or os.environ.get("FG_BENCH_FORCE_NATIVE_RCCL") == "1"):   # (forced in the rehearsal mode: exercises the failure path, RCCL refuses two ranks on one device)
         ok = 1
         try:
             ids = [E.comm_unique_id() if rank == 0 else None]
@@ -432,12 +441,17 @@ def run_rank(args):
                   "note": "statistics of the K timed draws themselves: with few steps / a short warmup they are NOT the 1e-3 evidence (a chain of "
                           "20 draws after 5 warmup transitions has not mixed) -- see `validity`"},
     }
+    progress(rank, f"hmc leg done: {value:.4g} leapfrog-steps/s over {world} rank(s)")
     if not args.no_extras:
         out["mh"] = leg_mh(args, E, W, torch, clock, stream, world, rank, local_rank)
+        progress(rank, "mh leg done")
         out["smc"] = leg_smc(args, E, W, torch, clock, stream, world, rank, local_rank)
+        progress(rank, "smc leg done")
         if rank == 0:
             out["extras"] = extras(args, E, W, local_rank)
+            progress(rank, "extras done")
             out["validity"] = validity(E, W, D, local_rank)
+            progress(rank, "validity leg done")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             gpu_dense = out.get("extras", {}).get("hmc_fd_dense_leapfrog_steps_per_sec")
@@ -552,10 +566,8 @@ def validity(E, W, D, dev):
     eng = E.Engine(cp, C, seed=2, device=dev)
     d_draws = eng.device_alloc(ns * cp.d * C * 8)
     st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE), ns, nw, d_draws)
-    prov = D.EngineMoments(eng, d_draws, ns, cp.d)
-    cd = D.ChainDiagnostics(prov)
-    rhat, mean = cd.split_rhat(), cd.pooled_mean()
-    prov.close()
+    r = eng.diag_rhat_ess(d_draws, ns, cp.d, None)          # this engine's chains only: rank 0 runs this leg alone, so NO collective here
+    rhat, mean = r["r_hat"], r["mean"]
     eng.device_free(d_draws)
     eng.close()
     _, tm, _ = W.normal_sites_truth(N_SITES)
