@@ -466,8 +466,13 @@ int fg_program::finalize() {
                 }
                 if (ok) {
                     if (pool.size() & 1) pool.push_back(0.0);
-                    sh.kind = 4; sh.F = F; sh.toff = (uint32_t)pool.size(); sh.tn = K; sh.zslot = FG_OPND_IDX(Lz.opnd[0]);
-                    pool.insert(pool.end(), opts.begin(), opts.end());
+                    // an option list already in the pool is shared (a mixture's observations all select among the same means): the
+                    // pool stays small enough to be staged into LDS by the kernels that look options up per lane
+                    size_t at = pool.size();
+                    for (size_t o = 0; o + opts.size() <= pool.size(); o += 2)
+                        if (std::memcmp(&pool[o], opts.data(), opts.size() * sizeof(double)) == 0) { at = o; break; }
+                    sh.kind = 4; sh.F = F; sh.toff = (uint32_t)at; sh.tn = K; sh.zslot = FG_OPND_IDX(Lz.opnd[0]);
+                    if (at == pool.size()) pool.insert(pool.end(), opts.begin(), opts.end());
                     continue;
                 }
             }
