@@ -10,3 +10,6 @@ from .model import (Bernoulli, Beta, Binomial, Categorical, Cauchy, ChiSquared, 
                     observe, plate, pure, sample, sequence_vec, traverse_vec, zip_models)
 from .inference import (ChainBatch, HMCConfig, ResamplingMethod, SMCConfig, SMCResult, SiteProposal, adaptive_mcmc_chain,  # noqa: F401
                         adaptive_mcmc_chain_with_overrides, adaptive_smc, hmc_chain)
+from .diagnostics import (ParameterSummary, classic_r_hat_f64, effective_sample_size, effective_sample_size_multichain,  # noqa: F401
+                          geweke_diagnostic, r_hat_f64, summarize_f64_parameter)
+from .validation import effective_sample_size_mcmc  # noqa: F401

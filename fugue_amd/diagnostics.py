@@ -14,6 +14,7 @@ tests.  The final formulas run on the host in float64 and follow the reference l
 from __future__ import annotations
 
 import math
+from dataclasses import dataclass
 from typing import Optional, Protocol
 
 import numpy as np
@@ -210,3 +211,52 @@ def geweke_diagnostic(chain: np.ndarray) -> float:
     if se == 0.0:
         return 0.0
     return float((a.sum() / len(a) - b.sum() / len(b)) / se)
+
+
+# ---- the reference's per-parameter entry points over a many-chain result (fugue_amd.inference.ChainBatch) -----------------
+@dataclass
+class ParameterSummary:                 # diagnostics.rs:306-318
+    mean: float
+    std: float
+    quantiles: dict
+    r_hat: float
+    ess: float
+
+
+def _site_draws(chains, address: str) -> np.ndarray:
+    """[n_samples][1][n_chains] f64 draws of one site (extract_f64_values, diagnostics.rs:206-216)."""
+    return np.ascontiguousarray(chains.get_f64(address))[:, None, :]
+
+
+def r_hat_f64(chains, address: str) -> float:
+    """Split R-hat of one f64 site over the chains of a ChainBatch (r_hat_f64, diagnostics.rs:218-224, 240-260)."""
+    return float(ChainDiagnostics(HostMoments(_site_draws(chains, address))).split_rhat()[0])
+
+
+def classic_r_hat_f64(chains, address: str) -> float:
+    """classic_r_hat_f64 (diagnostics.rs:226-238): whole chains, no split."""
+    return float(ChainDiagnostics(HostMoments(_site_draws(chains, address))).classic_rhat()[0])
+
+
+def effective_sample_size_multichain(values: np.ndarray) -> float:
+    """effective_sample_size_multichain (mcmc_utils.rs:214-229) of draws [n_samples][n_chains]."""
+    x = np.asarray(values, dtype=np.float64)
+    return float(ChainDiagnostics(HostMoments(x[:, None, :])).ess()[0])
+
+
+def summarize_f64_parameter(chains, address: str) -> ParameterSummary:
+    """summarize_f64_parameter (diagnostics.rs:320-392): pooled mean / std (n - 1) / quantiles, split R-hat, multi-chain ESS."""
+    x = _site_draws(chains, address)
+    allv = x.ravel()
+    if allv.size == 0:
+        return ParameterSummary(float("nan"), float("nan"), {}, float("nan"), 0.0)
+    cd = ChainDiagnostics(HostMoments(x))
+    mean = float(allv.sum() / allv.size)
+    std = float(np.sqrt(((allv - mean) ** 2).sum() / (allv.size - 1))) if allv.size > 1 else float("nan")
+    return ParameterSummary(mean, std, quantiles_f64(allv), float(cd.split_rhat()[0]), float(cd.ess()[0]))
+
+
+def effective_sample_size(particles) -> float:
+    """effective_sample_size (smc.rs:230-233) of a weighted population (SMCResult): 1 / sum w_i^2."""
+    w = np.asarray(particles.weights, dtype=np.float64)
+    return float(1.0 / (w * w).sum()) if w.size else 0.0
