@@ -103,6 +103,12 @@ class Expr:
     def min(self, o): return Expr("min", (self, as_expr(o)))
     def max(self, o): return Expr("max", (self, as_expr(o)))
 
+    # comparisons of sampled values: only `guard` consumes them (model.rs:710-716 guards are weights, not structure)
+    def __lt__(self, o): return Cond(as_expr(o) - self)
+    def __gt__(self, o): return Cond(self - as_expr(o))
+    def __le__(self, o): return Cond(as_expr(o) - self)
+    def __ge__(self, o): return Cond(self - as_expr(o))
+
     def is_const(self) -> bool:
         return self.op == "const"
 
@@ -121,6 +127,18 @@ class Expr:
         if self.op == "data":
             return f"data{self.a}[{self.b}]"
         return f"{self.op}({', '.join(map(repr, self.args))})"
+
+
+class Cond:
+    """`a < b` on expressions of sampled values: true iff `margin` > 0.  Not a Python bool -- a model whose STRUCTURE depends on
+    it cannot be flattened -- but `guard(cond)` is only a weight (0 or -inf), which the site program can express."""
+    __slots__ = ("margin",)
+
+    def __init__(self, margin: "Expr"):
+        self.margin = margin
+
+    def __bool__(self):
+        raise StructureError("a comparison of sampled values was used in Python control flow; only guard(...) accepts it")
 
 
 Number = Union[int, float, Expr]
@@ -429,8 +447,15 @@ def factor(logw: Number) -> Model:
     return Model("factor", logw, None)
 
 
-def guard(pred: bool) -> Model:
-    """model.rs:710-716"""
+def guard(pred) -> Model:
+    """model.rs:710-716: `pure(())` when the predicate holds, `factor(-inf)` otherwise.  A predicate on sampled values
+    (`guard(phi.abs() < 0.95)`) becomes the weight ln(clamp(margin * 1e300, 0, 1)): 0 when margin >= 1e-300, -inf when
+    margin <= 0 (strict and non-strict comparisons coincide: the boundary has measure zero)."""
+    if isinstance(pred, Cond):
+        m = pred.margin
+        if m.is_const():
+            return pure(None) if m.value > 0.0 else factor(float("-inf"))
+        return factor((m * 1e300).clamp(0.0, 1.0).ln())
     return pure(None) if pred else factor(float("-inf"))
 
 
