@@ -383,6 +383,8 @@ def run_rank(args):
     if r is not None:
         rhat, ess, n_chains_diag = r["r_hat"], (r["ess"] if K >= 4 else np.full(d, float("nan"))), r["chains"]
     else:
+        if diag_path.startswith("library (single"):
+            diag_path = "torch.distributed collectives + library combination"
         prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
         cd = D.ChainDiagnostics(prov, device=None if one_device else coll_dev)
         rhat = cd.split_rhat()
