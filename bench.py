@@ -64,6 +64,8 @@ def parse(argv=None):
                          "analytic: closed-form derivative (not the reference's arithmetic)")
     ap.add_argument("--launch", type=int, default=25, help="transitions fused per kernel launch")
     ap.add_argument("--leapfrog", type=int, default=16, help="L (HMCConfig::default is 16; other values are for experiments only)")
+    ap.add_argument("--spinup", type=float, default=0.4, help="seconds of untimed throw-away transitions on a scratch engine before the measured "
+                    "engine starts (the GPU's clocks settle over the first tens of ms of f64 load); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the MH / SMC / dense-FD / validity legs")
     ap.add_argument("--cpu-chains", type=int, default=4096)
@@ -241,8 +243,10 @@ def executed_from_pmc(chains, n_launch, grad, launch_ms):
     try:
         p = json.load(open(os.path.join(ROOT, "profiles", "round2_hmc_pmc.json")))
         c, m = p["config"], p["per_launch"]
-        if (c["chains"], c["grad"], c["transitions_per_launch"]) != (chains, grad, n_launch):
+        if (c["chains"], c["grad"]) != (chains, grad) or n_launch < 1:
             return None
+        k = n_launch / c["transitions_per_launch"]                               # counts scale with the transitions of a launch
+        m = {key: v * k for key, v in m.items()}
         flops = 64.0 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2.0 * m["SQ_INSTS_VALU_FMA_F64"])
         f64 = m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + m["SQ_INSTS_VALU_FMA_F64"]
         simd_cycles = launch_ms * 1e-3 * 2.1e9 * 1024                          # 256 CUs x 4 SIMDs at the ~2.1 GHz the clock holds under f64 load
@@ -334,6 +338,17 @@ def run_rank(args):
     eng.set_stream(stream.cuda_stream)                    # kernels + torch events share one stream
     draws = torch.empty((K, d, C), dtype=torch.float64, device=f"cuda:{local_rank}")
 
+    # ---- clock spin-up: throw-away transitions of the same kernel on a scratch engine (own state, own seed), so that the
+    # measured engine's W + K transitions run at the clocks the GPU settles to under this load rather than on its way there
+    if args.spinup > 0:
+        scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=local_rank)
+        scratch.set_stream(stream.cuda_stream)
+        scratch.hmc_init(cfg, 0)
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < args.spinup:
+            scratch.hmc_step(4 * args.launch)
+            torch.cuda.synchronize()
+        scratch.close()
     # ---- untimed by the contract (reported separately): HmcSession::new + W adaptive warmup transitions
     eng.hmc_init(cfg, Wn)
     warm_events = []
@@ -417,7 +432,7 @@ def run_rank(args):
         "config": {"workload": "C2-normal32: hmc_chain, 32-site conjugate Normal (x#i~N(0,1), y#i~N(x#i,0.5)=0.2i-1), "
                                f"{C} chains/GPU, L=16, HMCConfig::default", "chains_per_gpu": C, "n_sites": N_SITES,
                    "n_leapfrog": L, "grad": args.grad, "grad_note": "fd_sparse = the engine's default in the C ABI, Python and bench",
-                   "transitions_per_launch": n_launch, "sharding": f"chains x{world}" if world > 1 else "single GPU"},
+                   "transitions_per_launch": n_launch, "clock_spinup_seconds": args.spinup, "sharding": f"chains x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS, "traffic": measured_traffic(C, n_launch, args.grad),
                      "kernel": "k_hmc_sep_steps" if args.grad == "fd_sparse" else "k_hmc_stream_steps", "avg_launch_ms": launch_ms,
