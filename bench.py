@@ -338,8 +338,13 @@ def run_rank(args):
     eng.set_stream(stream.cuda_stream)                    # kernels + torch events share one stream
     draws = torch.empty((K, d, C), dtype=torch.float64, device=f"cuda:{local_rank}")
 
-    # ---- clock spin-up: throw-away transitions of the same kernel on a scratch engine (own state, own seed), so that the
-    # measured engine's W + K transitions run at the clocks the GPU settles to under this load rather than on its way there
+    # ---- untimed by the contract (reported separately): HmcSession::new + W adaptive warmup transitions
+    eng.hmc_init(cfg, Wn)
+    warm_events = []
+    t_warm = clock.region(lambda: warm_events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n), Wn, args.launch)) if Wn > 0 else None)
+    # ---- clock spin-up, directly before the timed region: throw-away transitions of the same kernel on a scratch engine (own
+    # state, own seed; the measured engine is not touched), so that the K timed transitions run at the clocks the GPU settles
+    # to under this load rather than on its way there (session set-up and a short warmup leave it mostly idle)
     if args.spinup > 0:
         scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=local_rank)
         scratch.set_stream(stream.cuda_stream)
@@ -349,10 +354,6 @@ def run_rank(args):
             scratch.hmc_step(4 * args.launch)
             torch.cuda.synchronize()
         scratch.close()
-    # ---- untimed by the contract (reported separately): HmcSession::new + W adaptive warmup transitions
-    eng.hmc_init(cfg, Wn)
-    warm_events = []
-    t_warm = clock.region(lambda: warm_events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n), Wn, args.launch)) if Wn > 0 else None)
     # ---- timed: exactly K sampling transitions
     events = []
     dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n, draws[done].data_ptr()), K, args.launch)))
