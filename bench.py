@@ -495,6 +495,15 @@ def leg_mh(args, E, W, torch, clock, stream, world, rank, dev):
     nw, ns, per = 200, 400, 100
     eng.mh_init(nw)
     eng.mh_step(per)                                       # untimed: first-launch effects
+    if args.spinup > 0:                                    # clock spin-up on a scratch engine, as in the HMC leg
+        scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=dev)
+        scratch.set_stream(stream.cuda_stream)
+        scratch.mh_init(0)
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < args.spinup:
+            scratch.mh_step(4 * per)
+            torch.cuda.synchronize()
+        scratch.close()
     eng.mh_init(nw)
     events = []
     dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), nw + ns, per)))
@@ -525,6 +534,13 @@ def leg_smc(args, E, W, torch, clock, stream, world, rank, dev):
     eng = E.Engine(cp, N, seed=42 + rank, device=dev)
     eng.set_stream(stream.cuda_stream)
     eng.smc_run(rejuvenation_steps=3, download=False)      # untimed: allocations, first-launch effects
+    if args.spinup > 0:                                    # clock spin-up: the same run on a scratch population
+        scratch = E.Engine(cp, N, seed=987654321 + rank, device=dev)
+        scratch.set_stream(stream.cuda_stream)
+        t_sp = time.perf_counter()
+        while time.perf_counter() - t_sp < args.spinup:
+            scratch.smc_run(rejuvenation_steps=3, download=False)
+        scratch.close()
     res = {}
     dt = clock.region(lambda: res.update(eng.smc_run(rejuvenation_steps=3, download=False)))   # particles and weights stay in HBM
     eng.close()
