@@ -95,19 +95,22 @@ try:
     print("bench under the profiler: value %.4g, avg_launch_ms %.4f" % (j["value"], j["roofline"]["avg_launch_ms"]))
 except Exception as e:                                            # noqa: BLE001
     print("no bench line:", e)
-# the stats average above mixes the 8 adapting launches, the 40 timed launches and the validity leg's two 200-transition launches:
-# list every dispatch of the headline kernel and average the launches of the timed region (all with 25 transitions, after warmup)
+# the stats average above mixes adapting launches, the clock spin-up's scratch launches, the 40 timed launches and the validity leg's
+# two 200-transition launches: list every dispatch of the headline kernel in order and average the launches of the timed region
+# (order in `python3 bench.py`: 8 adapting, spin-up, 40 timed, ..., 2 validity = the last two)
 kt = first("bench/**/*kernel_trace.csv")
 if kt:
     rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if "k_hmc_sep_steps" in r["Kernel_Name"]]
-    with open(os.path.join(P, "round2_hmc_timed_region.txt"), "w") as fo:
-        fo.write("k_hmc_sep_steps dispatches of `python3 bench.py` under rocprofv3 --kernel-trace, in order, ms:\n")
-        fo.write("  8 adapting launches (warmup 200 / 25): %s\n" % " ".join("%.3f" % x for x in d[:8]))
-        fo.write("  40 timed launches (steps 1000 / 25):   %s\n" % " ".join("%.3f" % x for x in d[8:48]))
-        fo.write("  validity leg (200 + 200 in two launches): %s\n" % " ".join("%.3f" % x for x in d[48:]))
-        if len(d) >= 48:
-            fo.write("average of the 40 timed launches: %.4f ms  (bench.py's HIP-event avg_launch_ms in the same run: see round2_bench_full.json)\n" % (sum(d[8:48]) / 40))
+    if len(d) >= 50:
+        adapt, spin, timed, valid = d[:8], d[8:-42], d[-42:-2], d[-2:]
+        with open(os.path.join(P, "round2_hmc_timed_region.txt"), "w") as fo:
+            fo.write("k_hmc_sep_steps dispatches of `python3 bench.py` under rocprofv3 --kernel-trace, in order, ms:\n")
+            fo.write("  8 adapting launches (warmup 200 / 25): %s\n" % " ".join("%.3f" % x for x in adapt))
+            fo.write("  clock spin-up on the scratch engine (%d launches of 100 transitions, untimed): mean %.3f\n" % (len(spin), sum(spin) / max(1, len(spin))))
+            fo.write("  40 timed launches (steps 1000 / 25):   %s\n" % " ".join("%.3f" % x for x in timed))
+            fo.write("  validity leg (200 + 200 in two launches): %s\n" % " ".join("%.3f" % x for x in valid))
+            fo.write("average of the 40 timed launches: %.4f ms  (bench.py's HIP-event avg_launch_ms in the same run: see round2_bench_full.json)\n" % (sum(timed) / 40))
 ks = first("smc/**/*kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(P, "round2_smc_kernel_stats.csv"))
