@@ -4,7 +4,7 @@
 # libraries of their own under gpurun_out/exp_libs/ (FG_LIB_PATH selects them; the product library is never touched)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-python -c "from fugue_amd import build; build.build()" > /dev/null
+ls fugue_amd/lib/obj/*.o > /dev/null 2>&1 || python fugue_amd/build.py --force > /dev/null    # the objects do not travel to the GPU box
 O=gpurun_out/exp_libs; mkdir -p $O
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -DFG_BUILD -Wno-unused-function -w"
 OBJS=$(ls -t fugue_amd/lib/obj/*.o | awk -F/ '{split($NF,a,"."); if (!(a[1] in seen)) {seen[a[1]]=1; print}}' | grep -v "/fg_mh\.")
