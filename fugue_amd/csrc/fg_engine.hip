@@ -675,7 +675,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         if (live && mh.kind != kind0) M.kind[g] = mh.kind;
         if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
         else slots[tslot * tw] = mh.old_cell;
-        if (!adapt && draws && live) {
+        if ((!adapt || M.rec_all) && draws && live) {
             long long *row = draws + (long long)(t - first_sample_t) * M.n_rec * X.C + c;
             for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
         }
@@ -793,6 +793,12 @@ int fg_engine_set_values(fg_engine *e, const void *h) {
     NEED_ENGINE(e);
     if (!h) return FG_E_BAD_ARG;
     HIPCHK(hipMemcpyAsync(e->d_values, h, (size_t)e->S * e->C * 8, hipMemcpyHostToDevice, e->stream));
+    // a live sampler session caches the log-joint of its current state: re-score it at the new values (what the reference's
+    // callers do after editing a trace: crates/fugue-wasm/src/mh.rs:239-255 runs ScoreGivenTrace)
+    for (double *lj : { e->mh_ready ? e->M.lw : (double *)nullptr, e->hmc_ready ? e->H.lj : (double *)nullptr })
+        if (lj) hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
+                                   (double *)nullptr, lj);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     return FG_OK;
 }
@@ -1267,6 +1273,12 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
     return FG_OK;
 }
 
+int fg_mh_set_recording(fg_engine *e, int during_adaptation) {
+    NEED_ENGINE(e);
+    e->M.rec_all = during_adaptation ? 1 : 0;
+    return FG_OK;
+}
+
 int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec, void *d_draws) {
     NEED_ENGINE(e);
     if (!e->mh_ready) { fg_set_error("fg_mh_step before fg_mh_init"); return FG_E_STATE; }
@@ -1285,7 +1297,7 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
     }
     e->M.rec = e->d_rec; e->M.n_rec = n_rec;
     const int iter = e->mh_iter;
-    const int first_sample_t = std::max(iter, e->mh_warmup) - iter;
+    const int first_sample_t = e->M.rec_all ? 0 : std::max(iter, e->mh_warmup) - iter;
     if (n_steps > 0) {                                                  // multi-wave tiles when every statement has a score-stream record
         const int rc = fg_mh_mw_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
         if (rc == FG_OK) { e->mh_iter += n_steps; return FG_OK; }

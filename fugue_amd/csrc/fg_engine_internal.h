@@ -59,6 +59,7 @@ struct FgMhDev {
     unsigned long long *n_acc;                           // [C] accepted proposals
     const int *rec;                                      // [n_rec] recorded sites
     int n_rec;
+    int rec_all;                                         // record during adaptation too (fg_mh_set_recording: incremental sessions)
 };
 
 struct fg_engine {

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 if (live && kind_new != kind0) M.kind[g] = kind_new;
                 if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
                 else slots[tslot * tw] = old_cell;
-                if (!adapt && draws && live) {                             // recorded cells of the CURRENT state (mh.rs:1010)
+                if ((!adapt || M.rec_all) && draws && live) {              // recorded cells of the CURRENT state (mh.rs:1010)
                     long long *row = draws + (long long)(t - 1 - first_sample_t) * M.n_rec * X.C + c;
                     for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
                 }

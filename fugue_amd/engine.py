@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "fg_hmc_config_default", "fg_hmc_init", "fg_hmc_step", "fg_hmc_step_info", "fg_hmc_get_mass", "fg_hmc_run", "fg_hmc_get_stats", "fg_hmc_get_step_sizes",
     "fg_hmc_get_log_joint", "fg_hmc_set_step_size", "fg_hmc_set_n_leapfrog", "fg_hmc_is_warming_up", "fg_hmc_iterations", "fg_hmc_step_recorded",
     "fg_state_size", "fg_state_export", "fg_state_import", "fg_hmc_grad", "fg_hmc_transition_injected",
-    "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
+    "fg_hmc_find_eps_injected", "fg_mh_init", "fg_mh_step", "fg_mh_set_recording", "fg_mh_run", "fg_mh_get_stats", "fg_mh_get_scales",
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_smc_prior_particles", "fg_smc_normalize", "fg_smc_ess", "fg_smc_resample", "fg_smc_rejuvenate",
     "fg_smc_get_weights", "fg_smc_set_log_weights", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_diag_rhat_ess", "fg_diag_combine", "fg_diag_geweke",
@@ -161,6 +161,7 @@ def lib():
     L.fg_hmc_find_eps_injected.argtypes = [vp, C.POINTER(fg_hmc_config), dp, dp]
     L.fg_mh_init.argtypes = [vp, C.c_int, C.POINTER(fg_site_proposal)]
     L.fg_mh_step.argtypes = [vp, C.c_int, ip, C.c_int, vp]
+    L.fg_mh_set_recording.argtypes = [vp, C.c_int]
     L.fg_mh_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(fg_site_proposal), ip, C.c_int, vp, C.POINTER(fg_mh_stats)]
     L.fg_mh_get_stats.argtypes = [vp, C.POINTER(fg_mh_stats)]
     L.fg_mh_get_scales.argtypes = [vp, dp]
@@ -528,6 +529,10 @@ class Engine:
     def mh_step(self, n: int, rec_sites: Sequence[int] = (), d_draws: Optional[int] = None):
         rec = (C.c_int32 * max(1, len(rec_sites)))(*rec_sites)
         _check(lib().fg_mh_step(self.h, int(n), rec, len(rec_sites), d_draws))
+
+    def mh_set_recording(self, during_adaptation: bool):
+        """Record after every step, adapting or not (incremental sessions: fugue_amd.session)."""
+        _check(lib().fg_mh_set_recording(self.h, 1 if during_adaptation else 0))
 
     def mh_run(self, n_samples: int, n_warmup: int, overrides=None, rec_sites: Sequence[int] = (), d_draws=None) -> fg_mh_stats:
         rec = (C.c_int32 * max(1, len(rec_sites)))(*rec_sites)

@@ -146,7 +146,7 @@ void *fg_engine_stream(fg_engine *e);                       /* hipStream_t */
 /* run on a caller-owned hipStream_t (e.g. PyTorch's current stream) instead of the engine's own */
 int   fg_engine_set_stream(fg_engine *e, void *hip_stream);
 int64_t fg_engine_n_chains(const fg_engine *e);
-/* current trace values, cells [S][C] */
+/* current trace values, cells [S][C]; set_values re-scores the cached log-joint of a live HMC / MH session at the new values */
 int fg_engine_set_values(fg_engine *e, const void *h_cells);
 int fg_engine_get_values(fg_engine *e, void *h_cells);
 void *fg_engine_values_device(fg_engine *e);                 /* d_cells [S][C] */
@@ -250,6 +250,9 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *h_overrides);
  * sampling-phase step the current values of h_rec_sites[0..n_rec) are appended to
  * d_draws [n_sampling_steps][n_rec][C] (8-byte cells).  n_rec = 0 records nothing. */
 int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec, void *d_draws);
+/* Incremental drivers (the step(n) / values_since protocol of crates/fugue-wasm/src/mh.rs:92-168, whose chains adapt for ever
+ * and keep every state): with during_adaptation != 0 fg_mh_step records after EVERY step, d_draws [n_steps][n_rec][C]. */
+int fg_mh_set_recording(fg_engine *e, int during_adaptation);
 int fg_mh_run(fg_engine *e, int n_samples, int n_warmup, const fg_site_proposal *h_overrides,
               const int32_t *h_rec_sites, int n_rec, void *d_draws, fg_mh_stats *h_stats);
 int fg_mh_get_stats(fg_engine *e, fg_mh_stats *h_stats);

@@ -99,6 +99,7 @@ extern "C" {
     // ---- single-site MH (mh.rs:921-1014)
     pub fn fg_mh_init(e: *mut fg_engine, n_warmup: c_int, overrides: *const fg_site_proposal) -> c_int;
     pub fn fg_mh_step(e: *mut fg_engine, n: c_int, rec_sites: *const i32, n_rec: c_int, d_draws: *mut c_void) -> c_int;
+    pub fn fg_mh_set_recording(e: *mut fg_engine, during_adaptation: c_int) -> c_int;
     pub fn fg_mh_run(e: *mut fg_engine, n_samples: c_int, n_warmup: c_int, overrides: *const fg_site_proposal, rec_sites: *const i32, n_rec: c_int,
                      d_draws: *mut c_void, stats: *mut fg_mh_stats) -> c_int;
     // ---- SMC (smc.rs:230-349, 455-790)
