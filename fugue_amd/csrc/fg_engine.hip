@@ -289,6 +289,13 @@ static __device__ __noinline__ FgAcc3 fg_cold_score_exec(const FgIns *ins, int n
     fg_exec<FG_MODE_SCORE, false>(ins, n_ins, pool, slots, tw, A, nullptr, nullptr, 0, false);
     return A;
 }
+// propose_and_score (SingleSiteProposalHandler, mh.rs:298-570) behind a call as well: taken only when some lane's site needs
+// the model to make its proposal (undecided kinds, prior-resample kinds, computed Categorical tables)
+static __device__ __noinline__ FgAcc3 fg_cold_mh_exec(const FgIns *ins, int n_ins, const double *pool, double *slots, int tw, bool live, FgMhCtx *mh) {
+    FgAcc3 A = {0.0, 0.0, 0.0};
+    fg_exec<FG_MODE_MH, false>(ins, n_ins, pool, slots, tw, A, nullptr, nullptr, 0, live, mh);
+    return A;
+}
 
 // SS: the program has a score stream (endpoint score = one pass over records); without it the endpoint score is the
 // interpreter's scoring run, kept in its own instantiations
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         const int kind0 = mh.kind;
         mh.rng = rng;                                                      // at block 1
         fg_rng_block(rng, ra, rb);
-        mh.z = fg_gaussian_z_of(ra, rb);
+        mh.z = fg_cold_gaussian_z(ra, rb);
         mh.next_block = 2;
         mh.lqf = 0.0; mh.lqr = 0.0;
         mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
@@ -649,27 +656,18 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
             } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
             if (P.sstream && P.sstream_kinds == 0) fg_score_stream<0>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
             else if (P.sstream) fg_score_stream<2>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
-            else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
+            else A = fg_cold_score_exec(P.ins_fast, P.n_ins, P.pool, slots, tw);
         } else
-            fg_exec<FG_MODE_MH, false>(P.ins, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, live, &mh);   // propose_and_score
+            A = fg_cold_mh_exec(P.ins, P.n_ins, P.pool, slots, tw, live, &mh);   // propose_and_score
         const double prop_lw = fg_total(A);
         const double log_alpha = prop_lw - lw + (mh.lqr - mh.lqf);         // + dim_term == 0 (fixed structure)  mh.rs:731-732
-        FgStream ru = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_MH);
-        ru.c1 = (uint32_t)mh.next_block;
-        const double u = fg_rng_u01(ru);                                   // only consulted when log_alpha < 0
-        const bool accept = (log_alpha >= 0.0) || (u < exp(log_alpha));    // mh.rs:733
+        const double u = fg_cold_u01_pair((uint32_t)X.seed, (uint32_t)(X.seed >> 32), X.chain0 + (uint32_t)c, (uint32_t)mh.next_block, (uint32_t)iter, FG_RNG_MH).a;   // only consulted when log_alpha < 0
+        const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));    // mh.rs:733
         if (adapt) {                                                       // DiminishingAdaptation::update  mcmc_utils.rs:88-150
             const uint32_t tot = M.tot[g] + 1u;
             const uint32_t acn = M.acc[g] + (accept ? 1u : 0u);
             double sc = mh.scale, ls = M.log_scale[g];
-            if (tot >= 10u) {
-                const double rate = (double)acn / (double)tot;
-                const double step = 1.0 / pow((double)tot, 0.7);
-                ls += step * (rate - 0.44);
-                const double ns = exp(ls);
-                sc = (fg_finite(ns) && ns > 0.0) ? fmin(fmax(ns, 0.001), 100.0) : 1.0;
-                ls = (sc == 1.0) ? 0.0 : log(sc);
-            }
+            if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
             if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
         }
         if (live && mh.kind != kind0) M.kind[g] = mh.kind;

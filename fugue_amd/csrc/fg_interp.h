@@ -286,8 +286,9 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                         lp = -0.5 * z * z - fg_ins_h(I, 0) - 0.5 * FG_LN_2PI;
                     }
                 } else {
-                    const double hh[5] = { fg_ins_h(I, 0), fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4) };
-                    lp = fg_logpdf(code, hoisted, (op & FG_F_POW2SCALE) != 0u, xf, xi, p0, p1, p2, hh, (op & FG_F_SCALEHOIST) != 0u);
+                    // out of line: the other sixteen densities (lgamma, log1p, pow ...) stay out of the interpreter loop's registers
+                    lp = fg_logpdf_cold(code, hoisted, (op & FG_F_POW2SCALE) != 0u, xf, xi, p0, p1, p2, fg_ins_h(I, 0), fg_ins_h(I, 1), fg_ins_h(I, 2),
+                                        fg_ins_h(I, 3), fg_ins_h(I, 4), (op & FG_F_SCALEHOIST) != 0u);
                 }
             }
             if (observe) A.lik += lp;                    // interpreters.rs:76-83

@@ -1,0 +1,14 @@
+"""adaptive_mcmc_chain on models that need the interpreter kernel k_mh_steps (FG_MH_MW=0 forces it for any model)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fugue_amd import engine as E
+from tests.models import ZOO
+C = 65536
+for name in sys.argv[1:] or ["alldists", "hier_scale", "coin", "refmodel8"]:
+    cp = E.compile_model(ZOO[name]())
+    eng = E.Engine(cp, C, seed=2)
+    eng.mh_init(100)
+    eng.mh_step(100); eng.synchronize()
+    t0 = time.perf_counter(); eng.mh_step(200); eng.synchronize(); dt = time.perf_counter() - t0
+    print(f"{name:12s} S={cp.S:3d} statements={cp.S + cp.O:4d} records={cp.stream_records}  {C * 200 / dt:.3e} chain-steps/s  accept {eng.mh_stats().accept_rate:.3f}", flush=True)
+    eng.close()
