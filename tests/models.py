@@ -157,3 +157,10 @@ def indep_mixed() -> M.Program:
 
 
 ZOO["indep_mixed"] = indep_mixed
+
+
+# random programs (tests/random_models.py): every ZOO-wide test (site tables, log-joint, prior draws vs the oracle) covers them too
+from tests.random_models import random_program  # noqa: E402
+
+for _k in range(6):
+    ZOO[f"rand{_k}"] = (lambda k: (lambda: random_program(2000 + k)))(_k)

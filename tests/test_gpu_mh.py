@@ -8,6 +8,7 @@ from fugue_amd import engine as E
 from fugue_amd import model as M
 from fugue_amd import workloads as W
 from tests.models import ZOO
+from tests.random_models import random_program
 
 pytestmark = pytest.mark.gpu
 
@@ -53,6 +54,16 @@ def test_mh_chain_matches_oracle(oracle, name):
             assert np.allclose(final[j, good].view(np.float64), ofinal[j, good].view(np.float64), rtol=1e-9, atol=1e-12), cp.site_names[j]
         else:
             assert np.array_equal(final[j, good], ofinal[j, good]), cp.site_names[j]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_mh_random_models_match_oracle(oracle, seed):
+    """Random programs (tests/random_models.py: chains of Normals, scale / rate / probability sites, Categorical selects with zero
+    entries in their tables, free discrete sites) through adaptive_mcmc_chain against the oracle: discrete draws exact, f64 1e-9."""
+    prog = random_program(1000 + seed)
+    cp, eng, st, draws, odraws, ofinal, oscales, ost = _run_both(oracle, prog, C=64, nw=80, ns=40, seed=21 + seed, chain0=seed)
+    _compare(cp, draws, odraws, max_bad_chains=1)
+    assert abs(st.accept_rate - ost.accept_rate) < 3e-3
 
 
 def test_mh_positive_support_uses_log_space_walk(oracle):

@@ -72,7 +72,7 @@ def test_prior_init_matches_oracle(oracle, name):
         _close(acc[:, c], oacc, 1e-10, 1e-10)
 
 
-@pytest.mark.parametrize("name", ["readme", "normal32", "coin", "refmodel8", "ridge", "mixture", "alldists", "hier_scale", "ridge7", "linreg"])
+@pytest.mark.parametrize("name", ["readme", "normal32", "coin", "refmodel8", "ridge", "mixture", "alldists", "hier_scale", "ridge7", "linreg", "rand0", "rand1", "rand2", "rand3", "rand4", "rand5"])
 def test_fd_gradient_matches_oracle(oracle, name):
     """grad_log_joint (hmc.rs:304-329): dense FD vs oracle, and sparse FD vs dense.
     A central difference with h=1e-5 amplifies a 1-ulp difference in log pi by 1/(2h), so
