@@ -191,7 +191,8 @@ def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, tar
                                        ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_DENSE),
                                        ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE),
                                        ("hier", E.GRAD_FD_SPARSE), ("hier", E.GRAD_FD_DENSE), ("ridge7", E.GRAD_FD_SPARSE),
-                                       ("hier_scale", E.GRAD_FD_SPARSE), ("linreg", E.GRAD_FD_SPARSE), ("mixture", E.GRAD_FD_SPARSE)])
+                                       ("hier_scale", E.GRAD_FD_SPARSE), ("linreg", E.GRAD_FD_SPARSE), ("mixture", E.GRAD_FD_SPARSE),
+                                       ("rand0", E.GRAD_FD_SPARSE), ("rand1", E.GRAD_FD_DENSE), ("rand2", E.GRAD_FD_SPARSE), ("rand4", E.GRAD_FD_SPARSE)])
 def test_hmc_session_matches_oracle_teacher_forced(oracle, name, mode):
     """HmcSession (hmc.rs:667-920) step by step: prior init, Alg. 4 step size, every transition's
     HmcStepInfo, the dual-averaging recursion and the frozen step size -- each checked against
