@@ -423,7 +423,8 @@ def run_rank(args):
     n_stmt = 2 * N_SITES                                                      # S + O statements of the model
     evals_sparse = (2 * d * (L + 1)) * 2 + n_stmt                             # 2 signs x 2 dependent statements per coordinate per gradient + endpoint score
     evals_dense = (2 * d * (L + 1)) * n_stmt + n_stmt                         # 2 d (S + O) per gradient
-    evals = {E.GRAD_FD_SPARSE: evals_sparse, E.GRAD_FD_DENSE: evals_dense, E.GRAD_ANALYTIC: d * (L + 1) * 2 + n_stmt}[mode]
+    evals_dense_executed = (L + 1) * (n_stmt + 2 * 2 * d)                    # the dense kernel evaluates every statement once per gradient + the moved ones at +-h; the rest of the two scoring runs is additions
+    evals = {E.GRAD_FD_SPARSE: evals_sparse, E.GRAD_FD_DENSE: evals_dense_executed, E.GRAD_ANALYTIC: d * (L + 1) * 2 + n_stmt}[mode]
     achieved_tflops = C * n_launch * evals * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
     alg_bytes_per_launch = C * n_launch * (L * 32 * d + 8 * d + 16)           # 32 d B / leapfrog step (+ draw row, lj, eps)
     out = {
@@ -444,8 +445,9 @@ def run_rank(args):
                              "FETCH_SIZE + WRITE_SIZE per launch (separate rocprofv3 --pmc passes, profiles/)",
                      "executed": executed_from_pmc(C, n_launch, args.grad, launch_ms),
                      "dense_semantics": {"logpdf_evals_per_transition": evals_dense,
-                                         "note": "SURVEY 8d's 2 d (S+O) log-pdfs per gradient is what FG_GRAD_FD_DENSE performs (see hmc_fd_dense); the "
-                                                 "sparse default never forms the terms that cancel in the reference's subtraction"},
+                                         "note": "SURVEY 8d's 2 d (S+O) log-pdfs per gradient are the two whole scoring runs of grad_log_joint; FG_GRAD_FD_DENSE adds "
+                                                 "every one of their terms in order but evaluates only the densities that moved (see hmc_fd_dense), and the sparse "
+                                                 "default never forms the terms that cancel in the reference's subtraction"},
                      "hbm_nominal": {"achieved": alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "note": "SURVEY 8d algorithmic bytes (32 d B per leapfrog step, as if q and p round-tripped HBM) / time: NOT a "
                                              "claim -- q, p stay in LDS for a whole launch and the kernel is not HBM bound"}},
@@ -567,10 +569,13 @@ def extras(args, E, W, dev):
     cp = E.compile_model(W.normal_sites(N_SITES))
     eng = E.Engine(cp, C, seed=1, device=dev)
     eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_FD_DENSE), 0)
-    eng.hmc_step(2); eng.synchronize()
-    t0 = time.perf_counter(); eng.hmc_step(10); eng.synchronize(); dt = time.perf_counter() - t0
-    out["hmc_fd_dense_leapfrog_steps_per_sec"] = C * 10 * 16 / dt
-    out["hmc_fd_dense_valu_f64_tflops"] = C * 10 * ((2 * N_SITES * 17) * 2 * N_SITES + 2 * N_SITES) * FLOPS_PER_NORMAL_LOGPDF / dt / 1e12
+    eng.hmc_step(10); eng.synchronize()
+    t0 = time.perf_counter(); eng.hmc_step(50); eng.synchronize(); dt = time.perf_counter() - t0
+    out["hmc_fd_dense_leapfrog_steps_per_sec"] = C * 50 * 16 / dt
+    out["hmc_fd_dense_note"] = ("grad_log_joint verbatim (hmc.rs:304-329): every g_i is the difference of two whole log-joints.  The kernel performs the "
+                                "additions of both full scoring runs (2 d (S + O) per gradient) but evaluates only the densities that moved: SURVEY 8d's "
+                                "2 d (S + O) log-pdfs x 8 flops per gradient would be %.1f TFLOP/s at this rate and is NOT executed") % (
+        C * 50 * ((2 * N_SITES * 17) * 2 * N_SITES + 2 * N_SITES) * FLOPS_PER_NORMAL_LOGPDF / dt / 1e12)
     eng.close()
     eng = E.Engine(cp, C, seed=1, device=dev)
     eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_ANALYTIC), 0)

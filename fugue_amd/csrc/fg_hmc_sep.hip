@@ -41,9 +41,15 @@ struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
     { const double c = fg_dbl(a##k[2], a##k[3]); const double zp = FG_SEP_Z(k, qp - c), zm = FG_SEP_Z(k, qm - c); \
       outp = FG_SEP_LP(k, zp); outm = FG_SEP_LP(k, zm); }
 // record k at q (endpoint score term; NaN z -> -inf like FG_OP_NORMAL_FAST)
-#define FG_SEP_TERM(k)                                                                                 \
+#define FG_SEP_TERM_TO(k, dst)                                                                         \
     { const double z = FG_SEP_Z(k, q - fg_dbl(a##k[2], a##k[3])); const double lp = FG_SEP_LP(k, z); \
-      terms[a##k[1] * tw] = (z != z) ? FG_NEG_INF : lp; }
+      (dst)[a##k[1] * tw] = (z != z) ? FG_NEG_INF : lp; }
+#define FG_SEP_TERM(k) FG_SEP_TERM_TO(k, terms)
+// record k at q + h and q - h with the guard of a scoring run (the dense mode adds these into whole log-joints)
+#define FG_SEPD_OWN(k, outp, outm) double outp, outm;                                                  \
+    { const double c_ = fg_dbl(a##k[2], a##k[3]); const double zp_ = FG_SEP_Z(k, qp - c_), zm_ = FG_SEP_Z(k, qm - c_); \
+      const double lp_ = FG_SEP_LP(k, zp_), lm_ = FG_SEP_LP(k, zm_);                                    \
+      outp = (zp_ != zp_) ? FG_NEG_INF : lp_; outm = (zm_ != zm_) ? FG_NEG_INF : lm_; }
 
 // The whole trajectory of one coordinate: (q, p) -> (q', p') after L leapfrog steps (hmc.rs:353-407) with step size e, then
 // the endpoint-score terms of its statements.  NOBS observe records follow the coordinate's own sample record; P2: every
@@ -99,7 +105,13 @@ __device__ __noinline__ FgD3 fg_sep_trajectory_checked(const FG_AS4 char *rb, do
     return r;
 }
 
-template <bool MASS>
+// DENSE = grad_log_joint verbatim (FG_GRAD_FD_DENSE, hmc.rs:304-329): g_i is the difference of two WHOLE log-joints.  Of their
+// S + O terms only the coordinate's own change with the sign of the perturbation, but every term takes part in the two in-order
+// sums.  So per gradient every wave first leaves the terms of its statements at the current q in LDS rows (double-buffered:
+// one barrier per gradient), then forms, for each own coordinate, log_prior and log_likelihood at q + h e_i and q - h e_i by
+// adding ALL rows in program order with the coordinate's own terms substituted -- the additions of two full scoring runs,
+// without re-evaluating the S + O - (own) densities that did not move.  q and p live in LDS rows between gradients.
+template <bool MASS, bool DENSE>
 __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSegSep seg, int iter0, int n_steps,
                                                                              int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                              double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
@@ -121,7 +133,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     double *kin0 = lds + (long long)srows * tw + lane;
     double *kin1 = kin0 + (long long)d * tw;
     double *terms = kin1 + (long long)d * tw;
-    double *xch = terms + (long long)n_s * tw;                     // rows: 0 step size, 1 accepted, 2 divergence bits
+    double *xch = terms + (long long)(DENSE ? 2 * n_s : n_s) * tw;   // rows: 0 step size, 1 accepted, 2 divergence bits
+    double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only: positions and momenta between gradients
     const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
     const double *mi = MASS ? H.m_inv + c : nullptr;
     const double *ms = MASS ? H.mass_sqrt + c : nullptr;
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             const fg_u32x16 r = fg_fetch_grec(P.sstream, (int)f.sidx);
             FgAcc3 dummy = {0.0, 0.0, 0.0};
             terms[f.trow * tw] = fg_score_one<0>(r, slots[r[0] * tw], slots[r[1] * tw], P.pool, slots, tw, dummy);
+            if (DENSE) terms[((long long)n_s + f.trow) * tw] = terms[f.trow * tw];
         }
         if (iter0 < n_warmup) e_cur = eps;
         else {                                                 // frozen_or_current: hmc.rs:789-798
@@ -159,6 +173,78 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         // its kinetic term, the whole trajectory in registers, the endpoint's kinetic and score terms
         bool bad = false;
         double zb = 0.0;
+        const double *termsE = terms;                                // rows of the endpoint's score terms
+        if (DENSE) {
+            for (int i = k0; i < k1; ++i) {                          // p0 ~ N(0, M), its kinetic term, the start position
+                double z;
+                if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
+                else z = zb;
+                const double p = MASS ? z * ms[(long long)i * X.C] : z;
+                const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
+                kin0[i * tw] = MASS ? p * p * mii : p * p;
+                prow[i * tw] = p;
+                qrow[i * tw] = fg_as_double(X.values[(long long)P.f64_site[i] * X.C + c]);
+            }
+            int tb = 0;
+            for (int gs = 0; gs <= L; ++gs) {                        // leapfrog, hmc.rs:353-407
+                double *T = terms + (long long)tb * n_s * tw;
+                for (int i = k0; i < k1; ++i) {                      // the own statements at the current q
+                    const FgSepCoord cd = P.sep_coord[i];
+                    const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
+                    const int nobs = (cd.n & 7) - 1;
+                    constexpr bool P2 = false;
+                    FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
+                    const double q = qrow[i * tw];
+                    FG_SEP_TERM_TO(0, T)
+                    if (nobs >= 1) FG_SEP_TERM_TO(1, T)
+                    if (nobs >= 2) FG_SEP_TERM_TO(2, T)
+                    if (nobs >= 3) FG_SEP_TERM_TO(3, T)
+                }
+                __syncthreads();                                     // every statement's term at q is in T
+                for (int i = k0; i < k1; ++i) {                      // two full in-order scoring sums per own coordinate, own terms substituted
+                    const FgSepCoord cd = P.sep_coord[i];
+                    const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
+                    const int nobs = (cd.n & 7) - 1;
+                    constexpr bool P2 = false;
+                    FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
+                    const double q = qrow[i * tw];
+                    const double qp = q + h, qm = q - h;             // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
+                    double Pp = 0.0, Pm = 0.0, Lp = 0.0, Lm = 0.0;
+                    {                                                // log_prior: the coordinate's own sample statement is its only prior term
+                        FG_SEPD_OWN(0, tp0, tm0)
+                        const int r0 = (int)a0[1];
+                        for (int k = 0; k < r0; ++k) { const double v = T[k * tw]; Pp += v; Pm += v; }
+                        Pp += tp0; Pm += tm0;
+                        for (int k = r0 + 1; k < n_pri; ++k) { const double v = T[k * tw]; Pp += v; Pm += v; }
+                    }
+                    {                                                // log_likelihood: its observe statements, in program (= row) order
+                        int k = n_pri;
+                        if (nobs >= 1) { FG_SEPD_OWN(1, tp1, tm1) const int r1 = (int)a1[1]; for (; k < r1; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; } Lp += tp1; Lm += tm1; ++k; }
+                        if (nobs >= 2) { FG_SEPD_OWN(2, tp2, tm2) const int r2 = (int)a2[1]; for (; k < r2; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; } Lp += tp2; Lm += tm2; ++k; }
+                        if (nobs >= 3) { FG_SEPD_OWN(3, tp3, tm3) const int r3 = (int)a3[1]; for (; k < r3; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; } Lp += tp3; Lm += tm3; ++k; }
+                        for (; k < n_s; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; }
+                    }
+                    const double n = (Pp + Lp + 0.0) - (Pm + Lm + 0.0);   // total_log_weight at q + h e_i minus at q - h e_i (log_factors = 0)
+                    double g = fg_div_const(n, two_h, rcp_2h);          // hmc.rs:322
+                    const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
+                    if (__builtin_expect(__any(!((ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;
+                    bad = bad || !fg_finite(g);
+                    const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
+                    double p = prow[i * tw] + hk * g;                   // hmc.rs:389 / :400
+                    if (gs > 0 && gs < L) p = p + hk * g;               // trailing kick of this step + leading kick of the next
+                    prow[i * tw] = p;
+                    if (gs < L) qrow[i * tw] = q + (MASS ? e * mii : e) * p;   // hmc.rs:391-393
+                }
+                tb ^= 1;                                                // the next gradient's terms go to the other buffer
+            }
+            termsE = terms + (long long)(tb ^ 1) * n_s * tw;             // the terms of the last gradient are the endpoint's
+            for (int i = k0; i < k1; ++i) {
+                const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
+                const double p = prow[i * tw];
+                if (live) H.p0_scratch[(long long)i * X.C + c] = qrow[i * tw];   // the proposal row
+                kin1[i * tw] = MASS ? p * p * mii : p * p;
+            }
+        } else
         for (int i = k0; i < k1; ++i) {
             double z;
             if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
@@ -193,9 +279,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             for (int i = 0; i < d; ++i) { s0 += kin0[i * tw]; s1 += kin1[i * tw]; }
             double pri = 0.0, lik = 0.0;
             const int n_lik = n_s - n_pri, nb = n_pri < n_lik ? n_pri : n_lik;
-            for (int k = 0; k < nb; ++k) { pri += terms[k * tw]; lik += terms[(n_pri + k) * tw]; }
-            for (int k = nb; k < n_pri; ++k) pri += terms[k * tw];
-            for (int k = nb; k < n_lik; ++k) lik += terms[(n_pri + k) * tw];
+            for (int k = 0; k < nb; ++k) { pri += termsE[k * tw]; lik += termsE[(n_pri + k) * tw]; }
+            for (int k = nb; k < n_pri; ++k) pri += termsE[k * tw];
+            for (int k = nb; k < n_lik; ++k) lik += termsE[(n_pri + k) * tw];
             const double h0 = -lj + 0.5 * s0;                        // hmc.rs:442-443
             const double lj_new = pri + lik + 0.0;                   // total_log_weight (log_factors = 0: no factor statement has a record)
             bool div = fg_as_i64(xch[2 * tw]) != 0;
@@ -266,9 +352,12 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 // Launch for `n` transitions from iteration `iter0`; returns FG_E_UNSUPPORTED when the program / configuration is not an
 // independent-sites FD-sparse run (the caller then takes the gradient-stream kernel).
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
-    if (!e->P.sep || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
+    const bool dense = e->cfg.grad_mode == FG_GRAD_FD_DENSE;
+    if (!e->P.sep || (e->cfg.grad_mode != FG_GRAD_FD_SPARSE && !dense) || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
     const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
-    const size_t lds = (size_t)((e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * e->d + e->P.n_sstream + 3) * FG_WAVE * sizeof(double);
+    const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
+                        (dense ? (size_t)e->P.n_sstream + 2 * (size_t)e->d : 0);     // dense: second term buffer, q and p rows
+    const size_t lds = rows * FG_WAVE * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
     // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates.
@@ -283,19 +372,21 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const int pairs = (e->d + 1) / 2;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
     for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, 2 * (int)((long long)pairs * w / W));
-    static bool attr_set_dev[64][2];
-    const int mass = e->H.use_mass ? 1 : 0;
-    bool &attr_set = attr_set_dev[e->device & 63][mass];
+    static bool attr_set_dev[64][4];
+    const int mass = e->H.use_mass ? 1 : 0, variant = 2 * (dense ? 1 : 0) + mass;
+    const void *fn = variant == 0 ? (const void *)k_hmc_sep_steps<false, false> : variant == 1 ? (const void *)k_hmc_sep_steps<true, false>
+                   : variant == 2 ? (const void *)k_hmc_sep_steps<false, true> : (const void *)k_hmc_sep_steps<true, true>;
+    bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
-        const hipError_t he = mass ? hipFuncSetAttribute((const void *)k_hmc_sep_steps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                                   : hipFuncSetAttribute((const void *)k_hmc_sep_steps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-    if (mass) hipLaunchKernelGGL(k_hmc_sep_steps<true>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, e->n_warmup, welford_on,
-                                 draws, first_sample_t, pos_all, info);
-    else hipLaunchKernelGGL(k_hmc_sep_steps<false>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, e->n_warmup, welford_on,
-                            draws, first_sample_t, pos_all, info);
+#define FG_SEP_LAUNCH(M, D) hipLaunchKernelGGL((k_hmc_sep_steps<M, D>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, \
+                                               e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
+    if (variant == 0) FG_SEP_LAUNCH(false, false); else if (variant == 1) FG_SEP_LAUNCH(true, false);
+    else if (variant == 2) FG_SEP_LAUNCH(false, true); else FG_SEP_LAUNCH(true, true);
+#undef FG_SEP_LAUNCH
     HIPCHK(hipGetLastError());
     return FG_OK;
 }

@@ -346,11 +346,14 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
 
 
+@pytest.mark.parametrize("mode", [E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE])
 @pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("readme", False), ("indep_mixed", True), ("indep_mixed", False)])
-def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
+def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """Independent-sites programs run whole trajectories in registers (k_hmc_sep_steps, 1..16 waves per tile) and evaluate
     the endpoint score as parallel terms summed in program order; the arithmetic per coordinate and per accumulator is the
-    gradient-stream kernel's, so draws, step sizes, mass matrix, log-joint and statistics agree BIT FOR BIT with it."""
+    gradient-stream kernel's, so draws, step sizes, mass matrix, log-joint and statistics agree BIT FOR BIT with it -- in the
+    dependency-aware mode and in the dense mode (grad_log_joint verbatim: whole log-joints at q +- h e_i, formed from term rows with
+    the coordinate's own terms substituted, against the dense stream that re-evaluates every statement)."""
     cp = E.compile_model(ZOO[name]())
     assert cp.stream_records[0] > 0 and lib_sep_records(cp) > 0
     C, nw, ns = 150, 40, 25
@@ -360,7 +363,7 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
-        st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
+        st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
         draws = eng.download(d, (ns, cp.d, C))
         eng.device_free(d)
         pos, info = eng.hmc_step_info(3)

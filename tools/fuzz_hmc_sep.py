@@ -49,18 +49,19 @@ for it in range(n_models):
     if rng.integers(0, 3) == 0:                                    # a pinned, far too large step: trajectories blow up (the checked re-run path)
         eps0, nw, mass = float(rng.choice([2.0, 50.0, 1e6, 1e160])), 0, False
     W = int(rng.choice([0, 1, 2, 4, 8, 16]))
+    mode = E.GRAD_FD_DENSE if rng.integers(0, 3) == 0 else E.GRAD_FD_SPARSE
     out = []
     for sep in (1, 0):
         os.environ["FG_HMC_SEP"] = str(sep)
         os.environ["FG_HMC_WAVES"] = str(W if sep else 0)
         eng = E.Engine(cp, C, seed=100 + it)
         buf = eng.device_alloc(max(1, ns * cp.d * C) * 8)
-        st = eng.hmc_run(E.hmc_config(n_leapfrog=L, adapt_mass=mass, init_step_size=eps0), ns, nw, buf)
+        st = eng.hmc_run(E.hmc_config(n_leapfrog=L, adapt_mass=mass, init_step_size=eps0, grad_mode=mode), ns, nw, buf)
         out.append((eng.download(buf, (ns, cp.d, C), dtype=np.int64), eng.get_values(), eng.hmc_step_sizes(), eng.hmc_log_joint(), int(st.n_divergent), eng.hmc_mass()))
         eng.device_free(buf); eng.close()
     ok = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(out[0], out[1]))
     bad += 0 if ok else 1
     n_sep = E.lib().fg_program_stream_records(cp.h, 3)
-    print(f"model {it:3d}: d={d:2d} records={cp.stream_records} sep={n_sep:3d} C={C:3d} L={L:2d} warm={nw:2d} n={ns:2d} mass={int(mass)} W={W:2d} eps0={eps0} div={out[0][4]:4d} -> {'identical' if ok else 'MISMATCH'}", flush=True)
+    print(f"model {it:3d}: d={d:2d} records={cp.stream_records} sep={n_sep:3d} C={C:3d} L={L:2d} warm={nw:2d} n={ns:2d} mass={int(mass)} W={W:2d} dense={int(mode == E.GRAD_FD_DENSE)} eps0={eps0} div={out[0][4]:4d} -> {'identical' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
