@@ -61,7 +61,9 @@ struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 // endpoint p proves every g was finite; a non-finite one sends the coordinate through the CHECK = true instance again.
 // The uniform conditions on gs are real scalar branches (the empty asm keeps the compiler from turning them into selects:
 // two v_cndmask per f64 and a compare in a loop that is bound by VALU issue).
-template <int NOBS, bool P2, bool CHECK>
+// AN = FG_GRAD_ANALYTIC: g_i = sum over the coordinate's records of d lp / d q_i = -(q - c) / sigma^2, one evaluation per record,
+// the additions of fg_grec_math's analytic branch in the same order ((x - mu) is +-(q - c) and its coefficient -+1: the same bits).
+template <int NOBS, bool P2, bool CHECK, bool AN = false>
 __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double &q_io, double &p_io, double emi, double hk, int L, double h, double two_h,
                                                   double rcp_2h, double *terms, int tw, int nobs_rt) {
 #define FG_SEP_HAS(k) (NOBS >= 0 ? NOBS >= (k) : nobs_rt >= (k))
@@ -69,6 +71,18 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double 
     double q = q_io, p = p_io;
     bool bad = false;
     for (int gs = 0; gs <= L; ++gs) {
+        double g;
+        if (AN) {
+#define FG_SEP_ANTERM(k) { const double dl = q - fg_dbl(a##k[2], a##k[3]);                                                   \
+        const double w = (P2 || (a##k[0] & FG_G_POW2)) ? (dl * fg_dbl(a##k[4], a##k[5])) * fg_dbl(a##k[4], a##k[5])         \
+                                                       : (dl / fg_dbl(b##k[0], b##k[1])) / fg_dbl(b##k[0], b##k[1]); g = g - w; }
+            g = 0.0;
+            FG_SEP_ANTERM(0)
+            if (FG_SEP_HAS(1)) FG_SEP_ANTERM(1)
+            if (FG_SEP_HAS(2)) FG_SEP_ANTERM(2)
+            if (FG_SEP_HAS(3)) FG_SEP_ANTERM(3)
+#undef FG_SEP_ANTERM
+        } else {
         const double qp = q + h, qm = q - h;                     // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
         FG_SEP_DUAL(0, tp, tm)
         if (FG_SEP_HAS(1)) {
@@ -79,9 +93,10 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double 
             tp = tp + sp; tm = tm + sm;                          // log_prior + log_likelihood
         }
         const double n = tp - tm;
-        double g = fg_div_const(n, two_h, rcp_2h);               // (lp - lm) / (2h), hmc.rs:322
+        g = fg_div_const(n, two_h, rcp_2h);                      // (lp - lm) / (2h), hmc.rs:322
         const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
         if (__builtin_expect(__any(!((ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953] (n = 0 too: a true division is always right)
+        }
         if (CHECK) bad = bad || !fg_finite(g);
         const double kick = hk * g;
         p = p + kick;                                            // hmc.rs:389 / :400
@@ -98,9 +113,10 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double 
 }
 
 // the checked re-run of a coordinate whose endpoint momentum came out non-finite: any record mix, out of line
+template <bool AN>
 __device__ __noinline__ FgD3 fg_sep_trajectory_checked(const FG_AS4 char *rb, double q, double p, double emi, double hk, int L, double h,
                                                        double two_h, double rcp_2h, double *terms, int tw, int nobs) {
-    const bool bad = fg_sep_trajectory<-1, false, true>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+    const bool bad = fg_sep_trajectory<-1, false, true, AN>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
     FgD3 r; r.a = q; r.b = p; r.c = bad ? 1.0 : 0.0;
     return r;
 }
@@ -111,12 +127,14 @@ __device__ __noinline__ FgD3 fg_sep_trajectory_checked(const FG_AS4 char *rb, do
 // one barrier per gradient), then forms, for each own coordinate, log_prior and log_likelihood at q + h e_i and q - h e_i by
 // adding ALL rows in program order with the coordinate's own terms substituted -- the additions of two full scoring runs,
 // without re-evaluating the S + O - (own) densities that did not move.  q and p live in LDS rows between gradients.
-template <bool MASS, bool DENSE>
+// MODE: 0 = dependency-aware finite difference (FG_GRAD_FD_SPARSE), 1 = DENSE, 2 = analytic (FG_GRAD_ANALYTIC)
+template <bool MASS, int MODE>
 __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSegSep seg, int iter0, int n_steps,
                                                                              int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                              double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;
+    constexpr bool DENSE = MODE == 1, AN = MODE == 2;
     const int lane = threadIdx.x & (FG_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long chain = (long long)blockIdx.x * tw + lane;
@@ -259,12 +277,12 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
             const int nobs = (cd.n & 7) - 1;
             const double q0 = q, p0 = p;
-#define FG_SEP_CALL(NO, PP) fg_sep_trajectory<NO, PP, false>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, NO)
+#define FG_SEP_CALL(NO, PP) fg_sep_trajectory<NO, PP, false, AN>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, NO)
             if (cd.n & 256) { if (nobs == 1) FG_SEP_CALL(1, true); else if (nobs == 0) FG_SEP_CALL(0, true); else if (nobs == 2) FG_SEP_CALL(2, true); else FG_SEP_CALL(3, true); }
             else { if (nobs == 1) FG_SEP_CALL(1, false); else if (nobs == 0) FG_SEP_CALL(0, false); else if (nobs == 2) FG_SEP_CALL(2, false); else FG_SEP_CALL(3, false); }
 #undef FG_SEP_CALL
             if (__builtin_expect(__any(!fg_finite(p)), 0)) {           // some force component may have been non-finite: the exact per-step test
-                const FgD3 r = fg_sep_trajectory_checked(rb, q0, p0, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+                const FgD3 r = fg_sep_trajectory_checked<AN>(rb, q0, p0, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
                 q = r.a; p = r.b; bad = bad || r.c != 0.0;
             }
             if (live) H.p0_scratch[(long long)i * X.C + c] = q;       // the proposal row
@@ -352,8 +370,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 // Launch for `n` transitions from iteration `iter0`; returns FG_E_UNSUPPORTED when the program / configuration is not an
 // independent-sites FD-sparse run (the caller then takes the gradient-stream kernel).
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
-    const bool dense = e->cfg.grad_mode == FG_GRAD_FD_DENSE;
-    if (!e->P.sep || (e->cfg.grad_mode != FG_GRAD_FD_SPARSE && !dense) || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
+    const bool dense = e->cfg.grad_mode == FG_GRAD_FD_DENSE, analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
+    if (!e->P.sep || (e->cfg.grad_mode != FG_GRAD_FD_SPARSE && !dense && !analytic) || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
     const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
     const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
                         (dense ? (size_t)e->P.n_sstream + 2 * (size_t)e->d : 0);     // dense: second term buffer, q and p rows
@@ -372,20 +390,22 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const int pairs = (e->d + 1) / 2;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
     for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, 2 * (int)((long long)pairs * w / W));
-    static bool attr_set_dev[64][4];
-    const int mass = e->H.use_mass ? 1 : 0, variant = 2 * (dense ? 1 : 0) + mass;
-    const void *fn = variant == 0 ? (const void *)k_hmc_sep_steps<false, false> : variant == 1 ? (const void *)k_hmc_sep_steps<true, false>
-                   : variant == 2 ? (const void *)k_hmc_sep_steps<false, true> : (const void *)k_hmc_sep_steps<true, true>;
+    static bool attr_set_dev[64][6];
+    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = 2 * mode + mass;
+    const void *fns[6] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
+                           (const void *)k_hmc_sep_steps<true, 1>, (const void *)k_hmc_sep_steps<false, 2>, (const void *)k_hmc_sep_steps<true, 2> };
     bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
-        const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t he = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
 #define FG_SEP_LAUNCH(M, D) hipLaunchKernelGGL((k_hmc_sep_steps<M, D>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, \
                                                e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
-    if (variant == 0) FG_SEP_LAUNCH(false, false); else if (variant == 1) FG_SEP_LAUNCH(true, false);
-    else if (variant == 2) FG_SEP_LAUNCH(false, true); else FG_SEP_LAUNCH(true, true);
+    switch (variant) {
+        case 0: FG_SEP_LAUNCH(false, 0); break; case 1: FG_SEP_LAUNCH(true, 0); break; case 2: FG_SEP_LAUNCH(false, 1); break;
+        case 3: FG_SEP_LAUNCH(true, 1); break;  case 4: FG_SEP_LAUNCH(false, 2); break; default: FG_SEP_LAUNCH(true, 2); break;
+    }
 #undef FG_SEP_LAUNCH
     HIPCHK(hipGetLastError());
     return FG_OK;

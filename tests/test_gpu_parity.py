@@ -346,7 +346,7 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
 
 
-@pytest.mark.parametrize("mode", [E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE])
+@pytest.mark.parametrize("mode", [E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE, E.GRAD_ANALYTIC])
 @pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("readme", False), ("indep_mixed", True), ("indep_mixed", False)])
 def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """Independent-sites programs run whole trajectories in registers (k_hmc_sep_steps, 1..16 waves per tile) and evaluate

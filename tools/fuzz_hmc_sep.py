@@ -49,7 +49,7 @@ for it in range(n_models):
     if rng.integers(0, 3) == 0:                                    # a pinned, far too large step: trajectories blow up (the checked re-run path)
         eps0, nw, mass = float(rng.choice([2.0, 50.0, 1e6, 1e160])), 0, False
     W = int(rng.choice([0, 1, 2, 4, 8, 16]))
-    mode = E.GRAD_FD_DENSE if rng.integers(0, 3) == 0 else E.GRAD_FD_SPARSE
+    mode = [E.GRAD_FD_SPARSE, E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE, E.GRAD_ANALYTIC][int(rng.integers(0, 4))]
     out = []
     for sep in (1, 0):
         os.environ["FG_HMC_SEP"] = str(sep)
@@ -62,6 +62,6 @@ for it in range(n_models):
     ok = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(out[0], out[1]))
     bad += 0 if ok else 1
     n_sep = E.lib().fg_program_stream_records(cp.h, 3)
-    print(f"model {it:3d}: d={d:2d} records={cp.stream_records} sep={n_sep:3d} C={C:3d} L={L:2d} warm={nw:2d} n={ns:2d} mass={int(mass)} W={W:2d} dense={int(mode == E.GRAD_FD_DENSE)} eps0={eps0} div={out[0][4]:4d} -> {'identical' if ok else 'MISMATCH'}", flush=True)
+    print(f"model {it:3d}: d={d:2d} records={cp.stream_records} sep={n_sep:3d} C={C:3d} L={L:2d} warm={nw:2d} n={ns:2d} mass={int(mass)} W={W:2d} mode={mode} eps0={eps0} div={out[0][4]:4d} -> {'identical' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
