@@ -39,7 +39,7 @@ doc = {
               "width), so the values are reported raw next to the bytes the kernel is known to write (draw rows), which calibrates them.",
 }
 # HMC headline: bench.py --steps 100 --warmup 50 --launch 25 -> 2 warmup launches + 4 sampling launches of k_hmc_sep_steps
-hf, hw = pick(counters("hmc_fetch"), "k_hmc_sep_steps<false, false>"), pick(counters("hmc_write"), "k_hmc_sep_steps<false, false>")
+hf, hw = pick(counters("hmc_fetch"), "k_hmc_sep_steps<false, 0>"), pick(counters("hmc_write"), "k_hmc_sep_steps<false, 0>")
 f, w = hf.get("FETCH_SIZE", []), hw.get("WRITE_SIZE", [])
 if f and w:
     fs, ws = f[-4:], w[-4:]
@@ -76,7 +76,7 @@ json.dump(doc, open(os.path.join(P, "round2_hbm_traffic.json"), "w"), indent=1)
 # instruction counts of the headline kernel per launch (bench.py --steps 50 --warmup 25 --launch 25: the last two launches sample)
 mix = {}
 for d in ("hmc_pmc1", "hmc_pmc2", "hmc_pmc3"):
-    for c, v in pick(counters(d), "k_hmc_sep_steps<false, false>").items():
+    for c, v in pick(counters(d), "k_hmc_sep_steps<false, 0>").items():
         mix[c] = sum(v[-2:]) / max(1, len(v[-2:]))
 if mix:
     json.dump({"_about": "rocprofv3 --pmc passes over k_hmc_sep_steps (tools/prof_round2.sh), wave-instruction counts per 25-transition sampling launch "
@@ -101,7 +101,7 @@ except Exception as e:                                            # noqa: BLE001
 kt = first("bench/**/*kernel_trace.csv")
 if kt:
     rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if "k_hmc_sep_steps<false, false>" in r["Kernel_Name"]]   # not the dense variant of the extras leg
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if "k_hmc_sep_steps<false, 0>" in r["Kernel_Name"]]   # not the dense variant of the extras leg
     if len(d) >= 50:
         adapt, spin, timed, valid = d[:8], d[8:-42], d[-42:-2], d[-2:]
         with open(os.path.join(P, "round2_hmc_timed_region.txt"), "w") as fo:
