@@ -616,8 +616,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         const long long g = (long long)target * X.C + c;
         const int tslot = P.site_slot[target];                             // per-lane gather (site -> LDS slot)
         mh.target = tslot;
-        mh.scale = M.scale[g];                                             // get_scale  mcmc_utils.rs:70-77
-        mh.kind = M.kind[g];
+        { const fg_u32x4 a0 = *(const fg_u32x4 *)(M.ad + g); mh.scale = fg_dbl(a0[0], a0[1]); mh.kind = (int)a0[2]; }   // get_scale  mcmc_utils.rs:70-77
         const int kind0 = mh.kind;
         mh.rng = rng;                                                      // at block 1
         fg_rng_block(rng, ra, rb);
@@ -664,13 +663,19 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
         const double u = fg_cold_u01_pair((uint32_t)X.seed, (uint32_t)(X.seed >> 32), X.chain0 + (uint32_t)c, (uint32_t)mh.next_block, (uint32_t)iter, FG_RNG_MH).a;   // only consulted when log_alpha < 0
         const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));    // mh.rs:733
         if (adapt) {                                                       // DiminishingAdaptation::update  mcmc_utils.rs:88-150
-            const uint32_t tot = M.tot[g] + 1u;
-            const uint32_t acn = M.acc[g] + (accept ? 1u : 0u);
-            double sc = mh.scale, ls = M.log_scale[g];
+            const fg_u32x4 a1 = *(const fg_u32x4 *)((const char *)(M.ad + g) + 16);
+            const uint32_t tot = a1[2] + 1u;
+            const uint32_t acn = a1[3] + (accept ? 1u : 0u);
+            double sc = mh.scale, ls = fg_dbl(a1[0], a1[1]);
             if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
-            if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
+            if (live) {
+                const unsigned long long lb = (unsigned long long)__double_as_longlong(ls);
+                const fg_u32x4 w1 = { (uint32_t)lb, (uint32_t)(lb >> 32), tot, acn };
+                *(fg_u32x4 *)((char *)(M.ad + g) + 16) = w1;
+                M.ad[g].scale = sc;
+            }
         }
-        if (live && mh.kind != kind0) M.kind[g] = mh.kind;
+        if (live && mh.kind != kind0) M.ad[g].kind = mh.kind;
         if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
         else slots[tslot * tw] = mh.old_cell;
         if ((!adapt || M.rec_all) && draws && live) {
@@ -1221,13 +1226,17 @@ int fg_hmc_find_eps_injected(fg_engine *e, const fg_hmc_config *cfg, const doubl
 }
 
 
+__global__ void k_mh_adapt_init(FgMhAdapt *ad, long long n) {        // DiminishingAdaptation::new: scale 1.0, ln scale 0.0, no counts (mcmc_utils.rs:51-62)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { FgMhAdapt a; a.scale = 1.0; a.kind = 0; a.pad = 0; a.log_scale = 0.0; a.tot = 0u; a.acc = 0u; ad[i] = a; }
+}
+
 // ------------------------------------------------------------------ MH host side
 int fg_internal_mh_alloc(fg_engine *e) {
     size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S);
     auto A = [&](auto **p, size_t n) { int rc = dev_alloc(p, n); if (!rc) e->mh_allocs.push_back((void *)*p); return rc; };
     if (!e->M.lw) {
-        if (A(&e->M.lw, C) || A(&e->M.scale, S * C) || A(&e->M.log_scale, S * C) || A(&e->M.acc, S * C) || A(&e->M.tot, S * C) ||
-            A(&e->M.kind, S * C) || A(&e->M.n_acc, C))
+        if (A(&e->M.lw, C) || A(&e->M.ad, S * C) || A(&e->M.n_acc, C))
             return FG_E_HIP;
     }
     return FG_OK;
@@ -1257,13 +1266,9 @@ int fg_mh_init(fg_engine *e, int n_warmup, const fg_site_proposal *overrides) {
     if (n_warmup < 0) return FG_E_BAD_ARG;
     size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S);
     if (int rc0 = fg_internal_mh_alloc(e)) return rc0;
-    HIPCHK(hipMemsetAsync(e->M.log_scale, 0, S * C * 8, e->stream));
-    HIPCHK(hipMemsetAsync(e->M.acc, 0, S * C * 4, e->stream));
-    HIPCHK(hipMemsetAsync(e->M.tot, 0, S * C * 4, e->stream));
-    HIPCHK(hipMemsetAsync(e->M.kind, 0, S * C * 4, e->stream));
     HIPCHK(hipMemsetAsync(e->M.n_acc, 0, C * 8, e->stream));
     const int TB = 256;
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((S * C + TB - 1) / TB)), dim3(TB), 0, e->stream, e->M.scale, (long long)(S * C), 1.0);
+    hipLaunchKernelGGL(k_mh_adapt_init, dim3((unsigned)((S * C + TB - 1) / TB)), dim3(TB), 0, e->stream, e->M.ad, (long long)(S * C));   // scale 1, log_scale 0, no counts, kind undecided
     if (int rc1 = fg_internal_mh_set_overrides(e, overrides)) return rc1;
     int rc = fg_launch_prior(e, 0, FG_RNG_PRIOR, nullptr, e->M.lw);       // mh.rs:950-957
     if (rc) return rc;
@@ -1338,7 +1343,9 @@ int fg_mh_get_scales(fg_engine *e, double *h_scales) {
     NEED_ENGINE(e);
     if (!h_scales || !e->mh_ready) return FG_E_BAD_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(h_scales, e->M.scale, (size_t)e->S * e->C * 8, hipMemcpyDeviceToHost));
+    std::vector<FgMhAdapt> ad((size_t)e->S * e->C);
+    HIPCHK(hipMemcpy(ad.data(), e->M.ad, ad.size() * sizeof(FgMhAdapt), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < ad.size(); ++k) h_scales[k] = ad[k].scale;
     return FG_OK;
 }
 int fg_mh_get_log_weight(fg_engine *e, double *h_lw) {

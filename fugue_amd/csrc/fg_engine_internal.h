@@ -51,10 +51,15 @@ struct FgHmcDev {
     int L; double h, target; int grad_mode; int use_mass;
 };
 
+// DiminishingAdaptation's state of one (site, chain) (mcmc_utils.rs:40-62) + the decided proposal kind, as two 16-byte groups:
+// what a proposal reads {scale, kind} and what an update reads and writes {log_scale, total, accepted} are one 16-byte access each
+// (lanes hold different sites: every access of a wave touches 64 different lines, so the NUMBER of accesses is the cost).
+struct alignas(16) FgMhAdapt { double scale; int32_t kind, pad; double log_scale; uint32_t tot, acc; };
+static_assert(sizeof(FgMhAdapt) == 32, "FgMhAdapt is two 16-byte groups");
+
 struct FgMhDev {
-    double *lw, *scale, *log_scale;
-    uint32_t *acc, *tot;
-    int *kind;
+    double *lw;
+    FgMhAdapt *ad;                                       // [S][C]
     const int *ov_kind; const double *ov_lo, *ov_hi;    // [S] overrides or null
     unsigned long long *n_acc;                           // [C] accepted proposals
     const int *rec;                                      // [n_rec] recorded sites

@@ -158,8 +158,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 const long long st = fg_as_i64(b[4 * tw]);
                 n_tslot = (int)(uint32_t)st; n_tv = (uint32_t)(st >> 32);
                 n_g = (long long)n_target * X.C + c;
-                n_scale = M.scale[n_g];                                    // get_scale  mcmc_utils.rs:70-77
-                n_kind = M.kind[n_g];
+                const fg_u32x4 a0 = *(const fg_u32x4 *)(M.ad + n_g);       // {scale, kind}: get_scale  mcmc_utils.rs:70-77
+                n_scale = fg_dbl(a0[0], a0[1]);
+                n_kind = (int)a0[2];
             }
             if (t > 0 && !(exp_mask & 2)) {                                // finish step t - 1
                 const int itp = iter - 1;
@@ -183,13 +184,19 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
                 double sc = scale;
                 if (adapt) {                                               // DiminishingAdaptation::update  mcmc_utils.rs:88-150
-                    const uint32_t tot = M.tot[g] + 1u;
-                    const uint32_t acn = M.acc[g] + (accept ? 1u : 0u);
-                    double ls = M.log_scale[g];
+                    const fg_u32x4 a1 = *(const fg_u32x4 *)((const char *)(M.ad + g) + 16);   // {log_scale, total, accepted}
+                    const uint32_t tot = a1[2] + 1u;
+                    const uint32_t acn = a1[3] + (accept ? 1u : 0u);
+                    double ls = fg_dbl(a1[0], a1[1]);
                     if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
-                    if (live) { M.tot[g] = tot; M.acc[g] = acn; M.scale[g] = sc; M.log_scale[g] = ls; }
+                    if (live) {
+                        const unsigned long long lb = (unsigned long long)__double_as_longlong(ls);
+                        const fg_u32x4 w1 = { (uint32_t)lb, (uint32_t)(lb >> 32), tot, acn };
+                        *(fg_u32x4 *)((char *)(M.ad + g) + 16) = w1;
+                        M.ad[g].scale = sc;
+                    }
                 }
-                if (live && kind_new != kind0) M.kind[g] = kind_new;
+                if (live && kind_new != kind0) M.ad[g].kind = kind_new;
                 if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
                 else slots[tslot * tw] = old_cell;
                 if ((!adapt || M.rec_all) && draws && live) {              // recorded cells of the CURRENT state (mh.rs:1010)

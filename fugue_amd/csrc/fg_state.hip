@@ -158,7 +158,7 @@ static size_t state_bytes(const fg_engine *e, uint32_t &flags) {
     size_t n = sizeof(FgStateHeader) + S * C * 8;
     if (flags & 1u) n += 9 * C * 8;                                      // lj eps frozen da_mu da_leb da_hbar da_m alpha_sum n_div
     if (flags & 2u) n += 4 * d * C * 8 + C * 8;                          // m_inv mass_sqrt w_mean w_m2, w_n
-    if (flags & 4u) n += C * 8 + 2 * S * C * 8 + 2 * S * C * 4 + S * C * 4 + C * 8;   // lw, scale log_scale, acc tot, kind, n_acc
+    if (flags & 4u) n += C * 8 + S * C * sizeof(FgMhAdapt) + C * 8;        // lw, {scale, kind, log_scale, tot, acc} per (site, chain), n_acc
     if (flags & 8u) n += S * sizeof(fg_site_proposal);
     return n;
 }
@@ -176,7 +176,7 @@ int fg_state_export(fg_engine *e, void *h_buf, size_t capacity) {
     if (!h_buf || capacity < need) { fg_set_error("fg_state_export: buffer too small (fg_state_size)"); return FG_E_BAD_ARG; }
     HIPCHK(hipStreamSynchronize(e->stream));
     FgStateHeader hd; std::memset(&hd, 0, sizeof(hd));
-    hd.magic = FG_STATE_MAGIC; hd.version = 1; hd.flags = fl; hd.C = e->C; hd.S = e->S; hd.d = e->d; hd.n_slots = e->n_slots;
+    hd.magic = FG_STATE_MAGIC; hd.version = 2; hd.flags = fl; hd.C = e->C; hd.S = e->S; hd.d = e->d; hd.n_slots = e->n_slots;
     hd.seed = e->seed; hd.chain0 = e->chain0; hd.iter = e->iter; hd.n_warmup = e->n_warmup; hd.mass_adapt_at = e->mass_adapt_at; hd.use_mass = e->H.use_mass;
     hd.cfg = e->cfg; hd.mh_iter = e->mh_iter; hd.mh_warmup = e->mh_warmup; hd.bytes = need;
     char *o = (char *)h_buf;
@@ -194,8 +194,7 @@ int fg_state_export(fg_engine *e, void *h_buf, size_t capacity) {
         HIPCHK(dl(e->H.w_n, C * 8));
     }
     if (fl & 4u) {
-        HIPCHK(dl(e->M.lw, C * 8)); HIPCHK(dl(e->M.scale, S * C * 8)); HIPCHK(dl(e->M.log_scale, S * C * 8));
-        HIPCHK(dl(e->M.acc, S * C * 4)); HIPCHK(dl(e->M.tot, S * C * 4)); HIPCHK(dl(e->M.kind, S * C * 4)); HIPCHK(dl(e->M.n_acc, C * 8));
+        HIPCHK(dl(e->M.lw, C * 8)); HIPCHK(dl(e->M.ad, S * C * sizeof(FgMhAdapt))); HIPCHK(dl(e->M.n_acc, C * 8));
     }
     if (fl & 8u) { std::vector<fg_site_proposal> ov(S); std::copy(e->mh_overrides.begin(), e->mh_overrides.end(), ov.begin()); std::memcpy(o, ov.data(), S * sizeof(fg_site_proposal)); o += S * sizeof(fg_site_proposal); }
     return FG_OK;
@@ -205,7 +204,7 @@ int fg_state_import(fg_engine *e, const void *h_buf, size_t size) {
     NEED_ENGINE(e);
     if (!h_buf || size < sizeof(FgStateHeader)) { fg_set_error("fg_state_import: truncated blob"); return FG_E_BAD_ARG; }
     FgStateHeader hd; std::memcpy(&hd, h_buf, sizeof(hd));
-    if (hd.magic != FG_STATE_MAGIC || hd.version != 1) { fg_set_error("fg_state_import: not a fugue_amd state blob (magic / version)"); return FG_E_BAD_ARG; }
+    if (hd.magic != FG_STATE_MAGIC || hd.version != 2) { fg_set_error("fg_state_import: not a fugue_amd state blob (magic / version)"); return FG_E_BAD_ARG; }
     if (hd.C != e->C || hd.S != e->S || hd.d != e->d || hd.n_slots != e->n_slots) {
         fg_set_error("fg_state_import: the blob was exported from a different program or chain count"); return FG_ERR_UNEXPECTED_STRUCTURE; }
     if (hd.bytes > size) { fg_set_error("fg_state_import: truncated blob"); return FG_E_BAD_ARG; }
@@ -231,8 +230,7 @@ int fg_state_import(fg_engine *e, const void *h_buf, size_t size) {
     }
     if (fl & 4u) {
         if (int rc = fg_internal_mh_alloc(e)) return rc;
-        HIPCHK(ul(e->M.lw, C * 8)); HIPCHK(ul(e->M.scale, S * C * 8)); HIPCHK(ul(e->M.log_scale, S * C * 8));
-        HIPCHK(ul(e->M.acc, S * C * 4)); HIPCHK(ul(e->M.tot, S * C * 4)); HIPCHK(ul(e->M.kind, S * C * 4)); HIPCHK(ul(e->M.n_acc, C * 8));
+        HIPCHK(ul(e->M.lw, C * 8)); HIPCHK(ul(e->M.ad, S * C * sizeof(FgMhAdapt))); HIPCHK(ul(e->M.n_acc, C * 8));
         e->mh_iter = hd.mh_iter; e->mh_warmup = hd.mh_warmup; e->mh_ready = true;
         if (fl & 8u) {
             std::vector<fg_site_proposal> ov(S); std::memcpy(ov.data(), o, S * sizeof(fg_site_proposal)); o += S * sizeof(fg_site_proposal);
