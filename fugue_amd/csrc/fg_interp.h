@@ -232,7 +232,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 const double p1 = fg_operand(FG_I_OPND(I, 2), FG_I_IMM(I, 2), slots, pool, tw);
                 const double p2 = fg_operand(FG_I_OPND(I, 3), FG_I_IMM(I, 3), slots, pool, tw);
                 if (MODE == FG_MODE_PRIOR && !observe) {
-                    const long long cell = fg_sample_dist(code, hoisted, p0, p1, p2, *rng);
+                    const long long cell = fg_sample_cold(code, hoisted, p0, p1, p2, rng);
                     slots[aux * tw] = fg_as_double(cell);
                 }
                 if (MODE == FG_MODE_MH && !observe) {
