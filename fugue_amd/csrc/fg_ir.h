@@ -102,7 +102,7 @@ static_assert(sizeof(FgGradRec) == 64, "FgGradRec must be 64 bytes");
 #define FG_SEP_MAXREC 4
 struct FgSepRec { uint32_t flags, trow; double c, inv, lns, sigma; double pad1[3]; };   // dwords 0..7 = one s_load_dwordx8, sigma = dwords 8..9
 static_assert(sizeof(FgSepRec) == 64, "FgSepRec must be 64 bytes");
-struct FgSepCoord { int off, n; };     // records of coordinate k: sep[off .. off + (n & 7)); bit 8 of n: every sigma is a power of two
+struct FgSepCoord { int off, n; };     // records of coordinate k: sep[off .. off + (n & 7)); bit 8 of n: every sigma is a power of two; bit 9: and record 0 is Normal(0, 1)
 struct FgSepFree { uint32_t sidx, trow; };   // score-stream statements that read no coordinate: evaluated once per launch
 
 struct FgProgramDev {

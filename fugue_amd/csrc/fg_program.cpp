@@ -686,6 +686,10 @@ int fg_program::finalize() {
             bool p2 = true;
             for (int q = 0; q < cds[k].n && ok; q++) p2 = p2 && (recs[cds[k].off + q].flags & FG_G_POW2);
             if (ok && p2) cds[k].n |= 256;
+            if (ok && p2) {                                              // the own sample statement is Normal(0, 1): c = 0, 1 / sigma = 1, ln sigma = 0
+                const FgSepRec &r0 = recs[cds[k].off];
+                if (r0.c == 0.0 && r0.inv == 1.0 && r0.lns == 0.0 && r0.sigma == 1.0) cds[k].n |= 512;
+            }
         }
         if ((size_t)n_slots + 2 * f64_slot.size() + (size_t)n_sstream + 3 > 320) ok = false;     // q, kinetic and term rows of a tile in 160 KB of LDS
         if (ok) {
