@@ -48,6 +48,18 @@ struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 // record 0 when the coordinate's own sample statement is Normal(0, 1) (U0): q - 0, * 1 and - ln 1 change no bit of any double
 // (x - 0.0 = x, x * 1.0 = x for every x incl. -0.0, inf, NaN), so they are not issued: 6 of the 42 instructions of a coordinate-step
 #define FG_SEP_LP_U(z) (-0.5 * (z) * (z) - 0.5 * FG_LN_2PI)
+// The same values in one instruction less (hot loop only).  -0.5 * z is exact, so RN(RN(-0.5 z) z) = -0.5 RN(z z) and the
+// reference's RN(RN(-0.5 z z) - ln sigma) is ONE correctly rounded -0.5 m - ln sigma of m = RN(z z): an fma whose product is
+// exact.  Two corners differ before the last subtraction and not after it: m subnormal (halving rounds; the difference is
+// below 2^-1074 next to a 0.9189 that swallows it) -- and z z in [2^1024, 2^1025), where the reference's (-0.5 z) z is still
+// finite and this is -inf: the force is then non-finite, so is the endpoint momentum, and the coordinate takes the checked
+// instance (the unfused arithmetic) again.  The endpoint's score term is always the unfused form.
+#define FG_SEP_LPF(k, z) (__builtin_fma(-0.5, (z) * (z), -fg_dbl(a##k[6], a##k[7])) - 0.5 * FG_LN_2PI)
+#define FG_SEP_LPF_U(z) __builtin_fma(-0.5, (z) * (z), -0.5 * FG_LN_2PI)
+#define FG_SEP_DUALF(k, outp, outm)                                                                    \
+    double outp, outm;                                                                                 \
+    { const double c = fg_dbl(a##k[2], a##k[3]); const double zp = FG_SEP_Z(k, qp - c), zm = FG_SEP_Z(k, qm - c); \
+      outp = FG_SEP_LPF(k, zp); outm = FG_SEP_LPF(k, zm); }
 // record k at q + h and q - h with the guard of a scoring run (the dense mode adds these into whole log-joints)
 #define FG_SEPD_OWN(k, outp, outm) double outp, outm;                                                  \
     { const double c_ = fg_dbl(a##k[2], a##k[3]); const double zp_ = FG_SEP_Z(k, qp - c_), zm_ = FG_SEP_Z(k, qm - c_); \
@@ -88,6 +100,17 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double 
         } else {
         const double qp = q + h, qm = q - h;                     // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
         double tp, tm;
+        if (!CHECK) {                                            // fused forms: a non-finite force re-runs the coordinate with CHECK
+            if (U0) { tp = FG_SEP_LPF_U(qp); tm = FG_SEP_LPF_U(qm); }
+            else { FG_SEP_DUALF(0, tp_, tm_) tp = tp_; tm = tm_; }
+            if (FG_SEP_HAS(1)) {
+                FG_SEP_DUALF(1, lp1, lm1)
+                double sp = lp1, sm = lm1;
+                if (FG_SEP_HAS(2)) { FG_SEP_DUALF(2, lp2, lm2) sp += lp2; sm += lm2; }
+                if (FG_SEP_HAS(3)) { FG_SEP_DUALF(3, lp3, lm3) sp += lp3; sm += lm3; }
+                tp = tp + sp; tm = tm + sm;                      // log_prior + log_likelihood
+            }
+        } else {
         if (U0) { tp = FG_SEP_LP_U(qp); tm = FG_SEP_LP_U(qm); }
         else { FG_SEP_DUAL(0, tp_, tm_) tp = tp_; tm = tm_; }
         if (FG_SEP_HAS(1)) {
@@ -97,10 +120,11 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double 
             if (FG_SEP_HAS(3)) { FG_SEP_DUAL(3, lp3, lm3) sp += lp3; sm += lm3; }
             tp = tp + sp; tm = tm + sm;                          // log_prior + log_likelihood
         }
+        }
         const double n = tp - tm;
         g = fg_div_const(n, two_h, rcp_2h);                      // (lp - lm) / (2h), hmc.rs:322
-        const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
-        if (__builtin_expect(__any(!((ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953] (n = 0 too: a true division is always right)
+        const double an = __builtin_fabs(n);                     // |n| outside [2^-823, 2^953] (0 and NaN too): a true division is always right
+        if (__builtin_expect(__any(!(an >= 0x1p-823 && an <= 0x1p953)), 0)) g = n / two_h;
         }
         if (CHECK) bad = bad || !fg_finite(g);
         const double kick = hk * g;

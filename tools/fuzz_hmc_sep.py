@@ -18,6 +18,7 @@ def random_model():
     stm = []
     for i in range(d):
         mu0, s0 = float(rng.normal()), float(rng.choice(SIG[:7]))
+        if rng.random() < 0.35: mu0, s0 = 0.0, 1.0           # the standard-normal own record has its own instance
         obs = [(float(rng.normal(scale=2.0)), float(rng.choice(SIG)), bool(rng.integers(0, 2))) for _ in range(int(rng.integers(0, 4)))]
         stm.append((mu0, s0, obs))
     n_const = int(rng.integers(0, 3))
