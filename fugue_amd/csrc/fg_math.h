@@ -266,26 +266,79 @@ FG_HD void fg_rng_block(FgStream &s, unsigned long long &a, unsigned long long &
 // rand 0.8 `Standard` f64: 53 bits scaled into [0,1)
 FG_HD double fg_u01_of(unsigned long long x) { return (double)(x >> 11) * 0x1.0p-53; }
 FG_HD double fg_rng_u01(FgStream &s) { unsigned long long a, b; fg_rng_block(s, a, b); return fg_u01_of(a); }
+// ln x and (sin, cos) of an angle in [0, 2 pi) for the normal generators below, which run once per coordinate pair per
+// transition (HMC) and once per step (MH) and were a fifth of the instructions of those kernels through ocml's general-purpose
+// log / sincos (table lookups, Payne-Hanek reduction, double-double arithmetic for < 1 ulp over the whole range).  These are
+// the classic fdlibm kernels (e_log.c, k_sin.c, k_cos.c, the first Cody-Waite round of e_rem_pio2.c: error < 1 ulp each) for the
+// inputs that occur here -- x a positive normal number, the angle below 2 pi -- in ~40 instructions apiece.  The generators'
+// values are pinned by no reference test (rand_distr's ziggurat is not reproduced); the oracle computes the same
+// expressions with glibc and the parity tests compare with tolerances far above an ulp.  tests/cpp/test_fast_math.cpp checks
+// both against libm on the host build.
+FG_HD double fg_fast_log(double x) {            // x > 0, normal
+    const long long bx = fg_as_i64(x);
+    int hx = (int)(bx >> 32);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;     // significand above sqrt(2): halve it
+    k += i >> 20;
+    const double m = fg_as_double(((long long)(hx | (i ^ 0x3ff00000)) << 32) | (bx & 0xffffffffLL));   // [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0, dk = (double)k, d = 2.0 + f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(d);
+#else
+    double y = (double)(float)(1.0 / d);         // a seed of the same quality as v_rcp_f64 (host build: tests only)
+#endif
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    double sq = f * y;
+    sq = __builtin_fma(__builtin_fma(-sq, d, f), y, sq);             // f / (2 + f)
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(sq, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+FG_HD void fg_fast_sincos(double x, double &sn, double &cs) {   // 0 <= x < 2 pi (any |x| < ~1e5 reduces accurately)
+    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+    const double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);   // 33-bit head of pi / 2: the product is exact
+    const double w = fn * 6.07710050650619224932e-11;
+    const double y0 = r - w, y1 = (r - y0) - w;
+    const double z = y0 * y0;
+    // k_sin
+    const double v = z * y0;
+    const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double s0 = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+    // k_cos
+    const double w2 = z * z;
+    const double rc = z * __builtin_fma(z, __builtin_fma(z, 2.48015872894767294178e-05, -1.38888888888741095749e-03), 4.16666666666666019037e-02) +
+                      (w2 * w2) * __builtin_fma(z, __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07);
+    const double hz = 0.5 * z, wc = 1.0 - hz;
+    const double c0 = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    const int n = (int)fn;
+    const double sa = (n & 1) ? c0 : s0, ca = (n & 1) ? s0 : c0;
+    sn = (n & 2) ? -sa : sa;
+    cs = ((n + 1) & 2) ? -ca : ca;
+}
 FG_HD void fg_rng_normal_pair(FgStream &s, double &z0, double &z1) {   // Box-Muller, u1 in (0,1]
     unsigned long long a, b; fg_rng_block(s, a, b);
     double u1 = ((double)(a >> 11) + 1.0) * 0x1.0p-53;
     double u2 = fg_u01_of(b);
-    double r = sqrt(-2.0 * log(u1));
+    double r = sqrt(-2.0 * fg_fast_log(u1));
     double th = 2.0 * M_PI * u2;
-#if defined(__HIP_DEVICE_COMPILE__)
     double sn, cs;
-    sincos(th, &sn, &cs);                    // one argument reduction for both (the same values as cos() and sin())
+    fg_fast_sincos(th, sn, cs);
     z0 = r * cs; z1 = r * sn;
-#else
-    z0 = r * cos(th); z1 = r * sin(th);
-#endif
 }
 FG_HD double fg_rng_normal(FgStream &s) { double a, b; fg_rng_normal_pair(s, a, b); return a; }
 // gaussian_z: /root/reference/src/inference/mh.rs:128-132
 FG_HD double fg_gaussian_z_of(unsigned long long a, unsigned long long b) {
     double u1 = fmax(fg_u01_of(a), 1e-10);
     double u2 = fg_u01_of(b);
-    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+    double sn, cs;
+    fg_fast_sincos(2.0 * M_PI * u2, sn, cs);
+    return sqrt(-2.0 * fg_fast_log(u1)) * cs;
 }
 FG_HD double fg_rng_gaussian_z(FgStream &s) { unsigned long long a, b; fg_rng_block(s, a, b); return fg_gaussian_z_of(a, b); }
 // gen_range(0..n): widening multiply (bias < n * 2^-64)

@@ -61,10 +61,70 @@ __device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, 
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
-struct FgMhSeg { int r[FG_MH_WMAX + 1]; };     // records [r[w], r[w + 1]) are wave w's share
+// Phase B works on a KIND-SORTED copy of the score stream: every record writes its own term row and the in-order sums are
+// the control wave's, so the order in which the terms are evaluated is free.  Sorted by kind, four records of one kind are
+// evaluated together in straight-line code -- their LDS round trips (operands; for an option select the option entry, then
+// the slot it names; for a Categorical table the entry) overlap instead of following each other record by record, which is
+// what a step of a mixture model waited for (C5: +15 %).
+//   class 0  Normal(x; options[z], sigma = 2^k)     class 1  Categorical site with a constant table
+//   class 2  everything else: the pipelined one-at-a-time loop of fg_mh_terms (plain Normals measured faster there than four
+//            at a time: the loop fetches records two ahead, a group of four waits for its own)
+#define FG_MH_NCLS 3
+struct FgMhSeg { int r[FG_MH_NCLS][FG_MH_WMAX + 1]; };   // records [r[c][w], r[c][w + 1]) of the sorted stream are wave w's share of class c
+
+// the common path of fg_score_one, operation for operation
+template <int RK>
+__device__ __forceinline__ double fg_mh_lp_plain(const fg_u32x16 &r, double xs, double m) {
+    const double x = xs + fg_dbl(r[4], r[5]);
+    const double z = (x - m) * fg_dbl(r[10], r[11]);
+    const double lp = -0.5 * z * z - fg_dbl(r[12], r[13]) - 0.5 * FG_LN_2PI;
+    return (z != z) ? FG_NEG_INF : lp;
+}
+template <int RK, int CLS>
+__device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend, const double *tab, const double *slots, int tw, double *terms) {
+    fg_u32x16 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fg_fetch_grec(g, k + i < kend ? k + i : kend - 1);   // a short group repeats its last record (same term, same row)
+    __builtin_amdgcn_sched_barrier(0);                         // the four scalar fetches are in flight together
+    double xs[4], ms[4], lp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xs[i] = slots[r[i][0] * tw]; if (CLS == 0) ms[i] = slots[r[i][1] * tw]; }
+    __builtin_amdgcn_sched_barrier(0);                         // ... and so are the operand reads
+    if (CLS == 0) {                                            // fg_nsel_mu_lane, four at a time
+        bool ok[4]; double hdr[4], cst[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long zi = fg_as_i64(ms[i]);
+            ok[i] = zi >= 0 && zi < (long long)r[i][7];
+            const double *ent = tab + r[i][6] + 2 * (ok[i] ? (int)zi : 0);
+            hdr[i] = ent[0]; cst[i] = ent[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = slots[(uint32_t)fg_as_i64(hdr[i]) * tw];    // a constant option names the always-zero slot
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool is_const = (uint32_t)(fg_as_i64(hdr[i]) >> 32) != 0u;
+            const double m = ok[i] ? (is_const ? cst[i] : v[i]) : NAN;
+            lp[i] = fg_mh_lp_plain<RK>(r[i], xs[i], m);
+        }
+    } else {                                                   // ln p[z] of a constant table (distribution.rs:785-791)
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long zi = fg_as_i64(xs[i]);
+            const uint32_t base = r[i][6], K = r[i][7];
+            ok[i] = zi >= 0 && zi < (long long)K;
+            lp[i] = tab[base + K + (ok[i] ? (int)zi : 0)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lp[i] = ok[i] ? lp[i] : FG_NEG_INF;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) terms[r[i][3] * tw] = lp[i];
+}
 
 template <int RK>
-__global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
+__global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt /* the kind-sorted score stream */, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
                                                                            long long *draws, int first_sample_t, int exp_mask /* timing experiments only (FG_MH_EXP): results are wrong when non-zero */,
                                                                            int pool_n /* > 0: the constant pool (pool_n doubles) is staged into LDS behind the exchange rows */) {
     extern __shared__ double lds[];
@@ -256,8 +316,13 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
         __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
         // ---- phase B: every wave scores its share of the statements
         if (!(exp_mask & 1)) {
-            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(P.sstream, seg.r[wv], seg.r[wv + 1], P.pool, pool_l, slots, tw, terms);
-            else fg_mh_terms<RK>(P.sstream, seg.r[wv], seg.r[wv + 1], P.pool, nullptr, slots, tw, terms);
+            const double *tab = (RK != 0 && pool_n > 0) ? pool_l : P.pool;
+            if (RK >= 2) {
+                for (int k = seg.r[0][wv]; k < seg.r[0][wv + 1]; k += 4) fg_mh_group4<RK, 0>(srt, k, seg.r[0][wv + 1], tab, slots, tw, terms);
+                for (int k = seg.r[1][wv]; k < seg.r[1][wv + 1]; k += 4) fg_mh_group4<RK, 1>(srt, k, seg.r[1][wv + 1], tab, slots, tw, terms);
+            }
+            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(srt, seg.r[2][wv], seg.r[2][wv + 1], P.pool, pool_l, slots, tw, terms);
+            else fg_mh_terms<RK>(srt, seg.r[2][wv], seg.r[2][wv + 1], P.pool, nullptr, slots, tw, terms);
         }
         __syncthreads();
     }
@@ -284,10 +349,33 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         while (W < FG_MH_WMAX && resident * W < 16 && n_s >= 4 * W) W *= 2;
     }
     if (W < 2) W = 2;                                                       // control wave + random-number wave
+    // the kind-sorted copy of the score stream (once per engine); within a class the records keep their program order
+    auto cls_of = [](const FgGradRec &r) {
+        if (r.flags & FG_G_CATC) return 1;
+        if (r.flags & (FG_G_GEN | FG_G_LIN)) return 2;
+        return ((r.flags & FG_G_NSEL) && (r.flags & FG_G_POW2)) ? 0 : 2;
+    };
+    if (!e->d_mh_srt) {
+        std::vector<FgGradRec> srt;
+        e->mh_cls_off[0] = 0;
+        for (int c = 0; c < FG_MH_NCLS; ++c) {
+            for (int k = 0; k < n_s; ++k) if (cls_of(p->sstream[k]) == c) srt.push_back(p->sstream[k]);
+            e->mh_cls_off[c + 1] = (int)srt.size();
+        }
+        for (int q = 0; q < 4; ++q) srt.push_back(p->sstream[(size_t)n_s + (size_t)(q & 1)]);    // readable records past the end (fetched ahead, never evaluated)
+        if (dev_upload(&e->d_mh_srt, srt)) return FG_E_HIP;
+    }
     FgMhSeg seg;
-    // the random-number wave has its own work in phase A; in phase B all waves share the records evenly
-    for (int w = 0; w <= FG_MH_WMAX; ++w) seg.r[w] = n_s;
-    for (int w = 0; w < W; ++w) seg.r[w] = (int)((long long)n_s * w / W);
+    // in phase B all waves share the records of every class evenly; the remainders of successive classes go to different waves
+    int shift = 0;
+    for (int c = 0; c < FG_MH_NCLS; ++c) {
+        const int a = e->mh_cls_off[c], n = e->mh_cls_off[c + 1] - a;
+        int cnt[FG_MH_WMAX] = {0};
+        for (int w = 0; w < W; ++w) cnt[(w + shift) % W] = (int)((long long)n * (w + 1) / W - (long long)n * w / W);
+        int at = a;
+        for (int w = 0; w <= FG_MH_WMAX; ++w) { seg.r[c][w] = at; if (w < W) at += cnt[w]; }
+        shift += n % W;
+    }
     const int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
     static bool attr_set_dev[64][4];
@@ -298,9 +386,9 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-    if (rk == 2) hipLaunchKernelGGL(k_mh_mw_steps<2>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
-    else if (rk == 3) hipLaunchKernelGGL(k_mh_mw_steps<3>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
-    else hipLaunchKernelGGL(k_mh_mw_steps<0>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
+    if (rk == 2) hipLaunchKernelGGL(k_mh_mw_steps<2>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
+    else if (rk == 3) hipLaunchKernelGGL(k_mh_mw_steps<3>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
+    else hipLaunchKernelGGL(k_mh_mw_steps<0>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
     HIPCHK(hipGetLastError());
     return FG_OK;
 }

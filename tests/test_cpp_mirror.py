@@ -43,3 +43,13 @@ def test_constant_division_matches_ieee_division(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches 0" in r.stdout
+
+
+def test_fast_log_and_sincos_are_within_one_ulp(tmp_path):
+    """fg_fast_log / fg_fast_sincos (the normal generators' transcendentals) against libm on 4e6 generator inputs."""
+    exe = str(tmp_path / "test_fast_math")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_fast_math.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fast math ok" in r.stdout
