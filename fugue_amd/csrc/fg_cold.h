@@ -43,13 +43,17 @@ static __device__ __noinline__ FgD3 fg_cold_da_update(double hbar, double leb, d
     return r;
 }
 // DiminishingAdaptation::update past the 10th proposal (mcmc_utils.rs:88-150): returns {scale, log_scale}
-static __device__ __noinline__ FgD2 fg_cold_mh_adapt(double log_scale, uint32_t acc, uint32_t tot) {
+// step_tab[n] = 1 / n^0.7 for n < step_n, computed once per session on the host (the counts are small integers: one L2-resident
+// load instead of ocml's ~150-instruction pow on the control wave's path); larger counts take pow
+static __device__ __noinline__ FgD2 fg_cold_mh_adapt(double log_scale, uint32_t acc, uint32_t tot, const double *step_tab, uint32_t step_n) {
     const double rate = (double)acc / (double)tot;
-    const double step = 1.0 / pow((double)tot, 0.7);
+    double step;
+    if (tot < step_n) step = step_tab[tot];
+    else step = 1.0 / pow((double)tot, 0.7);
     double ls = log_scale + step * (rate - 0.44);
     const double ns = exp(ls);
     const double sc = (fg_finite(ns) && ns > 0.0) ? fmin(fmax(ns, 0.001), 100.0) : 1.0;
-    ls = (sc == 1.0) ? 0.0 : log(sc);
+    ls = (sc == 1.0) ? 0.0 : fg_fast_log(sc);            // sc in [1e-3, 100]
     FgD2 r; r.a = sc; r.b = ls;
     return r;
 }

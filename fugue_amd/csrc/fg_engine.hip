@@ -667,7 +667,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
             const uint32_t tot = a1[2] + 1u;
             const uint32_t acn = a1[3] + (accept ? 1u : 0u);
             double sc = mh.scale, ls = fg_dbl(a1[0], a1[1]);
-            if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
+            if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot, M.step_tab, M.step_n); sc = r.a; ls = r.b; }
             if (live) {
                 const unsigned long long lb = (unsigned long long)__double_as_longlong(ls);
                 const fg_u32x4 w1 = { (uint32_t)lb, (uint32_t)(lb >> 32), tot, acn };
@@ -1282,10 +1282,25 @@ int fg_mh_set_recording(fg_engine *e, int during_adaptation) {
     return FG_OK;
 }
 
+// 1 / n^0.7 for every proposal count an adapting session can reach (a site is proposed at most once per step), capped at 2^20
+// entries; built by the host's pow when a session first steps inside its warmup (fg_mh_init and fg_state_import both end here)
+static int fg_mh_step_table(fg_engine *e) {
+    const uint32_t want = (uint32_t)std::min<long long>((long long)e->mh_warmup + 1, 1LL << 20);
+    if (e->M.step_n >= want) return FG_OK;
+    std::vector<double> tab((size_t)want);
+    for (uint32_t n = 0; n < want; ++n) tab[n] = 1.0 / std::pow((double)n, 0.7);
+    double *d = nullptr;
+    if (dev_upload(&d, tab)) return FG_E_HIP;
+    e->mh_allocs.push_back(d);
+    e->M.step_tab = d; e->M.step_n = want;
+    return FG_OK;
+}
+
 int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec, void *d_draws) {
     NEED_ENGINE(e);
     if (!e->mh_ready) { fg_set_error("fg_mh_step before fg_mh_init"); return FG_E_STATE; }
     if (n_steps < 0 || n_rec < 0 || (n_rec > 0 && !h_rec_sites)) return FG_E_BAD_ARG;
+    if (n_steps > 0 && e->mh_iter < e->mh_warmup) { if (int rc = fg_mh_step_table(e)) return rc; }
     if (e->S == 0) { e->mh_iter += n_steps; return FG_OK; }             // no latent sites: nothing to move (mh.rs:713-715)
     if (n_rec > 0) {
         for (int r = 0; r < n_rec; r++)

@@ -65,6 +65,7 @@ struct FgMhDev {
     const int *rec;                                      // [n_rec] recorded sites
     int n_rec;
     int rec_all;                                         // record during adaptation too (fg_mh_set_recording: incremental sessions)
+    const double *step_tab; uint32_t step_n;             // 1 / n^0.7 for n < step_n (DiminishingAdaptation's step, mcmc_utils.rs:118)
 };
 
 struct fg_engine {
@@ -81,7 +82,7 @@ struct fg_engine {
     FgCoord *d_coord = nullptr;
     FgGradRec *d_gstream = nullptr, *d_sstream = nullptr;
     FgSepRec *d_sep = nullptr; FgSepCoord *d_sep_coord = nullptr; FgSepFree *d_sep_free = nullptr; uint32_t *d_sobs = nullptr; int *d_site_rec = nullptr;
-    FgGradRec *d_mh_srt = nullptr; int mh_cls_off[4] = {0, 0, 0, 0};   // kind-sorted score stream of the multi-wave MH kernel (fg_mh.hip), class boundaries
+    FgGradRec *d_mh_srt = nullptr; int mh_cls_off[7] = {0, 0, 0, 0, 0, 0, 0};   // kind-sorted score stream of the multi-wave MH kernel (fg_mh.hip), class boundaries
     bool mh_mw_disabled = false;  // FG_MH_MW=0: keep every program on the one-wave-per-tile MH kernel (A/B tests)
     bool mh_has_prior_resample = false;   // an override asks for PriorResample on some site (needs the model-driven proposal path)
     bool sep_disabled = false;   // FG_HMC_SEP=0: keep independent-sites programs on the gradient-stream kernel (A/B tests)

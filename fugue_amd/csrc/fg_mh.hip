@@ -35,23 +35,37 @@
 #else
 #define FG_MH_FETCH(RC) RC = fg_fetch_grec(g, k + 2);
 #endif
+// PAT = operand pattern of a run of plain Normal records with sigma = 2^k (the host sorts them together): 1 x and mu are sites,
+// 2 x is a constant (an observation), 3 mu is a constant; 0 = any record (fg_score_one).  A pattern run reads only the
+// operands that are sites and forms -0.5 z z - ln sigma as one fma with an exact product (the rounding of the reference's two
+// operations, fg_hmc_sep.hip).  It leaves out the "z != z -> -inf" select of the scoring kernels: a NaN term (only inf - inf
+// operands produce one) makes log_alpha NaN, a -inf term makes it -inf, and both reject (mh.rs:733: `log_alpha >= 0 || u <
+// exp(log_alpha)` is false either way) -- the term rows are rewritten by the next step and never stored.  The same holds
+// for z z in [2^1024, 2^1025), where the fused form is -inf and the reference's finite but below -2^1023.
 #ifdef FG_EXP_MH_NOLDS
 #define FG_MH_OPND(RB, XB, MB) XB = xa; MB = ma;
 #else
-#define FG_MH_OPND(RB, XB, MB) XB = slots[RB[0] * tw]; MB = slots[RB[1] * tw];
+#define FG_MH_OPND(RB, XB, MB) if (PAT != 2) XB = slots[RB[0] * tw]; if (PAT != 3) MB = slots[RB[1] * tw];
 #endif
 #define FG_MH_TSTAGE(RA, XA, MA, RB, XB, MB, RC)                                                  \
     __builtin_amdgcn_s_waitcnt(0xc07f);                                                           \
     FG_MH_FETCH(RC)                                                                               \
     FG_MH_OPND(RB, XB, MB)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                            \
-    { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy, lane_pool); } \
+    if (PAT == 0) { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy, lane_pool); } \
+    else {                                                                                        \
+        const double x_ = PAT == 2 ? fg_dbl(RA[4], RA[5]) : XA, m_ = PAT == 3 ? fg_dbl(RA[6], RA[7]) : MA; \
+        const double z_ = (x_ - m_) * fg_dbl(RA[10], RA[11]);                                     \
+        terms[RA[3] * tw] = __builtin_fma(-0.5, z_ * z_, -fg_dbl(RA[12], RA[13])) - 0.5 * FG_LN_2PI; \
+    }                                                                                             \
     if (++k >= r1) break;
-template <int RK>
+template <int RK, int PAT = 0>
 __device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, const double *pool, const double *lane_pool, const double *slots, int tw, double *terms) {
     if (r0 >= r1) return;
     fg_u32x16 ra = fg_fetch_grec(g, r0), rb = fg_fetch_grec(g, r0 + 1), rc;
-    double xa = slots[ra[0] * tw], ma = slots[ra[1] * tw], xb, mb, xc, mc;
+    double xa = 0.0, ma = 0.0, xb = 0.0, mb = 0.0, xc = 0.0, mc = 0.0;
+    if (PAT != 2) xa = slots[ra[0] * tw];
+    if (PAT != 3) ma = slots[ra[1] * tw];
     int k = r0;
     for (;;) {
         FG_MH_TSTAGE(ra, xa, ma, rb, xb, mb, rc)
@@ -67,9 +81,10 @@ __device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, 
 // the slot it names; for a Categorical table the entry) overlap instead of following each other record by record, which is
 // what a step of a mixture model waited for (C5: +15 %).
 //   class 0  Normal(x; options[z], sigma = 2^k)     class 1  Categorical site with a constant table
-//   class 2  everything else: the pipelined one-at-a-time loop of fg_mh_terms (plain Normals measured faster there than four
+//   classes 2, 3, 4  plain Normals with sigma = 2^k by operand pattern (site / site, constant x, constant mu) and
+//   class 5  everything else: the pipelined one-at-a-time loop of fg_mh_terms (plain Normals measured faster there than four
 //            at a time: the loop fetches records two ahead, a group of four waits for its own)
-#define FG_MH_NCLS 3
+#define FG_MH_NCLS 6
 struct FgMhSeg { int r[FG_MH_NCLS][FG_MH_WMAX + 1]; };   // records [r[c][w], r[c][w + 1]) of the sorted stream are wave w's share of class c
 
 // the common path of fg_score_one, operation for operation
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                     const uint32_t tot = a1[2] + 1u;
                     const uint32_t acn = a1[3] + (accept ? 1u : 0u);
                     double ls = fg_dbl(a1[0], a1[1]);
-                    if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot); sc = r.a; ls = r.b; }
+                    if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot, M.step_tab, M.step_n); sc = r.a; ls = r.b; }
                     if (live) {
                         const unsigned long long lb = (unsigned long long)__double_as_longlong(ls);
                         const fg_u32x4 w1 = { (uint32_t)lb, (uint32_t)(lb >> 32), tot, acn };
@@ -321,8 +336,11 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 for (int k = seg.r[0][wv]; k < seg.r[0][wv + 1]; k += 4) fg_mh_group4<RK, 0>(srt, k, seg.r[0][wv + 1], tab, slots, tw, terms);
                 for (int k = seg.r[1][wv]; k < seg.r[1][wv + 1]; k += 4) fg_mh_group4<RK, 1>(srt, k, seg.r[1][wv + 1], tab, slots, tw, terms);
             }
-            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(srt, seg.r[2][wv], seg.r[2][wv + 1], P.pool, pool_l, slots, tw, terms);
-            else fg_mh_terms<RK>(srt, seg.r[2][wv], seg.r[2][wv + 1], P.pool, nullptr, slots, tw, terms);
+            fg_mh_terms<RK, 1>(srt, seg.r[2][wv], seg.r[2][wv + 1], P.pool, nullptr, slots, tw, terms);
+            fg_mh_terms<RK, 2>(srt, seg.r[3][wv], seg.r[3][wv + 1], P.pool, nullptr, slots, tw, terms);
+            fg_mh_terms<RK, 3>(srt, seg.r[4][wv], seg.r[4][wv + 1], P.pool, nullptr, slots, tw, terms);
+            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(srt, seg.r[5][wv], seg.r[5][wv + 1], P.pool, pool_l, slots, tw, terms);
+            else fg_mh_terms<RK>(srt, seg.r[5][wv], seg.r[5][wv + 1], P.pool, nullptr, slots, tw, terms);
         }
         __syncthreads();
     }
@@ -350,10 +368,16 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     }
     if (W < 2) W = 2;                                                       // control wave + random-number wave
     // the kind-sorted copy of the score stream (once per engine); within a class the records keep their program order
-    auto cls_of = [](const FgGradRec &r) {
+    const uint32_t zero_slot = (uint32_t)(e->n_slots - 1);
+    auto cls_of = [zero_slot](const FgGradRec &r) {
         if (r.flags & FG_G_CATC) return 1;
-        if (r.flags & (FG_G_GEN | FG_G_LIN)) return 2;
-        return ((r.flags & FG_G_NSEL) && (r.flags & FG_G_POW2)) ? 0 : 2;
+        if ((r.flags & (FG_G_GEN | FG_G_LIN)) || !(r.flags & FG_G_POW2)) return 5;
+        if (r.flags & FG_G_NSEL) return 0;
+        const bool xc = r.xi == zero_slot, mc = r.mi == zero_slot;                // a constant operand reads the always-zero slot and carries its value as the immediate
+        if (!xc && !mc && r.ximm == 0.0 && r.mimm == 0.0) return 2;
+        if (xc && !mc && r.mimm == 0.0) return 3;
+        if (!xc && mc && r.ximm == 0.0) return 4;
+        return 5;
     };
     if (!e->d_mh_srt) {
         std::vector<FgGradRec> srt;
