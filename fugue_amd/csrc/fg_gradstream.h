@@ -128,6 +128,73 @@ __device__ __forceinline__ double fg_nsel_mu_lane(const fg_u32x16 &r, double zs,
     return ok ? v : NAN;
 }
 
+// Two in-order sums of LDS rows, side by side: sa = ((0 + A[0]) + A[1]) + ... over na rows, sb likewise over nb rows -- the
+// additions of a sequential scoring run (interpreters.rs:76-163).  The wave that adds is alone on the path of its tile and
+// issues one instruction per four cycles, so the loop is written for instruction count: rows are read at COMPILE-TIME offsets
+// from a moving base (the compiler pairs them into ds_read2st64_b64 -- the row stride is 64 x 8 B -- and spends no address
+// arithmetic per row), CH rows of each chain are in flight (fg_inorder_sum1: and the next CH already requested while the
+// current ones are added).  A tail shorter than CH reads CH rows all the same (what lies behind a chain's last row is still the tile's LDS)
+// and adds +0.0 in place of the strangers: a running sum that started from +0.0 is never -0.0, so `+ 0.0` changes no bit.
+template <int CH>
+__device__ __forceinline__ void fg_inorder_tail(const double *p, int rem, int tw, double &acc) {
+    double x[CH];
+    for (; rem >= CH; rem -= CH, p += (long long)CH * tw) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) x[q] = p[q * tw];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) acc += x[q];
+    }
+    if (rem > 0) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) x[q] = p[q * tw];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) acc += (q < rem) ? x[q] : 0.0;
+    }
+}
+template <int CH = 8>
+__device__ __forceinline__ void fg_inorder_sums2(const double *A, int na, const double *B, int nb, int tw, double &sa, double &sb) {
+    const int n = na < nb ? na : nb;
+    double a = 0.0, b = 0.0;
+    const double *pa = A, *pb = B;
+    int k = 0;
+    for (; k + CH <= n; k += CH, pa += (long long)CH * tw, pb += (long long)CH * tw) {    // both chains, CH rows of each in flight
+        double x[CH], u[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { x[q] = pa[q * tw]; u[q] = pb[q * tw]; }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { a += x[q]; b += u[q]; }
+    }
+    fg_inorder_tail<CH>(pa, na - k, tw, a);
+    fg_inorder_tail<CH>(pb, nb - k, tw, b);
+    sa = a; sb = b;
+}
+
+// one chain of the above (a kernel whose waves take one sum each)
+template <int CH = 8>
+__device__ __forceinline__ double fg_inorder_sum1(const double *A, int na, int tw) {
+    double a = 0.0;
+    const double *pa = A;
+    int k = 0;
+    double x[CH], y[CH];
+#define FG_SUM_LOAD(X) { _Pragma("unroll") for (int q = 0; q < CH; ++q) X[q] = pa[q * tw]; pa += (long long)CH * tw; k += CH; }
+#define FG_SUM_ADD(X) { _Pragma("unroll") for (int q = 0; q < CH; ++q) a += X[q]; }
+    if (na >= CH) {
+        FG_SUM_LOAD(x)
+        for (;;) {
+            if (k + CH > na) { FG_SUM_ADD(x) break; }
+            FG_SUM_LOAD(y)
+            FG_SUM_ADD(x)
+            if (k + CH > na) { FG_SUM_ADD(y) break; }
+            FG_SUM_LOAD(x)
+            FG_SUM_ADD(y)
+        }
+    }
+#undef FG_SUM_LOAD
+#undef FG_SUM_ADD
+    fg_inorder_tail<CH>(pa, na - k, tw, a);
+    return a;
+}
+
 struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
 struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
 

@@ -27,6 +27,14 @@
 
 #define FG_MH_WMAX 16
 
+// FG_MH_PROF (experiment builds, tools/prof_mh_phases.py): cycles tile 0's waves spend in each part of a step
+#ifdef FG_MH_PROF
+__device__ unsigned long long fg_mh_prof[FG_MH_WMAX][8];
+#define FG_PROF_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_[i] += now_ - tprev_; tprev_ = now_; }
+#else
+#define FG_PROF_T(i)
+#endif
+
 // records [r0, r1) of the score stream at the current tile state -> term rows (row = the record's `coord` field).  Records
 // are fetched two ahead into three rotating 16-SGPR buffers (the loop is unrolled by three so that no buffer is ever
 // copied), operands one ahead; s_waitcnt by hand (SMEM returns out of order).
@@ -87,49 +95,46 @@ __device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, 
 #define FG_MH_NCLS 6
 struct FgMhSeg { int r[FG_MH_NCLS][FG_MH_WMAX + 1]; };   // records [r[c][w], r[c][w + 1]) of the sorted stream are wave w's share of class c
 
-// the common path of fg_score_one, operation for operation
-template <int RK>
-__device__ __forceinline__ double fg_mh_lp_plain(const fg_u32x16 &r, double xs, double m) {
-    const double x = xs + fg_dbl(r[4], r[5]);
-    const double z = (x - m) * fg_dbl(r[10], r[11]);
-    const double lp = -0.5 * z * z - fg_dbl(r[12], r[13]) - 0.5 * FG_LN_2PI;
-    return (z != z) ? FG_NEG_INF : lp;
-}
-template <int RK, int CLS>
+// Four records of class 0 (CLS = 0) or class 1 at the tile's state -> their term rows.  `tab`: the constant pool -- the LDS copy
+// when the kernel staged it (the call sites pass the shared-memory pointer itself, so the lookups are ds_reads), else global.
+//   class 0: x is the observation (the record's immediate), mu = the site named by option z of a list of sites; an index
+//            outside the list makes mu NaN (fg_nsel_mu_lane) and the term NaN where the scoring kernels write -inf: both
+//            reject (see FG_MH_TSTAGE) and the rows are rewritten by the next step;
+//   class 1: ln p[z] from the table's precomputed logarithms, -inf outside it (distribution.rs:785-791).
+template <int CLS>
 __device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend, const double *tab, const double *slots, int tw, double *terms) {
     fg_u32x16 r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = fg_fetch_grec(g, k + i < kend ? k + i : kend - 1);   // a short group repeats its last record (same term, same row)
     __builtin_amdgcn_sched_barrier(0);                         // the four scalar fetches are in flight together
-    double xs[4], ms[4], lp[4];
+    double zs[4], lp[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xs[i] = slots[r[i][0] * tw]; if (CLS == 0) ms[i] = slots[r[i][1] * tw]; }
+    for (int i = 0; i < 4; ++i) zs[i] = slots[r[i][CLS == 0 ? 1 : 0] * tw];                 // the index site
     __builtin_amdgcn_sched_barrier(0);                         // ... and so are the operand reads
-    if (CLS == 0) {                                            // fg_nsel_mu_lane, four at a time
-        bool ok[4]; double hdr[4], cst[4], v[4];
+    bool ok[4];
+    if (CLS == 0) {
+        uint32_t sl[4]; double v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long zi = fg_as_i64(ms[i]);
-            ok[i] = zi >= 0 && zi < (long long)r[i][7];
-            const double *ent = tab + r[i][6] + 2 * (ok[i] ? (int)zi : 0);
-            hdr[i] = ent[0]; cst[i] = ent[1];
+            const unsigned long long zi = (unsigned long long)fg_as_i64(zs[i]);
+            ok[i] = zi < (unsigned long long)r[i][7];                                        // 0 <= z < K
+            sl[i] = ((const uint32_t *)(tab + r[i][6]))[4 * (ok[i] ? (uint32_t)zi : 0u)];   // option entry {u32 slot, u32 is_const = 0, f64 unused}
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = slots[(uint32_t)fg_as_i64(hdr[i]) * tw];    // a constant option names the always-zero slot
+        for (int i = 0; i < 4; ++i) v[i] = slots[sl[i] * tw];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool is_const = (uint32_t)(fg_as_i64(hdr[i]) >> 32) != 0u;
-            const double m = ok[i] ? (is_const ? cst[i] : v[i]) : NAN;
-            lp[i] = fg_mh_lp_plain<RK>(r[i], xs[i], m);
+            const double m = ok[i] ? v[i] : NAN;
+            const double z = (fg_dbl(r[i][4], r[i][5]) - m) * fg_dbl(r[i][10], r[i][11]);
+            lp[i] = __builtin_fma(-0.5, z * z, -fg_dbl(r[i][12], r[i][13])) - 0.5 * FG_LN_2PI;
         }
-    } else {                                                   // ln p[z] of a constant table (distribution.rs:785-791)
-        bool ok[4];
+    } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long zi = fg_as_i64(xs[i]);
+            const unsigned long long zi = (unsigned long long)fg_as_i64(zs[i]);
             const uint32_t base = r[i][6], K = r[i][7];
-            ok[i] = zi >= 0 && zi < (long long)K;
-            lp[i] = tab[base + K + (ok[i] ? (int)zi : 0)];
+            ok[i] = zi < (unsigned long long)K;
+            lp[i] = tab[base + K + (ok[i] ? (uint32_t)zi : 0u)];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) lp[i] = ok[i] ? lp[i] : FG_NEG_INF;
@@ -138,7 +143,7 @@ __device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend
     for (int i = 0; i < 4; ++i) terms[r[i][3] * tw] = lp[i];
 }
 
-template <int RK>
+template <int RK, bool SPLIT /* the two in-order sums on two waves */>
 __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt /* the kind-sorted score stream */, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
                                                                            long long *draws, int first_sample_t, int exp_mask /* timing experiments only (FG_MH_EXP): results are wrong when non-zero */,
                                                                            int pool_n /* > 0: the constant pool (pool_n doubles) is staged into LDS behind the exchange rows */) {
@@ -153,13 +158,19 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     const int n_s = P.n_sstream, n_pri = P.n_prior_terms, n_lik = n_s - n_pri;
     double *slots = lds + lane;
     double *terms = lds + (long long)P.n_slots * tw + lane;
-    // exchange rows, double-buffered by step parity (8 rows each): 0 target site, 1 gaussian_z, 2 u(block 1), 3 u(block 2),
+    // exchange rows, double-buffered by step parity (8 rows each; row 16: the log_likelihood sum on its way to the control wave):
+    // 0 target site, 1 gaussian_z, 2 u(block 1), 3 u(block 2),
     // 4 {LDS slot, value type} of the target, 5 Categorical targets: {pool base, K} of the constant table, 6 their proposed
     // index, 7 its prior log-probability
     double *xch = terms + (long long)n_s * tw;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     const int rng_wave = W - 1;
     const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
+
+    // small constant pools (Categorical tables, option lists) are read per lane: from the LDS copy a lookup costs an LDS round
+    // trip instead of a vector-memory one
+    double *pool_l = lds + (long long)(P.n_slots + n_s + 17) * tw;
+    auto pool_rd = [&](int idx) __attribute__((always_inline)) { return pool_n > 0 ? pool_l[idx] : P.pool[idx]; };
 
     // Everything of step `it` that does not depend on the chain's state -> buffer (it & 1).
     //   part 0: gen_range target (mh.rs:716) with its site-table entries, the uniform of block 1 and -- for a Categorical
@@ -186,13 +197,13 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 for (int i0 = 0; i0 < cK; i0 += 4) {                  // four table entries in flight
                     double pv[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) pv[q] = (i0 + q < cK) ? P.pool[cb + i0 + q] : 0.0;
+                    for (int q = 0; q < 4; ++q) pv[q] = (i0 + q < cK) ? pool_rd(cb + i0 + q) : 0.0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (i0 + q < cK) { cum += pv[q]; if (idx == cK && !(cum < u1)) idx = i0 + q; }
                 }
                 const int prop = idx < cK - 1 ? idx : cK - 1;
                 b[6 * tw] = fg_as_double((long long)prop);
-                b[7 * tw] = P.pool[cb + cK + prop];                   // the table's precomputed ln p (-inf for p <= 0)
+                b[7 * tw] = pool_rd(cb + cK + prop);                  // the table's precomputed ln p (-inf for p <= 0)
             }
         } else {
             rng.c1 = 1; fg_rng_block(rng, ra, rb);
@@ -212,48 +223,67 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
         fg_load_values(P, X, c, slots, tw);
         lw = M.lw[c];
     }
-    // small constant pools (Categorical tables, option lists) are read per lane by the record evaluators: from LDS a lookup
-    // costs an LDS round trip instead of a vector-memory one
-    double *pool_l = lds + (long long)(P.n_slots + n_s + 16) * tw;
     for (int k = (int)threadIdx.x; k < pool_n; k += (int)blockDim.x) pool_l[k] = P.pool[k];
+    if (pool_n > 0) __syncthreads();                               // the random-number waves read the staged tables below
     if (wv == rng_wave) { publish_rng(iter0, 0); if (n_steps > 1) publish_rng(iter0 + 1, 0); }
     if (wv == rng_wave1) { publish_rng(iter0, 1); if (n_steps > 1) publish_rng(iter0 + 1, 1); }
+    // this wave's share of every record class, read once (indexing the kernel argument by the wave number inside the step loop
+    // is a scalar-memory round trip per class per step)
+    // -- for the instantiations with lookup classes, whose phase B is a chain of round trips; the fast-Normal one measured faster
+    // re-reading its three bounds than keeping them (it is short of scalar registers)
+    int sa_[FG_MH_NCLS], sb_[FG_MH_NCLS];
+#pragma unroll
+    for (int q = 0; q < FG_MH_NCLS; ++q) { sa_[q] = RK == 0 ? 0 : seg.r[q][wv]; sb_[q] = RK == 0 ? 0 : seg.r[q][wv + 1]; }
+#define sa(q) (RK == 0 ? seg.r[q][wv] : sa_[q])
+#define sb(q) (RK == 0 ? seg.r[q][wv + 1] : sb_[q])
     __syncthreads();
+#ifdef FG_MH_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t <= n_steps; ++t) {
         const int iter = iter0 + t;
         // ---- phase A
-        if (wv == 0) {
-            // the next proposal's inputs first: its adaptation state comes from HBM / L2 while step t - 1 is being finished
-            const double *b = xch + (long long)(8 * (iter & 1)) * tw;
-            int n_target = 0, n_tslot = 0; uint32_t n_tv = 0u; long long n_g = 0;
-            double n_scale = 1.0; int n_kind = 0;
-            const bool do_prop = t < n_steps && !(exp_mask & 4);
-            if (do_prop) {
-                n_target = (int)fg_as_i64(b[0]);
-                const long long st = fg_as_i64(b[4 * tw]);
-                n_tslot = (int)(uint32_t)st; n_tv = (uint32_t)(st >> 32);
-                n_g = (long long)n_target * X.C + c;
-                const fg_u32x4 a0 = *(const fg_u32x4 *)(M.ad + n_g);       // {scale, kind}: get_scale  mcmc_utils.rs:70-77
-                n_scale = fg_dbl(a0[0], a0[1]);
-                n_kind = (int)a0[2];
+        // the next proposal's inputs first: its adaptation state comes from HBM / L2 while step t - 1 is being finished
+        const double *b = xch + (long long)(8 * (iter & 1)) * tw;
+        int n_target = 0, n_tslot = 0; uint32_t n_tv = 0u; long long n_g = 0;
+        double n_scale = 1.0; int n_kind = 0;
+        const bool do_prop = t < n_steps && !(exp_mask & 4);
+#define FG_MH_NEXT_INPUTS                                                                                                   \
+        if (do_prop) {                                                                                                      \
+            n_target = (int)fg_as_i64(b[0]);                                                                                \
+            const long long st = fg_as_i64(b[4 * tw]);                                                                      \
+            n_tslot = (int)(uint32_t)st; n_tv = (uint32_t)(st >> 32);                                                       \
+            n_g = (long long)n_target * X.C + c;                                                                            \
+            const fg_u32x4 a0 = *(const fg_u32x4 *)(M.ad + n_g);           /* {scale, kind}: get_scale  mcmc_utils.rs:70-77 */ \
+            n_scale = fg_dbl(a0[0], a0[1]);                                                                                 \
+            n_kind = (int)a0[2];                                                                                            \
+        }
+        // log_prior and log_likelihood of step t - 1's proposal: the terms in program order.  SPLIT (long programs): one chain per
+        // wave -- a wave alone on its tile's path issues an instruction every 6 to 9 cycles
+        // (profiles/round1_f64_issue_microbench.txt), so the two independent sums run side by side on two waves and meet at a barrier
+        double pri = 0.0, lik = 0.0;
+        if (SPLIT) {
+            if (wv == 0) { FG_MH_NEXT_INPUTS }
+            if (t > 0 && !(exp_mask & 2)) {
+                if (wv == 0) pri = fg_inorder_sum1(terms, n_pri, tw);
+                else if (wv == 1) xch[16 * tw] = fg_inorder_sum1(terms + (long long)n_pri * tw, n_lik, tw);
+                // LDS only crosses this barrier: wait for the LDS counter and leave the control wave's adaptation-state gather (64
+                // lines from L2, issued above) in flight -- __syncthreads() would drain it here
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                if (wv == 0) lik = xch[16 * tw];
             }
+        }
+        if (wv == 0) {
+            if (!SPLIT) {                                                  // short programs: both chains on the control wave, no third barrier
+                FG_MH_NEXT_INPUTS
+                if (t > 0 && !(exp_mask & 2)) fg_inorder_sums2(terms, n_pri, terms + (long long)n_pri * tw, n_lik, tw, pri, lik);
+            }
+#undef FG_MH_NEXT_INPUTS
             if (t > 0 && !(exp_mask & 2)) {                                // finish step t - 1
                 const int itp = iter - 1;
                 const bool adapt = itp < n_warmup;
-                // log_prior and log_likelihood: the terms in program order (two independent chains), eight rows of each in flight
-                double pri = 0.0, lik = 0.0;
-                const int nb = n_pri < n_lik ? n_pri : n_lik;
-                int k = 0;
-                for (; k + 8 <= nb; k += 8) {
-                    double a[8], l[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { a[q] = terms[(k + q) * tw]; l[q] = terms[(n_pri + k + q) * tw]; }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { pri += a[q]; lik += l[q]; }
-                }
-                for (; k < nb; ++k) { pri += terms[k * tw]; lik += terms[(n_pri + k) * tw]; }
-                for (int q = nb; q < n_pri; ++q) pri += terms[q * tw];
-                for (int q = nb; q < n_lik; ++q) lik += terms[(n_pri + q) * tw];
+                FG_PROF_T(0)
                 const double prop_lw = pri + lik + 0.0;                    // total_log_weight (no factor statement has a record)
                 const double log_alpha = prop_lw - lw + (lqr - lqf);       // + dim_term == 0 (fixed structure)  mh.rs:731-732
                 const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
@@ -281,6 +311,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                 // the state fetched above is stale where the next proposal hits the site just updated
                 if (do_prop && n_g == g) { n_scale = sc; n_kind = kind_new; }
             }
+            FG_PROF_T(1)
             if (do_prop) {                                                 // proposal of step t (mh.rs:183-294, 516-530, 557-567)
                 FgMhCtx mh;
                 mh.z = b[tw];
@@ -316,7 +347,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
                     const long long prop = fg_as_i64(b[6 * tw]);
                     const long long cur = fg_as_i64(mh.old_cell);
                     mh.lqf += b[7 * tw];                                   // prior log-probabilities of the proposed and the current index
-                    mh.lqr += (cur < 0 || cur >= (long long)cat_K) ? FG_NEG_INF : P.pool[cat_base + cat_K + (int)cur];
+                    mh.lqr += (cur < 0 || cur >= (long long)cat_K) ? FG_NEG_INF : pool_rd(cat_base + cat_K + (int)cur);
                     mh.next_block = 2;
                     slots[tslot * tw] = fg_as_double(prop);
                 } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
@@ -328,23 +359,36 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
             if (wv == rng_wave1) publish_rng(iter + 1, 1);
         }
         if (t == n_steps) break;
+        FG_PROF_T(2)
         __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
+        FG_PROF_T(3)
         // ---- phase B: every wave scores its share of the statements
         if (!(exp_mask & 1)) {
-            const double *tab = (RK != 0 && pool_n > 0) ? pool_l : P.pool;
             if (RK >= 2) {
-                for (int k = seg.r[0][wv]; k < seg.r[0][wv + 1]; k += 4) fg_mh_group4<RK, 0>(srt, k, seg.r[0][wv + 1], tab, slots, tw, terms);
-                for (int k = seg.r[1][wv]; k < seg.r[1][wv + 1]; k += 4) fg_mh_group4<RK, 1>(srt, k, seg.r[1][wv + 1], tab, slots, tw, terms);
+                if (pool_n > 0) {
+                    for (int k = sa(0); k < sb(0); k += 4) fg_mh_group4<0>(srt, k, sb(0), pool_l, slots, tw, terms);
+                    for (int k = sa(1); k < sb(1); k += 4) fg_mh_group4<1>(srt, k, sb(1), pool_l, slots, tw, terms);
+                } else {
+                    for (int k = sa(0); k < sb(0); k += 4) fg_mh_group4<0>(srt, k, sb(0), P.pool, slots, tw, terms);
+                    for (int k = sa(1); k < sb(1); k += 4) fg_mh_group4<1>(srt, k, sb(1), P.pool, slots, tw, terms);
+                }
             }
-            fg_mh_terms<RK, 1>(srt, seg.r[2][wv], seg.r[2][wv + 1], P.pool, nullptr, slots, tw, terms);
-            fg_mh_terms<RK, 2>(srt, seg.r[3][wv], seg.r[3][wv + 1], P.pool, nullptr, slots, tw, terms);
-            fg_mh_terms<RK, 3>(srt, seg.r[4][wv], seg.r[4][wv + 1], P.pool, nullptr, slots, tw, terms);
-            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(srt, seg.r[5][wv], seg.r[5][wv + 1], P.pool, pool_l, slots, tw, terms);
-            else fg_mh_terms<RK>(srt, seg.r[5][wv], seg.r[5][wv + 1], P.pool, nullptr, slots, tw, terms);
+            fg_mh_terms<RK, 1>(srt, sa(2), sb(2), P.pool, nullptr, slots, tw, terms);
+            fg_mh_terms<RK, 2>(srt, sa(3), sb(3), P.pool, nullptr, slots, tw, terms);
+            fg_mh_terms<RK, 3>(srt, sa(4), sb(4), P.pool, nullptr, slots, tw, terms);
+            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(srt, sa(5), sb(5), P.pool, pool_l, slots, tw, terms);
+            else fg_mh_terms<RK>(srt, sa(5), sb(5), P.pool, nullptr, slots, tw, terms);
         }
+        FG_PROF_T(4)
         __syncthreads();
+        FG_PROF_T(5)
     }
+#ifdef FG_MH_PROF
+    if (blockIdx.x == 0 && lane == 0) for (int q = 0; q < 8; ++q) fg_mh_prof[wv][q] = prof_[q];
+#endif
     if (wv == 0 && live) { M.lw[c] = lw; M.n_acc[c] += nacc; }
+#undef sa
+#undef sb
 }
 
 int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
@@ -354,7 +398,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     if (e->mh_has_prior_resample) return FG_E_UNSUPPORTED;
     for (int j = 0; j < e->S; j++) if (p->site_vtype[j] == FG_USIZE && p->site_cat[2 * j + 1] <= 0) return FG_E_UNSUPPORTED;
     const int n_s = e->P.n_sstream;
-    size_t lds = (size_t)(e->n_slots + n_s + 16) * FG_WAVE * sizeof(double);
+    size_t lds = (size_t)(e->n_slots + n_s + 17) * FG_WAVE * sizeof(double);   // site values, term rows, 2 x 8 exchange rows + the log_likelihood sum
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     int pool_n = 0;                                                          // stage the constant pool into LDS when it is small and the tile leaves room
     if (e->P.sstream_kinds != 0 && p->pool.size() * 8 <= 24 * 1024 && lds + p->pool.size() * 8 <= 160 * 1024 &&
@@ -369,11 +413,16 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     if (W < 2) W = 2;                                                       // control wave + random-number wave
     // the kind-sorted copy of the score stream (once per engine); within a class the records keep their program order
     const uint32_t zero_slot = (uint32_t)(e->n_slots - 1);
-    auto cls_of = [zero_slot](const FgGradRec &r) {
+    auto cls_of = [zero_slot, p](const FgGradRec &r) {
         if (r.flags & FG_G_CATC) return 1;
         if ((r.flags & (FG_G_GEN | FG_G_LIN)) || !(r.flags & FG_G_POW2)) return 5;
-        if (r.flags & FG_G_NSEL) return 0;
         const bool xc = r.xi == zero_slot, mc = r.mi == zero_slot;                // a constant operand reads the always-zero slot and carries its value as the immediate
+        if (r.flags & FG_G_NSEL) {                                                 // class 0: an observation against options that are all sites
+            uint32_t w[2]; std::memcpy(w, &r.mimm, 8);
+            bool sites_only = xc;
+            for (uint32_t q = 0; q < w[1] && sites_only; ++q) sites_only = (uint32_t)(fg_as_i64(p->pool[w[0] + 2 * q]) >> 32) == 0u;
+            return sites_only ? 0 : 5;
+        }
         if (!xc && !mc && r.ximm == 0.0 && r.mimm == 0.0) return 2;
         if (xc && !mc && r.mimm == 0.0) return 3;
         if (!xc && mc && r.ximm == 0.0) return 4;
@@ -401,18 +450,33 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         shift += n % W;
     }
     const int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
+    // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
+    // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
+    const int split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
-    static bool attr_set_dev[64][4];
-    bool &attr_set = attr_set_dev[e->device & 63][rk];
+    static bool attr_set_dev[64][8];
+    const int variant = 2 * (rk == 0 ? 0 : (rk == 2 ? 1 : 2)) + split_sums;
+    const void *fns[6] = { (const void *)k_mh_mw_steps<0, false>, (const void *)k_mh_mw_steps<0, true>, (const void *)k_mh_mw_steps<2, false>,
+                           (const void *)k_mh_mw_steps<2, true>, (const void *)k_mh_mw_steps<3, false>, (const void *)k_mh_mw_steps<3, true> };
+    bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
-        const void *fn = rk == 0 ? (const void *)k_mh_mw_steps<0> : (rk == 2 ? (const void *)k_mh_mw_steps<2> : (const void *)k_mh_mw_steps<3>);
-        const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t he = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-    if (rk == 2) hipLaunchKernelGGL(k_mh_mw_steps<2>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
-    else if (rk == 3) hipLaunchKernelGGL(k_mh_mw_steps<3>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
-    else hipLaunchKernelGGL(k_mh_mw_steps<0>, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t, exp_mask, pool_n);
+#define FG_MH_LAUNCH(R, SP) hipLaunchKernelGGL((k_mh_mw_steps<R, SP>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, \
+                                               e->mh_warmup, draws, first_sample_t, exp_mask, pool_n)
+    switch (variant) {
+        case 0: FG_MH_LAUNCH(0, false); break; case 1: FG_MH_LAUNCH(0, true); break; case 2: FG_MH_LAUNCH(2, false); break;
+        case 3: FG_MH_LAUNCH(2, true); break;  case 4: FG_MH_LAUNCH(3, false); break; default: FG_MH_LAUNCH(3, true); break;
+    }
+#undef FG_MH_LAUNCH
     HIPCHK(hipGetLastError());
     return FG_OK;
 }
+
+#ifdef FG_MH_PROF
+extern "C" int fg_debug_mh_prof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_mh_prof), sizeof(unsigned long long) * FG_MH_WMAX * 8) == hipSuccess ? 0 : -1;
+}
+#endif
