@@ -25,7 +25,41 @@ __device__ __forceinline__ double fg_uniform(double v) {
 // ---- linear predictors (FG_G_LIN): mu = c0 + s_0 c_0 + s_1 c_1 + ... in term order, two roundings per term like the
 // interpreter's LOAD / FG_OP_DOT sequence it replaces.  Terms {u32 slot, u32 0, f64 c} are read four at a time with
 // scalar loads; with 4 waves on the SIMD the exposed load latency of one wave is covered by the others.
+// `DUAL`: the same products are added to two running sums (the suffix of a finite-difference pair, below).  The next group of
+// four terms is requested before the current one is used (the pool is padded by one group, so the look-ahead past a record's
+// last term stays inside it): a record of d terms is d / 4 round trips of ~one LDS latency instead of d / 4 scalar-memory
+// latencies followed by d / 4 LDS latencies.
+template <bool DUAL>
+__device__ __forceinline__ void fg_lin_run(const FG_AS4 char *tb, uint32_t t0, uint32_t t1, const double *slots, int tw, double &mu, double &mu2) {
+    uint32_t t = t0;
+    if (t + 4 <= t1) {
+        fg_u32x16 q = *(const FG_AS4 fg_u32x16 *)(tb + 16 * t);
+        for (;;) {
+            const fg_u32x16 qn = *(const FG_AS4 fg_u32x16 *)(tb + 16 * (t + 4));
+            const double v0 = slots[q[0] * tw], v1 = slots[q[4] * tw], v2 = slots[q[8] * tw], v3 = slots[q[12] * tw];
+            const double p0 = v0 * fg_dbl(q[2], q[3]), p1 = v1 * fg_dbl(q[6], q[7]), p2 = v2 * fg_dbl(q[10], q[11]), p3 = v3 * fg_dbl(q[14], q[15]);
+            mu = mu + p0; mu = mu + p1; mu = mu + p2; mu = mu + p3;
+            if (DUAL) { mu2 = mu2 + p0; mu2 = mu2 + p1; mu2 = mu2 + p2; mu2 = mu2 + p3; }
+            t += 4;
+            if (t + 4 > t1) break;
+            q = qn;
+        }
+    }
+    for (; t < t1; ++t) {
+        const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+        const double pr = slots[q[0] * tw] * fg_dbl(q[2], q[3]);
+        mu = mu + pr;
+        if (DUAL) mu2 = mu2 + pr;
+    }
+}
+// short runs (the two- and three-term predictors of hierarchical models) keep the plain loop: the look-ahead version measured
+// 20 % slower on them
 __device__ __forceinline__ double fg_lin_prefix(const FG_AS4 char *tb, uint32_t t0, uint32_t t1, const double *slots, int tw, double mu) {
+    if (t1 - t0 >= 8u && t1 > t0) {
+        double unused = 0.0;
+        fg_lin_run<false>(tb, t0, t1, slots, tw, mu, unused);
+        return mu;
+    }
     uint32_t t = t0;
     for (; t + 4 <= t1; t += 4) {
         const fg_u32x16 q = *(const FG_AS4 fg_u32x16 *)(tb + 16 * t);
@@ -47,18 +81,27 @@ __device__ __forceinline__ double fg_lin_mu(const fg_u32x16 &r, const double *po
     return fg_lin_prefix(tb, 0u, r[15], slots, tw, fg_dbl(r[6], r[7]));
 }
 // means at q_i + h and q_i - h: the terms before the first one that reads q_i are common to both, from there on the
-// two sums are carried side by side (a term that does not read q_i contributes the same product to both)
+// two sums are carried side by side (a term that does not read q_i contributes the same product to both).  FG_G_LIN1: q_i is
+// read by that one term only (a regression's x_ij beta_j) -- the rest of the suffix needs no test per term and runs four
+// terms at a time like the prefix.
 __device__ __forceinline__ void fg_lin_mu_dual(const fg_u32x16 &r, const double *pool, const double *slots, int tw, double h,
                                                double &mup, double &mum) {
     const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + r[14]);
     const uint32_t n = r[15], pos = r[2] >> 16, ci = r[3];
     const double mu = fg_lin_prefix(tb, 0u, pos < n ? pos : n, slots, tw, fg_dbl(r[6], r[7]));
     double mp = mu, mm = mu;
-    for (uint32_t t = pos; t < n; ++t) {
-        const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+    if ((r[2] & FG_G_LIN1) && pos + 6u <= n) {
+        const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * pos);
         const double v = slots[q[0] * tw], c = fg_dbl(q[2], q[3]);
-        if (q[0] == ci) { mp = mp + (v + h) * c; mm = mm + (v - h) * c; }      // the perturbed slot holds orig +- h (hmc.rs:317-319)
-        else { const double pr = v * c; mp = mp + pr; mm = mm + pr; }
+        mp = mp + (v + h) * c; mm = mm + (v - h) * c;             // the perturbed slot holds orig +- h (hmc.rs:317-319)
+        fg_lin_run<true>(tb, pos + 1u, n, slots, tw, mp, mm);
+    } else {
+        for (uint32_t t = pos; t < n; ++t) {
+            const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
+            const double v = slots[q[0] * tw], c = fg_dbl(q[2], q[3]);
+            if (q[0] == ci) { mp = mp + (v + h) * c; mm = mm + (v - h) * c; }
+            else { const double pr = v * c; mp = mp + pr; mm = mm + pr; }
+        }
     }
     mup = mp; mum = mm;
 }

@@ -22,7 +22,7 @@
 #include "../../include/fugue_amd.h"
 
 #define FG_WAVE 64            /* hardware wavefront width */
-#define FG_MW_MAX 4           /* waves per 64-chain tile in the multi-wave HMC kernel */
+#define FG_MW_MAX 16          /* waves per 64-chain tile in the multi-wave HMC kernel */
 #ifndef FG_MIN_WAVES
 #define FG_MIN_WAVES 2       /* __launch_bounds__ 2nd arg: waves per SIMD the register budget must allow */
 #endif

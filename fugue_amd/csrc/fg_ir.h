@@ -74,8 +74,9 @@ enum : uint32_t { FG_S_OBS = 1u,      // score stream: the record is an observe 
                   FG_G_GEN = 1024u,    // any of the 17 distributions with leaf operands (fg_logpdf): layout below, kind in flags >> 16
                   FG_G_GEN_HOISTED = 2048u, FG_G_GEN_SH = 4096u, FG_G_GEN_INVALID = 8192u, FG_G_GEN_XINT = 16384u,
                   FG_G_GEN_P0SLOT = 1u << 24, FG_G_GEN_P1SLOT = 1u << 25, FG_G_GEN_P2SLOT = 1u << 26,
-                  FG_G_LIN = 256u      // mu = mimm + sum_t slot[s_t] c_t: maskx = pool offset of the terms {u32 s, u32 0, f64 c},
+                  FG_G_LIN = 256u,     // mu = mimm + sum_t slot[s_t] c_t: maskx = pool offset of the terms {u32 s, u32 0, f64 c},
                                        //   maskm = their number, flags >> 16 = first term that reads the record's coordinate
+                  FG_G_LIN1 = 512u     // ... and no other term reads it
 };
 struct FgGradRec {
     uint32_t xi, mi;        // slot indices of x and mu (the zero slot for constants)

@@ -567,8 +567,9 @@ int fg_program::finalize() {
         }
         if (sh.kind == 2) {
             uint32_t pos = sh.tn;                                      // first term that reads the coordinate (tn: none)
-            if (coord_k >= 0) for (uint32_t t = 0; t < sh.tn; t++) if (sh.tslot[t] == (uint32_t)coord_k) { pos = t; break; }
-            r.flags |= FG_G_LIN | (pos << 16);
+            uint32_t hits = 0;
+            if (coord_k >= 0) for (uint32_t t = 0; t < sh.tn; t++) if (sh.tslot[t] == (uint32_t)coord_k) { if (!hits) pos = t; ++hits; }
+            r.flags |= FG_G_LIN | (pos << 16) | (hits == 1u ? FG_G_LIN1 : 0u);
             r.maskx = sh.toff; r.maskm = sh.tn;                        // LIN: pool offset and number of terms
         }
         if (coord_k >= 0) {

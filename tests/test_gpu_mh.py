@@ -133,9 +133,11 @@ def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypat
     C, nw, ns = 150, 120, 40
     rec = list(range(cp.S))
     out = []
-    for mw, W in ((0, 1), (1, 2), (1, 4), (1, 8), (1, 16)):
+    # (multi-wave kernel?, waves per tile, the two in-order sums on two waves? -- the engine picks that for programs of >= 64 statements)
+    for mw, W, split in ((0, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (1, 2, 1), (1, 4, 1), (1, 16, 1)):
         monkeypatch.setenv("FG_MH_MW", str(mw))
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
+        monkeypatch.setenv("FG_MH_SPLIT", str(split))
         eng = E.Engine(cp, C, seed=13, chain_offset=3)
         d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
         st = eng.mh_run(ns, nw, None, rec, d)

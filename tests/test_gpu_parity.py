@@ -326,12 +326,12 @@ def test_hmc_posterior_closed_form():
                                                   ("ridge7", True, E.GRAD_FD_SPARSE), ("ridge", False, E.GRAD_FD_SPARSE),     # linear-predictor records
                                                   ("hier_scale", True, E.GRAD_FD_SPARSE), ("linreg", False, E.GRAD_FD_SPARSE)])   # general records
 def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
-    """k_hmc_stream_steps splits a tile's coordinates over 1, 2 or 4 waves; the per-coordinate operations and
+    """k_hmc_stream_steps splits a tile's coordinates over 1 ... 16 waves; the per-coordinate operations and
     their order are the same, so draws, step sizes, mass matrix and log-joint must agree BIT FOR BIT."""
     cp = E.compile_model(ZOO[name]())
     C, nw, ns = 192, 40, 25
     out = []
-    for W in (1, 2, 4):
+    for W in (1, 2, 4, 8, 16):
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
@@ -442,7 +442,7 @@ def test_hmc_analytic_mode_posterior_and_wave_invariance(name, monkeypatch):
     cp = E.compile_model(ZOO[name]())
     C, nw, ns = 256, 60, 60
     out = []
-    for W_ in (1, 2, 4):
+    for W_ in (1, 2, 4, 8):
         monkeypatch.setenv("FG_HMC_WAVES", str(W_))
         eng = E.Engine(cp, C, seed=8)
         d = eng.device_alloc(ns * cp.d * C * 8)
