@@ -272,7 +272,7 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDe
 // f64 op, the SIMD's f64 pipe takes one per ~4.3 cycles from >= 2 waves: tools/mb_clock.hip,
 // profiles/round1_f64_issue_microbench.txt), and the LDS tile (36 KB for the 32-site model) caps a CU at 4 tiles,
 // i.e. ONE wave per SIMD however many chains there are -- nothing overlaps anything.
-// Here a tile of 64 chains is owned by a workgroup of W waves (W = 1, 2 or 4): every coordinate's finite-difference
+// Here a tile of 64 chains is owned by a workgroup of W waves (W = 1 ... 16): every coordinate's finite-difference
 // gradient, half-kick, drift and commit is independent of the other coordinates' within one leapfrog step, so wave w
 // does coordinates [seg.c[w], seg.c[w+1]) -- its run of whole coordinates of the gradient stream -- on the SHARED LDS
 // tile, with a workgroup barrier between "all p kicked" and "q drifted" (hmc.rs:389-400: the same operations per
