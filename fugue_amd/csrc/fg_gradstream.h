@@ -212,6 +212,24 @@ __device__ __forceinline__ void fg_inorder_sums2(const double *A, int na, const 
     sa = a; sb = b;
 }
 
+// rows [0, rem) of p added, in order, to TWO running sums (the two whole log-joints of a dense finite difference share every
+// term that did not move): the same chunking, the same +0.0 padding of the last chunk
+template <int CH>
+__device__ __forceinline__ void fg_inorder_run2(const double *p, int rem, int tw, double &a, double &b) {
+    double x[CH];
+    for (; rem >= CH; rem -= CH, p += (long long)CH * tw) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) x[q] = p[q * tw];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { a += x[q]; b += x[q]; }
+    }
+    if (rem > 0) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) x[q] = p[q * tw];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const double v = (q < rem) ? x[q] : 0.0; a += v; b += v; }
+    }
+}
 // one chain of the above (a kernel whose waves take one sum each)
 template <int CH = 8>
 __device__ __forceinline__ double fg_inorder_sum1(const double *A, int na, int tw) {

@@ -259,18 +259,20 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                     const double qp = q + h, qm = q - h;             // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
                     double Pp = 0.0, Pm = 0.0, Lp = 0.0, Lm = 0.0;
                     {                                                // log_prior: the coordinate's own sample statement is its only prior term
+                        // the rows between the own ones: eight at compile-time offsets per chunk (ds_read2st64_b64, no address arithmetic or
+                        // loop control per row; fg_inorder_run2)
                         FG_SEPD_OWN(0, tp0, tm0)
                         const int r0 = (int)a0[1];
-                        for (int k = 0; k < r0; ++k) { const double v = T[k * tw]; Pp += v; Pm += v; }
+                        fg_inorder_run2<8>(T, r0, tw, Pp, Pm);
                         Pp += tp0; Pm += tm0;
-                        for (int k = r0 + 1; k < n_pri; ++k) { const double v = T[k * tw]; Pp += v; Pm += v; }
+                        fg_inorder_run2<8>(T + (long long)(r0 + 1) * tw, n_pri - r0 - 1, tw, Pp, Pm);
                     }
                     {                                                // log_likelihood: its observe statements, in program (= row) order
                         int k = n_pri;
-                        if (nobs >= 1) { FG_SEPD_OWN(1, tp1, tm1) const int r1 = (int)a1[1]; for (; k < r1; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; } Lp += tp1; Lm += tm1; ++k; }
-                        if (nobs >= 2) { FG_SEPD_OWN(2, tp2, tm2) const int r2 = (int)a2[1]; for (; k < r2; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; } Lp += tp2; Lm += tm2; ++k; }
-                        if (nobs >= 3) { FG_SEPD_OWN(3, tp3, tm3) const int r3 = (int)a3[1]; for (; k < r3; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; } Lp += tp3; Lm += tm3; ++k; }
-                        for (; k < n_s; ++k) { const double v = T[k * tw]; Lp += v; Lm += v; }
+                        if (nobs >= 1) { FG_SEPD_OWN(1, tp1, tm1) const int r1 = (int)a1[1]; fg_inorder_run2<8>(T + (long long)k * tw, r1 - k, tw, Lp, Lm); Lp += tp1; Lm += tm1; k = r1 + 1; }
+                        if (nobs >= 2) { FG_SEPD_OWN(2, tp2, tm2) const int r2 = (int)a2[1]; fg_inorder_run2<8>(T + (long long)k * tw, r2 - k, tw, Lp, Lm); Lp += tp2; Lm += tm2; k = r2 + 1; }
+                        if (nobs >= 3) { FG_SEPD_OWN(3, tp3, tm3) const int r3 = (int)a3[1]; fg_inorder_run2<8>(T + (long long)k * tw, r3 - k, tw, Lp, Lm); Lp += tp3; Lm += tm3; k = r3 + 1; }
+                        fg_inorder_run2<8>(T + (long long)k * tw, n_s - k, tw, Lp, Lm);
                     }
                     const double n = (Pp + Lp + 0.0) - (Pm + Lm + 0.0);   // total_log_weight at q + h e_i minus at q - h e_i (log_factors = 0)
                     double g = fg_div_const(n, two_h, rcp_2h);          // hmc.rs:322
