@@ -19,9 +19,9 @@ keyed by the global chain id; no data-path collective; the R-hat all-gather runs
 anything here touches HIP) and relays rank 0's line.
 
 One JSON line on stdout (rank 0):
-  roofline      the dominant kernel (k_hmc_stream_steps): f64 VALU work actually performed / HIP-event time against the f64
+  roofline      the dominant kernel (k_hmc_sep_steps): algorithmic log-pdf evaluations x 8 flops / HIP-event time against the f64
                 vector peak; the SURVEY 8d HBM-nominal figure (state as if it round-tripped HBM) is kept as a note only --
-                the kernel keeps q, p in LDS; `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch (profiles/).
+                the kernel keeps q, p in registers; `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch (profiles/).
   cpu_baseline  the CPU oracle (C restatement of the reference algorithm, dense FD) on this box's host cores, bounded
                 sample, beside the dense-FD GPU rate.
   mh, smc       the other halves of the metric: adaptive_mcmc_chain on the reference's own bench model
@@ -195,6 +195,26 @@ def measured_traffic(chains, n_launch, grad):
         except Exception:
             continue
     return None
+
+
+def measured_traffic_mh(chains, n_adapting, n_sampling, steps_per_launch):
+    """HBM bytes per launch of the MH kernel on reference_model(20), averaged over the leg's launches, from the committed PMC
+    passes (bytes per chain step of an adapting / a sampling launch); null when the profile is absent."""
+    try:
+        b = json.load(open(os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")))["mh"]["reference_model20_bytes_per_chain_step"]
+        per_step = (b["adapting"] * n_adapting + b["sampling"] * n_sampling) / (n_adapting + n_sampling)
+        return per_step * chains * steps_per_launch
+    except Exception:                                                          # noqa: BLE001
+        return None
+
+
+def measured_traffic_smc():
+    """HBM bytes of one adaptive_smc run at 1 048 576 particles (FETCH_SIZE + WRITE_SIZE summed over its kernels)."""
+    try:
+        s = json.load(open(os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")))["smc"]
+        return s["fetch_bytes_per_run"] + s["write_bytes_per_run"]
+    except Exception:                                                          # noqa: BLE001
+        return None
 
 
 NATIVE_RCCL_TIMEOUT_S = float(os.environ.get("FG_BENCH_RCCL_TIMEOUT", "120"))
@@ -419,7 +439,7 @@ def run_rank(args):
 
     total_lf = world * C * K * L
     value = total_lf / dt
-    # ---- roofline of the dominant kernel (k_hmc_stream_steps): the f64 work the launch performs / HIP-event time
+    # ---- roofline of the dominant kernel (k_hmc_sep_steps; k_hmc_stream_steps for the other gradient modes' fallbacks): algorithmic f64 work / HIP-event time
     n_stmt = 2 * N_SITES                                                      # S + O statements of the model
     evals_sparse = (2 * d * (L + 1)) * 2 + n_stmt                             # 2 signs x 2 dependent statements per coordinate per gradient + endpoint score
     evals_dense = (2 * d * (L + 1)) * n_stmt + n_stmt                         # 2 d (S + O) per gradient
@@ -437,11 +457,11 @@ def run_rank(args):
                    "transitions_per_launch": n_launch, "clock_spinup_seconds": args.spinup, "sharding": f"chains x{world}" if world > 1 else "single GPU"},
         "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS, "traffic": measured_traffic(C, n_launch, args.grad),
-                     "kernel": "k_hmc_sep_steps" if args.grad == "fd_sparse" else "k_hmc_stream_steps", "avg_launch_ms": launch_ms,
+                     "kernel": "k_hmc_sep_steps", "avg_launch_ms": launch_ms,
                      "logpdf_evals_per_transition": evals, "flops_per_logpdf": FLOPS_PER_NORMAL_LOGPDF,
                      "note": "achieved = log-pdf evaluations the launch performs x 8 flops / HIP-event time; peak = f64 vector FMA peak "
                              "(2 flops/instr at 2.4 GHz) -- the arithmetic is unfused add/mul (reference rounding, 1 flop/instr) and the clock "
-                             "sits near 2.1 GHz under f64 load, so ~34 TFLOP/s is the ceiling of this instruction mix.  traffic = measured "
+                             "sits near 2.1 GHz under f64 load, so ~36 TFLOP/s is the ceiling of this instruction mix.  traffic = measured "
                              "FETCH_SIZE + WRITE_SIZE per launch (separate rocprofv3 --pmc passes, profiles/)",
                      "executed": executed_from_pmc(C, n_launch, args.grad, launch_ms),
                      "dense_semantics": {"logpdf_evals_per_transition": evals_dense,
@@ -450,7 +470,7 @@ def run_rank(args):
                                                  "default never forms the terms that cancel in the reference's subtraction"},
                      "hbm_nominal": {"achieved": alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "note": "SURVEY 8d algorithmic bytes (32 d B per leapfrog step, as if q and p round-tripped HBM) / time: NOT a "
-                                             "claim -- q, p stay in LDS for a whole launch and the kernel is not HBM bound"}},
+                                             "claim -- q, p stay in registers for a whole trajectory and the kernel is not HBM bound"}},
         "incl_warmup": {"leapfrog_steps_per_sec": world * C * (K + Wn) * L / (dt + t_warm) if Wn > 0 else value,
                         "warmup_seconds": t_warm, "note": "SURVEY 8d counts leapfrog steps over warmup + sampling; `value` follows the bench contract (K timed "
                                                           "sampling transitions after W untimed warmup transitions)"},
@@ -520,7 +540,7 @@ def leg_mh(args, E, W, torch, clock, stream, world, rank, dev):
             "config": {"workload": f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91: S=20, O=19), {C} chains/GPU, "
                                    f"{nw} adapting + {ns} sampling steps, all timed", "steps_per_launch": n_launch},
             "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
+                         "traffic": measured_traffic_mh(C, nw, ns, n_launch) if C == CHAINS_PER_GPU else None, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
                          "note": "(S + O) log-pdfs x 8 flops per chain step / HIP-event time",
                          "hbm_nominal": {"achieved": C * n_launch * bytes_per_step / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "note": "SURVEY 8d: 8 S + 40 B per chain step; the value row lives in LDS across a launch"}},
@@ -555,7 +575,7 @@ def leg_smc(args, E, W, torch, clock, stream, world, rank, dev):
             "seconds_per_run": dt, "tempering_steps": n_steps, "log_evidence": res["log_evidence"], "log_evidence_closed_form": -1.9305103088617774,
             "config": {"workload": f"C4: adaptive_smc, {N} particles, Systematic / 0.5 / 3 rejuvenation moves, mu~N(0,1); y~N(mu,0.5)=1.5",
                        "sharding": "replicas only" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": measured_traffic_smc(),
                          "kernel": "whole fg_smc_run (next_beta bisection + reweight + scan + resample + gather + rejuvenation)",
                          "bytes_per_particle_per_tempering_step": per_particle_step,
                          "note": "SURVEY 8d algorithmic bytes x particles x tempering steps / wall time of the whole run (host-timed, launch gaps "

@@ -59,6 +59,11 @@ mf, mw_ = pick(counters("mh_fetch"), "k_mh_mw_steps"), pick(counters("mh_write")
 if mf and mw_:
     doc["mh"] = {"kernel": "k_mh_mw_steps", "command": "python3 tools/bench_mh.py (reference_model(20) at 65536 chains, then C5 mixture(32) at 262144 chains)",
                  "FETCH_SIZE_KiB_per_launch": mf.get("FETCH_SIZE", []), "WRITE_SIZE_KiB_per_launch": mw_.get("WRITE_SIZE", [])}
+    f_, w_ = mf.get("FETCH_SIZE", []), mw_.get("WRITE_SIZE", [])
+    if len(f_) >= 2 and len(w_) >= 2:       # launches 0, 1 = reference_model(20): 100 adapting steps, then 400 sampling steps, 65 536 chains
+        doc["mh"]["reference_model20_bytes_per_chain_step"] = {
+            "adapting": (f_[0] + w_[0]) * KIB / (65536 * 100), "sampling": (f_[1] + w_[1]) * KIB / (65536 * 400),
+            "note": "FETCH_SIZE + WRITE_SIZE of the launch / (chains x steps); read by bench.py for mh.roofline.traffic"}
 # SMC: tools/bench_smc.py -> 4 runs of fg_smc_run at 1 048 576 particles; total over every kernel / 4
 for name, d in (("fetch", "smc_fetch"), ("write", "smc_write")):
     acc = counters(d)
