@@ -20,6 +20,14 @@
 #include "fg_cold.h"
 
 #define FG_SEP_WMAX 16
+
+// FG_HMC_PROF (experiment builds, tools/prof_hmc_phases.py): cycles tile 0's waves spend in each part of a transition
+#ifdef FG_HMC_PROF
+__device__ unsigned long long fg_hmc_prof[FG_SEP_WMAX][8];
+#define FG_PROF_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_[i] += now_ - tprev_; tprev_ = now_; }
+#else
+#define FG_PROF_T(i)
+#endif
 struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 
 #define FG_SEP_LOAD(k) \
@@ -213,6 +221,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         xch[2 * tw] = 0.0;
     }
     __syncthreads();
+#ifdef FG_HMC_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < n_steps; ++t) {
         const int iter = iter0 + t;
         const bool warming = iter < n_warmup;
@@ -322,17 +333,15 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             kin1[i * tw] = MASS ? p * p * mii : p * p;
         }
         if (bad) atomicOr((unsigned long long *)(xch + 2 * tw), 1ull);
+        FG_PROF_T(0)
         __syncthreads();                                         // every coordinate's endpoint and terms
+        FG_PROF_T(1)
         if (wv == 0) {
             // four in-order sums, interleaved (independent chains): H0's and the endpoint's kinetic energy in coordinate
             // order, log_prior and log_likelihood in program order (score_full, hmc.rs:283-299)
-            double s0 = 0.0, s1 = 0.0;
-            for (int i = 0; i < d; ++i) { s0 += kin0[i * tw]; s1 += kin1[i * tw]; }
-            double pri = 0.0, lik = 0.0;
-            const int n_lik = n_s - n_pri, nb = n_pri < n_lik ? n_pri : n_lik;
-            for (int k = 0; k < nb; ++k) { pri += termsE[k * tw]; lik += termsE[(n_pri + k) * tw]; }
-            for (int k = nb; k < n_pri; ++k) pri += termsE[k * tw];
-            for (int k = nb; k < n_lik; ++k) lik += termsE[(n_pri + k) * tw];
+            double s0, s1, pri, lik;
+            fg_inorder_sums2<8>(kin0, d, kin1, d, tw, s0, s1);
+            fg_inorder_sums2<8>(termsE, n_pri, termsE + (long long)n_pri * tw, n_s - n_pri, tw, pri, lik);
             const double h0 = -lj + 0.5 * s0;                        // hmc.rs:442-443
             const double lj_new = pri + lik + 0.0;                   // total_log_weight (log_factors = 0: no factor statement has a record)
             bool div = fg_as_i64(xch[2 * tw]) != 0;
@@ -367,7 +376,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             if (t + 1 < n_steps) xch[0] = e_cur;
             xch[2 * tw] = 0.0;
         }
+        FG_PROF_T(2)
         __syncthreads();
+        FG_PROF_T(3)
         const bool acc = xch[tw] != 0.0;
         unsigned long long wn = 0;
         if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
@@ -392,7 +403,11 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             __syncthreads();                                      // all waves hold the old count
             if (wv == 0 && live) H.w_n[c] = wn;
         }
+        FG_PROF_T(4)
     }
+#ifdef FG_HMC_PROF
+    if (blockIdx.x == 0 && lane == 0) for (int q = 0; q < 8; ++q) fg_hmc_prof[wv][q] = prof_[q];
+#endif
     if (wv == 0 && live) {
         H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
         H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
@@ -443,3 +458,9 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     HIPCHK(hipGetLastError());
     return FG_OK;
 }
+
+#ifdef FG_HMC_PROF
+extern "C" int fg_debug_hmc_prof(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_hmc_prof), sizeof(unsigned long long) * FG_SEP_WMAX * 8) == hipSuccess ? 0 : -1;
+}
+#endif
