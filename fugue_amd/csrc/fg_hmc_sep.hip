@@ -192,6 +192,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     double *xch = terms + (long long)(DENSE ? 2 * n_s : n_s) * tw;   // rows: 0 step size, 1 accepted, 2 divergence bits
     double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only: positions and momenta between gradients
     const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
+    const bool prio_turns = seg.c[FG_SEP_WMAX] < 0;               // host flag (the last boundary is otherwise d)
     const double *mi = MASS ? H.m_inv + c : nullptr;
     const double *ms = MASS ? H.mass_sqrt + c : nullptr;
     const double h = fg_uniform(H.h), two_h = fg_uniform(2.0 * H.h), rcp_2h = fg_uniform(1.0 / (2.0 * H.h));
@@ -307,6 +308,10 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             }
         } else
         for (int i = k0; i < k1; ++i) {
+            // The SIMD's arbiter serves its oldest wave first: of the two waves a tile has on a SIMD the younger one (waves 4..7 of
+            // 8) took 30 % longer over the same work and the tile waited for it at the barrier (tools/prof_hmc_phases.py).  The two
+            // take turns at the higher priority, one coordinate each: +4 % (either wave always ahead, or turns per transition: -3 %).
+            if (prio_turns) { if (((i - k0) ^ (wv >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             double z;
             if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
             else z = zb;
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             kin1[i * tw] = MASS ? p * p * mii : p * p;
         }
         if (bad) atomicOr((unsigned long long *)(xch + 2 * tw), 1ull);
+        if (prio_turns) { if (wv == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }   // wave 0's sums, accept and dual averaging are the tile's path
         FG_PROF_T(0)
         __syncthreads();                                         // every coordinate's endpoint and terms
         FG_PROF_T(1)
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             xch[2 * tw] = 0.0;
         }
         FG_PROF_T(2)
+        if (prio_turns) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         FG_PROF_T(3)
         const bool acc = xch[tw] != 0.0;
@@ -438,6 +445,7 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const int pairs = (e->d + 1) / 2;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
     for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, 2 * (int)((long long)pairs * w / W));
+    if (W == 8 && !(std::getenv("FG_HMC_PRIO") && std::atoi(std::getenv("FG_HMC_PRIO")) == 0)) seg.c[FG_SEP_WMAX] = -1;   // priority turns: two waves of a tile per SIMD
     static bool attr_set_dev[64][6];
     const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = 2 * mode + mass;
     const void *fns[6] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
