@@ -222,6 +222,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     if (wv == 0) {
         fg_load_values(P, X, c, slots, tw);
         lw = M.lw[c];
+        // the control wave's instruction stream is the path of its tile: it is served before the term and random-number waves
+        // of the tiles it shares a SIMD with (exp_mask bit 32 switches this off: A/B)
+        if (!(exp_mask & 32)) __builtin_amdgcn_s_setprio(2);
     }
     for (int k = (int)threadIdx.x; k < pool_n; k += (int)blockDim.x) pool_l[k] = P.pool[k];
     if (pool_n > 0) __syncthreads();                               // the random-number waves read the staged tables below
@@ -449,7 +452,8 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         for (int w = 0; w <= FG_MH_WMAX; ++w) { seg.r[c][w] = at; if (w < W) at += cnt[w]; }
         shift += n % W;
     }
-    const int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
+    int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
+    if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) exp_mask |= 32;
     // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
     // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
     const int split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
