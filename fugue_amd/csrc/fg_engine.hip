@@ -379,6 +379,9 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
         xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
         __syncthreads();
         if (wv == 0) {
+            // the endpoint score, accept and dual averaging are the tile's path: ahead of the other tiles' gradient waves (refmodel8 +6 %)
+            // -- except with linear predictors, whose endpoint score is long enough to starve them (linreg -18 %, C3 -7 %)
+            if (RK != 1) __builtin_amdgcn_s_setprio(2);
             bool div = false;
             for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
             FgAcc3 A = {0.0, 0.0, 0.0};
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
                 eps = r.a; da_hbar = r.b; da_leb = r.c;
             }
 #endif
+            if (RK != 1) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         const bool acc = xch[tw] != 0.0;
