@@ -145,7 +145,7 @@ __device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend
 
 template <int RK, bool SPLIT /* the two in-order sums on two waves */>
 __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt /* the kind-sorted score stream */, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
-                                                                           long long *draws, int first_sample_t, int exp_mask /* timing experiments only (FG_MH_EXP): results are wrong when non-zero */,
+                                                                           long long *draws, int first_sample_t, int exp_mask /* bits 1, 2, 4, 8: timing experiments only (FG_MH_EXP; results are wrong); 32: no wave priorities (A/B); 64: phase-B priority */,
                                                                            int pool_n /* > 0: the constant pool (pool_n doubles) is staged into LDS behind the exchange rows */) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     // index, 7 its prior log-probability
     double *xch = terms + (long long)n_s * tw;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    const bool b_prio = wv != 0 && (exp_mask & 64) != 0;
     const int rng_wave = W - 1;
     const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
 
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
         FG_PROF_T(2)
         __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
         FG_PROF_T(3)
-        // ---- phase B: every wave scores its share of the statements
+        // ---- phase B: every wave scores its share of the statements (on the step's path: ahead of other tiles' random-number waves)
+        if (b_prio) __builtin_amdgcn_s_setprio(1);
         if (!(exp_mask & 1)) {
             if (RK >= 2) {
                 if (pool_n > 0) {
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
             else fg_mh_terms<RK>(srt, sa(5), sb(5), P.pool, nullptr, slots, tw, terms);
         }
         FG_PROF_T(4)
+        if (b_prio) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         FG_PROF_T(5)
     }
@@ -454,6 +457,10 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     }
     int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
     if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) exp_mask |= 32;
+    else {   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
+        const long long n_cu = std::max(1, e->n_simd / 4);
+        if (std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu) >= 2) exp_mask |= 64;
+    }
     // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
     // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
     const int split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
