@@ -603,6 +603,18 @@ def extras(args, E, W, dev):
     t0 = time.perf_counter(); eng.hmc_step(100); eng.synchronize(); dt = time.perf_counter() - t0
     out["hmc_analytic_leapfrog_steps_per_sec"] = C * 100 * 16 / dt
     eng.close()
+    # C2 as BASELINE.json words it: the README model (d = 1), 65 536 chains x 1 000 steps after 200 warmup transitions
+    cp1 = E.compile_model(W.readme_normal())
+    eng = E.Engine(cp1, CHAINS_PER_GPU, seed=1, device=dev)
+    d1 = eng.device_alloc(1000 * cp1.d * CHAINS_PER_GPU * 8)
+    eng.hmc_run(E.hmc_config(), 50, 50, d1); eng.synchronize()
+    eng.close()
+    eng = E.Engine(cp1, CHAINS_PER_GPU, seed=1, device=dev)
+    t0 = time.perf_counter(); eng.hmc_run(E.hmc_config(), 1000, 200, d1); eng.synchronize(); dt = time.perf_counter() - t0
+    out["hmc_readme_model_leapfrog_steps_per_sec"] = CHAINS_PER_GPU * 1200 * 16 / dt
+    out["hmc_readme_model_workload"] = "C2 README model (mu~N(0,1); y~N(mu,0.5)=1.2), 65536 chains, 200 warmup + 1000 sampling transitions, L=16: %.1f ms" % (dt * 1e3)
+    eng.device_free(d1)
+    eng.close()
     # C5 on one GPU: 4-component mixture (4 f64 + 64 usize sites, 64 observations), adaptive_mcmc_chain at 262 144 chains
     data, _ = W.mixture_data(64)
     cp5 = E.compile_model(W.mixture(data))
