@@ -435,6 +435,33 @@ def test_analytic_mode_is_refused_where_unavailable():
         assert ei.value.code == E.FG_E_UNSUPPORTED
 
 
+def test_issue_priorities_change_no_result(monkeypatch):
+    """s_setprio only reorders the waves of a SIMD: the register-resident HMC kernel (waves taking turns, 8 waves per tile) and the
+    multi-wave MH kernel (control wave, phase B) give the same bits with the priorities switched off."""
+    out = {}
+    for prio in ("1", "0"):
+        monkeypatch.setenv("FG_HMC_PRIO", prio)
+        monkeypatch.setenv("FG_MH_PRIO", prio)
+        monkeypatch.setenv("FG_HMC_WAVES", "8")
+        res = []
+        for name in ("normal32", "refmodel8"):
+            cp = E.compile_model(ZOO[name]())
+            C, nw, ns = 320, 20, 15
+            eng = E.Engine(cp, C, seed=6)
+            d = eng.device_alloc(ns * cp.d * C * 8)
+            eng.hmc_run(E.hmc_config(n_leapfrog=5), ns, nw, d)
+            res.append(eng.download(d, (ns, cp.d, C)))
+            eng.device_free(d)
+            eng.close()
+            eng = E.Engine(cp, C, seed=6)
+            eng.mh_init(40); eng.mh_step(80); eng.synchronize()
+            res.append(eng.get_values()); res.append(eng.mh_scales())
+            eng.close()
+        out[prio] = res
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 @pytest.mark.parametrize("name", ["normal32", "ridge"])
 def test_hmc_analytic_mode_posterior_and_wave_invariance(name, monkeypatch):
     """hmc_chain with FG_GRAD_ANALYTIC: bit-identical for 1, 2, 4 waves per tile, close to the finite-difference chain
