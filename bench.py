@@ -358,13 +358,13 @@ def run_rank(args):
     eng.set_stream(stream.cuda_stream)                    # kernels + torch events share one stream
     draws = torch.empty((K, d, C), dtype=torch.float64, device=f"cuda:{local_rank}")
 
-    # ---- untimed by the contract (reported separately): HmcSession::new + W adaptive warmup transitions
     eng.hmc_init(cfg, Wn)
-    warm_events = []
-    t_warm = clock.region(lambda: warm_events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n), Wn, args.launch)) if Wn > 0 else None)
-    # ---- clock spin-up, directly before the timed region: throw-away transitions of the same kernel on a scratch engine (own
-    # state, own seed; the measured engine is not touched), so that the K timed transitions run at the clocks the GPU settles
-    # to under this load rather than on its way there (session set-up and a short warmup leave it mostly idle)
+    draws.zero_()                                         # the output buffer's pages are touched before anything is timed
+    # ---- clock spin-up first: throw-away transitions of the same kernel on a scratch engine (own state, own seed; the measured
+    # engine is not touched), so that the W warmup and the K timed transitions run at the clocks the GPU settles to under this
+    # load rather than on its way there (session set-up leaves it mostly idle).  The measured engine's W warmup transitions then
+    # run directly before the timed region: its first launch (cold translation caches for its state and draw rows: +9 % on a
+    # 20-transition launch) is a warmup launch whenever W > 0.
     if args.spinup > 0:
         scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=local_rank)
         scratch.set_stream(stream.cuda_stream)
@@ -373,11 +373,16 @@ def run_rank(args):
         while time.perf_counter() - t_sp < args.spinup:
             scratch.hmc_step(4 * args.launch)
             torch.cuda.synchronize()
-        scratch.close()
-    # ---- timed: exactly K sampling transitions
+    # ---- untimed by the contract (reported separately): W adaptive warmup transitions
+    warm_events = []
+    t_warm = clock.region(lambda: warm_events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n), Wn, args.launch)) if Wn > 0 else None)
+    # ---- timed: exactly K sampling transitions (the scratch engine is freed afterwards: hipFree would put an idle gap between
+    # the spin-up and the timed region)
     events = []
     dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n, draws[done].data_ptr()), K, args.launch)))
     launch_ms, n_launch = full_launch_ms(events)
+    if args.spinup > 0:
+        scratch.close()
 
     # ---- after the timed region: the ONLY cross-chain step -- split R-hat / multichain ESS.  Each rank reduces its own draws
     # to per-chain moments on its GPU; the library all-gathers those and all-reduces the pooled lag sums over RCCL / xGMI
@@ -525,11 +530,12 @@ def leg_mh(args, E, W, torch, clock, stream, world, rank, dev):
         while time.perf_counter() - t_sp < args.spinup:
             scratch.mh_step(4 * per)
             torch.cuda.synchronize()
-        scratch.close()
     eng.mh_init(nw)
     events = []
     dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), nw + ns, per)))
     launch_ms, n_launch = full_launch_ms(events)
+    if args.spinup > 0:
+        scratch.close()
     acc = eng.mh_stats().accept_rate
     eng.close()
     S, O = cp.S, cp.O
@@ -562,9 +568,10 @@ def leg_smc(args, E, W, torch, clock, stream, world, rank, dev):
         t_sp = time.perf_counter()
         while time.perf_counter() - t_sp < args.spinup:
             scratch.smc_run(rejuvenation_steps=3, download=False)
-        scratch.close()
     res = {}
     dt = clock.region(lambda: res.update(eng.smc_run(rejuvenation_steps=3, download=False)))   # particles and weights stay in HBM
+    if args.spinup > 0:
+        scratch.close()
     eng.close()
     n_steps = len(res["betas"])
     moves = (res["n_model_runs"] - N) / 2
