@@ -721,6 +721,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->n_simd = 4 * prop.multiProcessorCount;
     if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) e->mw_override = w; }
     if (const char *sp = std::getenv("FG_HMC_SEP")) e->sep_disabled = std::atoi(sp) == 0;
+    if (const char *sp = std::getenv("FG_HMC_LIN")) e->lin_disabled = std::atoi(sp) == 0;
     if (const char *sp = std::getenv("FG_MH_MW")) e->mh_mw_disabled = std::atoi(sp) == 0;
     // LDS tile of 64 chains: the score / prior / MH / SMC kernels need the slot rows only, the HMC kernels also the
     // momentum and the multi-wave exchange rows.  A model whose slots alone exceed the 160 KB of a CU cannot run at all;
@@ -740,6 +741,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (dev_upload(&e->d_gstream, p->gstream)) return fail("upload gstream");
     if (dev_upload(&e->d_sstream, p->sstream)) return fail("upload sstream");
     if (dev_upload(&e->d_sep, p->sep) || dev_upload(&e->d_sep_coord, p->sep_coord) || dev_upload(&e->d_sep_free, p->sep_free) || dev_upload(&e->d_site_rec, p->site_rec) || dev_upload(&e->d_sobs, p->sobs)) return fail("upload sep");
+    if (!p->lin_tab.empty() && (dev_upload(&e->d_lin_tab, p->lin_tab) || dev_upload(&e->d_lin_meta, p->lin_meta))) return fail("upload lin");
     if (dev_upload(&e->d_sub_off, p->sub_off)) return fail("upload sub_off");
     if (dev_upload(&e->d_f64_slot, p->f64_slot)) return fail("upload f64_slot");
     if (dev_upload(&e->d_site_slot, p->site_slot)) return fail("upload site_slot");
@@ -756,6 +758,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.sstream = p->n_sstream > 0 ? e->d_sstream : nullptr; e->P.n_sstream = p->n_sstream; e->P.sstream_kinds = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0); e->P.sstream_gen = p->sstream_has_genrec ? 1 : 0; e->P.sub = e->d_sub; e->P.sub_off = e->d_sub_off; e->P.pool = e->d_pool;
     e->P.f64_site = e->d_f64_slot; e->P.site_slot = e->d_site_slot; e->P.site_vtype = e->d_vtype; e->P.site_cat = e->d_site_cat;
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
+    e->P.lin_tab = e->d_lin_tab; e->P.lin_meta = e->d_lin_meta; e->P.lin_n = p->lin_n; e->P.lin_p2 = p->lin_p2;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
     if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) || set_lds(k_log_joint_stream, e->lds_score) ||
         set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false, true>, lds_hmc) ||
@@ -776,7 +779,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
     if (e->smc_arena) hipFree(e->smc_arena);
-    void *ptrs[] = { e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -968,6 +971,10 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
     const bool analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
     {   // independent-sites programs: whole trajectories in registers (fg_hmc_sep.hip)
         const int rc = fg_hmc_sep_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+        if (rc != FG_E_UNSUPPORTED) return rc;
+    }
+    {   // dense regressions: observation-major finite difference (fg_hmc_lin.hip)
+        const int rc = fg_hmc_lin_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
         if (rc != FG_E_UNSUPPORTED) return rc;
     }
     if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {

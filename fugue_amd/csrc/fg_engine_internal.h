@@ -86,6 +86,8 @@ struct fg_engine {
     bool mh_mw_disabled = false;  // FG_MH_MW=0: keep every program on the one-wave-per-tile MH kernel (A/B tests)
     bool mh_has_prior_resample = false;   // an override asks for PriorResample on some site (needs the model-driven proposal path)
     bool sep_disabled = false;   // FG_HMC_SEP=0: keep independent-sites programs on the gradient-stream kernel (A/B tests)
+    bool lin_disabled = false;   // FG_HMC_LIN=0: keep dense regressions on the gradient-stream kernel (A/B tests)
+    double *d_lin_tab = nullptr; int *d_lin_meta = nullptr;   // dense-regression table (fg_hmc_lin.hip)
     int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr, *d_site_cat = nullptr;
     double *d_pool = nullptr;
     FgProgramDev P{};
@@ -176,6 +178,9 @@ int dev_upload(T **p, const std::vector<T> &v) {
 
 // fg_hmc_sep.hip: register-resident trajectories for independent-sites programs (FG_E_UNSUPPORTED: not applicable)
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
+
+// fg_hmc_lin.hip: observation-major finite-difference gradient for dense regressions (FG_E_UNSUPPORTED: not applicable)
+int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
 
 // fg_engine.hip internals used by fg_state.hip
 extern "C" {

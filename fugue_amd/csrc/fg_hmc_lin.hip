@@ -1,0 +1,371 @@
+// fg_hmc_lin.hip -- HmcSession::step x n (hmc.rs:819-919) for DENSE REGRESSIONS: every coordinate's force terms are its own
+// prior record(s) plus the same N observe statements  y_i ~ Normal(c0_i + sum_t q[s_t] c_it, sigma_i), each reading all D
+// coordinates once in one common term order (BASELINE configs[2]: examples/linear_regression.rs:396-424 at 32 coefficients
+// x 1 024 observations).
+//
+// The reference's finite difference (grad_log_joint, hmc.rs:304-329) makes every (coordinate j, observation i, sign) a fresh
+// in-order sum over the predictor's D terms: O(D^2 N) additions per gradient.  The gradient stream (fg_gradstream.h) walks
+// them coordinate by coordinate, one record per (j, i): per record D products, the prefix sum up to the coordinate's term and
+// two suffix sums -- ~150 instructions per (j, i) pair at D = 32.  But the products P_it = q_t c_it and the prefix sums
+// S_it = c0_i + P_i0 + ... + P_i,t-1 are the SAME numbers for every coordinate: only the two suffix chains
+//     mu+-_ij = ((S_ij + (q_j +- h) c_ij) + P_i,j+1) + ... + P_i,D-1
+// belong to the pair.  So the traversal here is OBSERVATION-MAJOR: a wave owns M = D / W term positions, keeps all of q in
+// registers, and per observation forms the D products and the prefix ONCE, carrying the 2 M suffix chains of its own
+// coordinates side by side -- the same additions and multiplications in the same order per chain, hence bit-identical forces
+// (tests/test_gpu_parity.py::test_hmc_lin_kernel_is_bit_identical) at ~65 instead of ~150 instructions per pair.
+//
+// Which positions a wave owns decides how long its suffix chains are (position p costs 2 (D - p) additions).  Positions are
+// dealt in blocks of 2 W: wave w takes 2 W b + w and 2 W b + (2 W - 1 - w) of every block b, so every wave carries the same
+// number of additions.  The term loop is fully unrolled and the set of active chains changes at compile-time positions: one
+// straight-line instance per (D, W, wave) -- the kernel switches on the wave index once per gradient, not per term (round 2's
+// attempt tested four owned positions per term with scalar branches and gained 5 %).  Coefficients arrive by scalar loads,
+// half a row ahead; the hot loop touches no LDS (SMEM and LDS share a counter and SMEM returns out of order).
+//
+// Everything around the gradient is k_hmc_stream_steps' (fg_engine.hip): momentum pairs by whichever wave gets them,
+// barriers around the drift, wave 0's in-order kinetic sums, endpoint score (score stream, program order), accept and dual
+// averaging; commit / roll back by the owning wave.
+#include "fg_engine_internal.h"
+#include "fg_gradstream.h"
+#include "fg_cold.h"
+
+#define FG_LIN_WMAX 16
+
+// term position of own slot A of wave WV (ascending in A)
+template <int W, int WV, int A> struct FgLinPos { static constexpr int v = 2 * W * (A / 2) + ((A & 1) ? 2 * W - 1 - WV : WV); };
+__host__ __device__ constexpr int fg_lin_pos(int W, int wv, int a) { return 2 * W * (a / 2) + ((a & 1) ? 2 * W - 1 - wv : wv); }
+
+// table rows are 16-byte aligned (the coefficients start 16 bytes into a row): scalar loads need no more
+typedef fg_u32x16 fg_u32x16_r __attribute__((aligned(16)));
+typedef fg_u32x8 fg_u32x8_r __attribute__((aligned(16)));
+typedef __attribute__((address_space(3))) double fg_lds_double;
+
+// HB coefficients of one half row in SGPRs
+template <int HB> struct FgLinHalf;
+template <> struct FgLinHalf<16> {
+    fg_u32x16 a, b;
+    __device__ __forceinline__ void load(const FG_AS4 char *p) { a = *(const FG_AS4 fg_u32x16_r *)p; b = *(const FG_AS4 fg_u32x16_r *)(p + 64); }
+    __device__ __forceinline__ double get(int t) const { return t < 8 ? fg_dbl(a[2 * t], a[2 * t + 1]) : fg_dbl(b[2 * (t - 8)], b[2 * (t - 8) + 1]); }
+};
+template <> struct FgLinHalf<8> {
+    fg_u32x16 a;
+    __device__ __forceinline__ void load(const FG_AS4 char *p) { a = *(const FG_AS4 fg_u32x16_r *)p; }
+    __device__ __forceinline__ double get(int t) const { return fg_dbl(a[2 * t], a[2 * t + 1]); }
+};
+template <> struct FgLinHalf<4> {
+    fg_u32x8 a;
+    __device__ __forceinline__ void load(const FG_AS4 char *p) { a = *(const FG_AS4 fg_u32x8_r *)p; }
+    __device__ __forceinline__ double get(int t) const { return fg_dbl(a[2 * t], a[2 * t + 1]); }
+};
+
+__device__ __forceinline__ const FG_AS4 char *fg_uniform_ptr(const void *p) {
+    const unsigned long long b = (unsigned long long)(uintptr_t)p;
+    // readfirstlane returns int: through uint32_t, or a low word with its top bit set sign-extends over the high word
+    const unsigned long long u = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b) |
+                                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32);
+    return (const FG_AS4 char *)(uintptr_t)u;
+}
+
+// log-density of an own-coordinate prior record at q + h and q - h: fg_grec_math's arithmetic for a fast Normal whose other
+// operand is a constant (fg_gradstream.h)
+__device__ __forceinline__ void fg_lin_prior_pair(const fg_u32x16 &r, double qv, double h, double &lpp, double &lpm) {
+    const uint32_t fl = r[2];
+    double dlp, dlm;
+    if (fl & FG_G_PERT_X) { const double xp = qv + h, xm = qv - h, m = fg_dbl(r[6], r[7]); dlp = xp - m; dlm = xm - m; }
+    else { const double mp = qv + h, mm = qv - h, x = fg_dbl(r[4], r[5]); dlp = x - mp; dlm = x - mm; }
+    const double inv = fg_dbl(r[10], r[11]);
+    double zp = dlp * inv, zm = dlm * inv;
+    if (!(fl & FG_G_POW2)) {
+        const double sg = fg_dbl(r[8], r[9]);
+        if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; }
+        else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }
+    }
+    const double lns = fg_dbl(r[12], r[13]);
+    lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;
+    lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
+}
+
+// One gradient for the M own coordinates of wave WV: g_k = (lp(q + h e_k) - lp(q - h e_k)) / (2h) over the coordinate's prior
+// record(s) and the N observe statements, then the half-kick(s) on p_k.  Returns "some own force component was non-finite".
+template <int D, int W, int WV, bool P2>
+__device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const int *meta_v, const FgGradRec *gs_v, const fg_lds_double *slots,
+                                         fg_lds_double *pl, double h_v, double hk, int two_kicks_v) {
+    constexpr int M = D / W, HB = D / 2, ROWB = FG_LIN_ROW_DOUBLES(D) * 8, tw = FG_WAVE;
+    constexpr int PLAST = fg_lin_pos(W, WV, M - 1);
+    const FG_AS4 char *row = fg_uniform_ptr(tab_v);
+    const FG_AS4 int *meta = (const FG_AS4 int *)fg_uniform_ptr(meta_v);
+    const int N = __builtin_amdgcn_readfirstlane(n_obs_v);
+    const bool two_kicks = __builtin_amdgcn_readfirstlane(two_kicks_v) != 0;
+    const double h = fg_uniform(h_v), two_h = fg_uniform(2.0 * h_v), rcp_2h = fg_uniform(1.0 / (2.0 * h_v));
+    double q[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) q[t] = slots[meta[t] * tw];
+    double sp[M], sm[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) { sp[a] = 0.0; sm[a] = 0.0; }
+    FgLinHalf<HB> ca, cb;
+    fg_u32x4 ha = *(const FG_AS4 fg_u32x4 *)row;                  // c0
+    ca.load(row + 16);
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // this row's first half (requested half a row ago)
+        cb.load(row + 16 + 8 * HB);
+        const fg_u32x8 hb = *(const FG_AS4 fg_u32x8_r *)(row + 16 + 16 * HB);          // y, 1 / sigma, ln sigma, sigma
+        const fg_u32x4 hf = *(const FG_AS4 fg_u32x4 *)(row + 16 + 16 * HB + 32);     // flags
+        __builtin_amdgcn_sched_barrier(0);
+        double S = fg_dbl(ha[0], ha[1]);
+        double mp[M], mm[M];
+#define FG_LIN_TERM(t, CF)                                                                          \
+        {                                                                                           \
+            const double c_ = (CF);                                                                 \
+            const double P_ = q[t] * c_;                                                            \
+            _Pragma("unroll") for (int a = 0; a < M; ++a) {                                         \
+                if (fg_lin_pos(W, WV, a) < (t)) { mp[a] = mp[a] + P_; mm[a] = mm[a] + P_; }         \
+                if (fg_lin_pos(W, WV, a) == (t)) {                                                  \
+                    const double qp_ = q[t] + h, qm_ = q[t] - h;          /* the perturbed coordinate holds orig +- h (hmc.rs:317-319) */ \
+                    mp[a] = S + qp_ * c_; mm[a] = S + qm_ * c_;                                     \
+                }                                                                                   \
+            }                                                                                       \
+            if ((t) < PLAST) S = S + P_;                                                            \
+        }
+#pragma unroll
+        for (int t = 0; t < HB; ++t) FG_LIN_TERM(t, ca.get(t))
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // the second half and the statement's constants
+        ha = *(const FG_AS4 fg_u32x4 *)(row + ROWB);              // the next row's first half (one zero row follows the table)
+        ca.load(row + ROWB + 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = HB; t < D; ++t) FG_LIN_TERM(t, cb.get(t - HB))
+#undef FG_LIN_TERM
+        const double y = fg_dbl(hb[0], hb[1]), inv = fg_dbl(hb[2], hb[3]), lns = fg_dbl(hb[4], hb[5]);
+        const uint32_t fl = hf[0];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            const double dlp = y - mp[a], dlm = y - mm[a];
+            double zp = dlp * inv, zm = dlm * inv;                // exact quotient when sigma = 2^k
+            if (!P2 && !(fl & FG_G_POW2)) {                      // (x - mu) / sigma, distribution.rs:205
+                const double sg = fg_dbl(hb[6], hb[7]);
+                if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; }
+                else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }
+            }
+            const double lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;     // distribution.rs:207
+            const double lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
+            sp[a] += lpp; sm[a] += lpm;
+        }
+        row += ROWB;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // log_prior at q +- h e_k (the coordinate's own record(s), before the observe records in the stream), total_log_weight,
+    // the central difference and the kick(s): fg_grec_math's FG_G_END
+    const FG_AS4 char *gs = fg_uniform_ptr(gs_v);
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const int pos = fg_lin_pos(W, WV, a);
+        const int k = meta[pos], r0 = meta[D + 2 * k], nr = meta[D + 2 * k + 1];
+        double prip = 0.0, prim = 0.0;
+        for (int j = 0; j < nr; ++j) {
+            const fg_u32x16 r = *(const FG_AS4 fg_u32x16 *)(gs + 64 * (long long)(r0 + j));
+            double lpp, lpm;
+            fg_lin_prior_pair(r, q[pos], h, lpp, lpm);
+            prip += lpp; prim += lpm;
+        }
+        const double tp = prip + sp[a], tm = prim + sm[a];                   // total_log_weight (log_factors = +0.0 adds nothing)
+        const double n = tp - tm;
+        double g = fg_div_const(n, two_h, rcp_2h);                           // (lp - lm) / (2h), hmc.rs:322
+        const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
+        if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953]
+        bad = bad || !fg_finite(g);
+        double p = pl[k * tw] + hk * g;                                      // hmc.rs:389 / :400
+        if (two_kicks) p += hk * g;
+        pl[k * tw] = p;
+    }
+    return bad;
+}
+
+template <int D, int W, bool P2, int WV>
+struct FgLinDispatch {
+    static __device__ __forceinline__ bool run(int wv, const double *tab, int n_obs, const int *meta, const FgGradRec *gs, const fg_lds_double *slots,
+                                               fg_lds_double *pl, double h, double hk, int two_kicks) {
+        if (wv == WV) return fg_lin_grad<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
+        return FgLinDispatch<D, W, P2, WV + 1>::run(wv, tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
+    }
+};
+template <int D, int W, bool P2>
+struct FgLinDispatch<D, W, P2, W> {
+    static __device__ __forceinline__ bool run(int, const double *, int, const int *, const FgGradRec *, const fg_lds_double *, fg_lds_double *, double, double, int) { return false; }
+};
+
+template <int D, int W, bool P2>
+__global__ __launch_bounds__(FG_WAVE * W) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps, int n_warmup, int welford_on, double *draws, int first_sample_t,
+                     double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE, M = D / W;
+    const int lane = threadIdx.x & (FG_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long chain = (long long)blockIdx.x * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + lane;
+    double *pl = lds + (long long)P.n_slots * tw + lane;
+    double *xch = lds + (long long)(P.n_slots + D) * tw + lane;      // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    const int L = H.L;
+    const double *mi = H.use_mass ? H.m_inv + c : nullptr;
+    const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    int own[M];                                                   // the own coordinates (wave-uniform)
+#pragma unroll
+    for (int a = 0; a < M; ++a) own[a] = P.lin_meta[fg_lin_pos(W, wv, a)];
+    // wave 0 owns the per-chain sampler state
+    double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
+    unsigned long long da_m = 0, ndiv = 0;
+    if (wv == 0) {
+        fg_load_values(P, X, c, slots, tw);
+        lj = H.lj[c]; eps = H.eps[c]; frozen = H.frozen[c];
+        da_mu = H.da_mu[c]; da_leb = H.da_leb[c]; da_hbar = H.da_hbar[c]; da_m = H.da_m[c];
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const int iter = iter0 + t;
+        const bool warming = iter < n_warmup;
+        double h0 = 0.0, u = 0.0;
+        // p0 ~ N(0, M) (hmc.rs:436-441): Box-Muller pair j of the chain's (iteration) Philox stream is block j
+        constexpr int n_pairs = (D + 1) >> 1;
+        for (int j = wv; j < n_pairs; j += W) {
+            const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)j, (uint32_t)iter, FG_RNG_HMC);
+            const int i = 2 * j;
+            pl[i * tw] = zz.a * (ms ? ms[(long long)i * X.C] : 1.0);
+            if (i + 1 < D) pl[(i + 1) * tw] = zz.b * (ms ? ms[(long long)(i + 1) * X.C] : 1.0);
+        }
+        if (wv == 0) {
+            double e;
+            if (warming) e = eps;
+            else {                                             // frozen_or_current: hmc.rs:789-798
+                if (frozen == frozen) e = frozen;
+                else if (n_warmup > 0) e = fg_cold_exp(da_leb);
+                else e = eps;
+                frozen = e;
+            }
+            u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)n_pairs, (uint32_t)iter, FG_RNG_HMC).a;
+            xch[0] = e;
+        }
+        __syncthreads();
+        if (wv == 0) h0 = -lj + fg_kinetic(P, pl, tw, mi, X.C);  // hmc.rs:442-443 (all of p0, before any kick)
+        __syncthreads();
+        const double e = xch[0], hk = 0.5 * e;
+        bool bad = false;
+        for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
+            bad = FgLinDispatch<D, W, P2, 0>::run(wv, P.lin_tab, P.lin_n, P.lin_meta, P.gstream, (const fg_lds_double *)slots, (fg_lds_double *)pl, H.h, hk,
+                                                  (gs > 0 && gs < L) ? 1 : 0) || bad;
+            __syncthreads();                                     // every p kicked, every read of q done
+            if (gs < L) {
+#pragma unroll
+                for (int a = 0; a < M; ++a) {
+                    const int k = own[a];
+                    if (mi) slots[k * tw] += e * mi[(long long)k * X.C] * pl[k * tw];
+                    else slots[k * tw] += e * pl[k * tw];        // eps * 1.0 * p == eps * p
+                }
+                __syncthreads();
+            }
+        }
+        xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
+        __syncthreads();
+        if (wv == 0) {
+            bool div = false;
+            for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
+            FgAcc3 A = {0.0, 0.0, 0.0};
+            fg_score_stream<1>(P.sstream, P.n_sstream, P.pool, slots, tw, A);                                       // score_full, hmc.rs:283-299
+            const double lj_new = fg_total(A);
+            div = div || !fg_finite(lj_new);
+            double ap = 0.0; bool acc = false;
+            if (!div) {
+                const double h_new = -lj_new + fg_kinetic(P, pl, tw, mi, X.C);
+                ap = fg_cold_accept_prob(h0, h_new);             // hmc.rs:460
+                acc = u < ap;                                    // hmc.rs:461
+            }
+            if (acc) lj = lj_new;
+            xch[tw] = acc ? 1.0 : 0.0;
+            asum += ap; ndiv += div ? 1ull : 0ull;
+            if (live && info) {                                  // HmcStepInfo: hmc.rs:587-602
+                double *r = info + (long long)t * 4 * X.C + c;
+                r[0] = acc ? 1.0 : 0.0; r[X.C] = div ? 1.0 : 0.0; r[2 * X.C] = ap; r[3 * X.C] = e;
+            }
+            if (warming) {                                       // DualAveraging::update: hmc.rs:168-178
+                da_m += 1ull;
+                const FgD3 r = fg_cold_da_update(da_hbar, da_leb, (double)da_m, da_mu, H.target, ap);
+                eps = r.a; da_hbar = r.b; da_leb = r.c;
+            }
+        }
+        __syncthreads();
+        const bool acc = xch[tw] != 0.0;
+        unsigned long long wn = 0;
+        if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
+#pragma unroll
+        for (int a = 0; a < M; ++a) {                             // commit or roll back this wave's f64 sites
+            const int i = own[a];
+            const long long g = (long long)P.f64_site[i] * X.C + c;
+            if (acc) { if (live) X.values[g] = fg_as_i64(slots[i * tw]); }
+            else slots[i * tw] = fg_as_double(X.values[g]);
+            const double x = slots[i * tw];
+            if (live && pos_all) pos_all[((long long)t * D + i) * X.C + c] = x;
+            if (warming) {
+                if (welford_on) {                                 // Welford::push: hmc.rs:202-211
+                    const long long gi = (long long)i * X.C + c;
+                    const double n = (double)wn;
+                    double mean = H.w_mean[gi];
+                    const double delta = x - mean;
+                    mean += delta / n;
+                    const double delta2 = x - mean;
+                    if (live) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
+                }
+            } else if (draws && live) draws[((long long)(t - first_sample_t) * D + i) * X.C + c] = x;   // hmc.rs:577-582
+        }
+        if (warming && welford_on) {
+            __syncthreads();                                      // all waves hold the old count
+            if (wv == 0 && live) H.w_n[c] = wn;
+        }
+    }
+    if (wv == 0 && live) {
+        H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
+        H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
+        H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
+    }
+}
+
+// Launch for `n` transitions from iteration `iter0`; FG_E_UNSUPPORTED when the program / configuration is not a dense
+// regression in the sparse finite-difference mode (the caller then takes the gradient-stream kernel).
+int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
+    if (!e->P.lin_tab || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->lin_disabled || e->tw != FG_WAVE) return FG_E_UNSUPPORTED;
+    const int D = e->d;
+    if (D != 8 && D != 16 && D != 32) return FG_E_UNSUPPORTED;
+    const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
+    const size_t lds = (size_t)(e->n_slots + e->d + 2 + FG_LIN_WMAX) * FG_WAVE * sizeof(double);
+    if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
+    // waves per tile: D / 4 (four coordinates per wave) when the tiles alone fill the CUs' 16 wave slots, else D / 2
+    int W = D / 4;
+    {
+        const long long n_cu = std::max(1, e->n_simd / 4);
+        const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
+        if (resident * W < 16) W = D / 2;
+    }
+    if (e->mw_override == D / 4 || e->mw_override == D / 2) W = e->mw_override;
+    const int variant = (D == 32 ? 0 : (D == 16 ? 4 : 8)) + (W == D / 2 ? 2 : 0) + (e->P.lin_p2 ? 1 : 0);
+    static bool attr_set_dev[64][12];
+#define FG_LIN_KERNELS(X) X(0, 32, 8, false) X(1, 32, 8, true) X(2, 32, 16, false) X(3, 32, 16, true) X(4, 16, 4, false) X(5, 16, 4, true) \
+                          X(6, 16, 8, false) X(7, 16, 8, true) X(8, 8, 2, false) X(9, 8, 2, true) X(10, 8, 4, false) X(11, 8, 4, true)
+    const void *fn = nullptr;
+#define FG_LIN_FN(V, DD, WW, PP) if (variant == V) fn = (const void *)k_hmc_lin_steps<DD, WW, PP>;
+    FG_LIN_KERNELS(FG_LIN_FN)
+#undef FG_LIN_FN
+    bool &attr_set = attr_set_dev[e->device & 63][variant];
+    if (!attr_set && lds > 64 * 1024) {
+        const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
+        attr_set = true;
+    }
+#define FG_LIN_GO(V, DD, WW, PP) if (variant == V) hipLaunchKernelGGL((k_hmc_lin_steps<DD, WW, PP>), dim3(tiles), dim3(FG_WAVE * WW), lds, e->stream, e->P, e->X, e->H, \
+                                                                       iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
+    FG_LIN_KERNELS(FG_LIN_GO)
+#undef FG_LIN_GO
+#undef FG_LIN_KERNELS
+    HIPCHK(hipGetLastError());
+    return FG_OK;
+}

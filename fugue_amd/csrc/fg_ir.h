@@ -106,6 +106,11 @@ static_assert(sizeof(FgSepRec) == 64, "FgSepRec must be 64 bytes");
 struct FgSepCoord { int off, n; };     // records of coordinate k: sep[off .. off + (n & 7)); bit 8 of n: every sigma is a power of two; bit 9: and record 0 is Normal(0, 1)
 struct FgSepFree { uint32_t sidx, trow; };   // score-stream statements that read no coordinate: evaluated once per launch
 
+// Dense regressions (fg_hmc_lin.hip).  One table row per linear-predictor observe statement, read with scalar loads, all
+// doubles:  [c0, 0 | c_0 .. c_{D/2-1} | c_{D/2} .. c_{D-1} | y, 1/sigma, ln sigma, sigma | flags (FG_G_POW2 / FG_G_DIV as an integer), 0]
+// = D + 8 doubles, the coefficients in TERM order (term t reads coordinate lin_meta[t]); one zero row follows the last one (look-ahead).
+#define FG_LIN_ROW_DOUBLES(D) ((D) + 8)
+
 struct FgProgramDev {
     const FgIns  *ins;       // full program (generic opcodes only: PRIOR / MH / SCORE), n_ins
     const FgIns  *ins_fast;  // the same program with score-only fast opcodes substituted (HMC / SMC / log-joint)
@@ -129,6 +134,9 @@ struct FgProgramDev {
     int sstream_gen;           // the score stream holds general distribution records (FG_G_GEN)
     int sstream_kinds;         // record kinds in the score stream: 0 fast Normals, 1 + linear predictors, 2 + general records
     int n_ins, n_slots, S, d;
+    const double *lin_tab;     // dense-regression table (above) or null
+    const int *lin_meta;       // [d] coordinate at term position t, then [d][2] {first prior record of coordinate k in gstream, count}
+    int lin_n, lin_p2;         // observe statements in the table; every sigma is a power of two
 };
 
 // RNG stream purposes (counter word 3); shared spec with the test oracle

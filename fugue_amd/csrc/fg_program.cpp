@@ -699,6 +699,63 @@ int fg_program::finalize() {
             for (int q = 0; q < FG_SEP_MAXREC; q++) { FgSepRec z; std::memset(&z, 0, sizeof(z)); sep.push_back(z); }
         }
     }
+    // dense regressions (fg_hmc_lin.hip): every coordinate's records are >= 1 prior records that read only the coordinate itself,
+    // followed by the SAME N linear-predictor observe records, and every predictor reads all d coordinates once, in one common
+    // term order.  The table holds each statement's constants and coefficients once, in term order.
+    lin_tab.clear(); lin_meta.clear(); lin_n = 0; lin_p2 = 0;
+    if (n_gstream > 0 && n_sstream > 0 && sstream_has_lin && !sstream_has_gen && f64_slot.size() >= 2) {
+        const int d = (int)f64_slot.size();
+        bool ok = true;
+        std::vector<int> cstart((size_t)d + 1, n_gstream);
+        for (int k = n_gstream - 1; k >= 0; --k) cstart[gstream[k].coord] = k;
+        std::vector<int> npri((size_t)d, 0);
+        std::vector<uint32_t> stm;                                   // pool offsets of the statements' terms = their identity
+        for (int k = 0; k < d && ok; k++) {
+            const int b = cstart[k], e = cstart[k + 1];
+            int q = b;
+            for (; q < e && !(gstream[q].flags & FG_G_LIN); ++q) {
+                const FgGradRec &r = gstream[q];
+                const bool x_own = (r.flags & FG_G_PERT_X) != 0u, m_own = (r.flags & FG_G_PERT_M) != 0u;
+                if ((r.flags & (FG_G_GEN | FG_G_NSEL | FG_G_CATC | FG_G_SWITCH)) || x_own == m_own || (!x_own && !(r.flags & FG_G_X_CONST)) ||
+                    (!m_own && !(r.flags & FG_G_M_CONST))) ok = false;
+            }
+            npri[k] = q - b;
+            if (npri[k] < 1 || q == e || !(gstream[q].flags & FG_G_SWITCH)) ok = false;
+            std::vector<uint32_t> mine;
+            for (; q < e && ok; ++q) {
+                const FgGradRec &r = gstream[q];
+                if ((r.flags & (FG_G_LIN | FG_G_LIN1 | FG_G_X_CONST | FG_G_PERT_X)) != (FG_G_LIN | FG_G_LIN1 | FG_G_X_CONST) || (int)r.maskm != d) ok = false;
+                mine.push_back(r.maskx);
+            }
+            if (k == 0) stm = mine; else if (mine != stm) ok = false;
+        }
+        std::vector<int> coord_at((size_t)d, -1);
+        for (size_t s = 0; s < stm.size() && ok; s++)
+            for (int t = 0; t < d && ok; t++) {
+                const int slot = (int)fg_as_i64(pool[stm[s] + 2 * (size_t)t]);
+                if (s == 0) { coord_at[t] = slot; for (int u = 0; u < t; u++) if (coord_at[u] == slot) ok = false; }
+                else if (coord_at[t] != slot) ok = false;
+                if (slot < 0 || slot >= d) ok = false;
+            }
+        if (ok && !stm.empty()) {
+            const int rowd = FG_LIN_ROW_DOUBLES(d);
+            lin_n = (int)stm.size(); lin_p2 = 1;
+            lin_tab.assign(((size_t)lin_n + 1) * rowd, 0.0);
+            for (int s = 0; s < lin_n; s++) {
+                const FgGradRec &r = gstream[cstart[0] + npri[0] + s];
+                double *row = &lin_tab[(size_t)s * rowd];
+                row[0] = r.mimm;
+                for (int t = 0; t < d; t++) row[2 + t] = pool[r.maskx + 2 * (size_t)t + 1];
+                double *tail = row + 2 + d;
+                tail[0] = r.ximm + 0.0;                              // (x + hx) with hx = 0: what fg_grec_math forms for a constant x
+                tail[1] = r.inv; tail[2] = r.lns; tail[3] = r.sigma;
+                tail[4] = fg_as_double((long long)(r.flags & (FG_G_POW2 | FG_G_DIV)));
+                if (!(r.flags & FG_G_POW2)) lin_p2 = 0;
+            }
+            lin_meta.assign(coord_at.begin(), coord_at.end());
+            for (int k = 0; k < d; k++) { lin_meta.push_back(cstart[k]); lin_meta.push_back(npri[k]); }
+        }
+    }
     if (pool.empty()) pool.push_back(0.0);
     // the kernels prefetch two instructions ahead: keep two readable no-ops past each array
     n_ins = (int)ins.size();
@@ -801,6 +858,7 @@ int fg_program_stream_records(const fg_program *p, int which) {
     if (which == 0) return p->n_gstream;
     if (which == 1) return p->n_sstream;
     if (which == 3) return (int)p->sep_coord.size() > 0 ? (int)p->sep.size() - FG_SEP_MAXREC : 0;   // records of the register-resident trajectories
+    if (which == 4) return p->lin_n;                            // rows of the dense-regression table (fg_hmc_lin.hip)
     int k = p->sstream_has_gen ? 2 : (p->sstream_has_lin ? 1 : 0);
     for (int i = 0; i < p->n_gstream; i++) k = std::max(k, (p->gstream[i].flags & FG_G_GEN) ? 2 : ((p->gstream[i].flags & FG_G_LIN) ? 1 : 0));
     return k;

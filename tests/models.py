@@ -117,6 +117,10 @@ def hier_scale() -> M.Program:
 
 
 ZOO["hier_scale"] = hier_scale
+# dense regressions with 8 / 16 / 32 coefficients: the observation-major gradient kernel (fg_hmc_lin.hip), sigma 2^k and not
+ZOO["ridge8"] = lambda: W.ridge_regression(*W.ridge_data(20, 8)[:2])
+ZOO["ridge16"] = lambda: W.ridge_regression(*W.ridge_data(12, 16)[:2], sigma=0.8)
+ZOO["ridge32"] = lambda: W.ridge_regression(*W.ridge_data(16, 32)[:2])
 
 
 def linreg_forms() -> M.Program:

@@ -191,6 +191,7 @@ def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, tar
                                        ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_DENSE),
                                        ("ridge", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE),
                                        ("hier", E.GRAD_FD_SPARSE), ("hier", E.GRAD_FD_DENSE), ("ridge7", E.GRAD_FD_SPARSE),
+                                       ("ridge8", E.GRAD_FD_SPARSE), ("ridge16", E.GRAD_FD_SPARSE), ("ridge32", E.GRAD_FD_SPARSE),
                                        ("hier_scale", E.GRAD_FD_SPARSE), ("linreg", E.GRAD_FD_SPARSE), ("mixture", E.GRAD_FD_SPARSE),
                                        ("rand0", E.GRAD_FD_SPARSE), ("rand1", E.GRAD_FD_DENSE), ("rand2", E.GRAD_FD_SPARSE), ("rand4", E.GRAD_FD_SPARSE)])
 def test_hmc_session_matches_oracle_teacher_forced(oracle, name, mode):
@@ -364,6 +365,35 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        pos, info = eng.hmc_step_info(3)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
+                    eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
+        eng.close()
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
+
+
+@pytest.mark.parametrize("name,adapt_mass", [("ridge8", False), ("ridge8", True), ("ridge16", False), ("ridge16", True), ("ridge32", False), ("ridge32", True)])
+def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
+    """Dense regressions take the observation-major gradient (k_hmc_lin_steps: a wave owns D / W term positions, forms every
+    observation's products and prefix sums once and carries the suffix sums of its own coordinates side by side).  Per
+    (coordinate, observation, sign) the additions and multiplications are the gradient stream's in the same order, so draws,
+    step sizes, mass matrix, log-joint, statistics and per-transition info agree BIT FOR BIT with k_hmc_stream_steps -- for
+    both waves-per-tile layouts."""
+    cp = E.compile_model(ZOO[name]())
+    assert E.lib().fg_program_stream_records(cp.h, 4) > 0
+    C, nw, ns = 150, 40, 25
+    out = []
+    for lin, W_ in ((0, 1), (1, cp.d // 4), (1, cp.d // 2)):
+        monkeypatch.setenv("FG_HMC_LIN", str(lin))
+        monkeypatch.setenv("FG_HMC_WAVES", str(W_))
+        eng = E.Engine(cp, C, seed=21, chain_offset=5)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
         draws = eng.download(d, (ns, cp.d, C))
         eng.device_free(d)
         pos, info = eng.hmc_step_info(3)
