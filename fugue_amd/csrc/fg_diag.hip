@@ -91,6 +91,37 @@ __global__ void k_diag_acov_finish(const double *partial, int nblk, int n_lags, 
     out[j] = s;
 }
 
+// Sums over this engine's chains, for the all-reduce exchange (fg_diag_combine_reduced): block partials in a fixed tree, added in
+// block order by k_diag_acov_finish -- the result does not depend on scheduling.
+//   mode 0: row r = 6 i + k of the moments: sum_c mom[i][k][c]                                            (rows = 6 d)
+//   mode 1: row r = 2 i + k: k = 0: sum_c (mean_c - ov[i][0])^2; k = 1: sum_c (mean_h1_c - ov[i][1])^2 + (mean_h2_c - ov[i][1])^2   (rows = 2 d)
+__global__ __launch_bounds__(256) void k_diag_chain_sums(const double *mom, long long C, int mode, const double *ov, double *partial /*[rows][gridDim.x]*/) {
+    __shared__ double sh[4];
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    double v = 0.0;
+    if (c < C) {
+        if (mode == 0) v = mom[(long long)r * C + c];
+        else {
+            const int i = r >> 1;
+            const double *m6 = mom + (long long)i * 6 * C + c;
+            if (!(r & 1)) { const double a = m6[0] - ov[2 * i]; v = a * a; }
+            else { const double a = m6[2 * C] - ov[2 * i + 1], b = m6[4 * C] - ov[2 * i + 1]; v = a * a + b * b; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long long)r * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void k_diag_sum_partials(const double *partial, int nblk, int rows, double *out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long long)r * nblk + b];
+    out[r] = s;
+}
+
 // geweke_diagnostic (mcmc_utils.rs:354-421) of every (coordinate, chain) column: z = (mean of the first 10 % - mean of the
 // last 50 %) / sqrt of the two segments' spectral variances of the mean (spectral_variance_of_mean :392-421: s^2 tau / n with
 // tau summed over the initial positive autocorrelations).  One thread per column; the lag loop stops per chain.
@@ -185,12 +216,14 @@ int rccl_fail(Rccl *R, const char *what, int rc) {
 }
 const int kNcclFloat64 = 8, kNcclSum = 0;
 
-struct AcovCtx { fg_engine *e; const double *d_draws; int n, d; const double *d_mom; void *comm; };
+struct AcovCtx { fg_engine *e; const double *d_draws; int n, d; const double *d_mom; void *comm; double *d_small; double *d_part; long long bytes; };
 }  // namespace
 
 extern "C" {
 
 typedef int (*fg_acov_fn)(void *user, int lag0, int n_lags, double *h_sums);
+typedef int (*fg_reduce_fn)(void *user, int stage, const double *h_in, double *h_out);
+int fg_diag_combine_reduced(int64_t m, int n, int d, fg_reduce_fn reduce, fg_acov_fn acov, void *user, double *h_rhat, double *h_ess, double *h_mean, double *h_std);
 int fg_diag_combine(const double *h_moments, int64_t m, int n, int d, fg_acov_fn acov, void *user, double *h_rhat, double *h_ess, double *h_mean, double *h_std);
 
 int fg_diag_chain_moments(fg_engine *e, const double *d_draws, int n, int d, double *d_moments) {
@@ -281,6 +314,7 @@ static int acov_cb(void *user, int lag0, int n_lags, double *h_sums) {
         Rccl *R = rccl();
         const int nr = R->AllReduce(d_sums, d_sums, (size_t)A->d * n_lags, kNcclFloat64, kNcclSum, A->comm, e->stream);
         if (nr) rc = rccl_fail(R, "ncclAllReduce", nr);
+        A->bytes += (long long)A->d * n_lags * 8;
     }
     if (!rc) {
         hipError_t he = hipMemcpyAsync(h_sums, d_sums, (size_t)A->d * n_lags * 8, hipMemcpyDeviceToHost, e->stream);
@@ -290,6 +324,41 @@ static int acov_cb(void *user, int lag0, int n_lags, double *h_sums) {
     (void)hipFree(d_sums);
     return rc;
 }
+
+// The chain sums of fg_diag_combine_reduced: this engine's chains on the device, then -- with a communicator -- ONE all-reduce of
+// 6 d (stage 1) or 2 d (stage 2) doubles over RCCL / xGMI.
+static int reduce_cb(void *user, int stage, const double *h_in, double *h_out) {
+    AcovCtx *A = (AcovCtx *)user;
+    fg_engine *e = A->e;
+    const int rows = stage == 1 ? 6 * A->d : 2 * A->d;
+    const unsigned nb = (unsigned)((e->C + 255) / 256);
+    hipError_t he = hipSuccess;
+    double *d_ov = A->d_small + 8 * (size_t)A->d;                   // [2 d] overall means (stage 2 input)
+    if (stage == 2) he = hipMemcpyAsync(d_ov, h_in, (size_t)2 * A->d * 8, hipMemcpyHostToDevice, e->stream);
+    if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
+    hipLaunchKernelGGL(k_diag_chain_sums, dim3(nb, (unsigned)rows), dim3(256), 0, e->stream, A->d_mom, e->C, stage == 1 ? 0 : 1, (const double *)d_ov, A->d_part);
+    hipLaunchKernelGGL(k_diag_sum_partials, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, e->stream, (const double *)A->d_part, (int)nb, rows, A->d_small);
+    he = hipGetLastError();
+    if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
+    if (A->comm) {
+        Rccl *R = rccl();
+        const int nr = R->AllReduce(A->d_small, A->d_small, (size_t)rows, kNcclFloat64, kNcclSum, A->comm, e->stream);
+        if (nr) return rccl_fail(R, "ncclAllReduce", nr);
+        A->bytes += (long long)rows * 8;
+    }
+    he = hipMemcpyAsync(h_out, A->d_small, (size_t)rows * 8, hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
+    return FG_OK;
+}
+
+int fg_diag_set_exchange(fg_engine *e, int mode) {
+    NEED_ENGINE(e);
+    if (mode != FG_DIAG_REDUCE && mode != FG_DIAG_GATHER) return FG_E_BAD_ARG;
+    e->diag_mode = mode;
+    return FG_OK;
+}
+int64_t fg_diag_exchange_bytes(const fg_engine *e) { return e ? (int64_t)e->diag_bytes : 0; }
 
 // r_hat_f64 + effective_sample_size_multichain + summarize_f64_parameter for every coordinate of d_draws [n][d][C] over the
 // chains of EVERY rank of `comm` (NULL: this engine's chains).  All ranks call it with equal n, d and C and get the same
@@ -303,15 +372,33 @@ int fg_diag_rhat_ess(fg_engine *e, const double *d_draws, int n, int d, void *co
     int world = 1;
     if (comm) { const int rc = R->CommCount(comm, &world); if (rc) return rccl_fail(R, "ncclCommCount", rc); }
     const size_t per = (size_t)d * 6 * e->C;
-    double *d_mom = nullptr, *d_all = nullptr;
+    double *d_mom = nullptr, *d_all = nullptr, *d_small = nullptr, *d_part = nullptr;
     int rc = dev_alloc(&d_mom, per);
     if (rc) return rc;
     rc = fg_diag_chain_moments(e, d_draws, n, d, d_mom);
     std::vector<double> mom;
     const int64_t m = (int64_t)world * e->C;
-    if (!rc && comm) {                                              // every rank needs every chain's moments: all-gather over RCCL / xGMI
+    e->diag_bytes = 0;
+    if (!rc && e->diag_mode == FG_DIAG_REDUCE) {
+        // the default exchange: chains enter R-hat, the pooled moments and the ESS only through sums over chains -- all-reduces of
+        // 6 d, 2 d and 32 d (per lag chunk) doubles, nothing proportional to the chain count leaves the GPU
+        rc = dev_alloc(&d_small, (size_t)10 * d);
+        if (!rc) rc = dev_alloc(&d_part, (size_t)6 * d * ((e->C + 255) / 256));
+        if (!rc) {
+            AcovCtx A{ e, d_draws, n, d, d_mom, comm, d_small, d_part, 0 };
+            rc = fg_diag_combine_reduced(m, n, d, reduce_cb, acov_cb, &A, h_rhat, h_ess, h_mean, h_std);
+            e->diag_bytes = A.bytes;
+        }
+        if (d_small) (void)hipFree(d_small);
+        if (d_part) (void)hipFree(d_part);
+        if (out_total_chains) *out_total_chains = m;
+        (void)hipFree(d_mom);
+        return rc;
+    }
+    if (!rc && comm) {                                              // FG_DIAG_GATHER: every rank gets every chain's moments (all-gather over RCCL / xGMI)
         rc = dev_alloc(&d_all, per * world);
         if (!rc) { const int nr = R->AllGather(d_mom, d_all, per, kNcclFloat64, comm, e->stream); if (nr) rc = rccl_fail(R, "ncclAllGather", nr); }
+        e->diag_bytes += (long long)per * 8;
     }
     if (!rc) {
         std::vector<double> raw(per * world);
@@ -327,8 +414,9 @@ int fg_diag_rhat_ess(fg_engine *e, const double *d_draws, int n, int d, void *co
         }
     }
     if (!rc) {
-        AcovCtx A{ e, d_draws, n, d, d_mom, comm };
+        AcovCtx A{ e, d_draws, n, d, d_mom, comm, nullptr, nullptr, 0 };
         rc = fg_diag_combine(mom.data(), m, n, d, acov_cb, &A, h_rhat, h_ess, h_mean, h_std);
+        e->diag_bytes += A.bytes;
     }
     if (out_total_chains) *out_total_chains = m;
     (void)hipFree(d_mom);

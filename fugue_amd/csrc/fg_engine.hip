@@ -1025,8 +1025,10 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         }
 #undef FG_LAUNCH_STREAM
         HIPCHK(hipGetLastError());
+        e->last_hmc_kernel = std::string(dense_stream ? "k_hmc_stream_steps (dense stream) W=" : "k_hmc_stream_steps W=") + std::to_string(W);
         return FG_OK;
     }
+    e->last_hmc_kernel = "k_hmc_steps W=1";
     hipLaunchKernelGGL(k_hmc_steps, dim3(tiles), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
                        e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     HIPCHK(hipGetLastError());
@@ -1162,6 +1164,7 @@ int fg_hmc_set_n_leapfrog(fg_engine *e, int n_leapfrog) {     // hmc.rs:751-753
     e->H.L = e->cfg.n_leapfrog;
     return FG_OK;
 }
+const char *fg_hmc_last_kernel(const fg_engine *e) { return e ? e->last_hmc_kernel.c_str() : ""; }
 int fg_hmc_is_warming_up(const fg_engine *e) { return (e && e->hmc_ready && e->iter < e->n_warmup) ? 1 : 0; }   // hmc.rs:780-782
 int64_t fg_hmc_iterations(const fg_engine *e) { return (e && e->hmc_ready) ? (int64_t)e->iter : 0; }             // hmc.rs:785-787
 

@@ -115,6 +115,9 @@ struct fg_engine {
     size_t lds_score = 0;        // LDS tile of the score / prior / MH / SMC kernels (slots only)
     int tw = 64;               // tile width (threads per block)
     int n_simd = 1024;         // SIMDs on the device (4 per CU)
+    int diag_mode = 0;         // FG_DIAG_REDUCE / FG_DIAG_GATHER: how fg_diag_rhat_ess exchanges chain statistics between ranks
+    long long diag_bytes = 0;  // bytes this rank put into collectives during the last fg_diag_rhat_ess
+    std::string last_hmc_kernel;   // kernel (and waves per tile) the last fg_hmc_step launch ran (fg_hmc_last_kernel)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
 

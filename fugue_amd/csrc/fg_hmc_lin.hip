@@ -367,5 +367,6 @@ int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
 #undef FG_LIN_GO
 #undef FG_LIN_KERNELS
     HIPCHK(hipGetLastError());
+    e->last_hmc_kernel = "k_hmc_lin_steps W=" + std::to_string(W);
     return FG_OK;
 }

@@ -464,6 +464,7 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     }
 #undef FG_SEP_LAUNCH
     HIPCHK(hipGetLastError());
+    e->last_hmc_kernel = std::string(dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : "k_hmc_sep_steps W=")) + std::to_string(W);
     return FG_OK;
 }
 

@@ -6,10 +6,12 @@ Mirrors `r_hat_f64` / `classic_r_hat_f64` / `summarize_f64_parameter`
 
 This is the ONLY place chains interact, hence the only collective of the engine:
 every rank reduces its own draws to per-chain moments (`fg_diag_chain_moments`, [d][6][C_local])
-and pooled per-lag autocovariance sums (`fg_diag_autocov_sums`, [d][lags]) on its GPU; ranks then
-exchange only those -- `all_gather` of the chain means / sums of squares (R-hat needs every chain
-mean) and `all_reduce` of the lag sums -- over RCCL/xGMI (`backend="nccl"`), or gloo in the CPU
-tests.  The final formulas run on the host in float64 and follow the reference line by line.
+and pooled per-lag autocovariance sums (`fg_diag_autocov_sums`, [d][lags]) on its GPU.  Chains
+enter split R-hat, the pooled moments and the ESS only through SUMS over chains, so the ranks
+exchange `all_reduce`s of 6 d + 2 d doubles (+ 32 d per chunk of lags) -- over RCCL/xGMI
+(`backend="nccl"`), or gloo in the CPU tests; `exchange="gather"` keeps the older `all_gather` of
+every chain's moments (a single process's summation order).  The final formulas run in the
+library in float64 and follow the reference line by line.
 """
 from __future__ import annotations
 
@@ -117,40 +119,81 @@ class ChainDiagnostics:
     R-hat / Geyer-ESS formulas run in the library.  (A process that owns an RCCL communicator can skip this class and call
     `Engine.diag_rhat_ess(..., comm)`: the same computation with the collectives inside the library.)"""
 
-    def __init__(self, provider: MomentProvider, group=None, device=None):
+    def __init__(self, provider: MomentProvider, group=None, device=None, exchange: str = "reduce"):
         from . import engine as E
-        self.p, self.group, self.device = provider, group, device
+        assert exchange in ("reduce", "gather")
+        self.p, self.group, self.device, self.exchange = provider, group, device, exchange
         self.n, self.d = provider.n, provider.d
-        self._mom = _all_gather_concat(provider.moments(), group, device)        # [d][6][C_total]
-        self.m = self._mom.shape[2]
+        self.exchange_bytes = 0                          # bytes this rank contributed to collectives
+        if exchange == "gather":
+            local = provider.moments()
+            self._mom = _all_gather_concat(local, group, device)        # [d][6][C_total]
+            self.m = self._mom.shape[2]
+            if self.m != local.shape[2]:
+                self.exchange_bytes += local.nbytes
+        else:
+            self._local = np.ascontiguousarray(provider.moments())      # [d][6][C_local]
+            dist = _dist(group)
+            world = dist.get_world_size(group) if dist is not None else 1
+            self.m = self._local.shape[2] * world                       # chains are sharded evenly
+            self._world = world
+            self._sums = None
         self._res = None
         self._E = E
 
     def _acov(self, lag0: int, n_lags: int) -> np.ndarray:
-        return _all_reduce_sum(self.p.autocov_sums(lag0, n_lags), self.group, self.device)
+        a = self.p.autocov_sums(lag0, n_lags)
+        if _dist(self.group) is not None and _dist(self.group).get_world_size(self.group) > 1:
+            self.exchange_bytes += a.nbytes
+        return _all_reduce_sum(a, self.group, self.device)
+
+    def _reduce(self, stage: int, overall):
+        """Sums over this rank's chains, all-reduced: the chain sums of fg_diag_combine_reduced."""
+        mom = self._local
+        if stage == 1:
+            a = mom.sum(axis=2)                                          # [d][6]
+        else:
+            a = np.stack([((mom[:, 0] - overall[:, 0:1]) ** 2).sum(axis=1),
+                          ((mom[:, 2] - overall[:, 1:2]) ** 2 + (mom[:, 4] - overall[:, 1:2]) ** 2).sum(axis=1)], axis=1)    # [d][2]
+        if self._world > 1:
+            self.exchange_bytes += a.nbytes
+        out = _all_reduce_sum(np.ascontiguousarray(a), self.group, self.device)
+        if stage == 1:
+            self._sums = [out, None]
+        else:
+            self._sums[1] = out
+        return out
 
     def _combine(self):
         if self._res is None:
-            self._res = self._E.diag_combine(self._mom, self.n, self._acov)
+            if self.exchange == "gather":
+                self._res = self._E.diag_combine(self._mom, self.n, self._acov)
+            else:
+                self._res = self._E.diag_combine_reduced(self.m, self.n, self.d, self._reduce, self._acov)
         return self._res
 
     def split_rhat(self) -> np.ndarray:                 # r_hat_f64 (diagnostics.rs:218-224, 240-260)
         return self._combine()["r_hat"]
 
     def classic_rhat(self) -> np.ndarray:               # classic_r_hat_f64 (diagnostics.rs:226-238): whole chains, no split
-        whole = np.concatenate([self._mom[:, 0:2], self._mom[:, 0:2], self._mom[:, 0:2]], axis=1)     # halves := whole chain
-        m = self.m
+        m, n = self.m, float(self.n)
         out = np.empty(self.d)
+        if self.exchange == "reduce":                   # from the chain sums the combination already exchanged
+            self._combine()
+            s1, s2 = self._sums
         for i in range(self.d):
-            means, ssds, n = self._mom[i, 0], self._mom[i, 1], float(self.n)
             if m < 2:
                 out[i] = 1.0
                 continue
-            overall = means.sum() / m
-            b = n / (m - 1.0) * ((means - overall) ** 2).sum()
-            w = (ssds / (n - 1.0)).sum() / m
+            if self.exchange == "gather":
+                means, ssds = self._mom[i, 0], self._mom[i, 1]
+                overall = means.sum() / m
+                between, ssd = ((means - overall) ** 2).sum(), (ssds / (n - 1.0)).sum()
+            else:
+                between, ssd = s2[i, 0], s1[i, 1] / (n - 1.0)
+            b = n / (m - 1.0) * between
+            w = ssd / m
             out[i] = math.sqrt((((n - 1.0) / n) * w + b / n) / w) if w > 0 else float("nan")
-        del whole
         return out
 
     def pooled_mean(self) -> np.ndarray:

@@ -74,12 +74,15 @@ ABI_SYMBOLS = [
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_smc_prior_particles", "fg_smc_normalize", "fg_smc_ess", "fg_smc_resample", "fg_smc_rejuvenate",
     "fg_smc_get_weights", "fg_smc_set_log_weights", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_diag_rhat_ess", "fg_diag_combine", "fg_diag_geweke",
+    "fg_diag_combine_reduced", "fg_diag_set_exchange", "fg_diag_exchange_bytes", "fg_hmc_last_kernel",
     "fg_comm_unique_id", "fg_comm_init", "fg_comm_destroy", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
     "fg_dsl_compile", "fg_dsl_warning_count", "fg_dsl_warning",
 ]
 
 _lib = None
 ACOV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double))     # fg_acov_fn
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))     # fg_reduce_fn
+DIAG_REDUCE, DIAG_GATHER = 0, 1
 
 
 class DslError(ValueError):
@@ -183,6 +186,12 @@ def lib():
     L.fg_diag_geweke.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.fg_diag_rhat_ess.argtypes = [vp, vp, C.c_int, C.c_int, vp, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.fg_diag_combine.argtypes = [dp, C.c_int64, C.c_int, C.c_int, ACOV_FN, vp, dp, dp, dp, dp]
+    L.fg_diag_combine_reduced.argtypes = [C.c_int64, C.c_int, C.c_int, REDUCE_FN, ACOV_FN, vp, dp, dp, dp, dp]
+    L.fg_diag_set_exchange.argtypes = [vp, C.c_int]
+    L.fg_diag_exchange_bytes.restype = C.c_int64
+    L.fg_diag_exchange_bytes.argtypes = [vp]
+    L.fg_hmc_last_kernel.restype = C.c_char_p
+    L.fg_hmc_last_kernel.argtypes = [vp]
     L.fg_comm_unique_id.argtypes = [vp]
     L.fg_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.fg_comm_destroy.argtypes = [vp]
@@ -619,13 +628,20 @@ class Engine:
         finally:
             self.device_free(d_z)
 
-    def diag_rhat_ess(self, d_draws: int, n: int, d: int, comm: Optional[int] = None):
+    def diag_rhat_ess(self, d_draws: int, n: int, d: int, comm: Optional[int] = None, exchange: Optional[int] = None):
         """Split R-hat, multi-chain ESS, pooled mean / std of d_draws [n][d][C] over the chains of every rank of `comm`
-        (an RCCL communicator from `comm_init`; None = this engine's chains): computed inside the library."""
+        (an RCCL communicator from `comm_init`; None = this engine's chains): computed inside the library.  `exchange`:
+        DIAG_REDUCE (default: all-reduces of O(d) chain sums) or DIAG_GATHER (all-gather of every chain's moments)."""
         rhat, ess, mean, std = (np.zeros(d) for _ in range(4))
         tot = C.c_int64()
+        if exchange is not None:
+            _check(lib().fg_diag_set_exchange(self.h, int(exchange)))
         _check(lib().fg_diag_rhat_ess(self.h, d_draws, int(n), int(d), comm, _dp(rhat), _dp(ess), _dp(mean), _dp(std), C.byref(tot)))
-        return dict(r_hat=rhat, ess=ess, mean=mean, std=std, chains=tot.value)
+        return dict(r_hat=rhat, ess=ess, mean=mean, std=std, chains=tot.value, exchange_bytes=int(lib().fg_diag_exchange_bytes(self.h)))
+
+    def hmc_last_kernel(self) -> str:
+        """Kernel (and waves per tile) the engine's last HMC launch ran."""
+        return (lib().fg_hmc_last_kernel(self.h) or b"").decode()
 
     def comm_init(self, world_size: int, rank: int, unique_id: bytes) -> int:
         out = C.c_void_p()
@@ -701,6 +717,39 @@ def diag_combine(moments: np.ndarray, n: int, acov_sums):
     fn = ACOV_FN(cb)
     rhat, ess, mean, std = (np.zeros(d) for _ in range(4))
     rc = lib().fg_diag_combine(_dp(mom), m, int(n), d, fn, None, _dp(rhat), _dp(ess), _dp(mean), _dp(std))
+    if err:
+        raise err[0]
+    _check(rc)
+    return dict(r_hat=rhat, ess=ess, mean=mean, std=std)
+
+
+def diag_combine_reduced(m: int, n: int, d: int, reduce, acov_sums):
+    """`fg_diag_combine_reduced`: the same combination from sums over chains.  `reduce(stage, overall)` returns the sums over
+    ALL chains of all ranks ([d][6] for stage 1, [d][2] for stage 2 given the overall means [d][2]); `acov_sums(lag0, n_lags)`
+    the pooled lag sums [d][n_lags]."""
+    err = []
+
+    def rcb(_user, stage, h_in, h_out):
+        try:
+            ov = np.ctypeslib.as_array(h_in, shape=(d, 2)).copy() if stage == 2 else None
+            a = np.ascontiguousarray(reduce(int(stage), ov), dtype=np.float64)
+            C.memmove(h_out, a.ctypes.data, d * (6 if stage == 1 else 2) * 8)
+            return 0
+        except Exception as ex:      # pragma: no cover
+            err.append(ex)
+            return FG_E_BAD_ARG
+
+    def acb(_user, lag0, n_lags, out):
+        try:
+            a = np.ascontiguousarray(acov_sums(int(lag0), int(n_lags)), dtype=np.float64)
+            C.memmove(out, a.ctypes.data, d * n_lags * 8)
+            return 0
+        except Exception as ex:      # pragma: no cover
+            err.append(ex)
+            return FG_E_BAD_ARG
+    rfn, afn = REDUCE_FN(rcb), ACOV_FN(acb)
+    rhat, ess, mean, std = (np.zeros(d) for _ in range(4))
+    rc = lib().fg_diag_combine_reduced(int(m), int(n), int(d), rfn, afn, None, _dp(rhat), _dp(ess), _dp(mean), _dp(std))
     if err:
         raise err[0]
     _check(rc)

@@ -215,6 +215,11 @@ int fg_hmc_set_step_size(fg_engine *e, double eps);
 int     fg_hmc_set_n_leapfrog(fg_engine *e, int n_leapfrog);
 int     fg_hmc_is_warming_up(const fg_engine *e);
 int64_t fg_hmc_iterations(const fg_engine *e);
+/* Which kernel the engine's last fg_hmc_step / fg_hmc_run launch ran, with its waves per 64-chain tile, e.g.
+ * "k_hmc_sep_steps W=8" (independent sites: whole trajectories in registers), "k_hmc_lin_steps W=8" (dense regressions:
+ * observation-major gradient), "k_hmc_stream_steps W=4" (gradient / score streams), "k_hmc_steps W=1" (interpreter);
+ * "" before the first launch.  The pointer is valid until the engine's next launch. */
+const char *fg_hmc_last_kernel(const fg_engine *e);
 /* HmcSession::step_recorded (hmc.rs:811-817) for every chain: ONE transition, and for the n_recorded chains h_chain_ids
  * the leapfrog trajectory with the Hamiltonian at each integration point (LeapfrogPoint, hmc.rs:338-343):
  * h_traj [n_recorded][L+1][d] positions, h_ham [n_recorded][L+1], h_n_points [n_recorded] (L + 1, fewer when the
@@ -330,16 +335,34 @@ int fg_diag_geweke(fg_engine *e, const double *d_draws, int n, int d, double *d_
 /* r_hat_f64 (split R-hat, diagnostics.rs:218-224,240-304), effective_sample_size_multichain (mcmc_utils.rs:214-339) and the
  * pooled mean / sample std of summarize_f64_parameter (diagnostics.rs:331-352) for every coordinate of d_draws [n][d][C],
  * over the chains of EVERY rank of `rccl_comm` (an ncclComm_t; NULL = this engine's chains only).  With a communicator the
- * per-chain moments are all-gathered and the pooled lag sums all-reduced over RCCL / xGMI inside the call; all ranks call
+ * chain sums and the pooled lag sums are all-reduced over RCCL / xGMI inside the call (fg_diag_set_exchange); all ranks call
  * it with equal n, d and chain count and receive the same numbers.  h_* are [d]; any may be NULL. */
 int fg_diag_rhat_ess(fg_engine *e, const double *d_draws, int n, int d, void *rccl_comm, double *h_rhat, double *h_ess,
                      double *h_mean, double *h_std, int64_t *out_total_chains);
+/* How the ranks of `rccl_comm` exchange chain statistics inside fg_diag_rhat_ess.  FG_DIAG_REDUCE (default): chains enter split
+ * R-hat (diagnostics.rs:262-304), the pooled mean / std and the multi-chain ESS (mcmc_utils.rs:253-339) only through sums over
+ * chains, so every rank reduces its own chains on the device and the ranks all-reduce 6 d + 2 d doubles plus 32 d per chunk of
+ * lags -- nothing proportional to the chain count leaves a GPU.  FG_DIAG_GATHER: all-gather of every chain's moments
+ * ([d][6][C] per rank) and the combination in global chain order on every rank, as a single process would sum them.  The two
+ * agree to rounding of the sums over chains (~1e-15 relative).  fg_diag_exchange_bytes: bytes this rank contributed to
+ * collectives during the last fg_diag_rhat_ess (0 without a communicator). */
+#define FG_DIAG_REDUCE 0
+#define FG_DIAG_GATHER 1
+int fg_diag_set_exchange(fg_engine *e, int mode);
+int64_t fg_diag_exchange_bytes(const fg_engine *e);
 /* The combination alone, on host buffers (no GPU needed): h_moments [d][6][m] of ALL chains in global chain order;
  * `acov` returns h_sums [d][n_lags] = sum over all chains of the biased lag-t autocovariances for t in
  * [lag0, lag0 + n_lags) (it is asked for 32 lags at a time, only as far as Geyer's sequence runs). */
 typedef int (*fg_acov_fn)(void *user, int lag0, int n_lags, double *h_sums);
 int fg_diag_combine(const double *h_moments, int64_t m, int n, int d, fg_acov_fn acov, void *user, double *h_rhat,
                     double *h_ess, double *h_mean, double *h_std);
+/* The same combination from sums over chains (what FG_DIAG_REDUCE exchanges).  `reduce` returns sums over ALL chains of all ranks:
+ * stage 1: h_out [d][6] = sums of the six moment rows; stage 2: h_in [d][2] = overall means {full chains, half chains},
+ * h_out [d][2] = {sum_j (mean_j - in0)^2, sum_j (mean_h1_j - in1)^2 + (mean_h2_j - in1)^2} -- the reference's two-pass
+ * between-chain sums of squares (diagnostics.rs:275-289, mcmc_utils.rs:296-304) with the pass over chains distributed. */
+typedef int (*fg_reduce_fn)(void *user, int stage, const double *h_in, double *h_out);
+int fg_diag_combine_reduced(int64_t m, int n, int d, fg_reduce_fn reduce, fg_acov_fn acov, void *user, double *h_rhat,
+                            double *h_ess, double *h_mean, double *h_std);
 /* RCCL communicator of the ranks of one run (one process per GPU): rank 0 obtains a 128-byte id (ncclGetUniqueId), the
  * host distributes it by any means, every rank calls fg_comm_init.  RCCL is bound at run time (librccl.so). */
 int fg_comm_unique_id(void *out_128_bytes);

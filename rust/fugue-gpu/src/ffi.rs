@@ -50,6 +50,9 @@ pub struct fg_smc_config { pub resampling_method: i32, pub ess_threshold: f64, p
 pub struct fg_smc_result { pub log_evidence: f64, pub n_steps: i32, pub n_model_runs: i64 }
 
 pub type fg_acov_fn = Option<unsafe extern "C" fn(user: *mut c_void, lag0: c_int, n_lags: c_int, h_sums: *mut f64) -> c_int>;
+pub type fg_reduce_fn = Option<unsafe extern "C" fn(user: *mut c_void, stage: c_int, h_in: *const f64, h_out: *mut f64) -> c_int>;
+pub const FG_DIAG_REDUCE: c_int = 0;
+pub const FG_DIAG_GATHER: c_int = 1;
 
 #[link(name = "fugue_amd")]
 extern "C" {
@@ -96,6 +99,7 @@ extern "C" {
     pub fn fg_hmc_set_n_leapfrog(e: *mut fg_engine, n_leapfrog: c_int) -> c_int;
     pub fn fg_hmc_is_warming_up(e: *const fg_engine) -> c_int;
     pub fn fg_hmc_iterations(e: *const fg_engine) -> i64;
+    pub fn fg_hmc_last_kernel(e: *const fg_engine) -> *const c_char;
     // ---- single-site MH (mh.rs:921-1014)
     pub fn fg_mh_init(e: *mut fg_engine, n_warmup: c_int, overrides: *const fg_site_proposal) -> c_int;
     pub fn fg_mh_step(e: *mut fg_engine, n: c_int, rec_sites: *const i32, n_rec: c_int, d_draws: *mut c_void) -> c_int;
@@ -119,6 +123,10 @@ extern "C" {
     pub fn fg_diag_geweke(e: *mut fg_engine, d_draws: *const f64, n: c_int, d: c_int, d_z: *mut f64) -> c_int;
     pub fn fg_diag_combine(h_moments: *const f64, m: i64, n: c_int, d: c_int, acov: fg_acov_fn, user: *mut c_void, h_rhat: *mut f64, h_ess: *mut f64,
                            h_mean: *mut f64, h_std: *mut f64) -> c_int;
+    pub fn fg_diag_combine_reduced(m: i64, n: c_int, d: c_int, reduce: fg_reduce_fn, acov: fg_acov_fn, user: *mut c_void, h_rhat: *mut f64, h_ess: *mut f64,
+                                   h_mean: *mut f64, h_std: *mut f64) -> c_int;
+    pub fn fg_diag_set_exchange(e: *mut fg_engine, mode: c_int) -> c_int;
+    pub fn fg_diag_exchange_bytes(e: *const fg_engine) -> i64;
     pub fn fg_comm_unique_id(out_128_bytes: *mut c_void) -> c_int;
     pub fn fg_comm_init(e: *mut fg_engine, world: c_int, rank: c_int, id_128_bytes: *const c_void, out_comm: *mut *mut c_void) -> c_int;
     pub fn fg_comm_destroy(comm: *mut c_void) -> c_int;

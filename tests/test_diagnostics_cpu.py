@@ -19,11 +19,12 @@ def _chains(draws, i):                     # [n][d][C] -> [m][n] for the oracle
     return np.ascontiguousarray(draws[:, i, :].T)
 
 
+@pytest.mark.parametrize("exchange", ["reduce", "gather"])
 @pytest.mark.parametrize("n", [7, 50, 401])
-def test_rhat_and_ess_match_oracle(oracle, n):
+def test_rhat_and_ess_match_oracle(oracle, n, exchange):
     rng = np.random.default_rng(n)
     draws = np.stack([ar1(rng, n, 12, 0.6), rng.standard_normal((n, 12)) * 3 + 1, ar1(rng, n, 12, 0.95)], axis=1)
-    cd = D.ChainDiagnostics(NumpyMoments(draws))
+    cd = D.ChainDiagnostics(NumpyMoments(draws), exchange=exchange)
     for i in range(3):
         ch = _chains(draws, i)
         assert cd.split_rhat()[i] == pytest.approx(oracle.split_rhat(ch), rel=1e-11)
@@ -61,9 +62,10 @@ def test_reference_diagnostics_behaviour(oracle):
     assert oracle.classic_rhat(np.ones((1, 10))) == 1.0
 
 
-def test_distributed_diagnostics_world_size_2_gloo(oracle, tmp_path):
-    """The N > 1 path: two gloo ranks each own half of the chains, exchange only moments / lag sums
-    and must reproduce the single-process (and the oracle's) R-hat and ESS."""
+@pytest.mark.parametrize("exchange", ["reduce", "gather"])
+def test_distributed_diagnostics_world_size_2_gloo(oracle, tmp_path, exchange):
+    """The N > 1 path: two gloo ranks each own half of the chains, exchange only chain sums / lag sums (reduce: all-reduces of
+    O(d) doubles; gather: every chain's moments) and must reproduce the single-process (and the oracle's) R-hat and ESS."""
     rng = np.random.default_rng(3)
     draws = np.stack([ar1(rng, 300, 16, 0.7), rng.standard_normal((300, 16)) + 2.0], axis=1)
     np.save(tmp_path / "draws.npy", draws)
@@ -78,26 +80,31 @@ dist.init_process_group(backend="gloo")
 r, w = dist.get_rank(), dist.get_world_size()
 x = np.load({str(tmp_path / "draws.npy")!r})
 C = x.shape[2] // w
-cd = D.ChainDiagnostics(NumpyMoments(x[:, :, r * C:(r + 1) * C]))
-out = dict(split=cd.split_rhat().tolist(), classic=cd.classic_rhat().tolist(), ess=cd.ess().tolist(), m=cd.m)
+cd = D.ChainDiagnostics(NumpyMoments(x[:, :, r * C:(r + 1) * C]), exchange={exchange!r})
+out = dict(split=cd.split_rhat().tolist(), classic=cd.classic_rhat().tolist(), ess=cd.ess().tolist(), m=cd.m, mean=cd.pooled_mean().tolist(),
+           std=cd.pooled_std().tolist(), bytes=cd.exchange_bytes)
 if r == 0:
     json.dump(out, open({str(tmp_path / "out.json")!r}, "w"))
 dist.destroy_process_group()
 ''')
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
+                        "127.0.0.1", "--master-port", "29517" if exchange == "reduce" else "29519", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     out = json.load(open(tmp_path / "out.json"))
     assert out["m"] == 16
-    single = D.ChainDiagnostics(NumpyMoments(draws))
+    lag_chunks = out["bytes"] - (2 * 8 * 8 if exchange == "reduce" else 2 * 6 * 8 * 8)     # d = 2: 6 d + 2 d doubles, or [d][6][8 chains]
+    assert lag_chunks > 0 and lag_chunks % (2 * 32 * 8) == 0                             # + 32 d doubles per chunk of lags
+    single = D.ChainDiagnostics(NumpyMoments(draws), exchange=exchange)
     for i in range(2):
         ch = _chains(draws, i)
         assert out["split"][i] == pytest.approx(oracle.split_rhat(ch), rel=1e-11)
         assert out["classic"][i] == pytest.approx(oracle.classic_rhat(ch), rel=1e-11)
         assert out["ess"][i] == pytest.approx(oracle.ess_multichain(ch), rel=1e-9)
         assert out["ess"][i] == pytest.approx(single.ess()[i], rel=1e-12)
+        s = oracle.summarize(ch)
+        assert out["mean"][i] == pytest.approx(s["mean"], rel=1e-11, abs=1e-12) and out["std"][i] == pytest.approx(s["std"], rel=1e-10)
 
 
 def test_combine_is_native_and_needs_no_gpu():

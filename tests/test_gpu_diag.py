@@ -33,17 +33,19 @@ def test_chain_diagnostics_on_hmc_draws(oracle, ns):
     prov.close()
 
 
-def test_native_rhat_ess_entry_point_and_geweke(oracle):
-    """fg_diag_rhat_ess (moments + lag sums on the device, combination in C++) and fg_diag_geweke against the oracle;
-    with a one-rank RCCL communicator the same call goes through ncclAllGather / ncclAllReduce and must not change a bit."""
+@pytest.mark.parametrize("exchange", [E.DIAG_REDUCE, E.DIAG_GATHER])
+def test_native_rhat_ess_entry_point_and_geweke(oracle, exchange):
+    """fg_diag_rhat_ess (moments + lag sums on the device, combination in C++) and fg_diag_geweke against the oracle, in both
+    exchange modes (all-reduces of chain sums formed on the device; all-gather of every chain's moments); with a one-rank RCCL
+    communicator the same call goes through ncclAllReduce / ncclAllGather and must not change a bit."""
     cp = E.compile_model(W.normal_sites(4))
     C, ns, nw = 150, 240, 60
     eng = E.Engine(cp, C, seed=6)
     d_draws = eng.device_alloc(ns * cp.d * C * 8)
     eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=3), ns, nw, d_draws)
     draws = eng.download(d_draws, (ns, cp.d, C))
-    r = eng.diag_rhat_ess(d_draws, ns, cp.d)
-    assert r["chains"] == C
+    r = eng.diag_rhat_ess(d_draws, ns, cp.d, exchange=exchange)
+    assert r["chains"] == C and r["exchange_bytes"] == 0
     for i in range(cp.d):
         ch = np.ascontiguousarray(draws[:, i, :].T)
         assert r["r_hat"][i] == pytest.approx(oracle.split_rhat(ch), rel=1e-10)
@@ -62,4 +64,6 @@ def test_native_rhat_ess_entry_point_and_geweke(oracle):
         E.comm_destroy(comm)
     for k in ("r_hat", "ess", "mean", "std"):
         assert np.array_equal(r[k], r1[k])
+    lag_bytes = r1["exchange_bytes"] - (8 * cp.d * 8 if exchange == E.DIAG_REDUCE else 6 * cp.d * C * 8)
+    assert lag_bytes > 0 and lag_bytes % (32 * cp.d * 8) == 0                  # what the rank put into collectives: O(d) in the reduce mode
     eng.device_free(d_draws)
