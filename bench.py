@@ -1,34 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's headline metric on MI355X: leapfrog-steps/s (HMC) + chain-steps/s (MCMC) at 65 536
-chains per GPU, with SMC beside them.
+chains per GPU, with SMC and the coupled-model configurations beside them.
 
 Headline workload (BASELINE.json configs[1] + north_star): `hmc_chain` on the 32-site conjugate Normal model
 (x#i ~ N(0,1); y#i ~ N(x#i, 0.5) observed at 0.2 i - 1), 65 536 chains per GPU, HMCConfig::default() (L = 16, h = 1e-5,
-target accept 0.8), gradient mode FG_GRAD_FD_SPARSE -- the engine's ONE default (C ABI, Python and this file): the
-reference's central difference (hmc.rs:304-329) over the statements that read the perturbed coordinate.  The
-reference-verbatim dense mode (2 d whole-model runs per gradient) is measured beside it (`hmc_fd_dense`) and is what the
-CPU baseline is compared with like for like.
+target accept 0.8), gradient mode FG_GRAD_FD_SPARSE -- the engine's default: the reference's central difference
+(hmc.rs:304-329) over the statements that read the perturbed coordinate.  The reference-verbatim dense mode (2 d whole-model
+runs per gradient) is a leg of its own (`hmc_fd_dense`, with its roofline) and is what the CPU baseline is compared with.
 
 A bench "step" = ONE HMC transition (16 leapfrog steps, 17 gradients, endpoint score, accept/reject, adaptation) of EVERY
-chain.  `--warmup W` untimed transitions are the adaptive warmup (timed separately and reported as
-`incl_warmup`), the `--steps K` timed ones are sampling transitions whose draws go to a [K][d][C] buffer in HBM -- what
-`hmc_chain` returns.  value = world x chains x K x L / time (weak scaling: every rank runs its own 65 536 chains, Philox
-keyed by the global chain id; no data-path collective; the R-hat all-gather runs after the timed region).
+chain.  `--warmup W` untimed transitions are the adaptive warmup; then the K-transition timed region (`--steps K`, each
+bracketed by barrier + synchronize, MAX over ranks) runs `--repeats R` times back to back on the same engine into
+consecutive draw slabs [K][d][C] in HBM: `value` = world x chains x K x L / MEDIAN region time, `ms_per_step` = that
+median / K, the R values beside them (`timed_regions`).
+
+`--scaling weak` (default): every rank runs `--chains` chains (65 536).  `--scaling strong`: the job is `--chains` chains in
+total (BASELINE's C3 / C5 are fixed-size jobs sharded 8 x), split evenly over the ranks.  Either way chains are keyed by their
+global id (Philox), there is no data-path collective, and the only exchange is the R-hat / ESS all-reduce after the timed
+region, inside the library (fg_diag_rhat_ess: O(d) doubles per rank).
 
 `--gpus N` without a torchrun environment starts the N ranks itself (a `python -m torch.distributed.run` child, before
 anything here touches HIP) and relays rank 0's line.
 
 One JSON line on stdout (rank 0):
-  roofline      the dominant kernel (k_hmc_sep_steps): algorithmic log-pdf evaluations x 8 flops / HIP-event time against the f64
-                vector peak; the SURVEY 8d HBM-nominal figure (state as if it round-tripped HBM) is kept as a note only --
-                the kernel keeps q, p in registers; `traffic` = measured FETCH_SIZE + WRITE_SIZE per launch (profiles/).
-  cpu_baseline  the CPU oracle (C restatement of the reference algorithm, dense FD) on this box's host cores, bounded
-                sample, beside the dense-FD GPU rate.
-  mh, smc       the other halves of the metric: adaptive_mcmc_chain on the reference's own bench model
-                (benches/f_perf.rs:78-109) and adaptive_smc at 1 048 576 particles, each with its own roofline and
-                cpu_baseline (single-thread calibration against the published 15.3 / 73.1 us per transition).
-  validity      a fixed 200 + 200 run of the headline model at 65 536 chains (independent of --steps/--warmup):
-                |pooled mean - closed form| <= 1e-3 (north_star), split R-hat.
+  roofline      the dominant kernel (as reported by the engine: fg_hmc_last_kernel): algorithmic log-pdf evaluations x 8 flops /
+                HIP-event time against the f64 vector peak; `executed` and `traffic` from the committed rocprofv3 --pmc passes
+                of the same configuration (profiles/round3_pmc.json; `*_source` says which entry, or why there is none).
+  cpu_baseline  the CPU oracle (C restatement of the reference algorithm, dense FD) on this box's host cores, bounded sample.
+  hmc_fd_dense  the reference's arithmetic verbatim on the GPU: value, roofline, and the like-for-like ratio to cpu_baseline.
+  c3            BASELINE configs[2]: ridge regression, 32 coefficients x 1 024 observations (coordinates interact) at 65 536 and
+                8 192 chains per GPU, each with roofline; its own cpu_baseline.
+  mh, c5, smc   the MCMC / SMC halves of the metric, each with roofline (+ cpu_baseline).
+  validity      a fixed 200 + 200 run of the headline model at 65 536 chains: |pooled mean - closed form| <= 1e-3, split R-hat.
 """
 from __future__ import annotations
 
@@ -48,9 +51,11 @@ import numpy as np  # noqa: E402
 N_SITES = 32
 CHAINS_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
-F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz / 2 (f64 half rate)
+F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes x 2 flop (FMA) x 2.4 GHz
 FLOPS_PER_NORMAL_LOGPDF = 8.0  # a Normal log-pdf with ln(sigma) hoisted ~ 8 flops
 SMC_PARTICLES = 1 << 20
+C3_N, C3_P = 1024, 32
+EXIT_DIAGNOSTICS_FAILED = 3
 
 
 def parse(argv=None):
@@ -58,7 +63,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-transition timed region runs (median = value)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --chains per rank; strong: --chains in total, sharded over the ranks")
+    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU (weak) / in total (strong)")
     ap.add_argument("--grad", choices=["fd_sparse", "fd_dense", "analytic"], default="fd_sparse",
                     help="fd_sparse (engine default) / fd_dense (reference verbatim): the reference's central difference; "
                          "analytic: closed-form derivative (not the reference's arithmetic)")
@@ -67,7 +75,7 @@ def parse(argv=None):
     ap.add_argument("--spinup", type=float, default=0.4, help="seconds of untimed throw-away transitions on a scratch engine before the measured "
                     "engine starts (the GPU's clocks settle over the first tens of ms of f64 load); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the MH / SMC / dense-FD / validity legs")
+    ap.add_argument("--no-extras", action="store_true", help="headline leg only (no MH / SMC / C3 / C5 / dense / validity legs)")
     ap.add_argument("--cpu-chains", type=int, default=4096)
     ap.add_argument("--cpu-transitions", type=int, default=64)
     return ap.parse_args(argv)
@@ -137,8 +145,23 @@ def cpu_baseline_hmc(args, gpu_dense):
            "published_reference": "none for HMC (BASELINE.md: derived ~1.6e3 leapfrog-steps/s/thread at d=20)"}
     if gpu_dense:
         out["like_for_like"] = {"gpu_fd_dense_leapfrog_steps_per_sec": gpu_dense, "ratio": gpu_dense / out["value"],
-                                "note": "the oracle has only the reference's dense FD; compare it with the GPU's dense mode, not with the sparse headline"}
+                                "note": "the oracle has only the reference's dense FD; compare it with the GPU's dense mode (hmc_fd_dense), not with the sparse headline"}
     return out
+
+
+def cpu_baseline_c3(cores):
+    """The oracle on C3 (dense FD: 64 whole-model runs of 1 056 statements per gradient), bounded sample."""
+    from fugue_amd import workloads as W
+    from oracle import oracle as orc
+    X, y, _ = W.ridge_data(C3_N, C3_P)
+    om = orc.OracleModel(W.ridge_regression(X, y))
+    chains, nt = 8 * cores, 2
+    t0 = time.perf_counter()
+    om.hmc_run(1, chains, 0, nt, orc.HmcConfig.default(init_step_size=0.004), n_threads=cores, want_draws=False)
+    dt = time.perf_counter() - t0
+    return {"value": chains * nt * 16 / dt, "unit": "leapfrog-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{chains} chains x {nt} transitions (L=16, fixed step 0.004, dense FD = hmc.rs:304-329 verbatim) of the same model, {dt:.1f} s wall; "
+                      "C restatement, not the Rust binary"}
 
 
 def cpu_baseline_mh():
@@ -176,48 +199,54 @@ def cpu_baseline_smc(n=1 << 20):
     dt = time.perf_counter() - t0
     moves = (r["n_model_evals"] - n) / 2
     return {"value": moves / dt, "unit": "particle-moves/s", "cores": 1, "kind": "port",
+            "adaptation": "sequential: one shared DiminishingAdaptation updated after every particle (smc.rs:482,544-553) -- the reference's form",
             "sample": f"adaptive_smc, {n} particles, Systematic / 0.5 / 3 rejuvenation moves, {len(r['betas'])} tempering steps, {dt:.2f} s wall; "
-                      "sequential by construction (one shared DiminishingAdaptation, smc.rs:482); C restatement, not the Rust binary",
+                      "sequential by construction; C restatement, not the Rust binary",
             "seconds_scaled_to_1048576_particles": dt * (SMC_PARTICLES / n)}
 
 
 # ------------------------------------------------------------------------------------------ profile lookups
-def measured_traffic(chains, n_launch, grad):
-    """HBM bytes per launch of the HMC kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE in separate
-    --pmc passes, profiles/*hbm_traffic.json), scaled by transitions per launch; null when the run is not the profiled
-    configuration (chain count, gradient mode)."""
-    for name in ("round2_hbm_traffic.json", "round1_hbm_traffic.json"):
-        try:
-            p = json.load(open(os.path.join(ROOT, "profiles", name)))
-            c = p["config"]
-            if (c["chains"], c["grad"]) == (chains, grad):
-                return p["sampling_launch_bytes"]["total"] / c["transitions_per_launch"] * n_launch
-        except Exception:
-            continue
-    return None
+PMC_FILE = "round3_pmc.json"
 
 
-def measured_traffic_mh(chains, n_adapting, n_sampling, steps_per_launch):
-    """HBM bytes per launch of the MH kernel on reference_model(20), averaged over the leg's launches, from the committed PMC
-    passes (bytes per chain step of an adapting / a sampling launch); null when the profile is absent."""
+def pmc_entry(key):
+    """The committed rocprofv3 --pmc entry of one configuration (profiles/round3_pmc.json, written by tools/prof_round3_collect.py):
+    per-transition (or per-step / per-run) counter values of the dominant kernel and FETCH_SIZE / WRITE_SIZE bytes.  Returns
+    (entry or None, source string)."""
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
-        b = json.load(open(os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")))["mh"]["reference_model20_bytes_per_chain_step"]
-        per_step = (b["adapting"] * n_adapting + b["sampling"] * n_sampling) / (n_adapting + n_sampling)
-        return per_step * chains * steps_per_launch
-    except Exception:                                                          # noqa: BLE001
-        return None
+        doc = json.load(open(path))
+    except Exception as ex:                                                    # noqa: BLE001
+        return None, f"no profiles/{PMC_FILE} ({type(ex).__name__})"
+    ent = doc.get("entries", {}).get(key)
+    if ent is None:
+        return None, f"profiles/{PMC_FILE} has no entry `{key}` (this run is not a profiled configuration)"
+    return ent, f"profiles/{PMC_FILE}[{key}]"
 
 
-def measured_traffic_smc():
-    """HBM bytes of one adaptive_smc run at 1 048 576 particles (FETCH_SIZE + WRITE_SIZE summed over its kernels)."""
-    try:
-        s = json.load(open(os.path.join(ROOT, "profiles", "round2_hbm_traffic.json")))["smc"]
-        return s["fetch_bytes_per_run"] + s["write_bytes_per_run"]
-    except Exception:                                                          # noqa: BLE001
+def executed_from_pmc(ent, units, seconds):
+    """What the kernel actually issues, from the committed PMC counts (per unit) over this run's time: executed f64 flops
+    (add / mul = 1, fma = 2 per lane) and the share of SIMD cycles that issue a VALU instruction (a wave64 VALU instruction
+    holds its SIMD for 4 cycles)."""
+    m = ent.get("counters_per_unit") if ent else None
+    if not m or "SQ_INSTS_VALU" not in m:
         return None
+    add, mul, fma = m.get("SQ_INSTS_VALU_ADD_F64", 0.0), m.get("SQ_INSTS_VALU_MUL_F64", 0.0), m.get("SQ_INSTS_VALU_FMA_F64", 0.0)
+    flops = 64.0 * (add + mul + 2.0 * fma) * units
+    simd_cycles = seconds * 2.1e9 * 1024                                       # 256 CUs x 4 SIMDs at the ~2.1 GHz the clock holds under f64 load
+    return {"f64_tflops": flops / seconds / 1e12, "f64_share_of_valu": (add + mul + fma) / m["SQ_INSTS_VALU"],
+            "valu_issue_share_of_simd_cycles_at_2.1GHz": 4.0 * m["SQ_INSTS_VALU"] * units / simd_cycles,
+            "wave_instructions_per_unit": m["SQ_INSTS_VALU"], "unit": ent.get("unit", "transition")}
+
+
+def traffic_from_pmc(ent, units):
+    if not ent or "fetch_bytes_per_unit" not in ent:
+        return None
+    return (ent["fetch_bytes_per_unit"] + ent["write_bytes_per_unit"]) * units
 
 
 NATIVE_RCCL_TIMEOUT_S = float(os.environ.get("FG_BENCH_RCCL_TIMEOUT", "120"))
+T_START = time.perf_counter()
 
 
 def progress(rank, msg):
@@ -226,12 +255,10 @@ def progress(rank, msg):
     sys.stderr.flush()
 
 
-T_START = time.perf_counter()
-
-
 def call_with_timeout(fn, seconds):
     """fn() on a daemon thread (ctypes calls release the GIL); raises TimeoutError when it has not returned in time -- the
-    thread is then abandoned (the process ends with os._exit in that case, see main)."""
+    thread is then abandoned: the caller finishes its line from rank-local data and the process ends with os._exit
+    (non-zero), WITHOUT entering another collective on this device."""
     import threading
     box = {}
 
@@ -253,28 +280,6 @@ def call_with_timeout(fn, seconds):
 
 
 ABANDONED = []
-
-
-def executed_from_pmc(chains, n_launch, grad, launch_ms):
-    """What the dominant kernel actually issues per launch, from the committed PMC passes (profiles/round2_hmc_pmc.json) and
-    this run's launch time: executed f64 flops (add / mul = 1, fma = 2 per lane) and the share of SIMD cycles that issue a
-    VALU instruction (every wave64 VALU instruction holds its SIMD for 4 cycles).  null when the run is not the profiled
-    configuration."""
-    try:
-        p = json.load(open(os.path.join(ROOT, "profiles", "round2_hmc_pmc.json")))
-        c, m = p["config"], p["per_launch"]
-        if (c["chains"], c["grad"]) != (chains, grad) or n_launch < 1:
-            return None
-        k = n_launch / c["transitions_per_launch"]                               # counts scale with the transitions of a launch
-        m = {key: v * k for key, v in m.items()}
-        flops = 64.0 * (m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + 2.0 * m["SQ_INSTS_VALU_FMA_F64"])
-        f64 = m["SQ_INSTS_VALU_ADD_F64"] + m["SQ_INSTS_VALU_MUL_F64"] + m["SQ_INSTS_VALU_FMA_F64"]
-        simd_cycles = launch_ms * 1e-3 * 2.1e9 * 1024                          # 256 CUs x 4 SIMDs at the ~2.1 GHz the clock holds under f64 load
-        return {"f64_tflops": flops / (launch_ms * 1e-3) / 1e12, "f64_share_of_valu": f64 / m["SQ_INSTS_VALU"],
-                "valu_issue_share_of_simd_cycles_at_2.1GHz": 4.0 * m["SQ_INSTS_VALU"] / simd_cycles,
-                "note": "instruction counts from profiles/round2_hmc_pmc.json (rocprofv3 --pmc, same configuration) over this run's launch time"}
-    except Exception:                                                          # noqa: BLE001
-        return None
 
 
 class Clock:
@@ -316,9 +321,26 @@ def stepped(torch, stream, step_fn, total, per_launch):
 
 
 def full_launch_ms(events):
-    torch_sync_needed = [(e0.elapsed_time(e1), n) for e0, e1, n in events]
+    ms = [(e0.elapsed_time(e1), n) for e0, e1, n in events]
     n0 = events[0][2]
-    return float(np.mean([ms for ms, n in torch_sync_needed if n == n0])), n0
+    return float(np.mean([t for t, n in ms if n == n0])), n0
+
+
+def spread(vals):
+    v = sorted(vals)
+    return {"median": float(np.median(v)), "min": v[0], "max": v[-1], "all": list(vals)}
+
+
+def shard(total_or_per_rank, world, scaling):
+    if scaling == "weak":
+        return total_or_per_rank
+    if total_or_per_rank % (64 * world):
+        raise SystemExit(f"--scaling strong: {total_or_per_rank} chains do not split into whole 64-chain tiles over {world} ranks")
+    return total_or_per_rank // world
+
+
+class Ctx:
+    pass
 
 
 # ------------------------------------------------------------------------------------------ one rank
@@ -348,23 +370,28 @@ def run_rank(args):
 
     from fugue_amd import engine as E, workloads as W
     from fugue_amd import diagnostics as D
-    C, K, Wn, L = args.chains, args.steps, args.warmup, args.leapfrog
+    X = Ctx()
+    X.args, X.E, X.W, X.D, X.torch, X.dist, X.clock, X.world, X.rank, X.dev = args, E, W, D, torch, dist, clock, world, rank, local_rank
+    X.stream = torch.cuda.current_stream()
+    X.coll_dev, X.one_device = coll_dev, one_device
+    C, K, Wn, L, R = shard(args.chains, world, args.scaling), args.steps, args.warmup, args.leapfrog, max(1, args.repeats)
     cp = E.compile_model(W.normal_sites(N_SITES))
     d = cp.d
     mode = {"fd_sparse": E.GRAD_FD_SPARSE, "fd_dense": E.GRAD_FD_DENSE, "analytic": E.GRAD_ANALYTIC}[args.grad]
     cfg = E.hmc_config(grad_mode=mode, n_leapfrog=L)
     eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=local_rank)
-    stream = torch.cuda.current_stream()
+    stream = X.stream
     eng.set_stream(stream.cuda_stream)                    # kernels + torch events share one stream
-    draws = torch.empty((K, d, C), dtype=torch.float64, device=f"cuda:{local_rank}")
+    slab = K * d * C * 8
+    R = max(1, min(R, int(100e9 // max(1, slab))))        # consecutive draw slabs of the R timed regions (<= 100 GB of the 288 GB)
+    draws = torch.empty((R, K, d, C), dtype=torch.float64, device=f"cuda:{local_rank}")
 
     eng.hmc_init(cfg, Wn)
     draws.zero_()                                         # the output buffer's pages are touched before anything is timed
     # ---- clock spin-up first: throw-away transitions of the same kernel on a scratch engine (own state, own seed; the measured
-    # engine is not touched), so that the W warmup and the K timed transitions run at the clocks the GPU settles to under this
-    # load rather than on its way there (session set-up leaves it mostly idle).  The measured engine's W warmup transitions then
-    # run directly before the timed region: its first launch (cold translation caches for its state and draw rows: +9 % on a
-    # 20-transition launch) is a warmup launch whenever W > 0.
+    # engine is not touched), so that the W warmup and the timed transitions run at the clocks the GPU settles to under this
+    # load rather than on its way there.  The measured engine's W warmup transitions then run directly before the timed regions.
+    scratch = None
     if args.spinup > 0:
         scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=local_rank)
         scratch.set_stream(stream.cuda_stream)
@@ -374,77 +401,66 @@ def run_rank(args):
             scratch.hmc_step(4 * args.launch)
             torch.cuda.synchronize()
     # ---- untimed by the contract (reported separately): W adaptive warmup transitions
-    warm_events = []
-    t_warm = clock.region(lambda: warm_events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n), Wn, args.launch)) if Wn > 0 else None)
-    # ---- timed: exactly K sampling transitions (the scratch engine is freed afterwards: hipFree would put an idle gap between
-    # the spin-up and the timed region)
-    events = []
-    dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n, draws[done].data_ptr()), K, args.launch)))
+    t_warm = clock.region(lambda: stepped(torch, stream, lambda n, done: eng.hmc_step(n), Wn, args.launch) if Wn > 0 else None)
+    # ---- timed: R regions of exactly K sampling transitions each, into consecutive draw slabs
+    events, dts = [], []
+    for r in range(R):
+        ev = []
+        dts.append(clock.region(lambda: ev.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n, draws[r, done].data_ptr()), K, args.launch))))
+        events.extend(ev)
+    kernel = eng.hmc_last_kernel()
     launch_ms, n_launch = full_launch_ms(events)
-    if args.spinup > 0:
+    if scratch is not None:
         scratch.close()
+    dt = float(np.median(dts))
+    last = draws[R - 1]
 
-    # ---- after the timed region: the ONLY cross-chain step -- split R-hat / multichain ESS.  Each rank reduces its own draws
-    # to per-chain moments on its GPU; the library all-gathers those and all-reduces the pooled lag sums over RCCL / xGMI
-    # (fg_diag_rhat_ess, communicator created from an id that rank 0 obtains and torch.distributed's store hands out).
+    # ---- after the timed regions: the ONLY cross-chain step -- split R-hat / multichain ESS of the last slab.  Each rank reduces
+    # its own draws to chain sums on its GPU; the library all-reduces 6 d + 2 d doubles (+ 32 d per chunk of lags) over RCCL / xGMI
+    # (fg_diag_rhat_ess; communicator created from an id that rank 0 obtains and torch.distributed's store hands out).
     t_diag = time.perf_counter()
-    diag_path, comm = "library (single GPU)", None
-    if world > 1 and (not one_device or os.environ.get("FG_BENCH_FORCE_NATIVE_RCCL") == "1"):   # (forced in the rehearsal mode: exercises the failure path, RCCL refuses two ranks on one device)
-        ok = 1
+    diag_path, comm, failed, exch = "library (single GPU)", None, False, 0
+    r_ = None
+    if world == 1:
+        r_ = eng.diag_rhat_ess(last.data_ptr(), K, d, None)
+    elif not one_device or os.environ.get("FG_BENCH_FORCE_NATIVE_RCCL") == "1":    # (forced in the rehearsal mode: exercises the failure path)
         try:
             ids = [E.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            # under a watchdog: this path has only ever run with one rank (one GPU per development box); a communicator that
-            # cannot form must cost a bounded wait, not the run
+            # under a watchdog: a communicator that cannot form must cost a bounded wait, not the run
             comm = call_with_timeout(lambda: eng.comm_init(world, rank, ids[0]), NATIVE_RCCL_TIMEOUT_S)
-        except BaseException as ex:                              # every rank must take the same path
-            sys.stderr.write(f"rank {rank}: RCCL communicator in the library failed ({ex!r}); falling back to torch.distributed\n")
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0 and comm is not None:
-            E.comm_destroy(comm); comm = None
-        diag_path = "library: ncclAllGather + ncclAllReduce" if comm is not None else "torch.distributed collectives + library combination"
-    r = None
-    if world == 1:
-        r = eng.diag_rhat_ess(draws.data_ptr(), K, d, None)
-    elif comm is not None:
-        ok = 1
-        try:
-            r = call_with_timeout(lambda: eng.diag_rhat_ess(draws.data_ptr(), K, d, comm), NATIVE_RCCL_TIMEOUT_S)
-        except BaseException as ex:
-            sys.stderr.write(f"rank {rank}: fg_diag_rhat_ess over RCCL failed ({ex!r}); falling back to torch.distributed\n")
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            r, diag_path = None, "torch.distributed collectives + library combination (RCCL inside the library did not complete)"
-        else:
-            E.comm_destroy(comm)
-    if r is not None:
-        rhat, ess, n_chains_diag = r["r_hat"], (r["ess"] if K >= 4 else np.full(d, float("nan"))), r["chains"]
-    else:
-        if diag_path.startswith("library (single"):
-            diag_path = "torch.distributed collectives + library combination"
-        prov = D.EngineMoments(eng, draws.data_ptr(), K, d)
+            r_ = call_with_timeout(lambda: eng.diag_rhat_ess(last.data_ptr(), K, d, comm), NATIVE_RCCL_TIMEOUT_S)
+            call_with_timeout(lambda: E.comm_destroy(comm), NATIVE_RCCL_TIMEOUT_S)
+            diag_path = "library: ncclAllReduce of chain sums (6 d + 2 d + 32 d per lag chunk doubles)"
+            exch = r_["exchange_bytes"]
+        except BaseException as ex:                              # noqa: BLE001
+            # No torch.distributed collective from here on: a thread may still sit inside RCCL on this device.  The line is
+            # finished from this rank's own chains and the process exits non-zero (main).
+            sys.stderr.write(f"rank {rank}: the library's RCCL exchange failed ({ex!r}); finishing from rank-local data, exit code {EXIT_DIAGNOSTICS_FAILED}\n")
+            failed, r_ = True, None
+            diag_path = f"failed ({type(ex).__name__}: {ex}); R-hat / ESS below are of THIS rank's chains only"
+    if r_ is None and not failed and world > 1:                  # one-device rehearsal: the same reduce exchange over torch.distributed (gloo)
+        prov = D.EngineMoments(eng, last.data_ptr(), K, d)
         cd = D.ChainDiagnostics(prov, device=None if one_device else coll_dev)
-        rhat = cd.split_rhat()
-        ess = cd.ess() if K >= 4 else np.full(d, float("nan"))
-        n_chains_diag = cd.m
+        r_ = dict(r_hat=cd.split_rhat(), ess=cd.ess(), chains=cd.m)
+        exch = cd.exchange_bytes
         prov.close()
+        diag_path = "torch.distributed all-reduce of chain sums + library combination (rehearsal mode)"
+    if r_ is None:                                               # failure path: rank-local statistics, no collective
+        r_ = eng.diag_rhat_ess(last.data_ptr(), K, d, None)
+    rhat, ess, n_chains_diag = r_["r_hat"], (r_["ess"] if K >= 4 else np.full(d, float("nan"))), r_["chains"]
     t_diag = time.perf_counter() - t_diag
 
     st = eng.hmc_stats()
-    m = draws.mean(dim=(0, 2)).cpu().numpy()
-    v = draws.var(dim=(0, 2)).cpu().numpy()
+    m = last.mean(dim=(0, 2)).cpu().numpy()
+    v = last.var(dim=(0, 2)).cpu().numpy()
     _, tm, tv = W.normal_sites_truth(N_SITES)
     mean_err, var_err = float(np.abs(m - tm).max()), float(np.abs(v - tv).max())
     eng.close()
-    del draws
+    del draws, last
 
-    total_lf = world * C * K * L
-    value = total_lf / dt
-    # ---- roofline of the dominant kernel (k_hmc_sep_steps; k_hmc_stream_steps for the other gradient modes' fallbacks): algorithmic f64 work / HIP-event time
+    value = world * C * K * L / dt
+    # ---- roofline of the dominant kernel: algorithmic f64 work / HIP-event time
     n_stmt = 2 * N_SITES                                                      # S + O statements of the model
     evals_sparse = (2 * d * (L + 1)) * 2 + n_stmt                             # 2 signs x 2 dependent statements per coordinate per gradient + endpoint score
     evals_dense = (2 * d * (L + 1)) * n_stmt + n_stmt                         # 2 d (S + O) per gradient
@@ -452,27 +468,30 @@ def run_rank(args):
     evals = {E.GRAD_FD_SPARSE: evals_sparse, E.GRAD_FD_DENSE: evals_dense_executed, E.GRAD_ANALYTIC: d * (L + 1) * 2 + n_stmt}[mode]
     achieved_tflops = C * n_launch * evals * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
     alg_bytes_per_launch = C * n_launch * (L * 32 * d + 8 * d + 16)           # 32 d B / leapfrog step (+ draw row, lj, eps)
+    ent, src = pmc_entry(f"hmc|normal32|{C}|{args.grad}|L{L}")
     out = {
         "metric": "hmc_leapfrog_steps_per_sec", "value": value, "unit": "leapfrog-steps/s", "n_gpus": world,
-        "steps": K, "warmup": Wn, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "steps": K, "warmup": Wn, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "timed_regions": {"repeats": R, "steps_each": K, "seconds": spread(dts), "value": spread([world * C * K * L / t for t in dts]),
+                          "note": "value / ms_per_step are those of the MEDIAN region; every region is K transitions between barrier + synchronize, MAX over ranks"},
         "config": {"workload": "C2-normal32: hmc_chain, 32-site conjugate Normal (x#i~N(0,1), y#i~N(x#i,0.5)=0.2i-1), "
-                               f"{C} chains/GPU, L=16, HMCConfig::default", "chains_per_gpu": C, "n_sites": N_SITES,
-                   "n_leapfrog": L, "grad": args.grad, "grad_note": "fd_sparse = the engine's default in the C ABI, Python and bench",
-                   "transitions_per_launch": n_launch, "clock_spinup_seconds": args.spinup, "sharding": f"chains x{world}" if world > 1 else "single GPU"},
+                               f"{C} chains/GPU, L=16, HMCConfig::default", "chains_per_gpu": C, "chains_total": world * C, "n_sites": N_SITES,
+                   "n_leapfrog": L, "grad": args.grad, "grad_note": "fd_sparse = the engine's default in the C ABI, Python and bench; the reference-verbatim dense "
+                   "mode is the `hmc_fd_dense` leg", "transitions_per_launch": n_launch, "clock_spinup_seconds": args.spinup,
+                   "sharding": (f"{args.scaling}: chains x{world}" if world > 1 else "single GPU")},
         "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS, "traffic": measured_traffic(C, n_launch, args.grad),
-                     "kernel": "k_hmc_sep_steps", "avg_launch_ms": launch_ms,
+                     "frac": achieved_tflops / F64_VALU_PEAK_TFLOPS, "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src,
+                     "kernel": kernel, "avg_launch_ms": launch_ms,
                      "logpdf_evals_per_transition": evals, "flops_per_logpdf": FLOPS_PER_NORMAL_LOGPDF,
                      "note": "achieved = log-pdf evaluations the launch performs x 8 flops / HIP-event time; peak = f64 vector FMA peak "
                              "(2 flops/instr at 2.4 GHz) -- the arithmetic is unfused add/mul (reference rounding, 1 flop/instr) and the clock "
                              "sits near 2.1 GHz under f64 load, so ~36 TFLOP/s is the ceiling of this instruction mix.  traffic = measured "
-                             "FETCH_SIZE + WRITE_SIZE per launch (separate rocprofv3 --pmc passes, profiles/)",
-                     "executed": executed_from_pmc(C, n_launch, args.grad, launch_ms),
+                             "FETCH_SIZE + WRITE_SIZE per launch (separate rocprofv3 --pmc passes)",
+                     "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3), "executed_source": src,
                      "dense_semantics": {"logpdf_evals_per_transition": evals_dense,
-                                         "note": "SURVEY 8d's 2 d (S+O) log-pdfs per gradient are the two whole scoring runs of grad_log_joint; FG_GRAD_FD_DENSE adds "
-                                                 "every one of their terms in order but evaluates only the densities that moved (see hmc_fd_dense), and the sparse "
-                                                 "default never forms the terms that cancel in the reference's subtraction"},
+                                         "note": "SURVEY 8d's 2 d (S+O) log-pdfs per gradient are the two whole scoring runs of grad_log_joint; that arithmetic is the "
+                                                 "`hmc_fd_dense` leg -- the sparse default never forms the terms that cancel in the reference's subtraction"},
                      "hbm_nominal": {"achieved": alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "note": "SURVEY 8d algorithmic bytes (32 d B per leapfrog step, as if q and p round-tripped HBM) / time: NOT a "
                                              "claim -- q, p stay in registers for a whole trajectory and the kernel is not HBM bound"}},
@@ -482,46 +501,154 @@ def run_rank(args):
         "check": {"posterior_mean_max_abs_err": mean_err, "posterior_var_max_abs_err": var_err,
                   "accept_rate": st.accept_rate, "mean_step_size": st.mean_step_size, "n_divergent": int(st.n_divergent),
                   "split_rhat_max": float(np.max(rhat)), "ess_min": float(np.min(ess)), "chains_in_rhat": int(n_chains_diag),
-                  "diagnostics_seconds": t_diag, "diagnostics_path": diag_path,
-                  "note": "statistics of the K timed draws themselves: with few steps / a short warmup they are NOT the 1e-3 evidence (a chain of "
+                  "diagnostics_seconds": t_diag, "diagnostics_path": diag_path, "diagnostics_exchange_bytes_per_rank": int(exch),
+                  "note": "statistics of the K draws of the last timed region: with few steps / a short warmup they are NOT the 1e-3 evidence (a chain of "
                           "20 draws after 5 warmup transitions has not mixed) -- see `validity`"},
     }
-    progress(rank, f"hmc leg done: {value:.4g} leapfrog-steps/s over {world} rank(s)")
-    if not args.no_extras:
-        out["mh"] = leg_mh(args, E, W, torch, clock, stream, world, rank, local_rank)
-        progress(rank, "mh leg done")
-        out["smc"] = leg_smc(args, E, W, torch, clock, stream, world, rank, local_rank)
-        progress(rank, "smc leg done")
+    progress(rank, f"hmc leg done: {value:.4g} leapfrog-steps/s over {world} rank(s) [{kernel}]")
+    if failed:
+        # a thread of this process may still be inside RCCL: no further leg, no further collective
+        out["check"]["note"] += "; the cross-rank exchange FAILED -- remaining legs skipped"
         if rank == 0:
-            out["extras"] = extras(args, E, W, local_rank)
-            progress(rank, "extras done")
+            print(json.dumps(out), flush=True)
+        return EXIT_DIAGNOSTICS_FAILED
+    if not args.no_extras:
+        out["mh"] = leg_mh(X)
+        progress(rank, "mh leg done")
+        out["smc"] = leg_smc(X)
+        progress(rank, "smc leg done")
+        out["c3"] = leg_c3(X)
+        progress(rank, "c3 leg done")
+        out["c5"] = leg_c5(X)
+        progress(rank, "c5 leg done")
+        if rank == 0:
+            out["hmc_fd_dense"] = leg_dense(X)
+            out["extras"] = extras(X)
+            progress(rank, "dense + extras done")
             out["validity"] = validity(E, W, D, local_rank)
             progress(rank, "validity leg done")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            gpu_dense = out.get("extras", {}).get("hmc_fd_dense_leapfrog_steps_per_sec")
+            gpu_dense = out.get("hmc_fd_dense", {}).get("value")
             out["cpu_baseline"] = cpu_baseline_hmc(args, gpu_dense)
+            if "hmc_fd_dense" in out:
+                out["hmc_fd_dense"]["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")}
+                out["hmc_fd_dense"]["vs_cpu_baseline"] = gpu_dense / out["cpu_baseline"]["value"]
             if "mh" in out:
                 out["mh"]["cpu_baseline"] = cpu_baseline_mh()
             if "smc" in out:
                 out["smc"]["cpu_baseline"] = cpu_baseline_smc()
+            if "c3" in out:
+                out["c3"]["cpu_baseline"] = cpu_baseline_c3(host_cores())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def leg_mh(args, E, W, torch, clock, stream, world, rank, dev):
+def timed_hmc(X, cp, C, cfg, n_warm, n_timed, per_launch, repeats, seed=1, with_draws=False, local=False):
+    """`repeats` timed regions of `n_timed` transitions on one engine (after `n_warm` untimed ones); returns (list of
+    region seconds, avg full-launch ms, transitions per launch, kernel, stats).  local: a leg that rank 0 runs alone -- its
+    clock must not enter a collective."""
+    E, torch, stream = X.E, X.torch, X.stream
+    clock = Clock(torch, X.dist, 1, X.coll_dev) if local else X.clock
+    eng = E.Engine(cp, C, seed=seed, chain_offset=X.rank * C, device=X.dev)
+    eng.set_stream(stream.cuda_stream)
+    eng.hmc_init(cfg, 0)
+    d_draws = eng.device_alloc(max(1, n_timed) * cp.d * C * 8) if with_draws else None
+    if n_warm > 0:
+        eng.hmc_step(n_warm)
+    dts, events = [], []
+    for _ in range(repeats):
+        ev = []
+        dts.append(clock.region(lambda: ev.extend(stepped(torch, stream, lambda n, done: eng.hmc_step(n, (d_draws + done * cp.d * C * 8) if d_draws else None), n_timed, per_launch))))
+        events.extend(ev)
+    launch_ms, n_launch = full_launch_ms(events)
+    kernel, st = eng.hmc_last_kernel(), eng.hmc_stats()
+    if d_draws:
+        eng.device_free(d_draws)
+    eng.close()
+    return dts, launch_ms, n_launch, kernel, st
+
+
+def leg_c3(X):
+    """BASELINE configs[2]: linear_regression.rs ridge form, 32 Normal coefficients x 1 024 synthetic observations
+    (examples/linear_regression.rs:396-424 generalised) -- the coordinates interact through every observation.
+    Two chain counts: 65 536 per GPU, and 8 192 per GPU = BASELINE's own 8-GPU sharding of a 65 536-chain job."""
+    E, W, world = X.E, X.W, X.world
+    Xd, y, _ = W.ridge_data(C3_N, C3_P)
+    cp = E.compile_model(W.ridge_regression(Xd, y))
+    L, d = 16, cp.d
+    cfg = E.hmc_config(n_leapfrog=L, init_step_size=0.004)
+    # SURVEY 8d, FD reference semantics: per gradient 2 d whole-model runs of S prior log-pdfs + O x (1 log-pdf + d multiply-adds)
+    flops_grad = 2 * d * (cp.S * FLOPS_PER_NORMAL_LOGPDF + cp.O * (FLOPS_PER_NORMAL_LOGPDF + 2 * d))
+    flops_step = flops_grad * (L + 1) / L
+    out = {"metric": "hmc_leapfrog_steps_per_sec", "unit": "leapfrog-steps/s", "n_gpus": world,
+           "config": {"workload": f"C3: hmc_chain, ridge regression beta#j~N(0,1), y#i~N(sum_j beta#j X[i][j], 0.5), d={d}, O={cp.O}, L=16, fixed step 0.004, "
+                                  "fd_sparse (engine default)", "grad": "fd_sparse"},
+           "flops_per_leapfrog_step_dense_semantics": flops_step,
+           "flops_note": "SURVEY 8d: 2 d (S x 8 + O x (8 + 2 d)) flops per gradient x (L+1)/L -- the reference's 2 d whole-model runs; the kernel shares the "
+                         "products and prefix sums between coordinates and executes fewer (see roofline.executed)"}
+    for tag, total in (("chains_65536", 65536), ("chains_8192", 8192)):
+        C = shard(total, world, X.args.scaling) if X.args.scaling == "strong" else total
+        nt = 3 if total == 65536 else 6
+        dts, launch_ms, n_launch, kernel, st = timed_hmc(X, cp, C, cfg, 1, nt, 1, 3, seed=3)
+        dt = float(np.median(dts))
+        val = world * C * nt * L / dt
+        ent, src = pmc_entry(f"hmc|c3|{C}|fd_sparse|L{L}")
+        tfl = C * n_launch * flops_step * L / (launch_ms * 1e-3) / 1e12
+        out[tag] = {"value": val, "chains_per_gpu": C, "seconds_per_transition": dt / nt, "timed_regions": {"repeats": len(dts), "steps_each": nt, "value": spread([world * C * nt * L / t for t in dts])},
+                    "accept_rate": st.accept_rate,
+                    "roofline": {"bound": "valu_f64", "achieved": tfl, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F64_VALU_PEAK_TFLOPS,
+                                 "kernel": kernel, "avg_launch_ms": launch_ms, "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src,
+                                 "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3), "executed_source": src,
+                                 "note": "achieved = SURVEY 8d's dense-semantics flops of the transitions of a launch / HIP-event time (the work the reference's "
+                                         "arithmetic implies); executed = the f64 instructions the kernel issues (PMC), 1 flop per add / mul"}}
+    return out
+
+
+def leg_dense(X):
+    """The reference's arithmetic verbatim on the headline model (FG_GRAD_FD_DENSE: every g_i is the difference of two WHOLE
+    log-joints, hmc.rs:304-329) -- the only GPU figure the CPU baseline may be divided into."""
+    E, W = X.E, X.W
+    C, L = X.args.chains if X.args.scaling == "weak" else shard(X.args.chains, X.world, "strong"), 16
+    cp = E.compile_model(W.normal_sites(N_SITES))
+    nt = 50
+    dts, launch_ms, n_launch, kernel, st = timed_hmc(X, cp, C, E.hmc_config(grad_mode=E.GRAD_FD_DENSE), 10, nt, 25, 3, local=True)
+    dt = float(np.median(dts))
+    n_stmt, d = 2 * N_SITES, cp.d
+    evals_sem = (2 * d * (L + 1)) * n_stmt + n_stmt                            # SURVEY 8d
+    evals_exec = (L + 1) * (n_stmt + 2 * 2 * d) + n_stmt
+    adds = (L + 1) * 2 * d * n_stmt                                           # the in-order additions of the 2 d scoring runs per gradient
+    sem = C * n_launch * evals_sem * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
+    exe = C * n_launch * (evals_exec * FLOPS_PER_NORMAL_LOGPDF + adds) / (launch_ms * 1e-3) / 1e12
+    ent, src = pmc_entry(f"hmc|normal32|{C}|fd_dense|L{L}")
+    return {"metric": "hmc_leapfrog_steps_per_sec", "value": C * nt * L / dt, "unit": "leapfrog-steps/s", "n_gpus": 1,
+            "timed_regions": {"repeats": len(dts), "steps_each": nt, "value": spread([C * nt * L / t for t in dts])},
+            "config": {"workload": f"C2-normal32, {C} chains, L=16, FG_GRAD_FD_DENSE = grad_log_joint verbatim", "grad": "fd_dense"},
+            "roofline": {"bound": "valu_f64", "achieved": exe, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exe / F64_VALU_PEAK_TFLOPS,
+                         "kernel": kernel, "avg_launch_ms": launch_ms, "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src,
+                         "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3), "executed_source": src,
+                         "dense_semantics_tflops": sem,
+                         "note": "achieved = what the dense kernel computes: every statement's density once per gradient + the moved ones at +-h (x 8 flops) + ALL the "
+                                 "in-order additions of the 2 d whole scoring runs (1 flop each); dense_semantics_tflops = SURVEY 8d's 2 d (S+O) log-pdfs x 8 flops per "
+                                 "gradient at this rate (re-evaluating densities that did not move), which exceeds the peak and is NOT executed"}}
+
+
+def leg_mh(X):
     """The MCMC half of BASELINE's metric: adaptive_mcmc_chain on the reference's own bench model
     (benches/f_perf.rs:78-109: reference_model(20), 20 sample + 19 observe sites) at 65 536 chains per GPU; chain steps are
     counted over warmup + sampling: 200 adapting + 400 sampling steps, all timed."""
-    C = args.chains
+    args, E, W, torch, clock, stream, world, rank, dev = X.args, X.E, X.W, X.torch, X.clock, X.stream, X.world, X.rank, X.dev
+    C = shard(args.chains, world, args.scaling)
     cp = E.compile_model(W.reference_model(20))
     eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=dev)
     eng.set_stream(stream.cuda_stream)
     nw, ns, per = 200, 400, 100
     eng.mh_init(nw)
     eng.mh_step(per)                                       # untimed: first-launch effects
+    scratch = None
     if args.spinup > 0:                                    # clock spin-up on a scratch engine, as in the HMC leg
         scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=dev)
         scratch.set_stream(stream.cuda_stream)
@@ -530,85 +657,122 @@ def leg_mh(args, E, W, torch, clock, stream, world, rank, dev):
         while time.perf_counter() - t_sp < args.spinup:
             scratch.mh_step(4 * per)
             torch.cuda.synchronize()
-    eng.mh_init(nw)
-    events = []
-    dt = clock.region(lambda: events.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), nw + ns, per)))
+    dts, events = [], []
+    for _ in range(3):
+        eng.mh_init(nw)
+        ev = []
+        dts.append(clock.region(lambda: ev.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), nw + ns, per))))
+        events.extend(ev)
     launch_ms, n_launch = full_launch_ms(events)
-    if args.spinup > 0:
+    if scratch is not None:
         scratch.close()
     acc = eng.mh_stats().accept_rate
     eng.close()
+    dt = float(np.median(dts))
     S, O = cp.S, cp.O
     bytes_per_step = 8 * S + 40                            # value row + 1 value + adaptation RMW + lw
     tflops = C * n_launch * (S + O) * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
+    ent, src = pmc_entry(f"mh|refmodel20|{C}")
     return {"metric": "mh_chain_steps_per_sec", "value": world * C * (nw + ns) / dt, "unit": "chain-steps/s", "n_gpus": world,
-            "accept_rate": acc,
+            "accept_rate": acc, "timed_regions": {"repeats": len(dts), "steps_each": nw + ns, "value": spread([world * C * (nw + ns) / t for t in dts])},
             "config": {"workload": f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91: S=20, O=19), {C} chains/GPU, "
                                    f"{nw} adapting + {ns} sampling steps, all timed", "steps_per_launch": n_launch},
             "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
-                         "traffic": measured_traffic_mh(C, nw, ns, n_launch) if C == CHAINS_PER_GPU else None, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
+                         "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
+                         "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3),
                          "note": "(S + O) log-pdfs x 8 flops per chain step / HIP-event time",
                          "hbm_nominal": {"achieved": C * n_launch * bytes_per_step / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "note": "SURVEY 8d: 8 S + 40 B per chain step; the value row lives in LDS across a launch"}},
             "published_reference": "65 k chain-steps/s/thread (15.3 us per transition, Apple Silicon; benches/f_perf.rs:24-28)"}
 
 
-def leg_smc(args, E, W, torch, clock, stream, world, rank, dev):
+def leg_c5(X):
+    """BASELINE configs[4]: 4-component Gaussian mixture (4 f64 + 64 usize sites, 64 observations), adaptive_mcmc_chain at
+    262 144 chains (per GPU in the weak mode; in total, sharded, in the strong mode = BASELINE's 8 x 32 768)."""
+    args, E, W, torch, clock, stream, world, rank, dev = X.args, X.E, X.W, X.torch, X.clock, X.stream, X.world, X.rank, X.dev
+    C = 262144 if args.scaling == "weak" else shard(262144, world, "strong")
+    data, _ = W.mixture_data(64)
+    cp = E.compile_model(W.mixture(data))
+    eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=dev)
+    eng.set_stream(stream.cuda_stream)
+    eng.mh_init(200)
+    eng.mh_step(200)
+    dts, events = [], []
+    for _ in range(3):
+        ev = []
+        dts.append(clock.region(lambda: ev.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), 200, 100))))
+        events.extend(ev)
+    launch_ms, n_launch = full_launch_ms(events)
+    eng.close()
+    dt = float(np.median(dts))
+    tflops = C * n_launch * (cp.S + cp.O) * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
+    ent, src = pmc_entry(f"mh|c5|{C}")
+    return {"metric": "mh_chain_steps_per_sec", "value": world * C * 200 / dt, "unit": "chain-steps/s", "n_gpus": world,
+            "timed_regions": {"repeats": len(dts), "steps_each": 200, "value": spread([world * C * 200 / t for t in dts])},
+            "config": {"workload": f"C5: 4-component mixture, S={cp.S} (4 f64 + 64 usize), O={cp.O}, {C} chains/GPU, 200 sampling steps after 200 adapting"},
+            "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
+                         "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
+                         "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3),
+                         "note": "(S + O) log-pdfs x 8 flops per chain step / HIP-event time; Categorical table lookups counted as log-pdfs",
+                         "hbm_nominal": {"achieved": C * n_launch * (8 * cp.S + 40) / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}}
+
+
+def leg_smc(X):
     """C4: adaptive_smc, 1 048 576 particles, Systematic / ESS 0.5 / 3 rejuvenation moves (examples/smc_inference.rs:36-65).
     SMC does not shard without communication (next_beta, normalisation and resampling are global): N GPUs = N independent
     replicas with different seeds -- no collective is invented."""
+    args, E, W, clock, stream, world, rank, dev = X.args, X.E, X.W, X.clock, X.stream, X.world, X.rank, X.dev
     N = SMC_PARTICLES
     cp = E.compile_model(W.smc_normal())
     eng = E.Engine(cp, N, seed=42 + rank, device=dev)
     eng.set_stream(stream.cuda_stream)
     eng.smc_run(rejuvenation_steps=3, download=False)      # untimed: allocations, first-launch effects
+    scratch = None
     if args.spinup > 0:                                    # clock spin-up: the same run on a scratch population
         scratch = E.Engine(cp, N, seed=987654321 + rank, device=dev)
         scratch.set_stream(stream.cuda_stream)
         t_sp = time.perf_counter()
         while time.perf_counter() - t_sp < args.spinup:
             scratch.smc_run(rejuvenation_steps=3, download=False)
-    res = {}
-    dt = clock.region(lambda: res.update(eng.smc_run(rejuvenation_steps=3, download=False)))   # particles and weights stay in HBM
-    if args.spinup > 0:
+    res, dts = {}, []
+    for _ in range(5):
+        dts.append(clock.region(lambda: res.update(eng.smc_run(rejuvenation_steps=3, download=False))))   # particles and weights stay in HBM
+    if scratch is not None:
         scratch.close()
     eng.close()
+    dt = float(np.median(dts))
     n_steps = len(res["betas"])
     moves = (res["n_model_runs"] - N) / 2
     S = cp.S
     per_particle_step = 24 + 1040 + 12 + 16 * S + 3 * (16 * S + 24)      # SURVEY 8d: reweight + next_beta (65 passes x 16 B) + resample + gather + rejuvenation
     gbs = N * n_steps * per_particle_step / dt / 1e9
+    ent, src = pmc_entry(f"smc|c4|{N}")
     return {"metric": "smc_particle_moves_per_sec", "value": world * moves / dt, "unit": "particle-moves/s", "n_gpus": world,
-            "seconds_per_run": dt, "tempering_steps": n_steps, "log_evidence": res["log_evidence"], "log_evidence_closed_form": -1.9305103088617774,
+            "seconds_per_run": dt, "seconds_per_run_spread": spread(dts), "tempering_steps": n_steps, "log_evidence": res["log_evidence"],
+            "log_evidence_closed_form": -1.9305103088617774,
             "config": {"workload": f"C4: adaptive_smc, {N} particles, Systematic / 0.5 / 3 rejuvenation moves, mu~N(0,1); y~N(mu,0.5)=1.5",
+                       "adaptation": "batched: the shared DiminishingAdaptation is updated once per rejuvenation sweep from per-site counts (DESIGN deviation ii); the "
+                                     "CPU baseline beside it runs the reference's sequential form (one update per particle)",
                        "sharding": "replicas only" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": measured_traffic_smc(),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_from_pmc(ent, 1), "traffic_source": src,
                          "kernel": "whole fg_smc_run (next_beta bisection + reweight + scan + resample + gather + rejuvenation)",
                          "bytes_per_particle_per_tempering_step": per_particle_step,
                          "note": "SURVEY 8d algorithmic bytes x particles x tempering steps / wall time of the whole run (host-timed, launch gaps "
                                  "included); the 16 MB of (ll, lw) fit the L2 / Infinity Cache, so HBM is not what bounds the 65 ESS evaluations"}}
 
 
-def extras(args, E, W, dev):
-    """Side measurements on rank 0: the reference-verbatim dense finite difference, the opt-in analytic gradient and C5."""
+def extras(X):
+    """Side measurements on rank 0: the opt-in analytic gradient and C2 as BASELINE.json words it (the README model)."""
+    E, W, dev = X.E, X.W, X.dev
     out = {}
-    C = args.chains
+    C = X.args.chains if X.args.scaling == "weak" else shard(X.args.chains, X.world, "strong")
     cp = E.compile_model(W.normal_sites(N_SITES))
-    eng = E.Engine(cp, C, seed=1, device=dev)
-    eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_FD_DENSE), 0)
-    eng.hmc_step(10); eng.synchronize()
-    t0 = time.perf_counter(); eng.hmc_step(50); eng.synchronize(); dt = time.perf_counter() - t0
-    out["hmc_fd_dense_leapfrog_steps_per_sec"] = C * 50 * 16 / dt
-    out["hmc_fd_dense_note"] = ("grad_log_joint verbatim (hmc.rs:304-329): every g_i is the difference of two whole log-joints.  The kernel performs the "
-                                "additions of both full scoring runs (2 d (S + O) per gradient) but evaluates only the densities that moved: SURVEY 8d's "
-                                "2 d (S + O) log-pdfs x 8 flops per gradient would be %.1f TFLOP/s at this rate and is NOT executed") % (
-        C * 50 * ((2 * N_SITES * 17) * 2 * N_SITES + 2 * N_SITES) * FLOPS_PER_NORMAL_LOGPDF / dt / 1e12)
-    eng.close()
     eng = E.Engine(cp, C, seed=1, device=dev)
     eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_ANALYTIC), 0)
     eng.hmc_step(25); eng.synchronize()
     t0 = time.perf_counter(); eng.hmc_step(100); eng.synchronize(); dt = time.perf_counter() - t0
     out["hmc_analytic_leapfrog_steps_per_sec"] = C * 100 * 16 / dt
+    out["hmc_analytic_note"] = "closed-form derivative of the Normal force terms: NOT the reference's arithmetic, opt-in, never `value`"
     eng.close()
     # C2 as BASELINE.json words it: the README model (d = 1), 65 536 chains x 1 000 steps after 200 warmup transitions
     cp1 = E.compile_model(W.readme_normal())
@@ -621,17 +785,6 @@ def extras(args, E, W, dev):
     out["hmc_readme_model_leapfrog_steps_per_sec"] = CHAINS_PER_GPU * 1200 * 16 / dt
     out["hmc_readme_model_workload"] = "C2 README model (mu~N(0,1); y~N(mu,0.5)=1.2), 65536 chains, 200 warmup + 1000 sampling transitions, L=16: %.1f ms" % (dt * 1e3)
     eng.device_free(d1)
-    eng.close()
-    # C5 on one GPU: 4-component mixture (4 f64 + 64 usize sites, 64 observations), adaptive_mcmc_chain at 262 144 chains
-    data, _ = W.mixture_data(64)
-    cp5 = E.compile_model(W.mixture(data))
-    eng = E.Engine(cp5, 262144, seed=1, device=dev)
-    eng.mh_init(200)
-    eng.mh_step(200); eng.synchronize()
-    t0 = time.perf_counter(); eng.mh_step(200); eng.synchronize(); dt = time.perf_counter() - t0
-    out["mh_mixture_262144_chain_steps_per_sec"] = 262144 * 200 / dt
-    out["mh_mixture_hbm_nominal_gbs"] = 262144 * 200 * (8 * cp5.S + 40) / dt / 1e9
-    out["mh_mixture_workload"] = f"C5: 4-component mixture, S={cp5.S} (4 f64 + 64 usize), O={cp5.O}, 262144 chains on one GPU"
     eng.close()
     return out
 
@@ -661,10 +814,10 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
-    run_rank(args)
-    if ABANDONED:                                                # a thread is stuck inside a collective: do not wait for it at interpreter exit
+    rc = run_rank(args)
+    if ABANDONED or rc:                                          # a thread may be stuck inside a collective: do not wait for it at interpreter exit
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        os._exit(rc or EXIT_DIAGNOSTICS_FAILED)
 
 
 if __name__ == "__main__":

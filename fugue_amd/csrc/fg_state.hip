@@ -152,15 +152,18 @@ struct FgStateHeader {
 };
 static const uint64_t FG_STATE_MAGIC = 0x3145544154534746ull;   // "FGSTATE1"
 
-static size_t state_bytes(const fg_engine *e, uint32_t &flags) {
+static size_t state_bytes_of(const fg_engine *e, uint32_t flags) {
     const size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S), d = (size_t)std::max(1, e->d);
-    flags = (e->hmc_ready ? 1u : 0u) | ((e->hmc_ready && e->H.m_inv) ? 2u : 0u) | (e->mh_ready ? 4u : 0u) | ((e->mh_ready && !e->mh_overrides.empty()) ? 8u : 0u);
     size_t n = sizeof(FgStateHeader) + S * C * 8;
     if (flags & 1u) n += 9 * C * 8;                                      // lj eps frozen da_mu da_leb da_hbar da_m alpha_sum n_div
     if (flags & 2u) n += 4 * d * C * 8 + C * 8;                          // m_inv mass_sqrt w_mean w_m2, w_n
     if (flags & 4u) n += C * 8 + S * C * sizeof(FgMhAdapt) + C * 8;        // lw, {scale, kind, log_scale, tot, acc} per (site, chain), n_acc
     if (flags & 8u) n += S * sizeof(fg_site_proposal);
     return n;
+}
+static size_t state_bytes(const fg_engine *e, uint32_t &flags) {
+    flags = (e->hmc_ready ? 1u : 0u) | ((e->hmc_ready && e->H.m_inv) ? 2u : 0u) | (e->mh_ready ? 4u : 0u) | ((e->mh_ready && !e->mh_overrides.empty()) ? 8u : 0u);
+    return state_bytes_of(e, flags);
 }
 
 int64_t fg_state_size(fg_engine *e) {
@@ -177,7 +180,8 @@ int fg_state_export(fg_engine *e, void *h_buf, size_t capacity) {
     HIPCHK(hipStreamSynchronize(e->stream));
     FgStateHeader hd; std::memset(&hd, 0, sizeof(hd));
     hd.magic = FG_STATE_MAGIC; hd.version = 2; hd.flags = fl; hd.C = e->C; hd.S = e->S; hd.d = e->d; hd.n_slots = e->n_slots;
-    hd.seed = e->seed; hd.chain0 = e->chain0; hd.iter = e->iter; hd.n_warmup = e->n_warmup; hd.mass_adapt_at = e->mass_adapt_at; hd.use_mass = e->H.use_mass;
+    hd.seed = e->seed; hd.chain0 = e->chain0; hd.reserved1 = e->M.rec_all ? 1u : 0u;   // MhSession-style recording while adapting (fg_mh_set_recording)
+    hd.iter = e->iter; hd.n_warmup = e->n_warmup; hd.mass_adapt_at = e->mass_adapt_at; hd.use_mass = e->H.use_mass;
     hd.cfg = e->cfg; hd.mh_iter = e->mh_iter; hd.mh_warmup = e->mh_warmup; hd.bytes = need;
     char *o = (char *)h_buf;
     std::memcpy(o, &hd, sizeof(hd)); o += sizeof(hd);
@@ -207,19 +211,39 @@ int fg_state_import(fg_engine *e, const void *h_buf, size_t size) {
     if (hd.magic != FG_STATE_MAGIC || hd.version != 2) { fg_set_error("fg_state_import: not a fugue_amd state blob (magic / version)"); return FG_E_BAD_ARG; }
     if (hd.C != e->C || hd.S != e->S || hd.d != e->d || hd.n_slots != e->n_slots) {
         fg_set_error("fg_state_import: the blob was exported from a different program or chain count"); return FG_ERR_UNEXPECTED_STRUCTURE; }
-    if (hd.bytes > size) { fg_set_error("fg_state_import: truncated blob"); return FG_E_BAD_ARG; }
+    // Everything the uploads below will read is validated BEFORE the engine is touched: the flags name a layout, the layout
+    // names a size, and header and caller must both agree with it (a blob with flipped flag bits or a short `bytes` would
+    // otherwise make the copies run past the caller's buffer).
     const uint32_t fl = hd.flags;
+    if ((fl & ~15u) || ((fl & 2u) && !(fl & 1u)) || ((fl & 8u) && !(fl & 4u))) { fg_set_error("fg_state_import: unknown or inconsistent section flags"); return FG_E_BAD_ARG; }
+    const size_t expected = state_bytes_of(e, fl);
+    if (hd.bytes != expected || size < expected) { fg_set_error("fg_state_import: truncated or corrupted blob (size does not match its sections)"); return FG_E_BAD_ARG; }
+    if (fl & 1u) {
+        const fg_hmc_config &c = hd.cfg;
+        const bool ok = (c.grad_mode == FG_GRAD_FD_DENSE || c.grad_mode == FG_GRAD_FD_SPARSE || c.grad_mode == FG_GRAD_ANALYTIC) && c.n_leapfrog >= 1 &&
+                        c.n_leapfrog <= 100000 && c.finite_diff_eps > 0.0 && std::isfinite(c.finite_diff_eps) && hd.iter >= 0 && hd.n_warmup >= 0 &&
+                        (hd.use_mass == 0 || hd.use_mass == 1) && (hd.use_mass == 0 || (fl & 2u)) && hd.mass_adapt_at >= -1;
+        if (!ok) { fg_set_error("fg_state_import: corrupted HMC section header"); return FG_E_BAD_ARG; }
+    }
+    if ((fl & 4u) && (hd.mh_iter < 0 || hd.mh_warmup < 0)) { fg_set_error("fg_state_import: corrupted MH section header"); return FG_E_BAD_ARG; }
     const size_t C = (size_t)e->C, S = (size_t)std::max(1, e->S), d = (size_t)std::max(1, e->d);
+    std::vector<fg_site_proposal> ov;
+    if (fl & 8u) {
+        ov.resize(S);
+        std::memcpy(ov.data(), (const char *)h_buf + expected - S * sizeof(fg_site_proposal), S * sizeof(fg_site_proposal));
+        for (int j = 0; j < e->S; j++) if (ov[j].kind < 0 || ov[j].kind > 4) { fg_set_error("fg_state_import: corrupted proposal overrides"); return FG_E_BAD_ARG; }
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
-    // the random streams are keyed by (seed, global chain id, iteration): the importing engine takes the exporter's key
-    e->seed = hd.seed; e->chain0 = hd.chain0; e->X.seed = hd.seed; e->X.chain0 = hd.chain0;
+    if (fl & 1u) { if (int rc = fg_internal_hmc_alloc(e, (fl & 2u) != 0u)) return rc; }
+    if (fl & 4u) { if (int rc = fg_internal_mh_alloc(e)) return rc; }
+    // From here on only a HIP failure can interrupt: the sessions are marked not ready while their arrays are being replaced
+    // and committed (seed, counters, ready flags) only after every upload has succeeded.
+    const bool had_hmc = e->hmc_ready, had_mh = e->mh_ready;
+    e->hmc_ready = false; e->mh_ready = false;
     const char *o = (const char *)h_buf + sizeof(hd);
     auto ul = [&](void *dev, size_t bytes) { const hipError_t he = hipMemcpy(dev, o, bytes, hipMemcpyHostToDevice); o += bytes; return he; };
     HIPCHK(ul(e->d_values, S * C * 8));
     if (fl & 1u) {
-        if (int rc = fg_internal_hmc_alloc(e, (fl & 2u) != 0u)) return rc;
-        fg_internal_hmc_set_cfg(e, &hd.cfg);
-        e->H.use_mass = hd.use_mass; e->n_warmup = hd.n_warmup; e->iter = hd.iter; e->mass_adapt_at = hd.mass_adapt_at; e->hmc_ready = true;
         void *a[9] = { e->H.lj, e->H.eps, e->H.frozen, e->H.da_mu, e->H.da_leb, e->H.da_hbar, e->H.da_m, e->H.alpha_sum, e->H.n_div };
         for (void *p : a) HIPCHK(ul(p, C * 8));
     }
@@ -229,14 +253,17 @@ int fg_state_import(fg_engine *e, const void *h_buf, size_t size) {
         HIPCHK(ul(e->H.w_n, C * 8));
     }
     if (fl & 4u) {
-        if (int rc = fg_internal_mh_alloc(e)) return rc;
         HIPCHK(ul(e->M.lw, C * 8)); HIPCHK(ul(e->M.ad, S * C * sizeof(FgMhAdapt))); HIPCHK(ul(e->M.n_acc, C * 8));
-        e->mh_iter = hd.mh_iter; e->mh_warmup = hd.mh_warmup; e->mh_ready = true;
-        if (fl & 8u) {
-            std::vector<fg_site_proposal> ov(S); std::memcpy(ov.data(), o, S * sizeof(fg_site_proposal)); o += S * sizeof(fg_site_proposal);
-            if (int rc = fg_internal_mh_set_overrides(e, ov.data())) return rc;
-        } else if (int rc = fg_internal_mh_set_overrides(e, nullptr)) return rc;
+        if (int rc = fg_internal_mh_set_overrides(e, (fl & 8u) ? ov.data() : nullptr)) return rc;
     }
+    // commit.  The random streams are keyed by (seed, global chain id, iteration): the importing engine takes the exporter's key
+    e->seed = hd.seed; e->chain0 = hd.chain0; e->X.seed = hd.seed; e->X.chain0 = hd.chain0;
+    if (fl & 1u) {
+        fg_internal_hmc_set_cfg(e, &hd.cfg);
+        e->H.use_mass = hd.use_mass; e->n_warmup = hd.n_warmup; e->iter = hd.iter; e->mass_adapt_at = hd.mass_adapt_at; e->hmc_ready = true;
+    } else e->hmc_ready = had_hmc;
+    if (fl & 4u) { e->mh_iter = hd.mh_iter; e->mh_warmup = hd.mh_warmup; e->M.rec_all = hd.reserved1 ? 1 : 0; e->mh_ready = true; }
+    else e->mh_ready = had_mh;
     return FG_OK;
 }
 

@@ -104,10 +104,10 @@ class Expr:
     def max(self, o): return Expr("max", (self, as_expr(o)))
 
     # comparisons of sampled values: only `guard` consumes them (model.rs:710-716 guards are weights, not structure)
-    def __lt__(self, o): return Cond(as_expr(o) - self)
-    def __gt__(self, o): return Cond(self - as_expr(o))
-    def __le__(self, o): return Cond(as_expr(o) - self)
-    def __ge__(self, o): return Cond(self - as_expr(o))
+    def __lt__(self, o): return Cond(as_expr(o) - self, strict=True)
+    def __gt__(self, o): return Cond(self - as_expr(o), strict=True)
+    def __le__(self, o): return Cond(as_expr(o) - self, strict=False)
+    def __ge__(self, o): return Cond(self - as_expr(o), strict=False)
 
     def is_const(self) -> bool:
         return self.op == "const"
@@ -130,12 +130,15 @@ class Expr:
 
 
 class Cond:
-    """`a < b` on expressions of sampled values: true iff `margin` > 0.  Not a Python bool -- a model whose STRUCTURE depends on
-    it cannot be flattened -- but `guard(cond)` is only a weight (0 or -inf), which the site program can express."""
-    __slots__ = ("margin",)
+    """`a < b` / `a <= b` on expressions of sampled values: true iff `margin` > 0 (strict) or >= 0 (non-strict).  Not a Python
+    bool -- a model whose STRUCTURE depends on it cannot be flattened -- but `guard(cond)` is only a weight (0 or -inf), which
+    the site program can express.  Strictness matters wherever equality has positive probability: predicates on discrete
+    sites, or on expressions through floor / min / max / clamp (`guard(k >= 1)`, `guard(sigma.max(0.01) >= 0.01)`)."""
+    __slots__ = ("margin", "strict")
 
-    def __init__(self, margin: "Expr"):
+    def __init__(self, margin: "Expr", strict: bool = True):
         self.margin = margin
+        self.strict = strict
 
     def __bool__(self):
         raise StructureError("a comparison of sampled values was used in Python control flow; only guard(...) accepts it")
@@ -448,14 +451,19 @@ def factor(logw: Number) -> Model:
 
 
 def guard(pred) -> Model:
-    """model.rs:710-716: `pure(())` when the predicate holds, `factor(-inf)` otherwise.  A predicate on sampled values
-    (`guard(phi.abs() < 0.95)`) becomes the weight ln(clamp(margin * 1e300, 0, 1)): 0 when margin >= 1e-300, -inf when
-    margin <= 0 (strict and non-strict comparisons coincide: the boundary has measure zero)."""
+    """model.rs:710-716: `pure(())` when the predicate holds, `factor(-inf)` otherwise.  A predicate on sampled values becomes a
+    weight the site program can express: strict (`guard(phi.abs() < 0.95)`): ln(clamp(margin * 1e300, 0, 1)) = 0 when margin >=
+    1e-300, -inf when margin <= 0; non-strict (`guard(k >= 1)`): ln(clamp(margin * 1e300 + 1, 0, 1)) = 0 when margin >= 0, -inf
+    when margin <= -1e-300 -- equality is accepted exactly as the reference's bool does.  (Margins of magnitude below 1e-300
+    other than 0 get a finite weight; no f64 computation of a difference of O(1) quantities produces one.)"""
     if isinstance(pred, Cond):
         m = pred.margin
         if m.is_const():
-            return pure(None) if m.value > 0.0 else factor(float("-inf"))
-        return factor((m * 1e300).clamp(0.0, 1.0).ln())
+            ok = m.value > 0.0 if pred.strict else m.value >= 0.0
+            return pure(None) if ok else factor(float("-inf"))
+        if pred.strict:
+            return factor((m * 1e300).clamp(0.0, 1.0).ln())
+        return factor((m * 1e300 + 1.0).clamp(0.0, 1.0).ln())
     return pure(None) if pred else factor(float("-inf"))
 
 

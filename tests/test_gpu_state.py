@@ -92,6 +92,68 @@ def test_state_import_refuses_a_foreign_blob():
         E.Engine(cp1, 64, seed=1).state_import(b"garbage" * 40)
 
 
+def test_state_import_validates_the_layout_before_touching_the_engine():
+    """A blob whose header lies about its sections -- a short `bytes`, flipped flag bits, a truncated buffer -- is refused
+    before any copy runs (the copies would otherwise read past the caller's buffer), and a refused import leaves the engine
+    exactly as it was: same state, same session, still steppable and bit-identical to an engine that never saw the blob."""
+    import struct
+    cp = E.compile_model(ZOO["normal32"]())
+    C = 64
+    a = E.Engine(cp, C, seed=1)
+    a.hmc_init(E.hmc_config(), 5)
+    a.hmc_step(3)
+    blob = a.state_export()
+    # header layout (fg_state.hip FgStateHeader): magic u64, version u32, flags u32 at byte 12; `bytes` u64 is its last field
+    flags = struct.unpack_from("<I", blob, 12)[0]
+    assert flags == 1
+    hdr = len(blob) - (cp.S * C * 8 + 9 * C * 8)
+    bad = []
+    bad.append(blob[:len(blob) - 8])                                                       # truncated buffer, honest header
+    bad.append(blob[:hdr - 8] + struct.pack("<Q", len(blob) - 4096) + blob[hdr:])          # header claims fewer bytes than its sections need
+    bad.append(blob[:12] + struct.pack("<I", flags | 2) + blob[16:])                       # mass section flagged but absent
+    bad.append(blob[:12] + struct.pack("<I", flags | 4 | 8) + blob[16:])                   # MH sections flagged but absent
+    bad.append(blob[:12] + struct.pack("<I", flags | 64) + blob[16:])                      # unknown flag bit
+    bad.append(blob[:12] + struct.pack("<I", 2) + blob[16:])                               # mass adaptation without an HMC section
+    b, ref = E.Engine(cp, C, seed=9), E.Engine(cp, C, seed=9)
+    for e_ in (b, ref):
+        e_.hmc_init(E.hmc_config(), 4)
+        e_.hmc_step(2)
+    for x in bad:
+        with pytest.raises(E.EngineError):
+            b.state_import(x)
+        assert b.hmc_iterations() == 2 and np.array_equal(b.get_values(), ref.get_values())
+    b.hmc_step(6); ref.hmc_step(6)
+    assert np.array_equal(b.get_values(), ref.get_values()) and np.array_equal(b.hmc_step_sizes(), ref.hmc_step_sizes())
+    b.state_import(blob)                                                                   # the honest blob still imports
+    assert b.hmc_iterations() == 3 and np.array_equal(b.get_values(), a.get_values())
+
+
+def test_mh_resume_keeps_recording_while_adapting():
+    """An MhSession-style engine records every step, adapting or not (fg_mh_set_recording); export / import must carry that
+    switch, or the resumed engine writes no rows while it is still warming up."""
+    cp = E.compile_model(ZOO["refmodel8"]())
+    C, nw = 64, 1 << 20
+    rec = list(range(cp.S))
+
+    def run(eng, n):
+        buf = eng.device_alloc(n * cp.S * C * 8)
+        eng.upload_zeros(buf, n * cp.S * C * 8) if hasattr(eng, "upload_zeros") else None
+        eng.mh_step(n, rec, buf)
+        out = eng.download(buf, (n, cp.S, C), dtype=np.int64)
+        eng.device_free(buf)
+        return out
+    a = E.Engine(cp, C, seed=5)
+    a.mh_init(nw); a.mh_set_recording(True)
+    ref = run(a, 30)
+    b = E.Engine(cp, C, seed=5)
+    b.mh_init(nw); b.mh_set_recording(True)
+    first = run(b, 12)
+    c = E.Engine(cp, C, seed=123)
+    c.state_import(b.state_export())
+    rest = run(c, 18)
+    assert np.array_equal(first, ref[:12]) and np.array_equal(rest, ref[12:])
+
+
 @pytest.mark.parametrize("name,mode", [("readme", E.GRAD_FD_DENSE), ("normal32", E.GRAD_FD_SPARSE), ("refmodel8", E.GRAD_FD_SPARSE), ("alldists", E.GRAD_FD_DENSE)])
 def test_step_recorded_is_rng_neutral_and_matches_the_oracle(oracle, name, mode):
     """hmc.rs:1058-1087: a recorded trajectory has L + 1 points with finite Hamiltonians, recording does not perturb the

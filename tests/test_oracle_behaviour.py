@@ -144,3 +144,29 @@ def test_smc_example_config4(oracle):
     m = float((r["weights"] * mu).sum())
     v = float((r["weights"] * (mu - m) ** 2).sum())
     assert abs(m - 1.2) < 0.15 and abs(v - 0.2) < 0.1 and math.isfinite(r["log_evidence"])
+
+
+def test_guard_strictness_on_values_with_positive_probability_of_equality(oracle):
+    """model.rs:710-716: guard(bool) accepts exactly when the predicate holds.  `k >= 1` on a Poisson site must accept k == 1
+    and `k > 1` must reject it; a clamped expression sitting ON its bound satisfies `>=` and fails `>`."""
+    def build(pred):
+        return M.trace_model(lambda: M.sample(M.addr("k"), M.Poisson(2.0)).bind(
+            lambda k: M.sample(M.addr("s"), M.Normal(0.0, 1.0)).bind(lambda s: M.guard(pred(k, s)).map(lambda _: k))))
+    cases = {
+        "k>=1": (lambda k, s: k >= 1, {0: False, 1: True, 2: True}),
+        "k>1": (lambda k, s: k > 1, {0: False, 1: False, 2: True}),
+        "k<=1": (lambda k, s: k <= 1, {0: True, 1: True, 2: False}),
+        "k<1": (lambda k, s: k < 1, {0: True, 1: False, 2: False}),
+        "clamped>=": (lambda k, s: s.max(0.01) >= 0.01, {0: True, 1: True, 2: True}),       # s = -1 below: the clamped value sits on the bound
+        "clamped>": (lambda k, s: s.max(0.01) > 0.01, {0: False, 1: False, 2: False}),
+    }
+    for name, (pred, expect) in cases.items():
+        om = oracle.OracleModel(build(pred))
+        assert om.site_names == ["k", "s"]
+        for kv, ok in expect.items():
+            cells = np.array([kv, np.float64(-1.0).view(np.int64)], dtype=np.int64)
+            acc, _ = om.run_score(cells)
+            assert (acc[2] == 0.0) if ok else (acc[2] == -math.inf), (name, kv, acc)
+    # constant predicates (a literal margin): equality passes `>=` and fails `>`
+    assert len(M.trace_model(lambda: M.guard(M.Cond(M.as_expr(0.0), strict=False))).stmts) == 0
+    assert len(M.trace_model(lambda: M.guard(M.Cond(M.as_expr(0.0), strict=True))).stmts) == 1
