@@ -181,30 +181,130 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
     return bad;
 }
 
-template <int D, int W, bool P2, int WV>
+// The same gradient on a HALF TILE: 32 chains per workgroup, lanes l and l + 32 carry the same chain -- the lower half the
+// sums at q + h e_k, the upper half those at q - h e_k (one suffix chain, one density and one accumulator per own coordinate
+// and lane instead of two: a - b and a + (-b) are the same operation, so every number is the one the full tile forms).  The
+// two totals meet in one cross-lane exchange per coordinate and gradient.  Products and prefix sums are formed by both halves,
+// so a wave issues ~0.64 of the full tile's instructions for half the chains: worth it exactly when 64-chain tiles would leave
+// CUs idle (8 192 chains = 128 tiles on 256 CUs: BASELINE's 8-GPU sharding of C3).
+template <int D, int W, int WV, bool P2>
+__device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, const int *meta_v, const FgGradRec *gs_v, const fg_lds_double *slots,
+                                              fg_lds_double *pl, double h_v, double hk, int two_kicks_v) {
+    constexpr int M = D / W, HB = D / 2, ROWB = FG_LIN_ROW_DOUBLES(D) * 8, tw = FG_WAVE / 2;
+    constexpr int PLAST = fg_lin_pos(W, WV, M - 1);
+    const FG_AS4 char *row = fg_uniform_ptr(tab_v);
+    const FG_AS4 int *meta = (const FG_AS4 int *)fg_uniform_ptr(meta_v);
+    const int N = __builtin_amdgcn_readfirstlane(n_obs_v);
+    const bool two_kicks = __builtin_amdgcn_readfirstlane(two_kicks_v) != 0;
+    const double h = fg_uniform(h_v), two_h = fg_uniform(2.0 * h_v), rcp_2h = fg_uniform(1.0 / (2.0 * h_v));
+    const bool upper = (threadIdx.x & 32u) != 0u;
+    const double hs = upper ? -h : h;                             // this lane's perturbation
+    double q[D];
+#pragma unroll
+    for (int t = 0; t < D; ++t) q[t] = slots[meta[t] * tw];
+    double sa[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) sa[a] = 0.0;
+    FgLinHalf<HB> ca, cb;
+    fg_u32x4 ha = *(const FG_AS4 fg_u32x4 *)row;                  // c0
+    ca.load(row + 16);
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        cb.load(row + 16 + 8 * HB);
+        const fg_u32x8 hb = *(const FG_AS4 fg_u32x8_r *)(row + 16 + 16 * HB);
+        const fg_u32x4 hf = *(const FG_AS4 fg_u32x4 *)(row + 16 + 16 * HB + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        double S = fg_dbl(ha[0], ha[1]);
+        double mu[M];
+#define FG_LIN_TERM(t, CF)                                                                          \
+        {                                                                                           \
+            const double c_ = (CF);                                                                 \
+            const double P_ = q[t] * c_;                                                            \
+            _Pragma("unroll") for (int a = 0; a < M; ++a) {                                         \
+                if (fg_lin_pos(W, WV, a) < (t)) mu[a] = mu[a] + P_;                                 \
+                if (fg_lin_pos(W, WV, a) == (t)) { const double qs_ = q[t] + hs; mu[a] = S + qs_ * c_; }   \
+            }                                                                                       \
+            if ((t) < PLAST) S = S + P_;                                                            \
+        }
+#pragma unroll
+        for (int t = 0; t < HB; ++t) FG_LIN_TERM(t, ca.get(t))
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        ha = *(const FG_AS4 fg_u32x4 *)(row + ROWB);
+        ca.load(row + ROWB + 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = HB; t < D; ++t) FG_LIN_TERM(t, cb.get(t - HB))
+#undef FG_LIN_TERM
+        const double y = fg_dbl(hb[0], hb[1]), inv = fg_dbl(hb[2], hb[3]), lns = fg_dbl(hb[4], hb[5]);
+        const uint32_t fl = hf[0];
+#pragma unroll
+        for (int a = 0; a < M; ++a) {
+            const double dl = y - mu[a];
+            double z = dl * inv;
+            if (!P2 && !(fl & FG_G_POW2)) {
+                const double sg = fg_dbl(hb[6], hb[7]);
+                z = (fl & FG_G_DIV) ? dl / sg : fg_div_const(dl, sg, inv);
+            }
+            sa[a] += -0.5 * z * z - lns - 0.5 * FG_LN_2PI;
+        }
+        row += ROWB;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const FG_AS4 char *gs = fg_uniform_ptr(gs_v);
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const int pos = fg_lin_pos(W, WV, a);
+        const int k = meta[pos], r0 = meta[D + 2 * k], nr = meta[D + 2 * k + 1];
+        double pri = 0.0;
+        for (int j = 0; j < nr; ++j) {
+            const fg_u32x16 r = *(const FG_AS4 fg_u32x16 *)(gs + 64 * (long long)(r0 + j));
+            double lpp, lpm;
+            fg_lin_prior_pair(r, q[pos], h, lpp, lpm);
+            pri += upper ? lpm : lpp;
+        }
+        const double t_own = pri + sa[a];                                    // total_log_weight at q + hs e_k
+        const double t_oth = __shfl_xor(t_own, 32, 64);
+        const double n = upper ? t_oth - t_own : t_own - t_oth;              // lp(q + h e_k) - lp(q - h e_k), the same subtraction in both halves
+        double g = fg_div_const(n, two_h, rcp_2h);                           // (lp - lm) / (2h), hmc.rs:322
+        const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
+        if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953]
+        bad = bad || !fg_finite(g);
+        double p = pl[k * tw] + hk * g;                                      // hmc.rs:389 / :400 (both halves: the same value to the same cell)
+        if (two_kicks) p += hk * g;
+        pl[k * tw] = p;
+    }
+    return bad;
+}
+
+template <int D, int W, bool P2, bool HALF, int WV>
 struct FgLinDispatch {
     static __device__ __forceinline__ bool run(int wv, const double *tab, int n_obs, const int *meta, const FgGradRec *gs, const fg_lds_double *slots,
                                                fg_lds_double *pl, double h, double hk, int two_kicks) {
-        if (wv == WV) return fg_lin_grad<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
-        return FgLinDispatch<D, W, P2, WV + 1>::run(wv, tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
+        if (wv == WV) return HALF ? fg_lin_grad_half<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks)
+                                  : fg_lin_grad<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
+        return FgLinDispatch<D, W, P2, HALF, WV + 1>::run(wv, tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
     }
 };
-template <int D, int W, bool P2>
-struct FgLinDispatch<D, W, P2, W> {
+template <int D, int W, bool P2, bool HALF>
+struct FgLinDispatch<D, W, P2, HALF, W> {
     static __device__ __forceinline__ bool run(int, const double *, int, const int *, const FgGradRec *, const fg_lds_double *, fg_lds_double *, double, double, int) { return false; }
 };
 
-template <int D, int W, bool P2>
+// HALF: 32 chains per workgroup (fg_lin_grad_half); everything outside the gradient runs in both lane halves on the same chain
+// (same values to the same LDS cells), only the lower half stores to global memory; the halves share the momentum pairs.
+template <int D, int W, bool P2, bool HALF>
 __global__ __launch_bounds__(FG_WAVE * W) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps, int n_warmup, int welford_on, double *draws, int first_sample_t,
                      double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
-    constexpr int tw = FG_WAVE, M = D / W;
-    const int lane = threadIdx.x & (FG_WAVE - 1);
+    constexpr int tw = HALF ? FG_WAVE / 2 : FG_WAVE, M = D / W;
+    const int lane = threadIdx.x & (tw - 1);                       // chain of the tile
+    const int half = HALF ? (int)((threadIdx.x >> 5) & 1u) : 0;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long chain = (long long)blockIdx.x * tw + lane;
-    const bool live = chain < X.C;
-    const long long c = live ? chain : X.C - 1;
+    const bool live = chain < X.C && half == 0;
+    const long long c = chain < X.C ? chain : X.C - 1;
     double *slots = lds + lane;
     double *pl = lds + (long long)P.n_slots * tw + lane;
     double *xch = lds + (long long)(P.n_slots + D) * tw + lane;      // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
@@ -229,7 +329,7 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
         double h0 = 0.0, u = 0.0;
         // p0 ~ N(0, M) (hmc.rs:436-441): Box-Muller pair j of the chain's (iteration) Philox stream is block j
         constexpr int n_pairs = (D + 1) >> 1;
-        for (int j = wv; j < n_pairs; j += W) {
+        for (int j = HALF ? 2 * wv + half : wv; j < n_pairs; j += HALF ? 2 * W : W) {
             const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)j, (uint32_t)iter, FG_RNG_HMC);
             const int i = 2 * j;
             pl[i * tw] = zz.a * (ms ? ms[(long long)i * X.C] : 1.0);
@@ -253,7 +353,7 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
         const double e = xch[0], hk = 0.5 * e;
         bool bad = false;
         for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
-            bad = FgLinDispatch<D, W, P2, 0>::run(wv, P.lin_tab, P.lin_n, P.lin_meta, P.gstream, (const fg_lds_double *)slots, (fg_lds_double *)pl, H.h, hk,
+            bad = FgLinDispatch<D, W, P2, HALF, 0>::run(wv, P.lin_tab, P.lin_n, P.lin_meta, P.gstream, (const fg_lds_double *)slots, (fg_lds_double *)pl, H.h, hk,
                                                   (gs > 0 && gs < L) ? 1 : 0) || bad;
             __syncthreads();                                     // every p kicked, every read of q done
             if (gs < L) {
@@ -336,23 +436,29 @@ int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     if (!e->P.lin_tab || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->lin_disabled || e->tw != FG_WAVE) return FG_E_UNSUPPORTED;
     const int D = e->d;
     if (D != 8 && D != 16 && D != 32) return FG_E_UNSUPPORTED;
-    const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
-    const size_t lds = (size_t)(e->n_slots + e->d + 2 + FG_LIN_WMAX) * FG_WAVE * sizeof(double);
+    const long long n_cu = std::max(1, e->n_simd / 4);
+    const long long tiles64 = (e->C + FG_WAVE - 1) / FG_WAVE;
+    // half tiles (32 chains per workgroup) when 64-chain tiles would leave half of the CUs without one
+    bool half = 2 * tiles64 <= n_cu;
+    if (const char *hv = std::getenv("FG_HMC_LIN_HALF")) half = std::atoi(hv) != 0;
+    const int tw = half ? FG_WAVE / 2 : FG_WAVE;
+    const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
+    const size_t lds = (size_t)(e->n_slots + e->d + 2 + FG_LIN_WMAX) * tw * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
-    // waves per tile: D / 4 (four coordinates per wave) when the tiles alone fill the CUs' 16 wave slots, else D / 2
+    // waves per tile: D / 4 -- four coordinates per wave.  Two coordinates per wave (D / 2 waves) share a tile's products and
+    // prefix sums between fewer suffix chains (77 instead of 64 instructions per (coordinate, observation) pair) and measured
+    // slower at every chain count, also where they double the waves per SIMD (8 192 chains: 5.9e6 against 7.0e6 leapfrog-steps/s);
+    // FG_HMC_WAVES = D / 2 keeps that layout reachable for the bit-identity tests.
     int W = D / 4;
-    {
-        const long long n_cu = std::max(1, e->n_simd / 4);
-        const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
-        if (resident * W < 16) W = D / 2;
-    }
     if (e->mw_override == D / 4 || e->mw_override == D / 2) W = e->mw_override;
-    const int variant = (D == 32 ? 0 : (D == 16 ? 4 : 8)) + (W == D / 2 ? 2 : 0) + (e->P.lin_p2 ? 1 : 0);
-    static bool attr_set_dev[64][12];
-#define FG_LIN_KERNELS(X) X(0, 32, 8, false) X(1, 32, 8, true) X(2, 32, 16, false) X(3, 32, 16, true) X(4, 16, 4, false) X(5, 16, 4, true) \
-                          X(6, 16, 8, false) X(7, 16, 8, true) X(8, 8, 2, false) X(9, 8, 2, true) X(10, 8, 4, false) X(11, 8, 4, true)
+    const int variant = 2 * ((D == 32 ? 0 : (D == 16 ? 4 : 8)) + (W == D / 2 ? 2 : 0) + (e->P.lin_p2 ? 1 : 0)) + (half ? 1 : 0);
+    static bool attr_set_dev[64][24];
+#define FG_LIN_KERNELS2(X, H, O) X(0 + O, 32, 8, false, H) X(2 + O, 32, 8, true, H) X(4 + O, 32, 16, false, H) X(6 + O, 32, 16, true, H) X(8 + O, 16, 4, false, H) \
+                                 X(10 + O, 16, 4, true, H) X(12 + O, 16, 8, false, H) X(14 + O, 16, 8, true, H) X(16 + O, 8, 2, false, H) X(18 + O, 8, 2, true, H) \
+                                 X(20 + O, 8, 4, false, H) X(22 + O, 8, 4, true, H)
+#define FG_LIN_KERNELS(X) FG_LIN_KERNELS2(X, false, 0) FG_LIN_KERNELS2(X, true, 1)
     const void *fn = nullptr;
-#define FG_LIN_FN(V, DD, WW, PP) if (variant == V) fn = (const void *)k_hmc_lin_steps<DD, WW, PP>;
+#define FG_LIN_FN(V, DD, WW, PP, HH) if (variant == V) fn = (const void *)k_hmc_lin_steps<DD, WW, PP, HH>;
     FG_LIN_KERNELS(FG_LIN_FN)
 #undef FG_LIN_FN
     bool &attr_set = attr_set_dev[e->device & 63][variant];
@@ -361,12 +467,13 @@ int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-#define FG_LIN_GO(V, DD, WW, PP) if (variant == V) hipLaunchKernelGGL((k_hmc_lin_steps<DD, WW, PP>), dim3(tiles), dim3(FG_WAVE * WW), lds, e->stream, e->P, e->X, e->H, \
-                                                                       iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
+#define FG_LIN_GO(V, DD, WW, PP, HH) if (variant == V) hipLaunchKernelGGL((k_hmc_lin_steps<DD, WW, PP, HH>), dim3(tiles), dim3(FG_WAVE * WW), lds, e->stream, e->P, e->X, e->H, \
+                                                                           iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     FG_LIN_KERNELS(FG_LIN_GO)
 #undef FG_LIN_GO
 #undef FG_LIN_KERNELS
+#undef FG_LIN_KERNELS2
     HIPCHK(hipGetLastError());
-    e->last_hmc_kernel = "k_hmc_lin_steps W=" + std::to_string(W);
+    e->last_hmc_kernel = std::string(half ? "k_hmc_lin_steps (half tiles) W=" : "k_hmc_lin_steps W=") + std::to_string(W);
     return FG_OK;
 }

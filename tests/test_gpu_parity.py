@@ -383,14 +383,15 @@ def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
     observation's products and prefix sums once and carries the suffix sums of its own coordinates side by side).  Per
     (coordinate, observation, sign) the additions and multiplications are the gradient stream's in the same order, so draws,
     step sizes, mass matrix, log-joint, statistics and per-transition info agree BIT FOR BIT with k_hmc_stream_steps -- for
-    both waves-per-tile layouts."""
+    both waves-per-tile layouts, on full (64-chain) and half (32-chain) tiles."""
     cp = E.compile_model(ZOO[name]())
     assert E.lib().fg_program_stream_records(cp.h, 4) > 0
     C, nw, ns = 150, 40, 25
     out = []
-    for lin, W_ in ((0, 1), (1, cp.d // 4), (1, cp.d // 2)):
+    for lin, W_, half in ((0, 1, 0), (1, cp.d // 4, 0), (1, cp.d // 2, 0), (1, cp.d // 4, 1), (1, cp.d // 2, 1)):
         monkeypatch.setenv("FG_HMC_LIN", str(lin))
         monkeypatch.setenv("FG_HMC_WAVES", str(W_))
+        monkeypatch.setenv("FG_HMC_LIN_HALF", str(half))      # half tiles: 32 chains per workgroup, the two signs of the finite difference in the two lane halves
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)

@@ -1,0 +1,71 @@
+"""One profiled configuration per invocation (rocprofv3 sits in front: tools/prof_round3.sh).  Every dispatch of the kernel under
+study covers a known number of units (transitions / chain steps / runs); tools/prof_round3_collect.py divides by them.
+usage: python tools/prof_driver.py <key>      keys: see CONFIGS"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from fugue_amd import engine as E, workloads as W
+
+# key -> (kernel name substring, units per profiled dispatch, number of trailing dispatches to keep, unit name)
+CONFIGS = {
+    "hmc|normal32|65536|fd_sparse|L16": ("k_hmc_sep_steps", 25, 4, "transition"),
+    "hmc|normal32|8192|fd_sparse|L16": ("k_hmc_sep_steps", 25, 4, "transition"),
+    "hmc|normal32|65536|fd_dense|L16": ("k_hmc_sep_steps", 25, 3, "transition"),
+    "hmc|c3|65536|fd_sparse|L16": ("k_hmc_lin_steps", 1, 2, "transition"),
+    "hmc|c3|8192|fd_sparse|L16": ("k_hmc_lin_steps", 1, 3, "transition"),
+    "mh|refmodel20|65536": ("k_mh_mw_steps", 100, 6, "chain step of every chain"),
+    "mh|c5|262144": ("k_mh_mw_steps", 100, 2, "chain step of every chain"),
+    "smc|c4|1048576": ("", 1, 0, "run"),
+}
+
+
+def main(key):
+    parts = key.split("|")
+    if parts[0] == "hmc" and parts[1] == "normal32":
+        C, mode = int(parts[2]), {"fd_sparse": E.GRAD_FD_SPARSE, "fd_dense": E.GRAD_FD_DENSE}[parts[3]]
+        cp = E.compile_model(W.normal_sites(32))
+        eng = E.Engine(cp, C, seed=1)
+        n = CONFIGS[key][2]
+        d = eng.device_alloc(25 * cp.d * C * 8)
+        eng.hmc_init(E.hmc_config(grad_mode=mode), 25 if mode == E.GRAD_FD_SPARSE else 0)
+        eng.hmc_step(25 if mode == E.GRAD_FD_SPARSE else 10)
+        for _ in range(n):
+            eng.hmc_step(25, d)                      # sampling launches: draw rows written, as in the bench's timed region
+        eng.synchronize()
+        print(key, eng.hmc_last_kernel())
+    elif parts[0] == "hmc" and parts[1] == "c3":
+        C = int(parts[2])
+        X, y, _ = W.ridge_data(1024, 32)
+        cp = E.compile_model(W.ridge_regression(X, y))
+        eng = E.Engine(cp, C, seed=3)
+        eng.hmc_init(E.hmc_config(init_step_size=0.004), 0)
+        for _ in range(1 + CONFIGS[key][2]):
+            eng.hmc_step(1)
+        eng.synchronize()
+        print(key, eng.hmc_last_kernel())
+    elif key == "mh|refmodel20|65536":
+        eng = E.Engine(E.compile_model(W.reference_model(20)), 65536, seed=1)
+        eng.mh_init(200)
+        eng.mh_step(100)
+        eng.mh_init(200)
+        for _ in range(6):                           # 2 adapting + 4 sampling launches of 100 steps: the bench leg's mix
+            eng.mh_step(100)
+        eng.synchronize()
+    elif key == "mh|c5|262144":
+        data, _ = W.mixture_data(64)
+        eng = E.Engine(E.compile_model(W.mixture(data)), 262144, seed=1)
+        eng.mh_init(200)
+        for _ in range(4):                           # 2 adapting, then the 2 sampling launches that are kept
+            eng.mh_step(100)
+        eng.synchronize()
+    elif key == "smc|c4|1048576":
+        eng = E.Engine(E.compile_model(W.smc_normal()), 1 << 20, seed=42)
+        for _ in range(2):                           # two identical runs: the collector halves the totals
+            r = eng.smc_run(rejuvenation_steps=3, download=False)
+        print(key, len(r["betas"]), "tempering steps")
+    else:
+        raise SystemExit("unknown key " + key)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
