@@ -30,9 +30,15 @@ __device__ unsigned long long fg_hmc_prof[FG_SEP_WMAX][8];
 #endif
 struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 
+// a coordinate's records: by scalar loads from a wave-uniform pointer (SGPRs), or -- half tiles, where the two lane halves of a
+// wave run different coordinates -- by per-lane loads (VGPRs)
+__device__ __forceinline__ fg_u32x8 fg_sep_ld8(const FG_AS4 char *p) { return *(const FG_AS4 fg_u32x8 *)p; }
+__device__ __forceinline__ fg_u32x4 fg_sep_ld4(const FG_AS4 char *p) { return *(const FG_AS4 fg_u32x4 *)p; }
+__device__ __forceinline__ fg_u32x8 fg_sep_ld8(const char *p) { return *(const fg_u32x8 *)p; }
+__device__ __forceinline__ fg_u32x4 fg_sep_ld4(const char *p) { return *(const fg_u32x4 *)p; }
 #define FG_SEP_LOAD(k) \
-    const fg_u32x8 a##k = *(const FG_AS4 fg_u32x8 *)(rb + 64 * k); \
-    const fg_u32x4 b##k = *(const FG_AS4 fg_u32x4 *)(rb + 64 * k + 32);
+    const fg_u32x8 a##k = fg_sep_ld8(rb + 64 * k); \
+    const fg_u32x4 b##k = fg_sep_ld4(rb + 64 * k + 32);
 
 // (x - mu) / sigma of record k for the operand difference dl = q - c (x - mu is +dl or -dl: the quotient's sign flips with
 // it exactly -- multiplication, the FMA sequence of fg_div_const and IEEE division are odd functions under round-to-nearest
@@ -86,8 +92,8 @@ struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
 // two v_cndmask per f64 and a compare in a loop that is bound by VALU issue).
 // AN = FG_GRAD_ANALYTIC: g_i = sum over the coordinate's records of d lp / d q_i = -(q - c) / sigma^2, one evaluation per record,
 // the additions of fg_grec_math's analytic branch in the same order ((x - mu) is +-(q - c) and its coefficient -+1: the same bits).
-template <int NOBS, bool P2, bool CHECK, bool AN = false, bool U0 = false>
-__device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double &q_io, double &p_io, double emi, double hk, int L, double h, double two_h,
+template <int NOBS, bool P2, bool CHECK, bool AN = false, bool U0 = false, typename RB = const FG_AS4 char *>
+__device__ __forceinline__ bool fg_sep_trajectory(RB rb, double &q_io, double &p_io, double emi, double hk, int L, double h, double two_h,
                                                   double rcp_2h, double *terms, int tw, int nobs_rt) {
 #define FG_SEP_HAS(k) (NOBS >= 0 ? NOBS >= (k) : nobs_rt >= (k))
     FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
@@ -151,10 +157,10 @@ __device__ __forceinline__ bool fg_sep_trajectory(const FG_AS4 char *rb, double 
 }
 
 // the checked re-run of a coordinate whose endpoint momentum came out non-finite: any record mix, out of line
-template <bool AN>
-__device__ __noinline__ FgD3 fg_sep_trajectory_checked(const FG_AS4 char *rb, double q, double p, double emi, double hk, int L, double h,
+template <bool AN, typename RB>
+__device__ __noinline__ FgD3 fg_sep_trajectory_checked(RB rb, double q, double p, double emi, double hk, int L, double h,
                                                        double two_h, double rcp_2h, double *terms, int tw, int nobs) {
-    const bool bad = fg_sep_trajectory<-1, false, true, AN>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+    const bool bad = fg_sep_trajectory<-1, false, true, AN, false, RB>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
     FgD3 r; r.a = q; r.b = p; r.c = bad ? 1.0 : 0.0;
     return r;
 }
@@ -166,17 +172,24 @@ __device__ __noinline__ FgD3 fg_sep_trajectory_checked(const FG_AS4 char *rb, do
 // adding ALL rows in program order with the coordinate's own terms substituted -- the additions of two full scoring runs,
 // without re-evaluating the S + O - (own) densities that did not move.  q and p live in LDS rows between gradients.
 // MODE: 0 = dependency-aware finite difference (FG_GRAD_FD_SPARSE), 1 = DENSE, 2 = analytic (FG_GRAD_ANALYTIC)
-template <bool MASS, int MODE>
+// HALF (MODE 0, programs whose coordinates all have the same record shape with power-of-two sigmas): a tile is 32 chains, the
+// lower lane half of a wave runs coordinate i of a Box-Muller pair and the upper half coordinate i + 1 of the SAME chains -- half
+// the work per wave and twice the tiles when 64-chain tiles would leave CUs without one (8 192 chains on 256 CUs).  Per
+// (chain, coordinate) the arithmetic is unchanged; wave 0's in-order sums run in both halves on the same rows.
+template <bool MASS, int MODE, bool HALF = false>
 __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSegSep seg, int iter0, int n_steps,
                                                                              int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                              double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
-    constexpr int tw = FG_WAVE;
+    constexpr int tw = HALF ? FG_WAVE / 2 : FG_WAVE;
     constexpr bool DENSE = MODE == 1, AN = MODE == 2;
-    const int lane = threadIdx.x & (FG_WAVE - 1);
+    static_assert(!HALF || MODE == 0, "half tiles: sparse finite difference only");
+    const int lane = threadIdx.x & (tw - 1);                       // chain of the tile
+    const int half = HALF ? (int)((threadIdx.x >> 5) & 1u) : 0;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long chain = (long long)blockIdx.x * tw + lane;
-    const bool live = chain < X.C;
+    const bool live = chain < X.C;                                 // stores of the lane's own coordinate
+    const bool live0 = live && half == 0;                          // stores of per-chain state (one lane half)
     const long long c = live ? chain : X.C - 1;
     const int d = P.d, L = H.L, n_s = P.n_sstream, n_pri = P.n_prior_terms;
     // LDS tile [rows][64]: (site values, only when a statement reads no coordinate) | kinetic terms of p0 | kinetic terms of
@@ -307,35 +320,50 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                 kin1[i * tw] = MASS ? p * p * mii : p * p;
             }
         } else
-        for (int i = k0; i < k1; ++i) {
+        for (int i = k0; i < k1; i += HALF ? 2 : 1) {
             // The SIMD's arbiter serves its oldest wave first: of the two waves a tile has on a SIMD the younger one (waves 4..7 of
             // 8) took 30 % longer over the same work and the tile waited for it at the barrier (tools/prof_hmc_phases.py).  The two
             // take turns at the higher priority, one coordinate each: +4 % (either wave always ahead, or turns per transition: -3 %).
             if (prio_turns) { if (((i - k0) ^ (wv >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+            const bool on = !HALF || i + half < d;                   // odd d: the upper half idles on the last pair
+            const int ci = HALF ? (on ? i + half : i) : i;           // the lane's coordinate
             double z;
-            if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
+            if (HALF) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = (half && on) ? zz.b : zz.a; }   // an idle upper half repeats the lower half's coordinate: the same values to the same cells
+            else if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
             else z = zb;
-            double p = MASS ? z * ms[(long long)i * X.C] : z;
-            const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
-            kin0[i * tw] = MASS ? p * p * mii : p * p;                  // hmc.rs:442-443, summed in coordinate order by wave 0
-            const long long gq = (long long)P.f64_site[i] * X.C + c;
+            double p = MASS ? z * ms[(long long)ci * X.C] : z;
+            const double mii = MASS ? mi[(long long)ci * X.C] : 1.0;
+            if (on) kin0[ci * tw] = MASS ? p * p * mii : p * p;         // hmc.rs:442-443, summed in coordinate order by wave 0
+            const long long gq = (long long)P.f64_site[ci] * X.C + c;
             double q = fg_as_double(X.values[gq]);
             const double emi = MASS ? e * mii : e;
-            const FgSepCoord cd = P.sep_coord[i];
-            const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
+            const FgSepCoord cd = P.sep_coord[i];                      // half tiles: every coordinate has this one's record shape (host check)
             const int nobs = (cd.n & 7) - 1;
             const double q0 = q, p0 = p;
+            if (HALF) {
+                const char *rb = (const char *)(P.sep + P.sep_coord[ci].off);
+#define FG_SEP_CALLH(NO, UU) fg_sep_trajectory<NO, true, false, false, UU, const char *>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, NO)
+                if ((cd.n & 512) && nobs == 1) FG_SEP_CALLH(1, true);
+                else if (nobs == 1) FG_SEP_CALLH(1, false); else if (nobs == 0) FG_SEP_CALLH(0, false); else if (nobs == 2) FG_SEP_CALLH(2, false); else FG_SEP_CALLH(3, false);
+#undef FG_SEP_CALLH
+                if (__builtin_expect(__any(!fg_finite(p)), 0)) {       // some force component may have been non-finite: the exact per-step test
+                    const FgD3 r = fg_sep_trajectory_checked<AN, const char *>(rb, q0, p0, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+                    q = r.a; p = r.b; bad = bad || (on && r.c != 0.0);
+                }
+            } else {
+            const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
 #define FG_SEP_CALL(NO, PP) fg_sep_trajectory<NO, PP, false, AN>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, NO)
             if (!AN && (cd.n & 512) && nobs == 1) fg_sep_trajectory<1, true, false, false, true>(rb, q, p, emi, hk, L, h, two_h, rcp_2h, terms, tw, 1);
             else if (cd.n & 256) { if (nobs == 1) FG_SEP_CALL(1, true); else if (nobs == 0) FG_SEP_CALL(0, true); else if (nobs == 2) FG_SEP_CALL(2, true); else FG_SEP_CALL(3, true); }
             else { if (nobs == 1) FG_SEP_CALL(1, false); else if (nobs == 0) FG_SEP_CALL(0, false); else if (nobs == 2) FG_SEP_CALL(2, false); else FG_SEP_CALL(3, false); }
 #undef FG_SEP_CALL
             if (__builtin_expect(__any(!fg_finite(p)), 0)) {           // some force component may have been non-finite: the exact per-step test
-                const FgD3 r = fg_sep_trajectory_checked<AN>(rb, q0, p0, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
+                const FgD3 r = fg_sep_trajectory_checked<AN, const FG_AS4 char *>(rb, q0, p0, emi, hk, L, h, two_h, rcp_2h, terms, tw, nobs);
                 q = r.a; p = r.b; bad = bad || r.c != 0.0;
             }
-            if (live) H.p0_scratch[(long long)i * X.C + c] = q;       // the proposal row
-            kin1[i * tw] = MASS ? p * p * mii : p * p;
+            }
+            if (live && on) H.p0_scratch[(long long)ci * X.C + c] = q;       // the proposal row
+            if (on) kin1[ci * tw] = MASS ? p * p * mii : p * p;
         }
         if (bad) atomicOr((unsigned long long *)(xch + 2 * tw), 1ull);
         if (prio_turns) { if (wv == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }   // wave 0's sums, accept and dual averaging are the tile's path
@@ -362,7 +390,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             if (acc) lj = lj_new;
             xch[tw] = acc ? 1.0 : 0.0;
             asum += ap; ndiv += div ? 1ull : 0ull;
-            if (live && info) {                                  // HmcStepInfo: hmc.rs:587-602
+            if (live0 && info) {                                 // HmcStepInfo: hmc.rs:587-602
                 double *r = info + (long long)t * 4 * X.C + c;
                 r[0] = acc ? 1.0 : 0.0; r[X.C] = div ? 1.0 : 0.0; r[2 * X.C] = ap; r[3 * X.C] = e_cur;
             }
@@ -389,11 +417,13 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         const bool acc = xch[tw] != 0.0;
         unsigned long long wn = 0;
         if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
-        for (int i = k0; i < k1; ++i) {                           // commit or roll back the own f64 sites
+        for (int i0 = k0; i0 < k1; i0 += HALF ? 2 : 1) {          // commit or roll back the own f64 sites
+            const bool on = !HALF || i0 + half < d;
+            const int i = HALF ? (on ? i0 + half : i0) : i0;
             const long long g = (long long)P.f64_site[i] * X.C + c;
             const double x = acc ? H.p0_scratch[(long long)i * X.C + c] : fg_as_double(X.values[g]);
-            if (acc && live) X.values[g] = fg_as_i64(x);
-            if (live && pos_all) pos_all[((long long)t * d + i) * X.C + c] = x;
+            if (acc && live && on) X.values[g] = fg_as_i64(x);
+            if (live && on && pos_all) pos_all[((long long)t * d + i) * X.C + c] = x;
             if (warming) {
                 if (welford_on) {                                 // Welford::push: hmc.rs:202-211
                     const long long gi = (long long)i * X.C + c;
@@ -402,20 +432,20 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                     const double delta = x - mean;
                     mean += delta / n;
                     const double delta2 = x - mean;
-                    if (live) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
+                    if (live && on) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
                 }
-            } else if (draws && live) draws[((long long)(t - first_sample_t) * d + i) * X.C + c] = x;   // hmc.rs:577-582
+            } else if (draws && live && on) draws[((long long)(t - first_sample_t) * d + i) * X.C + c] = x;   // hmc.rs:577-582
         }
         if (warming && welford_on) {
             __syncthreads();                                      // all waves hold the old count
-            if (wv == 0 && live) H.w_n[c] = wn;
+            if (wv == 0 && live0) H.w_n[c] = wn;
         }
         FG_PROF_T(4)
     }
 #ifdef FG_HMC_PROF
     if (blockIdx.x == 0 && lane == 0) for (int q = 0; q < 8; ++q) fg_hmc_prof[wv][q] = prof_[q];
 #endif
-    if (wv == 0 && live) {
+    if (wv == 0 && live0) {
         H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
         H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
         H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
@@ -427,44 +457,59 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
     const bool dense = e->cfg.grad_mode == FG_GRAD_FD_DENSE, analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
     if (!e->P.sep || (e->cfg.grad_mode != FG_GRAD_FD_SPARSE && !dense && !analytic) || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
-    const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
+    const long long n_cu = std::max(1, e->n_simd / 4);
+    const long long tiles64 = (e->C + FG_WAVE - 1) / FG_WAVE;
+    // half tiles (32 chains per workgroup, the two coordinates of a Box-Muller pair in the two lane halves): when 64-chain tiles
+    // would leave half of the CUs without one, for programs whose coordinates all have one record shape with power-of-two sigmas
+    bool half = false;
+    if (!dense && !analytic && e->d >= 2) {
+        const std::vector<FgSepCoord> &cd = e->prog->sep_coord;
+        bool uniform = true;
+        for (const FgSepCoord &q : cd) uniform = uniform && q.n == cd[0].n && (q.n & 256);
+        half = uniform && 2 * tiles64 <= n_cu;
+        if (const char *hv = std::getenv("FG_HMC_SEP_HALF")) half = uniform && std::atoi(hv) != 0;
+    }
+    const int tw = half ? FG_WAVE / 2 : FG_WAVE;
+    const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
     const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
                         (dense ? (size_t)e->P.n_sstream + 2 * (size_t)e->d : 0);     // dense: second term buffer, q and p rows
-    const size_t lds = rows * FG_WAVE * sizeof(double);
+    const size_t lds = rows * tw * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
-    // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates.
+    // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates
+    // (a half tile: >= 1 pair, both coordinates at once).
+    const int pairs = (e->d + 1) / 2;
     int W = e->mw_override > 0 ? e->mw_override : 1;
     if (e->mw_override <= 0) {
-        const long long n_cu = std::max(1, e->n_simd / 4);
         const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
-        while (W < FG_SEP_WMAX && resident * W < 16 && e->d >= 4 * W) W *= 2;
+        while (W < FG_SEP_WMAX && resident * W < 16 && (half ? pairs >= 2 * W : e->d >= 4 * W)) W *= 2;
     }
     while (W > 1 && 2 * (W - 1) >= e->d + 1) W /= 2;             // no empty waves
     FgSegSep seg;
-    const int pairs = (e->d + 1) / 2;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
     for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, 2 * (int)((long long)pairs * w / W));
-    if (W == 8 && !(std::getenv("FG_HMC_PRIO") && std::atoi(std::getenv("FG_HMC_PRIO")) == 0)) seg.c[FG_SEP_WMAX] = -1;   // priority turns: two waves of a tile per SIMD
-    static bool attr_set_dev[64][6];
-    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = 2 * mode + mass;
-    const void *fns[6] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
-                           (const void *)k_hmc_sep_steps<true, 1>, (const void *)k_hmc_sep_steps<false, 2>, (const void *)k_hmc_sep_steps<true, 2> };
+    if (W == 8 && !half && !(std::getenv("FG_HMC_PRIO") && std::atoi(std::getenv("FG_HMC_PRIO")) == 0)) seg.c[FG_SEP_WMAX] = -1;   // priority turns: two waves of a tile per SIMD
+    static bool attr_set_dev[64][8];
+    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = half ? 6 + mass : 2 * mode + mass;
+    const void *fns[8] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
+                           (const void *)k_hmc_sep_steps<true, 1>, (const void *)k_hmc_sep_steps<false, 2>, (const void *)k_hmc_sep_steps<true, 2>,
+                           (const void *)k_hmc_sep_steps<false, 0, true>, (const void *)k_hmc_sep_steps<true, 0, true> };
     bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
         const hipError_t he = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-#define FG_SEP_LAUNCH(M, D) hipLaunchKernelGGL((k_hmc_sep_steps<M, D>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, \
+#define FG_SEP_LAUNCH(...) hipLaunchKernelGGL((k_hmc_sep_steps<__VA_ARGS__>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, \
                                                e->n_warmup, welford_on, draws, first_sample_t, pos_all, info)
     switch (variant) {
         case 0: FG_SEP_LAUNCH(false, 0); break; case 1: FG_SEP_LAUNCH(true, 0); break; case 2: FG_SEP_LAUNCH(false, 1); break;
-        case 3: FG_SEP_LAUNCH(true, 1); break;  case 4: FG_SEP_LAUNCH(false, 2); break; default: FG_SEP_LAUNCH(true, 2); break;
+        case 3: FG_SEP_LAUNCH(true, 1); break;  case 4: FG_SEP_LAUNCH(false, 2); break; case 5: FG_SEP_LAUNCH(true, 2); break;
+        case 6: FG_SEP_LAUNCH(false, 0, true); break; default: FG_SEP_LAUNCH(true, 0, true); break;
     }
 #undef FG_SEP_LAUNCH
     HIPCHK(hipGetLastError());
-    e->last_hmc_kernel = std::string(dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : "k_hmc_sep_steps W=")) + std::to_string(W);
+    e->last_hmc_kernel = std::string(dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : (half ? "k_hmc_sep_steps (half tiles) W=" : "k_hmc_sep_steps W="))) + std::to_string(W);
     return FG_OK;
 }
 

@@ -163,6 +163,21 @@ def indep_mixed() -> M.Program:
 ZOO["indep_mixed"] = indep_mixed
 
 
+def indep_uniform5() -> M.Program:
+    """Independent sites that all have ONE record shape with power-of-two sigmas (what the half-tile layout of the register-resident
+    kernel needs): an odd number of coordinates, a non-standard prior and two observes each."""
+    P = M.Program()
+    rng = np.random.default_rng(23)
+    for i in range(5):
+        x = P.sample(M.addr("x", i), M.Normal(0.3 - 0.1 * i, 2.0))
+        P.observe(M.addr("ya", i), M.Normal(x, 0.5), float(rng.normal(0.2 * i, 0.5)))
+        P.observe(M.addr("yb", i), M.Normal(x, 0.25), float(rng.normal(0.2 * i, 0.25)))
+    return P
+
+
+ZOO["indep_uniform5"] = indep_uniform5
+
+
 # random programs (tests/random_models.py): every ZOO-wide test (site tables, log-joint, prior draws vs the oracle) covers them too
 from tests.random_models import random_program  # noqa: E402
 

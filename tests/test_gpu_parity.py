@@ -348,7 +348,8 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", [E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE, E.GRAD_ANALYTIC])
-@pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("readme", False), ("indep_mixed", True), ("indep_mixed", False)])
+@pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("readme", False), ("indep_mixed", True), ("indep_mixed", False),
+                                             ("indep_uniform5", True)])
 def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """Independent-sites programs run whole trajectories in registers (k_hmc_sep_steps, 1..16 waves per tile) and evaluate
     the endpoint score as parallel terms summed in program order; the arithmetic per coordinate and per accumulator is the
@@ -359,15 +360,22 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     assert cp.stream_records[0] > 0 and lib_sep_records(cp) > 0
     C, nw, ns = 150, 40, 25
     out = []
-    for sep, W in ((0, 1), (1, 1), (1, 2), (1, 4), (1, 8), (1, 16)):
+    # half tiles (32 chains per workgroup, a Box-Muller pair's two coordinates in the two lane halves): sparse mode, programs whose
+    # coordinates share one record shape with power-of-two sigmas -- elsewhere the switch is ignored and the run repeats the full tile
+    layouts = [(0, 1, 0), (1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0)]
+    if mode == E.GRAD_FD_SPARSE and name in ("normal32", "indep_uniform5"):
+        layouts += [(1, 1, 1), (1, 2, 1), (1, 4, 1), (1, 16, 1)]
+    for sep, W, half in layouts:
         monkeypatch.setenv("FG_HMC_SEP", str(sep))
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
+        monkeypatch.setenv("FG_HMC_SEP_HALF", str(half))
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
         draws = eng.download(d, (ns, cp.d, C))
         eng.device_free(d)
         pos, info = eng.hmc_step_info(3)
+        assert ("half tiles" in eng.hmc_last_kernel()) == bool(half) and ("k_hmc_sep_steps" in eng.hmc_last_kernel()) == bool(sep)
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
                     eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
         eng.close()
