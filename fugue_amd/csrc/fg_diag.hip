@@ -167,6 +167,38 @@ __global__ void k_diag_geweke(const double *draws, int n, int d, long long C, do
     out[(long long)i * C + c] = z;
 }
 
+// ---- quantiles of summarize_f64_parameter (diagnostics.rs:355-371): sorted[round((len - 1) p)] over ALL draws of a coordinate, by
+// radix select on the order-preserving 64-bit key of a double, eight bits per pass: every pass histograms the next digit of the
+// elements that still match each wanted rank's prefix (block histograms in LDS, then 64-bit global counters); the host -- after an
+// all-reduce of the counters when the chains are sharded over ranks -- walks the digits to the one that holds the rank.  Eight
+// streaming passes over the draws, no sort, nothing proportional to the draw count leaves the GPU.
+#define FG_Q_MAX 8
+__device__ __forceinline__ unsigned long long fg_sort_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);          // ascending in the double's order (-0.0 just below +0.0, NaN above +inf)
+}
+__global__ __launch_bounds__(256) void k_diag_qhist(const double *draws, int n, int d, long long C, int pass, int n_q, const unsigned long long *prefix /*[d][n_q]*/,
+                                                    unsigned long long *hist /*[d][n_q][256]*/) {
+    __shared__ unsigned int sh[FG_Q_MAX * 256];
+    const int i = blockIdx.y;
+    for (int k = threadIdx.x; k < n_q * 256; k += blockDim.x) sh[k] = 0u;
+    __syncthreads();
+    unsigned long long pf[FG_Q_MAX];
+    for (int q = 0; q < n_q; ++q) pf[q] = prefix[(long long)i * n_q + q];
+    const int hi = 64 - 8 * pass;                                  // bits above the digit of this pass are decided
+    const long long total = (long long)n * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long t = e / C, c = e - t * C;
+        const unsigned long long key = fg_sort_key(draws[(t * d + i) * C + c]);
+        const unsigned int digit = (unsigned int)(key >> (hi - 8)) & 255u;
+        for (int q = 0; q < n_q; ++q)
+            if (pass == 0 || (key >> hi) == (pf[q] >> hi)) atomicAdd(&sh[q * 256 + digit], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_q * 256; k += blockDim.x)
+        if (sh[k]) atomicAdd(&hist[(long long)i * n_q * 256 + k], (unsigned long long)sh[k]);
+}
+
 // ---- RCCL, bound at run time ------------------------------------------------------------------------------------------
 struct FgUniqueId { char b[128]; };
 namespace {
@@ -214,7 +246,7 @@ int rccl_fail(Rccl *R, const char *what, int rc) {
     fg_set_error(std::string(what) + ": " + ((R && R->GetErrorString) ? R->GetErrorString(rc) : "RCCL error"));
     return FG_E_HIP;
 }
-const int kNcclFloat64 = 8, kNcclSum = 0;
+const int kNcclFloat64 = 8, kNcclUint64 = 5, kNcclSum = 0;
 
 struct AcovCtx { fg_engine *e; const double *d_draws; int n, d; const double *d_mom; void *comm; double *d_small; double *d_part; long long bytes; };
 }  // namespace
@@ -349,6 +381,58 @@ static int reduce_cb(void *user, int stage, const double *h_in, double *h_out) {
     he = hipMemcpyAsync(h_out, A->d_small, (size_t)rows * 8, hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
+    return FG_OK;
+}
+
+int fg_diag_quantiles(fg_engine *e, const double *d_draws, int n, int d, void *comm, const double *h_probs, int n_probs, double *h_out) {
+    NEED_ENGINE(e);
+    if (!d_draws || !h_probs || !h_out || n <= 0 || d <= 0 || n_probs < 1 || n_probs > FG_Q_MAX) return FG_E_BAD_ARG;
+    Rccl *R = comm ? rccl() : nullptr;
+    if (comm && !R) { fg_set_error("RCCL is not available (librccl.so not found)"); return FG_E_UNSUPPORTED; }
+    int world = 1;
+    if (comm) { const int rc = R->CommCount(comm, &world); if (rc) return rccl_fail(R, "ncclCommCount", rc); }
+    const unsigned long long len = (unsigned long long)world * (unsigned long long)e->C * (unsigned long long)n;
+    std::vector<unsigned long long> rank((size_t)d * n_probs), prefix((size_t)d * n_probs, 0ull);
+    for (int q = 0; q < n_probs; ++q) {
+        if (!(h_probs[q] >= 0.0 && h_probs[q] <= 1.0)) { fg_set_error("fg_diag_quantiles: probabilities must lie in [0, 1]"); return FG_E_BAD_ARG; }
+        const unsigned long long idx = (unsigned long long)std::round((double)(len - 1) * h_probs[q]);     // f64::round: half away from zero
+        for (int i = 0; i < d; ++i) rank[(size_t)i * n_probs + q] = idx;
+    }
+    unsigned long long *d_prefix = nullptr, *d_hist = nullptr;
+    const size_t nh = (size_t)d * n_probs * 256;
+    int rc = dev_alloc(&d_prefix, (size_t)d * n_probs);
+    if (!rc) rc = dev_alloc(&d_hist, nh);
+    std::vector<unsigned long long> hist(nh);
+    const long long total = (long long)n * e->C;
+    const unsigned nb = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    for (int pass = 0; pass < 8 && !rc; ++pass) {
+        hipError_t he = hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * 8, hipMemcpyHostToDevice, e->stream);
+        if (he == hipSuccess) he = hipMemsetAsync(d_hist, 0, nh * 8, e->stream);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_diag_qhist, dim3(nb, (unsigned)d), dim3(256), 0, e->stream, d_draws, n, d, e->C, pass, n_probs, (const unsigned long long *)d_prefix, d_hist);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess && comm) { const int nr = R->AllReduce(d_hist, d_hist, nh, kNcclUint64, kNcclSum, comm, e->stream); if (nr) { rc = rccl_fail(R, "ncclAllReduce", nr); break; } }
+        if (he == hipSuccess) he = hipMemcpyAsync(hist.data(), d_hist, nh * 8, hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); rc = FG_E_HIP; break; }
+        const int lo = 56 - 8 * pass;
+        for (size_t k = 0; k < (size_t)d * n_probs; ++k) {            // the digit whose cumulative count first exceeds the rank
+            const unsigned long long *hh = &hist[k * 256];
+            unsigned long long cum = 0; int dg = 0;
+            for (; dg < 255; ++dg) { if (cum + hh[dg] > rank[k]) break; cum += hh[dg]; }
+            rank[k] -= cum;
+            prefix[k] |= (unsigned long long)dg << lo;
+        }
+    }
+    if (d_prefix) (void)hipFree(d_prefix);
+    if (d_hist) (void)hipFree(d_hist);
+    if (rc) return rc;
+    for (size_t k = 0; k < (size_t)d * n_probs; ++k) {
+        const unsigned long long key = prefix[k];
+        const unsigned long long u = (key >> 63) ? (key & 0x7fffffffffffffffull) : ~key;
+        std::memcpy(&h_out[k], &u, 8);
+    }
     return FG_OK;
 }
 

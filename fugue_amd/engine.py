@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_smc_prior_particles", "fg_smc_normalize", "fg_smc_ess", "fg_smc_resample", "fg_smc_rejuvenate",
     "fg_smc_get_weights", "fg_smc_set_log_weights", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_diag_rhat_ess", "fg_diag_combine", "fg_diag_geweke",
-    "fg_diag_combine_reduced", "fg_diag_set_exchange", "fg_diag_exchange_bytes", "fg_hmc_last_kernel",
+    "fg_diag_combine_reduced", "fg_diag_set_exchange", "fg_diag_exchange_bytes", "fg_hmc_last_kernel", "fg_diag_quantiles",
     "fg_comm_unique_id", "fg_comm_init", "fg_comm_destroy", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
     "fg_dsl_compile", "fg_dsl_warning_count", "fg_dsl_warning",
 ]
@@ -187,6 +187,7 @@ def lib():
     L.fg_diag_rhat_ess.argtypes = [vp, vp, C.c_int, C.c_int, vp, dp, dp, dp, dp, C.POINTER(C.c_int64)]
     L.fg_diag_combine.argtypes = [dp, C.c_int64, C.c_int, C.c_int, ACOV_FN, vp, dp, dp, dp, dp]
     L.fg_diag_combine_reduced.argtypes = [C.c_int64, C.c_int, C.c_int, REDUCE_FN, ACOV_FN, vp, dp, dp, dp, dp]
+    L.fg_diag_quantiles.argtypes = [vp, vp, C.c_int, C.c_int, vp, dp, C.c_int, dp]
     L.fg_diag_set_exchange.argtypes = [vp, C.c_int]
     L.fg_diag_exchange_bytes.restype = C.c_int64
     L.fg_diag_exchange_bytes.argtypes = [vp]
@@ -638,6 +639,14 @@ class Engine:
             _check(lib().fg_diag_set_exchange(self.h, int(exchange)))
         _check(lib().fg_diag_rhat_ess(self.h, d_draws, int(n), int(d), comm, _dp(rhat), _dp(ess), _dp(mean), _dp(std), C.byref(tot)))
         return dict(r_hat=rhat, ess=ess, mean=mean, std=std, chains=tot.value, exchange_bytes=int(lib().fg_diag_exchange_bytes(self.h)))
+
+    def diag_quantiles(self, d_draws: int, n: int, d: int, probs=(0.025, 0.25, 0.5, 0.75, 0.975), comm: Optional[int] = None) -> np.ndarray:
+        """summarize_f64_parameter's quantiles (diagnostics.rs:355-371) of every coordinate of d_draws [n][d][C], selected on the
+        device over the draws of every rank of `comm`: [d][len(probs)]."""
+        pr = np.ascontiguousarray(probs, dtype=np.float64)
+        out = np.zeros((d, len(pr)))
+        _check(lib().fg_diag_quantiles(self.h, d_draws, int(n), int(d), comm, _dp(pr), len(pr), _dp(out)))
+        return out
 
     def hmc_last_kernel(self) -> str:
         """Kernel (and waves per tile) the engine's last HMC launch ran."""

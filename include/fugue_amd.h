@@ -350,6 +350,13 @@ int fg_diag_rhat_ess(fg_engine *e, const double *d_draws, int n, int d, void *rc
 #define FG_DIAG_GATHER 1
 int fg_diag_set_exchange(fg_engine *e, int mode);
 int64_t fg_diag_exchange_bytes(const fg_engine *e);
+/* The quantiles of summarize_f64_parameter (diagnostics.rs:355-371): for every coordinate of d_draws [n][d][C] and every
+ * probability p, sorted[round((len - 1) p)] of ALL len = ranks x C x n draws of the coordinate (the reference's "2.5%", "25%",
+ * "50%", "75%", "97.5%" are p = 0.025, 0.25, 0.5, 0.75, 0.975).  Radix select on the device (eight histogram passes over the
+ * draws; the 256-bin counters are all-reduced over `rccl_comm` when the chains are sharded): exactly the element a sort would put
+ * at that index.  n_probs <= 8; h_out [d][n_probs]. */
+int fg_diag_quantiles(fg_engine *e, const double *d_draws, int n, int d, void *rccl_comm, const double *h_probs, int n_probs,
+                      double *h_out);
 /* The combination alone, on host buffers (no GPU needed): h_moments [d][6][m] of ALL chains in global chain order;
  * `acov` returns h_sums [d][n_lags] = sum over all chains of the biased lag-t autocovariances for t in
  * [lag0, lag0 + n_lags) (it is asked for 32 lags at a time, only as far as Geyer's sequence runs). */

@@ -15,7 +15,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfugue_oracle.so")
+# FUGUE_ORACLE_LIB: another build of the same sources (the sanitizer build `make asan`, tests/test_sanitizers_cpu.py)
+_LIB_PATH = os.environ.get("FUGUE_ORACLE_LIB") or os.path.join(_HERE, "libfugue_oracle.so")
 
 DISTS = ["Bernoulli", "Beta", "Binomial", "Categorical", "Cauchy", "ChiSquared", "DiscreteUniform",
          "Exponential", "Gamma", "InverseGamma", "Laplace", "LogNormal", "Normal", "Poisson",
@@ -31,7 +32,7 @@ def build(force: bool = False) -> str:
                                               "fugue_oracle.h", "orc_internal.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
-    if force or stale:
+    if (force or stale) and not os.environ.get("FUGUE_ORACLE_LIB"):
         subprocess.run(["make", "-C", _HERE, "-s", "libfugue_oracle.so"], check=True)
     return _LIB_PATH
 

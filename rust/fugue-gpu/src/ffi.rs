@@ -125,6 +125,8 @@ extern "C" {
                            h_mean: *mut f64, h_std: *mut f64) -> c_int;
     pub fn fg_diag_combine_reduced(m: i64, n: c_int, d: c_int, reduce: fg_reduce_fn, acov: fg_acov_fn, user: *mut c_void, h_rhat: *mut f64, h_ess: *mut f64,
                                    h_mean: *mut f64, h_std: *mut f64) -> c_int;
+    pub fn fg_diag_quantiles(e: *mut fg_engine, d_draws: *const f64, n: c_int, d: c_int, rccl_comm: *mut c_void, h_probs: *const f64, n_probs: c_int,
+                             h_out: *mut f64) -> c_int;
     pub fn fg_diag_set_exchange(e: *mut fg_engine, mode: c_int) -> c_int;
     pub fn fg_diag_exchange_bytes(e: *const fg_engine) -> i64;
     pub fn fg_comm_unique_id(out_128_bytes: *mut c_void) -> c_int;

@@ -67,3 +67,42 @@ def test_native_rhat_ess_entry_point_and_geweke(oracle, exchange):
     lag_bytes = r1["exchange_bytes"] - (8 * cp.d * 8 if exchange == E.DIAG_REDUCE else 6 * cp.d * C * 8)
     assert lag_bytes > 0 and lag_bytes % (32 * cp.d * 8) == 0                  # what the rank put into collectives: O(d) in the reduce mode
     eng.device_free(d_draws)
+
+
+def test_quantiles_are_selected_on_the_device(oracle):
+    """fg_diag_quantiles == summarize_f64_parameter's rule sorted[round((len - 1) p)] (diagnostics.rs:355-371): on HMC draws
+    against the oracle's orc_summarize, and on adversarial values (ties, both zeros, infinities, denormals, one repeated value)
+    against a host sort -- the element itself, bit for bit."""
+    cp = E.compile_model(W.normal_sites(3))
+    C, ns = 130, 97
+    eng = E.Engine(cp, C, seed=8)
+    d_draws = eng.device_alloc(ns * cp.d * C * 8)
+    eng.hmc_run(E.hmc_config(n_leapfrog=3), ns, 30, d_draws)
+    draws = eng.download(d_draws, (ns, cp.d, C))
+    q = eng.diag_quantiles(d_draws, ns, cp.d)
+    for i in range(cp.d):
+        s = oracle.summarize(np.ascontiguousarray(draws[:, i, :].T))
+        assert [q[i, k] for k in range(5)] == [s["q2.5"], s["q25"], s["q50"], s["q75"], s["q97.5"]]
+        assert q[i].tolist() == [D.quantiles_f64(draws[:, i, :])[k] for k in ("2.5%", "25%", "50%", "75%", "97.5%")]
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((ns, cp.d, C))
+    x[:, 0] = np.round(x[:, 0] * 3) / 3                                       # heavy ties
+    x[::7, 0] = 0.0; x[1::7, 0] = -0.0
+    x[:, 1] = 2.5                                                             # a constant coordinate
+    x[:5, 2] = np.inf; x[5:9, 2] = -np.inf; x[9:12, 2] = 5e-324; x[12:15, 2] = -5e-324
+    buf = np.ascontiguousarray(x)
+    E._check(E.lib().fg_device_upload(eng.h, d_draws, buf.ctypes.data, buf.nbytes))
+    probs = (0.0, 0.001, 0.025, 0.5, 0.975, 0.999, 1.0)
+    q = eng.diag_quantiles(d_draws, ns, cp.d, probs)
+    for i in range(cp.d):
+        v = np.sort(x[:, i, :].ravel())
+        want = [v[int(np.floor((len(v) - 1) * p + 0.5))] for p in probs]
+        assert np.array_equal(q[i], np.array(want))                          # -0.0 == 0.0 here: the reference's comparison cannot tell them apart either
+    comm = eng.comm_init(1, 0, E.comm_unique_id())
+    try:
+        assert np.array_equal(eng.diag_quantiles(d_draws, ns, cp.d, probs, comm), q)
+    finally:
+        E.comm_destroy(comm)
+    with pytest.raises(E.EngineError):
+        eng.diag_quantiles(d_draws, ns, cp.d, (1.5,))
+    eng.device_free(d_draws)
