@@ -37,8 +37,12 @@ struct FgSmcScalars {      // device-resident scalars of one SMC run
 };
 // few, large blocks: a pass is dominated by what follows the sums -- one ticket atomic per block, the last block's sweep over the
 // blocks' partials -- not by the two exps per particle (512 x 256: 1.13 ms per run, 128 x 512: 1.00 ms, 2048 x 256: 2.3 ms)
+#ifndef ESS_BLOCKS
 #define ESS_BLOCKS 128
+#endif
+#ifndef ESS_THREADS
 #define ESS_THREADS 512
+#endif
 #define ESS_MAXC 8
 
 // ---------------------------------------------------------------------------------------
@@ -373,6 +377,196 @@ __global__ __launch_bounds__(ESS_THREADS) void k_smc_ess_pass_uniform(const doub
     __syncthreads();
     if (threadIdx.x == 0) fg_ess_decide(st, ess_c, nc);
 }
+
+// ---- next_beta for UNIFORM incoming weights WITHOUT a cross-block epilogue --------------------------------------------------
+// k_smc_ess_pass_uniform ends every pass with a ticket atomic per block, two fences and the last block's sweep + single-thread
+// decision: a chain of device-scope round trips.  Here the kernel boundary IS the grid barrier: pass p + 1 starts with EVERY block
+// combining the block partials of pass p (a fixed tree: the same numbers in every block) and walking the decision tree itself -- a
+// few hundred redundant additions per block instead of the epilogue -- then forms its candidates' sums and leaves its own
+// partials.  Bracket state and partials are double-buffered by pass parity; block 0 records the new bracket.  The decisions are
+// fg_ess_decide's: the same comparisons `ESS(mid) < target` on the reference's midpoints 0.5 (lo + hi) (smc.rs:612-619), three
+// levels per pass; pass 0 also evaluates b = 1 (smc.rs:604-607) and reduces the block maxima of ll itself.
+struct FgEssBracket { double lo, hi, bnew; int iters, done, first, pad; };
+#ifndef ESS2_BLOCKS
+#define ESS2_BLOCKS 256
+#endif
+#ifndef ESS2_THREADS
+#define ESS2_THREADS 512
+#endif
+#ifndef ESS2_UNROLL
+#define ESS2_UNROLL 4
+#endif
+// candidates of a pass over bracket B in heap order (node j has children 2 j + 1, 2 j + 2); returns their number
+__device__ __forceinline__ int fg_ess_candidates(const FgEssBracket &B, double *cand) {
+    int c0 = 0;
+    if (B.first) { cand[0] = 1.0; c0 = 1; }
+    const int left = 64 - B.iters, lv = B.first ? 3 : (left < 3 ? left : 3);
+    const int nn = (1 << lv) - 1;
+    double blo[7], bhi[7];
+    blo[0] = B.lo; bhi[0] = B.hi;
+    for (int j = 0; j < nn; ++j) {
+        const double mid = 0.5 * (blo[j] + bhi[j]);                 // smc.rs:613
+        cand[c0 + j] = mid;
+        if (2 * j + 2 < 7) { blo[2 * j + 1] = blo[j]; bhi[2 * j + 1] = mid; blo[2 * j + 2] = mid; bhi[2 * j + 2] = bhi[j]; }
+    }
+    return c0 + nn;
+}
+// the bracket after a pass whose candidates had effective sample sizes ess_c (fg_ess_decide as a pure function)
+__device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double *ess_c, double beta, double target) {
+    double cand[ESS_MAXC];
+    const int nc = fg_ess_candidates(B, cand);
+    int c0 = 0;
+    if (B.first) {                                                 // candidate 0 of the first pass is b = 1: smc.rs:604-607
+        B.first = 0; c0 = 1;
+        if (ess_c[0] >= target) { B.done = 1; B.bnew = 1.0; return B; }
+    }
+    const int ntree = nc - c0;
+    int node = 0, depth = 0;
+    double lo = B.lo, hi = B.hi;
+    while (node < ntree && B.iters + depth < 64) {                 // smc.rs:612-619, one level = one iteration
+        const double mid = cand[c0 + node];
+        if (ess_c[c0 + node] < target) { hi = mid; node = 2 * node + 1; } else { lo = mid; node = 2 * node + 2; }
+        ++depth;
+    }
+    B.lo = lo; B.hi = hi; B.iters += depth;
+    if (B.iters >= 64) { B.bnew = fmin(fmax(hi, beta + 1e-9), 1.0); B.done = 1; }   // smc.rs:620-621
+    return B;
+}
+// every candidate's ESS from the block partials of the previous pass: thread t takes blocks t, t + T, ...; lanes, then waves, in
+// index order -- the same tree, hence the same bits, in every block
+__device__ __forceinline__ void fg_ess_collect(const double *part /*[nb][ESS_MAXC][2]*/, int nb, int nc, long long n, bool allneg, double (*shl)[ESS_MAXC][2], double *ess_c) {
+    double a[ESS_MAXC], b[ESS_MAXC];
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) { a[q] = 0.0; b[q] = 0.0; }
+    for (int bk = threadIdx.x; bk < nb; bk += blockDim.x) {
+        const double *p = part + (long long)bk * ESS_MAXC * 2;
+#pragma unroll
+        for (int q = 0; q < ESS_MAXC; ++q) if (q < nc) { a[q] += p[2 * q]; b[q] += p[2 * q + 1]; }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) {
+        if (q < nc) {
+            for (int o = 32; o > 0; o >>= 1) { a[q] += __shfl_down(a[q], o, 64); b[q] += __shfl_down(b[q], o, 64); }
+            if (lane == 0) { shl[wv][q][0] = a[q]; shl[wv][q][1] = b[q]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nc) {
+        const int q = threadIdx.x;
+        double ta = shl[0][q][0], tb = shl[0][q][1];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) { ta += shl[k][q][0]; tb += shl[k][q][1]; }
+        const double e = ta * ta / tb;
+        ess_c[q] = (allneg || !(ta > 0.0) || !isfinite(e)) ? (double)n : e;                       // smc.rs:598-601
+    }
+    __syncthreads();
+}
+// pass `pass` of next_beta; beta_ptr: the current beta.  brk[2]: the bracket pass `pass` starts from is brk[pass & 1] once the
+// previous pass's decision is folded in (pass 0 builds it from beta); part[2][ESS2_BLOCKS][ESS_MAXC][2]; lmax[2]: {max ll, 0}.
+__global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll, long long n, int pass, const double *beta_ptr, double target, const double *part_max, int n_pmax,
+                                                                FgEssBracket *brk, double *part, double *lmax) {
+    __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
+    __shared__ double ess_c[ESS_MAXC];
+    __shared__ FgEssBracket shB;
+    __shared__ double shm[ESS2_THREADS / 64];
+    const double beta = *beta_ptr;
+    const int nb = (int)gridDim.x;
+    double L;
+    FgEssBracket B;
+    if (pass == 0) {                                               // max ll from the block maxima (max is exact: any order)
+        double m = -INFINITY;
+        for (int k = threadIdx.x; k < n_pmax; k += blockDim.x) m = fmax(m, part_max[k]);
+        L = block_reduce_max(m, shm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) lmax[0] = L;
+        B.lo = beta; B.hi = 1.0; B.bnew = 1.0; B.iters = 0; B.done = 0; B.first = 1; B.pad = 0;
+    } else {
+        L = lmax[0];
+        const FgEssBracket P = brk[(pass - 1) & 1];                 // what pass - 1 started from
+        if (P.done) B = P;
+        else {
+            double cand[ESS_MAXC];
+            const int ncp = fg_ess_candidates(P, cand);
+            fg_ess_collect(part + (size_t)((pass - 1) & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c);
+            if (threadIdx.x == 0) shB = fg_ess_step(P, ess_c, beta, target);
+            __syncthreads();
+            B = shB;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) brk[pass & 1] = B;
+    if (B.done) return;
+    // the candidates' sums over this block's particles (the two-exp form of k_smc_ess_pass_uniform)
+    const int first = B.first;
+    const int left = 64 - B.iters, lv = first ? 3 : (left < 3 ? left : 3);
+    const int nc = first + (1 << lv) - 1;
+    const double lo = B.lo, hi = B.hi;
+    const double d0 = lo - beta, d1 = 1.0 - beta, dl = (hi - lo) / (double)(1 << lv);
+    double s1[ESS_MAXC], s2[ESS_MAXC];
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+    const bool allneg = isinf(L) && L < 0.0;
+#define ESS_ADD(q, tv) { const double tv_ = (tv); s1[q] += tv_; s2[q] += tv_ * tv_; }
+    // ESS2_UNROLL particles per thread and trip: their loads go out together, then the arithmetic runs per particle in index order --
+    // the sums are the same as one at a time
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n && !allneg; i0 += ESS2_UNROLL * stride) {
+        double xs[ESS2_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ESS2_UNROLL; ++u) { const long long i = i0 + u * stride; xs[u] = i < n ? ll[i] - L : -INFINITY; }
+#pragma unroll
+        for (int u = 0; u < ESS2_UNROLL; ++u) {
+            const double x = xs[u];                                  // <= 0; -inf: the particle has no weight at any b > beta (or lies past the end)
+            if (isinf(x) && x < 0.0) continue;
+            const double E = exp(d0 * x), R = exp(dl * x);
+            const double p1 = E * R, p2 = p1 * R, p3 = p2 * R;
+            if (first) {                                             // candidate 0 = b = 1, then the depth-3 tree over [beta, 1]
+                ESS_ADD(0, exp(d1 * x))
+                const double p4 = p3 * R, p5 = p4 * R, p6 = p5 * R, p7 = p6 * R;
+                ESS_ADD(1, p4) ESS_ADD(2, p2) ESS_ADD(3, p6) ESS_ADD(4, p1) ESS_ADD(5, p3) ESS_ADD(6, p5) ESS_ADD(7, p7)
+            } else if (lv == 3) {
+                const double p4 = p3 * R, p5 = p4 * R, p6 = p5 * R, p7 = p6 * R;
+                ESS_ADD(0, p4) ESS_ADD(1, p2) ESS_ADD(2, p6) ESS_ADD(3, p1) ESS_ADD(4, p3) ESS_ADD(5, p5) ESS_ADD(6, p7)
+            } else if (lv == 2) { ESS_ADD(0, p2) ESS_ADD(1, p1) ESS_ADD(2, p3) }
+            else ESS_ADD(0, p1)
+        }
+    }
+#undef ESS_ADD
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < ESS_MAXC; ++q) {
+        if (q < nc) {
+            for (int o = 32; o > 0; o >>= 1) { s1[q] += __shfl_down(s1[q], o, 64); s2[q] += __shfl_down(s2[q], o, 64); }
+            if (lane == 0) { shl[wv][q][0] = s1[q]; shl[wv][q][1] = s2[q]; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nc) {
+        const int q = threadIdx.x;
+        double a = shl[0][q][0], b = shl[0][q][1];
+        for (int k = 1; k < ESS2_THREADS / 64; ++k) { a += shl[k][q][0]; b += shl[k][q][1]; }
+        double *p = part + ((size_t)(pass & 1) * ESS2_BLOCKS + blockIdx.x) * ESS_MAXC * 2 + 2 * q;
+        p[0] = a; p[1] = b;
+    }
+}
+// after the last pass: fold its decision in and publish beta' (st->bnew)
+__global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, int last_pass, int nb, const double *beta_ptr, double target, FgEssBracket *brk, const double *part,
+                                                                 const double *lmax, FgSmcScalars *st) {
+    __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
+    __shared__ double ess_c[ESS_MAXC];
+    const double beta = *beta_ptr, L = lmax[0];
+    FgEssBracket P = brk[last_pass & 1];
+    if (!P.done) {
+        double cand[ESS_MAXC];
+        const int ncp = fg_ess_candidates(P, cand);
+        fg_ess_collect(part + (size_t)(last_pass & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c);
+        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, beta, target);
+    }
+    if (threadIdx.x == 0) {
+        if (!P.done) P.bnew = fmin(fmax(P.hi, beta + 1e-9), 1.0);    // (not reached: 22 passes cover 64 iterations)
+        st->bnew = st->force_one ? 1.0 : P.bnew;                     // smc.rs:504-506: the step cap forces beta = 1
+        st->done = 1; st->lo = P.lo; st->hi = P.hi; st->iters = P.iters;
+        brk[last_pass & 1] = P;
+    }
+}
 __global__ __launch_bounds__(RED_THREADS) void k_smc_max_finish(const double *part_max, int nb, double *out) {   // max of the block maxima
     __shared__ double sh[RED_THREADS / 64];
     double m = -INFINITY;
@@ -649,11 +843,38 @@ namespace {
 
 struct Reducer {     // scratch for the two-pass reductions
     double *part_max = nullptr, *part_sum = nullptr, *ess_part = nullptr;
+    double *ess2 = nullptr;      // k_smc_ess2_pass: part[2][ESS2_BLOCKS][ESS_MAXC][2] | lmax[2] | FgEssBracket brk[2]
+    static size_t ess2_doubles() { return (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2 + 2 + 2 * sizeof(FgEssBracket) / 8 + 2; }
     int init() {
-        if (dev_alloc(&part_max, RED_BLOCKS) || dev_alloc(&part_sum, 2 * RED_BLOCKS) || dev_alloc(&ess_part, (size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8)) return FG_E_HIP;
+        if (dev_alloc(&part_max, RED_BLOCKS) || dev_alloc(&part_sum, 2 * RED_BLOCKS) || dev_alloc(&ess_part, (size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) || dev_alloc(&ess2, ess2_doubles())) return FG_E_HIP;
         return FG_OK;
     }
-    void free_all() { if (part_max) (void)hipFree(part_max); if (part_sum) (void)hipFree(part_sum); if (ess_part) (void)hipFree(ess_part); part_max = part_sum = ess_part = nullptr; }
+    void free_all() { if (part_max) (void)hipFree(part_max); if (part_sum) (void)hipFree(part_sum); if (ess_part) (void)hipFree(ess_part); if (ess2) (void)hipFree(ess2);
+                      part_max = part_sum = ess_part = ess2 = nullptr; }
+    // next_beta for uniform incoming weights (adaptive_smc: always) -> st->bnew.  beta_ptr: device address of the current beta.  The
+    // host looks at the bracket once, after the pass that folds in the decision about b = 1: a step that ends the ladder (ESS(1)
+    // >= target -- every run's last step) skips the other twenty launches.
+    int next_beta_uniform(hipStream_t s, const double *ll, long long n, FgSmcScalars *st, const double *beta_ptr, double target) {
+        double *part = ess2, *lmax = ess2 + (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2;
+        FgEssBracket *brk = (FgEssBracket *)(lmax + 2);
+        const int nb = (int)std::min<long long>(ESS2_BLOCKS, (n + ESS2_THREADS - 1) / ESS2_THREADS);
+        hipLaunchKernelGGL(k_smc_red_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, ll, (const double *)nullptr, n, (const double *)&st->one, (const double *)&st->one, part_max);
+        int last = 0;
+        const int n_pass = 22;                               // pass 0: b = 1 and levels 1-3; passes 1..20: three levels each; pass 21: the 64th
+        for (int pass = 0; pass < n_pass; ++pass) {
+            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, RED_BLOCKS, brk, part, lmax);
+            last = pass;
+            if (pass == 1) {
+                FgEssBracket hb;
+                HIPCHK(hipMemcpyAsync(&hb, &brk[1], sizeof(hb), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (hb.done) break;
+            }
+        }
+        hipLaunchKernelGGL(k_smc_ess2_final, dim3(1), dim3(ESS2_THREADS), 0, s, n, last, nb, beta_ptr, target, brk, (const double *)part, (const double *)lmax, st);
+        HIPCHK(hipGetLastError());
+        return FG_OK;
+    }
     // next_beta (smc.rs:588-622) -> st->bnew: ESS at b = 1, then 64 bisections, three levels per pass (k_smc_ess_pass)
     // uniform_lw: the caller guarantees that every lw_i is the same number (adaptive_smc: always) -> the two-exp pass
     int next_beta(hipStream_t s, const double *lw, const double *ll, long long n, FgSmcScalars *st, bool uniform_lw = false) {
@@ -731,6 +952,7 @@ int smc_workspace(fg_engine *e, SmcWs &W) {
     const size_t o_ll = carve(N * 8), o_lp = carve(N * 8), o_scale = carve(Sn * 8), o_ls = carve(Sn * 8), o_acc = carve(Sn * 8), o_tot = carve(Sn * 8),
                  o_st = carve(sizeof(FgSmcScalars)), o_lw = carve(N * 8), o_w = carve(N * 8), o_ll2 = carve(N * 8), o_lp2 = carve(N * 8), o_vals2 = carve(Sn * N * 8),
                  o_idx = carve(N * 8), o_pmax = carve(RED_BLOCKS * 8), o_psum = carve(2 * RED_BLOCKS * 8), o_ess = carve(((size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) * 8),
+                 o_ess2 = carve(Reducer::ess2_doubles() * 8),
                  o_chunk = carve((size_t)n_chunks * 8), o_cum = carve(N * 8), o_blk = carve(max_blk * 2 * Sn * 4), o_red = carve(64);
     if (e->smc_arena_bytes < arena_off) {
         if (e->smc_arena) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->smc_arena)); e->smc_arena = nullptr; e->smc_arena_bytes = 0; }
@@ -747,7 +969,7 @@ int smc_workspace(fg_engine *e, SmcWs &W) {
     W.st = (FgSmcScalars *)(ar + o_st);
     W.d_lw = (double *)(ar + o_lw); W.d_w = (double *)(ar + o_w); W.d_ll2 = (double *)(ar + o_ll2); W.d_lp2 = (double *)(ar + o_lp2);
     W.d_vals2 = (long long *)(ar + o_vals2); W.d_idx = (long long *)(ar + o_idx); W.d_red = (double *)(ar + o_red);
-    W.R.part_max = (double *)(ar + o_pmax); W.R.part_sum = (double *)(ar + o_psum); W.R.ess_part = (double *)(ar + o_ess);
+    W.R.part_max = (double *)(ar + o_pmax); W.R.part_sum = (double *)(ar + o_psum); W.R.ess_part = (double *)(ar + o_ess); W.R.ess2 = (double *)(ar + o_ess2);
     W.SC.chunk = (double *)(ar + o_chunk); W.SC.cum = (double *)(ar + o_cum); W.SC.cap = N; W.SC.external = true;
     return FG_OK;
 }
@@ -863,7 +1085,7 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
             steps += 1;
             // next_beta: ESS at b = 1, then 64 bisections on the device (smc.rs:588-622)
             if (steps >= 10000) { int one = 1; SMC_HIP(hipMemcpyAsync(&st->force_one, &one, sizeof(int), hipMemcpyHostToDevice, s)); }
-            SMC_TRY(R.next_beta(s, d_lw, M.ll, N, st, /*uniform_lw=*/true));      // log_w = -ln N at every step's start (smc.rs:476,538-540)
+            SMC_TRY(R.next_beta_uniform(s, M.ll, N, st, (const double *)&st->beta, h.target_ess));      // log_w = -ln N at every step's start (smc.rs:476,538-540)
             // reweight + evidence (smc.rs:512-529)
             SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
             hipLaunchKernelGGL(k_smc_apply, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, d_w, N, (const FgSmcScalars *)st);
