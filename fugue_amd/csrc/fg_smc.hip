@@ -34,6 +34,7 @@ struct FgSmcScalars {      // device-resident scalars of one SMC run
     double cand[8];
     int n_cand, iters, first;
     unsigned int ticket;
+    double dbeta;          // bnew - beta of the reweight in flight (k_smc_finish phase 3 advances beta itself; k_smc_apply uses this)
 };
 // few, large blocks: a pass is dominated by what follows the sums -- one ticket atomic per block, the last block's sweep over the
 // blocks' partials -- not by the two exps per particle (512 x 256: 1.13 ms per run, 128 x 512: 1.00 ms, 2048 x 256: 2.3 ms)
@@ -127,7 +128,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_smc_finish(FgSmcScalars *st, co
     const double lse1 = (empty || s1 == 0.0) ? -INFINITY : m + log(s1);          // numerical.rs:33-37
     const double lse2 = (empty || s2 == 0.0) ? -INFINITY : 2.0 * m + log(s2);
     st->lse1 = lse1; st->lse2 = lse2;
-    if (phase == 3) { st->log_norm = lse1; st->log_evidence += lse1; return; }
+    if (phase == 3) {                                              // the reweight's log-normaliser; beta advances here (nothing reads the old one after the sums)
+        st->log_norm = lse1; st->log_evidence += lse1;
+        st->dbeta = st->bnew - st->beta; st->beta = st->bnew;
+        return;
+    }
     if (phase == 4) return;
     const double ess = (!isfinite(lse1) || !isfinite(lse2)) ? (double)n : exp(2.0 * lse1 - lse2);   // smc.rs:598-601
     st->ess = ess;
@@ -387,6 +392,20 @@ __global__ __launch_bounds__(ESS_THREADS) void k_smc_ess_pass_uniform(const doub
 // fg_ess_decide's: the same comparisons `ESS(mid) < target` on the reference's midpoints 0.5 (lo + hi) (smc.rs:612-619), three
 // levels per pass; pass 0 also evaluates b = 1 (smc.rs:604-607) and reduces the block maxima of ll itself.
 struct FgEssBracket { double lo, hi, bnew; int iters, done, first, pad; };
+// Sum over the 64 lanes of a wave by DPP moves (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15 / 31 across the
+// rows): the total lands in lane 63.  No LDS round trip per step -- __shfl_down on a double is two ds_bpermute_b32 and a wait, and
+// the sixteen sums of a pass spent 4-5 us in them (tools/prof_smc_phases.sh) -- and a fixed tree: the same bits wherever it runs.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double fg_dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);                            // lanes without a source add +0.0
+}
+__device__ __forceinline__ double fg_wave_sum63(double v) {
+    v = fg_dpp_add<0x111, 0xf>(v); v = fg_dpp_add<0x112, 0xf>(v); v = fg_dpp_add<0x114, 0xf>(v); v = fg_dpp_add<0x118, 0xf>(v);
+    v = fg_dpp_add<0x142, 0xa>(v); v = fg_dpp_add<0x143, 0xc>(v);
+    return v;
+}
 #ifndef ESS2_BLOCKS
 #define ESS2_BLOCKS 256
 #endif
@@ -396,6 +415,7 @@ struct FgEssBracket { double lo, hi, bnew; int iters, done, first, pad; };
 #ifndef ESS2_UNROLL
 #define ESS2_UNROLL 4
 #endif
+static_assert(ESS2_BLOCKS <= ESS2_THREADS && ESS2_THREADS % 64 == 0, "fg_ess_collect: one thread per block partial");
 // candidates of a pass over bracket B in heap order (node j has children 2 j + 1, 2 j + 2); returns their number
 __device__ __forceinline__ int fg_ess_candidates(const FgEssBracket &B, double *cand) {
     int c0 = 0;
@@ -444,18 +464,19 @@ __device__ __forceinline__ void fg_ess_collect(const double *part /*[nb][ESS_MAX
         for (int q = 0; q < ESS_MAXC; ++q) if (q < nc) { a[q] += p[2 * q]; b[q] += p[2 * q + 1]; }
     }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nwv = (nb + 63) >> 6;                                // waves that hold partials (the others would add zeros)
+    if (wv < nwv) {
 #pragma unroll
-    for (int q = 0; q < ESS_MAXC; ++q) {
-        if (q < nc) {
-            for (int o = 32; o > 0; o >>= 1) { a[q] += __shfl_down(a[q], o, 64); b[q] += __shfl_down(b[q], o, 64); }
-            if (lane == 0) { shl[wv][q][0] = a[q]; shl[wv][q][1] = b[q]; }
+        for (int q = 0; q < ESS_MAXC; ++q) {                        // all candidates, no test per candidate: sixteen independent chains
+            a[q] = fg_wave_sum63(a[q]); b[q] = fg_wave_sum63(b[q]);
+            if (lane == 63) { shl[wv][q][0] = a[q]; shl[wv][q][1] = b[q]; }
         }
     }
     __syncthreads();
     if (threadIdx.x < (unsigned)nc) {
         const int q = threadIdx.x;
         double ta = shl[0][q][0], tb = shl[0][q][1];
-        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) { ta += shl[k][q][0]; tb += shl[k][q][1]; }
+        for (int k = 1; k < nwv; ++k) { ta += shl[k][q][0]; tb += shl[k][q][1]; }
         const double e = ta * ta / tb;
         ess_c[q] = (allneg || !(ta > 0.0) || !isfinite(e)) ? (double)n : e;                       // smc.rs:598-601
     }
@@ -463,12 +484,20 @@ __device__ __forceinline__ void fg_ess_collect(const double *part /*[nb][ESS_MAX
 }
 // pass `pass` of next_beta; beta_ptr: the current beta.  brk[2]: the bracket pass `pass` starts from is brk[pass & 1] once the
 // previous pass's decision is folded in (pass 0 builds it from beta); part[2][ESS2_BLOCKS][ESS_MAXC][2]; lmax[2]: {max ll, 0}.
+// FG_SMC_PROF (experiment builds, tools/prof_smc_phases.sh): 100 MHz real-time stamps of the phases of a pass, block 0 and the last block
+#ifdef FG_SMC_PROF
+__device__ long long fg_smc_prof[64][2][8];
+#define FG_SMC_T(i) { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && pass < 64) fg_smc_prof[pass][blockIdx.x != 0][i] = wall_clock64(); }
+#else
+#define FG_SMC_T(i)
+#endif
 __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll, long long n, int pass, const double *beta_ptr, double target, const double *part_max, int n_pmax,
                                                                 FgEssBracket *brk, double *part, double *lmax) {
     __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
     __shared__ double ess_c[ESS_MAXC];
     __shared__ FgEssBracket shB;
     __shared__ double shm[ESS2_THREADS / 64];
+    FG_SMC_T(0)
     const double beta = *beta_ptr;
     const int nb = (int)gridDim.x;
     double L;
@@ -486,12 +515,15 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
         else {
             double cand[ESS_MAXC];
             const int ncp = fg_ess_candidates(P, cand);
+            FG_SMC_T(1)
             fg_ess_collect(part + (size_t)((pass - 1) & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c);
+            FG_SMC_T(2)
             if (threadIdx.x == 0) shB = fg_ess_step(P, ess_c, beta, target);
             __syncthreads();
             B = shB;
         }
     }
+    FG_SMC_T(3)
     if (blockIdx.x == 0 && threadIdx.x == 0) brk[pass & 1] = B;
     if (B.done) return;
     // the candidates' sums over this block's particles (the two-exp form of k_smc_ess_pass_uniform)
@@ -530,15 +562,15 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
         }
     }
 #undef ESS_ADD
+    FG_SMC_T(4)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < ESS_MAXC; ++q) {
-        if (q < nc) {
-            for (int o = 32; o > 0; o >>= 1) { s1[q] += __shfl_down(s1[q], o, 64); s2[q] += __shfl_down(s2[q], o, 64); }
-            if (lane == 0) { shl[wv][q][0] = s1[q]; shl[wv][q][1] = s2[q]; }
-        }
+    for (int q = 0; q < ESS_MAXC; ++q) {                            // all candidates, no test per candidate (the unused ones are zeros)
+        s1[q] = fg_wave_sum63(s1[q]); s2[q] = fg_wave_sum63(s2[q]);
+        if (lane == 63) { shl[wv][q][0] = s1[q]; shl[wv][q][1] = s2[q]; }
     }
     __syncthreads();
+    FG_SMC_T(5)
     if (threadIdx.x < (unsigned)nc) {
         const int q = threadIdx.x;
         double a = shl[0][q][0], b = shl[0][q][1];
@@ -546,10 +578,18 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
         double *p = part + ((size_t)(pass & 1) * ESS2_BLOCKS + blockIdx.x) * ESS_MAXC * 2 + 2 * q;
         p[0] = a; p[1] = b;
     }
+    FG_SMC_T(6)
 }
+#ifdef FG_SMC_PROF
+extern "C" int fg_debug_smc_prof(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_smc_prof), sizeof(long long) * 64 * 2 * 8) == hipSuccess ? 0 : -1; }
+#endif
 // after the last pass: fold its decision in and publish beta' (st->bnew)
+// ... and the maximum of the reweight that follows: v_i = lw0 + (beta' - beta) ll_i is non-decreasing in ll_i (rounding is monotone),
+// so max v = lw0 + (beta' - beta) max ll, formed by the same two operations -- the reduction pass over v is not needed (part_max
+// [n_pmax] is what k_smc_red_sum reads the maximum from).
 __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, int last_pass, int nb, const double *beta_ptr, double target, FgEssBracket *brk, const double *part,
-                                                                 const double *lmax, FgSmcScalars *st) {
+                                                                 const double *lmax, FgSmcScalars *st, double lw0, double *part_max, int n_pmax) {
+    __shared__ double sh_bnew;
     __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
     __shared__ double ess_c[ESS_MAXC];
     const double beta = *beta_ptr, L = lmax[0];
@@ -563,9 +603,13 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, in
     if (threadIdx.x == 0) {
         if (!P.done) P.bnew = fmin(fmax(P.hi, beta + 1e-9), 1.0);    // (not reached: 22 passes cover 64 iterations)
         st->bnew = st->force_one ? 1.0 : P.bnew;                     // smc.rs:504-506: the step cap forces beta = 1
+        sh_bnew = st->bnew;
         st->done = 1; st->lo = P.lo; st->hi = P.hi; st->iters = P.iters;
         brk[last_pass & 1] = P;
     }
+    __syncthreads();
+    const double vmax = lw0 + (sh_bnew - beta) * L;                  // smc_v at the particle with the largest ll
+    for (int k = threadIdx.x; k < n_pmax; k += blockDim.x) part_max[k] = vmax;
 }
 __global__ __launch_bounds__(RED_THREADS) void k_smc_max_finish(const double *part_max, int nb, double *out) {   // max of the block maxima
     __shared__ double sh[RED_THREADS / 64];
@@ -597,7 +641,7 @@ __global__ void k_smc_ess_end(FgSmcScalars *st) {                   // smc.rs:50
 __global__ void k_smc_apply(double *lw, const double *ll, double *w, long long n, const FgSmcScalars *st) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double v = lw[i] + (st->bnew - st->beta) * ll[i];
+    const double v = lw[i] + st->dbeta * ll[i];
     const double nl = isfinite(st->log_norm) ? v - st->log_norm : -log((double)n);
     lw[i] = nl;
     if (w) w[i] = exp(nl);
@@ -854,7 +898,7 @@ struct Reducer {     // scratch for the two-pass reductions
     // next_beta for uniform incoming weights (adaptive_smc: always) -> st->bnew.  beta_ptr: device address of the current beta.  The
     // host looks at the bracket once, after the pass that folds in the decision about b = 1: a step that ends the ladder (ESS(1)
     // >= target -- every run's last step) skips the other twenty launches.
-    int next_beta_uniform(hipStream_t s, const double *ll, long long n, FgSmcScalars *st, const double *beta_ptr, double target) {
+    int next_beta_uniform(hipStream_t s, const double *ll, long long n, FgSmcScalars *st, const double *beta_ptr, double target, double lw0) {
         double *part = ess2, *lmax = ess2 + (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2;
         FgEssBracket *brk = (FgEssBracket *)(lmax + 2);
         const int nb = (int)std::min<long long>(ESS2_BLOCKS, (n + ESS2_THREADS - 1) / ESS2_THREADS);
@@ -871,7 +915,15 @@ struct Reducer {     // scratch for the two-pass reductions
                 if (hb.done) break;
             }
         }
-        hipLaunchKernelGGL(k_smc_ess2_final, dim3(1), dim3(ESS2_THREADS), 0, s, n, last, nb, beta_ptr, target, brk, (const double *)part, (const double *)lmax, st);
+        hipLaunchKernelGGL(k_smc_ess2_final, dim3(1), dim3(ESS2_THREADS), 0, s, n, last, nb, beta_ptr, target, brk, (const double *)part, (const double *)lmax, st, lw0, part_max, RED_BLOCKS);
+        HIPCHK(hipGetLastError());
+        return FG_OK;
+    }
+    // the reweight's log-sum-exp right after next_beta_uniform: its maximum is already in part_max
+    int run_sum_only(hipStream_t s, const double *lw, const double *ll, long long n, FgSmcScalars *st, const double *b_ptr, int phase) {
+        hipLaunchKernelGGL(k_smc_red_sum, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, lw, ll, n, b_ptr, (const double *)&st->beta,
+                           (const double *)part_max, part_sum);
+        hipLaunchKernelGGL(k_smc_finish, dim3(1), dim3(RED_THREADS), 0, s, st, (const double *)part_max, (const double *)part_sum, RED_BLOCKS, n, phase);
         HIPCHK(hipGetLastError());
         return FG_OK;
     }
@@ -1085,11 +1137,10 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
             steps += 1;
             // next_beta: ESS at b = 1, then 64 bisections on the device (smc.rs:588-622)
             if (steps >= 10000) { int one = 1; SMC_HIP(hipMemcpyAsync(&st->force_one, &one, sizeof(int), hipMemcpyHostToDevice, s)); }
-            SMC_TRY(R.next_beta_uniform(s, M.ll, N, st, (const double *)&st->beta, h.target_ess));      // log_w = -ln N at every step's start (smc.rs:476,538-540)
+            SMC_TRY(R.next_beta_uniform(s, M.ll, N, st, (const double *)&st->beta, h.target_ess, -std::log((double)N)));      // log_w = -ln N at every step's start (smc.rs:476,538-540)
             // reweight + evidence (smc.rs:512-529)
-            SMC_TRY(R.run(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
+            SMC_TRY(R.run_sum_only(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
             hipLaunchKernelGGL(k_smc_apply, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, d_w, N, (const FgSmcScalars *)st);
-            hipLaunchKernelGGL(k_smc_set_beta, dim3(1), dim3(1), 0, s, st);
             SMC_HIP(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
             SMC_HIP(hipStreamSynchronize(s));
             beta = h.beta;
