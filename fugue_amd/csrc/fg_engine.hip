@@ -15,9 +15,11 @@
 #include "fg_cold.h"
 
 // ---- run(PriorHandler, model) per chain: interpreters.rs:88-104 ----
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose,
                                                         double *acc_out /*[3][C]*/, double *lj_out /*[C]*/) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -35,9 +37,11 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_prior_init(FgProgramD
 }
 
 // ---- run(ScoreGivenTrace, model) per chain: interpreters.rs:138-163 ----
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint(FgProgramDev P, FgChainCtx X, double *acc_out, double *logp_out,
                                                        double *lj_out) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -55,8 +59,10 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint(FgProgramDe
 // ---- the same scoring run over the SCORE STREAM (one 64-byte record per statement, program order): what the HMC
 // endpoint, the MH pre-run proposal path and SMC rejuvenation evaluate.  rec_lp (optional) [n_sstream][C] receives every
 // record's log-density, so each record kind can be checked against the reference's known-answer values.
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_log_joint_stream(FgProgramDev P, FgChainCtx X, double *acc_out, double *rec_lp) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -188,10 +194,12 @@ __device__ __forceinline__ FgTransOut fg_hmc_transition(const FgProgramDev &P, c
 
 // HmcSession::step x n_steps (hmc.rs:819-919), d > 0, without the mass-matrix reset (the
 // host splits launches at that iteration).
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps,
                                                        int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                        double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -448,10 +456,12 @@ __global__ __launch_bounds__(FG_WAVE * FG_MW_MAX, 4) void k_hmc_stream_steps(FgP
 }
 
 // hmc_transition with injected momentum / uniform (test hook)
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_injected(FgProgramDev P, FgChainCtx X, FgHmcDev H, double eps,
                                                                      const double *p0, const double *u_in, int *acc_out,
                                                                      double *alpha_out, int *div_out) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -470,8 +480,10 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_transition_inject
 }
 
 // grad_log_joint (hmc.rs:304-329) at the current values (test hook)
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev P, FgChainCtx X, double h, int sparse /* 2: analytic */, double *grad, int *ok) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -509,9 +521,11 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_grad(FgProgramDev
 
 // find_reasonable_epsilon (hmc.rs:479-535).  Momentum comes from p0_scratch [d][C] when
 // `injected`, else from the chain's (instance) EPS stream and is written there.
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, uint32_t instance, int injected,
                                                           double *eps_out) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;                        // tile width: every lane of the wave owns a chain
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -598,9 +612,11 @@ __global__ void k_hmc_da_new(FgHmcDev H, long long C, const double *eps0) {
 // adaptive_mcmc_chain's step loop: n_steps x single_site_mh_step (mh.rs:698-744), exactly one
 // model run per step (mh.rs:1186-1202).  Recorded draws: [t][r][C] cells of the CURRENT state
 // after each sampling-phase step (mh.rs:1010).
+template <bool GT>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, int iter0, int n_steps,
                                                                     int n_warmup, long long *draws, int first_sample_t) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
+    double *lds = GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_;        // GT: the tile lives in global memory (programs beyond 160 KB of LDS)
     constexpr int tw = FG_WAVE;
     const long long chain = (long long)blockIdx.x * tw + threadIdx.x;
     const bool live = chain < X.C;
@@ -693,6 +709,11 @@ __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_mh_steps(FgProgramDev
 // ======================================================================================
 // engine
 // ======================================================================================
+// one-wave-per-tile kernels: the tile in LDS, or -- programs whose tile exceeds the 160 KB of a CU -- in a global scratch
+// [tiles][rows][64] (same addressing through generic pointers; L2-resident for moderate chain counts).  Such programs run
+// everything on these kernels: the reference's hmc_chain / adaptive_mcmc_chain have no size limit (hmc.rs:238-260).
+#define FG_LAUNCH_GT(e, K, GRID, BLOCK, LDS, STREAM, ...) do { if ((e)->gt) hipLaunchKernelGGL((K<true>), GRID, BLOCK, 0, STREAM, __VA_ARGS__); \
+                                                               else hipLaunchKernelGGL((K<false>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); } while (0)
 extern "C" {
 
 void fg_hmc_config_default(fg_hmc_config *c) {     // HMCConfig::default, hmc.rs:125-135
@@ -728,12 +749,17 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     // one that only fits without the momentum is refused by fg_hmc_init.
     e->lds_score = (size_t)e->n_slots * e->tw * sizeof(double);
     e->lds_bytes = (size_t)(e->n_slots + e->d + 2 + FG_MW_MAX) * e->tw * sizeof(double);
-    if (e->lds_score > 160 * 1024) {
-        fg_set_error("model needs more than 160 KB of LDS per 64-chain tile (sites + expression temporaries > 320 cells)");
-        delete e; return nullptr; }
-    const size_t lds_hmc = std::min<size_t>(e->lds_bytes, 160 * 1024);
+    // beyond one CU's LDS: the tile goes to a global scratch and every kernel of this engine is the one-wave-per-tile form (GT)
+    e->gt = e->lds_bytes > 160 * 1024;
+    if (const char *gv = std::getenv("FG_GLOBAL_TILE")) e->gt = e->gt || std::atoi(gv) != 0;      // tests: any program through the global-tile instantiations
+    const size_t lds_hmc = e->gt ? 0 : std::min<size_t>(e->lds_bytes, 160 * 1024), lds_sc = e->gt ? 0 : e->lds_score;
     auto fail = [&](const char *what) { fg_set_error(std::string("fg_engine_new: ") + what + ": " + fg_last_error()); fg_engine_free(e); return (fg_engine *)nullptr; };
     if (hipStreamCreate(&e->stream) != hipSuccess) return fail("hipStreamCreate");
+    if (e->gt) {
+        e->X.gtile_rows = e->n_slots + e->d + 2 + FG_MW_MAX;
+        if (dev_alloc(&e->d_gtile, (size_t)((e->C + e->tw - 1) / e->tw) * e->X.gtile_rows * e->tw)) return fail("alloc global tile");
+        e->X.gtile = e->d_gtile;
+    }
     if (dev_upload(&e->d_ins, p->ins)) return fail("upload ins");
     if (dev_upload(&e->d_sub, p->sub)) return fail("upload sub");
     if (dev_upload(&e->d_ins_fast, p->ins_fast)) return fail("upload ins_fast");
@@ -760,13 +786,13 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     e->P.n_ins = p->n_ins; e->P.n_slots = e->n_slots; e->P.S = e->S; e->P.d = e->d;
     e->P.lin_tab = e->d_lin_tab; e->P.lin_meta = e->d_lin_meta; e->P.lin_n = p->lin_n; e->P.lin_p2 = p->lin_p2;
     e->X.C = e->C; e->X.chain0 = e->chain0; e->X.seed = e->seed; e->X.values = e->d_values;
-    if (set_lds(k_prior_init, e->lds_score) || set_lds(k_log_joint, e->lds_score) || set_lds(k_log_joint_stream, e->lds_score) ||
-        set_lds(k_hmc_steps, lds_hmc) || set_lds(k_hmc_stream_steps<0, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false, true>, lds_hmc) ||
+    if (set_lds(k_prior_init<false>, lds_sc) || set_lds(k_log_joint<false>, lds_sc) || set_lds(k_log_joint_stream<false>, lds_sc) ||
+        set_lds(k_hmc_steps<false>, lds_hmc) || set_lds(k_hmc_stream_steps<0, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false, true>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false, true>, lds_hmc) ||
         set_lds(k_hmc_stream_steps<0, true, true>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true, true>, lds_hmc) ||
         set_lds(k_hmc_stream_steps<0, false, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, false, false>, lds_hmc) || set_lds(k_hmc_stream_steps<2, false, false>, lds_hmc) ||
-        set_lds(k_hmc_stream_steps<0, true, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true, false>, lds_hmc) || set_lds(k_hmc_transition_injected, lds_hmc) ||
-        set_lds(k_hmc_grad, lds_hmc) || set_lds(k_hmc_find_eps, lds_hmc) ||
-        set_lds(k_mh_steps, e->lds_score))
+        set_lds(k_hmc_stream_steps<0, true, false>, lds_hmc) || set_lds(k_hmc_stream_steps<1, true, false>, lds_hmc) || set_lds(k_hmc_transition_injected<false>, lds_hmc) ||
+        set_lds(k_hmc_grad<false>, lds_hmc) || set_lds(k_hmc_find_eps<false>, lds_hmc) ||
+        set_lds(k_mh_steps<false>, lds_sc))
         return fail("hipFuncSetAttribute");
     return e;
 }
@@ -779,7 +805,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
     if (e->smc_arena) hipFree(e->smc_arena);
-    void *ptrs[] = { e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -806,7 +832,7 @@ int fg_engine_set_values(fg_engine *e, const void *h) {
     // a live sampler session caches the log-joint of its current state: re-score it at the new values (what the reference's
     // callers do after editing a trace: crates/fugue-wasm/src/mh.rs:239-255 runs ScoreGivenTrace)
     for (double *lj : { e->mh_ready ? e->M.lw : (double *)nullptr, e->hmc_ready ? e->H.lj : (double *)nullptr })
-        if (lj) hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
+        if (lj) FG_LAUNCH_GT(e, k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
                                    (double *)nullptr, lj);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -841,7 +867,7 @@ int fg_device_upload(fg_engine *e, void *d, const void *h, size_t bytes) {
 }
 
 int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
-    hipLaunchKernelGGL(k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, iteration,
+    FG_LAUNCH_GT(e, k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, iteration,
                        purpose, d_acc, d_lj);
     HIPCHK(hipGetLastError());
     return FG_OK;
@@ -859,7 +885,7 @@ int fg_prior_init(fg_engine *e, uint32_t iteration, double *h_acc) {
 int fg_log_joint(fg_engine *e, double *h_acc, double *h_logp) {
     NEED_ENGINE(e);
     if (h_logp && !e->d_logp) { int rc = dev_alloc(&e->d_logp, (size_t)std::max(1, e->S) * e->C); if (rc) return rc; }
-    hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
+    FG_LAUNCH_GT(e, k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
                        h_logp ? e->d_logp : nullptr, (double *)nullptr);
     HIPCHK(hipGetLastError());
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream));
@@ -876,7 +902,7 @@ int fg_log_joint_stream(fg_engine *e, double *h_acc, double *h_rec_lp) {
     double *d_rec = nullptr;
     const size_t nrec = (size_t)e->P.n_sstream * e->C;
     if (h_rec_lp) { int rc = dev_alloc(&d_rec, nrec); if (rc) return rc; }
-    hipLaunchKernelGGL(k_log_joint_stream, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc, d_rec);
+    FG_LAUNCH_GT(e, k_log_joint_stream, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc, d_rec);
     hipError_t he = hipGetLastError();
     if (he == hipSuccess && h_acc) he = hipMemcpyAsync(h_acc, e->d_acc, (size_t)3 * e->C * 8, hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess && h_rec_lp) he = hipMemcpyAsync(h_rec_lp, d_rec, nrec * 8, hipMemcpyDeviceToHost, e->stream);
@@ -910,14 +936,14 @@ void fg_internal_hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg) {
 }
 
 static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
-    hipLaunchKernelGGL(k_hmc_find_eps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, instance,
+    FG_LAUNCH_GT(e, k_hmc_find_eps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, instance,
                        injected, d_eps_out);
     HIPCHK(hipGetLastError());
     return FG_OK;
 }
 
 static int hmc_lds_ok(const fg_engine *e) {
-    if (e->lds_bytes <= 160 * 1024) return FG_OK;
+    if (e->lds_bytes <= 160 * 1024 || e->gt) return FG_OK;
     fg_set_error("HMC needs sites + temporaries + momentum in one 160 KB LDS tile (2 * f64 sites + other slots + 6 > 320 cells); "
                  "adaptive_mcmc_chain / adaptive_smc still run for this model");
     return FG_E_LIMIT;
@@ -977,7 +1003,7 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         const int rc = fg_hmc_lin_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
         if (rc != FG_E_UNSUPPORTED) return rc;
     }
-    if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE) {
+    if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE && !e->gt) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
         // a tile, whatever the chain count; each wave should still own at least 2 coordinates
@@ -1029,7 +1055,7 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         return FG_OK;
     }
     e->last_hmc_kernel = "k_hmc_steps W=1";
-    hipLaunchKernelGGL(k_hmc_steps, dim3(tiles), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
+    FG_LAUNCH_GT(e, k_hmc_steps, dim3(tiles), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,
                        e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     HIPCHK(hipGetLastError());
     return FG_OK;
@@ -1177,7 +1203,7 @@ int fg_hmc_grad(fg_engine *e, double h, int grad_mode, double *h_grad, int32_t *
     double *d_g = nullptr;
     int rc = dev_alloc(&d_g, (size_t)std::max(1, e->d) * e->C);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_hmc_grad, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, h,
+    FG_LAUNCH_GT(e, k_hmc_grad, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, h,
                        grad_mode == FG_GRAD_ANALYTIC ? 2 : (grad_mode == FG_GRAD_FD_SPARSE ? 1 : 0), d_g, e->d_itmp);
     hipError_t le = hipGetLastError();
     if (le == hipSuccess) le = hipMemcpyAsync(h_grad, d_g, (size_t)e->d * e->C * 8, hipMemcpyDeviceToHost, e->stream);
@@ -1195,7 +1221,7 @@ static int hmc_prepare_injected(fg_engine *e, const fg_hmc_config *cfg) {
     if (rc) return rc;
     if (!e->hmc_ready) {      // standalone use: lj of the current values, identity mass
         e->H.use_mass = 0;
-        hipLaunchKernelGGL(k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, (double *)nullptr,
+        FG_LAUNCH_GT(e, k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, (double *)nullptr,
                            (double *)nullptr, e->H.lj);
         HIPCHK(hipGetLastError());
     }
@@ -1214,7 +1240,7 @@ int fg_hmc_transition_injected(fg_engine *e, const fg_hmc_config *cfg, double ep
     HIPCHK(hipMemcpyAsync(e->d_tmp, h_u, C * 8, hipMemcpyHostToDevice, e->stream));
     int *ia = e->d_itmp, *idv = e->d_itmp + C;
     double *al = e->d_acc;
-    hipLaunchKernelGGL(k_hmc_transition_injected, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H,
+    FG_LAUNCH_GT(e, k_hmc_transition_injected, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H,
                        eps, (const double *)e->H.p0_scratch, (const double *)e->d_tmp, ia, al, idv);
     HIPCHK(hipGetLastError());
     if (h_acc) HIPCHK(hipMemcpyAsync(h_acc, ia, C * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1335,7 +1361,7 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
         if (rc == FG_OK) { e->mh_iter += n_steps; return FG_OK; }
         if (rc != FG_E_UNSUPPORTED) return rc;
     }
-    hipLaunchKernelGGL(k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->M,
+    FG_LAUNCH_GT(e, k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->M,
                        iter, n_steps, e->mh_warmup, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
     HIPCHK(hipGetLastError());
     e->mh_iter += n_steps;

@@ -25,6 +25,8 @@ struct FgChainCtx {
     uint32_t chain0;      // global id of chain 0 (RNG stream key)
     unsigned long long seed;
     long long *values;    // [S][C]
+    double *gtile;        // global-memory tiles [tiles][gtile_rows][64] of the one-wave kernels, or null (tiles in LDS)
+    int gtile_rows;
 };
 
 __device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
@@ -86,6 +88,8 @@ struct fg_engine {
     bool mh_mw_disabled = false;  // FG_MH_MW=0: keep every program on the one-wave-per-tile MH kernel (A/B tests)
     bool mh_has_prior_resample = false;   // an override asks for PriorResample on some site (needs the model-driven proposal path)
     bool sep_disabled = false;   // FG_HMC_SEP=0: keep independent-sites programs on the gradient-stream kernel (A/B tests)
+    bool gt = false;             // the program's tile exceeds a CU's LDS: tiles in global memory, one-wave-per-tile kernels only
+    double *d_gtile = nullptr;
     bool lin_disabled = false;   // FG_HMC_LIN=0: keep dense regressions on the gradient-stream kernel (A/B tests)
     double *d_lin_tab = nullptr; int *d_lin_meta = nullptr;   // dense-regression table (fg_hmc_lin.hip)
     int *d_sub_off = nullptr, *d_f64_slot = nullptr, *d_site_slot = nullptr, *d_vtype = nullptr, *d_site_cat = nullptr;

@@ -433,6 +433,7 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
 // Launch for `n` transitions from iteration `iter0`; FG_E_UNSUPPORTED when the program / configuration is not a dense
 // regression in the sparse finite-difference mode (the caller then takes the gradient-stream kernel).
 int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
+    if (e->gt) return FG_E_UNSUPPORTED;                       // tiles in global memory: the one-wave-per-tile kernels (fg_engine.hip)
     if (!e->P.lin_tab || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->lin_disabled || e->tw != FG_WAVE) return FG_E_UNSUPPORTED;
     const int D = e->d;
     if (D != 8 && D != 16 && D != 32) return FG_E_UNSUPPORTED;

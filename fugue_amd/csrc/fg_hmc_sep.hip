@@ -456,6 +456,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 // independent-sites FD-sparse run (the caller then takes the gradient-stream kernel).
 int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
     const bool dense = e->cfg.grad_mode == FG_GRAD_FD_DENSE, analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
+    if (e->gt) return FG_E_UNSUPPORTED;                       // tiles in global memory: the one-wave-per-tile kernels (fg_engine.hip)
     if (!e->P.sep || (e->cfg.grad_mode != FG_GRAD_FD_SPARSE && !dense && !analytic) || e->d < 1 || e->sep_disabled) return FG_E_UNSUPPORTED;
     const long long n_cu = std::max(1, e->n_simd / 4);
     const long long tiles64 = (e->C + FG_WAVE - 1) / FG_WAVE;

@@ -398,6 +398,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
 }
 
 int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
+    if (e->gt) return FG_E_UNSUPPORTED;                       // tiles in global memory: the one-wave-per-tile kernels (fg_engine.hip)
     if (!e->P.sstream || e->S < 1 || n_steps < 1 || e->mh_mw_disabled) return FG_E_UNSUPPORTED;
     const fg_program *p = e->prog;
     // every site must take a model-independent proposal: Categorical sites need a constant table, no PriorResample override

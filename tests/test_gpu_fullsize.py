@@ -203,26 +203,72 @@ def test_c5_mixture_64_points_categorical_indices_exact_vs_oracle(oracle):
     assert bad.sum() <= 1, np.nonzero(bad)[0]                       # <= 1 acceptance on a 1e-13 knife edge
 
 
-def test_lds_limits_large_models():
-    """The 64-chain LDS tile bounds the model size: 150 f64 sites still run HMC (157 KB tile), 200 f64 sites only fit
-    the score tile -- HMC is refused with FG_E_LIMIT, MH and the log-joint still run -- and 400 sites fit nothing."""
-    from fugue_amd import model as M
-    C = 128
-    cp = E.compile_model(W.normal_sites(150))
-    eng = E.Engine(cp, C, seed=2)
-    d = eng.device_alloc(4 * cp.d * C * 8)
-    st = eng.hmc_run(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=4), 4, 10, d)
-    assert np.isfinite(eng.download(d, (4, cp.d, C))).all() and st.n_divergent == 0
-    eng.device_free(d)
-    cp = E.compile_model(W.normal_sites(200))
-    eng = E.Engine(cp, C, seed=2)
-    with pytest.raises(E.EngineError) as ei:
-        eng.hmc_init(E.hmc_config(), 0)
-    assert ei.value.code == E.FG_E_LIMIT
-    eng.prior_init()
-    assert np.isfinite(eng.log_joint().sum(axis=0)).all()
-    st = eng.mh_run(50, 50, None, [0, 199], eng_buf := eng.device_alloc(50 * 2 * C * 8))
-    assert 0.05 < st.accept_rate < 0.95
-    eng.device_free(eng_buf)
-    with pytest.raises(E.EngineError):
-        E.Engine(E.compile_model(W.normal_sites(400)), C, seed=2)
+def test_models_larger_than_one_lds_tile(oracle):
+    """hmc_chain has no size limit in the reference (hmc.rs:238-260).  A program whose 64-chain tile exceeds the 160 KB of a CU
+    keeps its tile in a global scratch and runs on the one-wave-per-tile kernels: 400 independent sites (tile 419 KB) and a
+    200-coefficient regression (215 KB) run the log-joint, HMC transitions under injected momentum / uniform against the oracle,
+    a short adaptive hmc_run and single-site MH."""
+    rng = np.random.default_rng(2)
+    X, y, _ = W.ridge_data(30, 200)
+    for name, prog in (("normal_sites(400)", W.normal_sites(400)), ("ridge 200 x 30", W.ridge_regression(X, y))):
+        cp, om = E.compile_model(prog), oracle.OracleModel(prog)
+        C = 96
+        eng = E.Engine(cp, C, seed=2)
+        eng.prior_init()
+        cells = eng.get_values()
+        acc = eng.log_joint()
+        for c in (0, 17, 95):
+            oacc, _ = om.run_score(cells[:, c])
+            assert np.allclose(acc[:, c], oacc, rtol=1e-12, atol=1e-12), name
+        p0, u = rng.standard_normal((cp.d, C)), rng.random(C)
+        cfg = E.hmc_config(n_leapfrog=3)
+        eps = 0.02
+        acc_, alpha, div, lj = eng.hmc_transition_injected(cfg, eps, p0, u)
+        nxt = eng.get_values()
+        for c in (0, 40, 95):
+            q = np.ascontiguousarray(cells[om.f64_sites, c]).view(np.float64)
+            qo, ljo, oacc, oalpha, odiv = om.hmc_transition(cells[:, c], q, om.log_joint_at(cells[:, c], q), eps, 3, p0[:, c], u[c])
+            assert odiv == bool(div[c]), name
+            if not odiv:
+                assert abs(alpha[c] - oalpha) < 1e-5 and (oacc == bool(acc_[c]) or abs(u[c] - oalpha) < 1e-5), name
+                if oacc == bool(acc_[c]):     # 1e-6: the reference's own FD noise (1 ulp of a log-joint of several hundred / 2h) through three kicks
+                    assert np.allclose(np.ascontiguousarray(nxt[om.f64_sites, c]).view(np.float64), qo, rtol=1e-6, atol=1e-6), name
+        d = eng.device_alloc(6 * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(n_leapfrog=4), 6, 12, d)
+        assert "k_hmc_steps" in eng.hmc_last_kernel(), eng.hmc_last_kernel()
+        assert np.isfinite(eng.download(d, (6, cp.d, C))).all() and st.n_divergent == 0 and st.accept_rate > 0.3, name
+        eng.device_free(d)
+        st = eng.mh_run(40, 40, None, [0, cp.S - 1], buf := eng.device_alloc(40 * 2 * C * 8))
+        assert 0.05 < st.accept_rate < 0.95, name
+        eng.device_free(buf)
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["normal32", "ridge", "hier_scale", "alldists", "mixture"])
+def test_global_tile_instantiations_change_no_result(name, monkeypatch):
+    """The global-tile instantiations of the one-wave kernels (prior, log-joint, HMC, MH) against their LDS instantiations on
+    programs that fit both: the same cells, draws, step sizes and MH chains, bit for bit."""
+    from tests.models import ZOO
+    cp = E.compile_model(ZOO[name]())
+    C = 100
+    out = []
+    for gt in ("0", "1"):
+        monkeypatch.setenv("FG_GLOBAL_TILE", gt)
+        monkeypatch.setenv("FG_HMC_SEP", "0"); monkeypatch.setenv("FG_HMC_LIN", "0"); monkeypatch.setenv("FG_HMC_WAVES", "1"); monkeypatch.setenv("FG_MH_MW", "0")
+        eng = E.Engine(cp, C, seed=4, chain_offset=3)
+        eng.prior_init()
+        cells, acc = eng.get_values(), eng.log_joint()
+        res = [cells, acc]
+        if cp.d > 0:
+            d = eng.device_alloc(8 * cp.d * C * 8)
+            st = eng.hmc_run(E.hmc_config(n_leapfrog=5), 8, 10, d)
+            res += [eng.download(d, (8, cp.d, C)), eng.hmc_step_sizes(), eng.hmc_log_joint(), st.accept_rate]
+            eng.device_free(d)
+        buf = eng.device_alloc(30 * cp.S * C * 8)
+        st = eng.mh_run(30, 30, None, list(range(cp.S)), buf)
+        res += [eng.download(buf, (30, cp.S, C), dtype=np.int64), eng.mh_scales(), st.accept_rate]
+        eng.device_free(buf)
+        eng.close()
+        out.append(res)
+    for a, b in zip(*out):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
