@@ -814,6 +814,67 @@ __global__ __launch_bounds__(FG_SMC_WPB(SCORE) * FG_WAVE, SCORE == 2 ? 1 : (SCOR
     unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
     for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
 }
+// The reference's OWN rejuvenation order (fg_smc_config.sequential_adaptation; smc.rs:482,544-553,698-713): particle-major, and ONE
+// DiminishingAdaptation that every move of every particle updates before the next one reads its scale -- a recurrence through all
+// N x steps moves, sequential by construction.  One wave walks the particles in order (all lanes carry the same particle; lane 0
+// stores): the moves, their random numbers and the update are k_smc_rejuv's / DiminishingAdaptation::update (mcmc_utils.rs:88-150)
+// one at a time.  Orders of magnitude slower than the batched sweeps (a few us per move): the mode exists so that parity with
+// the reference's semantics can be CHECKED (tests/test_gpu_smc.py against the oracle's unbatched form), not to be fast.
+template <int SCORE>
+__global__ __launch_bounds__(FG_WAVE) void k_smc_rejuv_seq(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st, uint32_t move0, int n_moves) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x;
+    double *slots = lds + lane;
+    const double beta = st->beta;
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32);
+    for (long long c = 0; c < X.C; ++c) {
+        fg_load_values(P, X, c, slots, tw);
+        const uint32_t gchain = X.chain0 + (uint32_t)c;
+        for (int r = 0; r < n_moves; ++r) {
+            const uint32_t move_id = move0 + (uint32_t)r;
+            FgStream rng = fg_stream(X.seed, gchain, move_id, FG_RNG_SMC_REJUV);
+            unsigned long long ra, rb;
+            fg_rng_block(rng, ra, rb);
+            const int k = (int)fg_pick(ra, (uint32_t)P.d);            // f64_sites[rng.gen_range(0..len)]  smc.rs:650
+            const int site = P.f64_site[k];
+            const double scale = __builtin_nontemporal_load(&M.scale[site]);     // get_scale: what the previous move left  smc.rs:651
+            const double z = fg_cold_normal_pair(sk0, sk1, gchain, 1u, move_id, FG_RNG_SMC_REJUV).a;
+            const double cur = slots[k * tw];
+            const double prop = cur + scale * z;
+            double pri[2], lik[2];
+            for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed  smc.rs:662-675
+                slots[k * tw] = pass ? prop : cur;
+                FgAcc3 A = {0.0, 0.0, 0.0};
+                if (SCORE >= 0) fg_score_stream<(SCORE < 0 ? 0 : SCORE)>(P.sstream, P.n_sstream, P.pool, slots, tw, A);
+                else fg_exec<FG_MODE_SCORE, false>(P.ins_fast, P.n_ins, P.pool, slots, tw, A, nullptr, nullptr, 0, false);
+                pri[pass] = A.prior; lik[pass] = A.lik + A.fac;
+            }
+            const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
+            const double u = fg_cold_u01_pair(sk0, sk1, gchain, 2u, move_id, FG_RNG_SMC_REJUV).a;
+            const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));                  // smc.rs:680
+            if (!accept) slots[k * tw] = cur;
+            // DiminishingAdaptation::update(site, accepted)  mcmc_utils.rs:88-150
+            const long long tot = M.tot[site] + 1, acc = M.acc[site] + (accept ? 1 : 0);
+            double sc = scale, ls = M.log_scale[site];
+            if (tot >= 10) {
+                const double rate = (double)acc / (double)tot;
+                ls += (1.0 / pow((double)tot, 0.7)) * (rate - 0.44);
+                const double ns = exp(ls);
+                sc = (isfinite(ns) && ns > 0.0) ? fmin(fmax(ns, 0.001), 100.0) : 1.0;
+                ls = (sc == 1.0) ? 0.0 : log(sc);
+            }
+            if (lane == 0) {
+                if (accept) X.values[(long long)site * X.C + c] = fg_as_i64(prop);
+                M.lprior[c] = accept ? pri[1] : pri[0];
+                M.ll[c] = accept ? lik[1] : lik[0];
+                M.tot[site] = tot; M.acc[site] = acc; M.scale[site] = sc; M.log_scale[site] = ls;
+            }
+            __threadfence();                                          // the next move reads this site's state
+        }
+    }
+}
+
 // per-sweep batched DiminishingAdaptation update (see file header; oracle: adapt_update_batched): block j adds site j's
 // per-block counts, thread 0 applies the update
 __global__ __launch_bounds__(256) void k_smc_adapt(FgSmcDev M, int S, int n_blk) {
@@ -1040,7 +1101,7 @@ extern "C" {
 
 void fg_smc_config_default(fg_smc_config *c) {      // SMCConfig::default, smc.rs:181-189
     if (!c) return;
-    c->resampling_method = FG_RESAMPLE_SYSTEMATIC; c->ess_threshold = 0.5; c->rejuvenation_steps = 0;
+    c->resampling_method = FG_RESAMPLE_SYSTEMATIC; c->ess_threshold = 0.5; c->rejuvenation_steps = 0; c->sequential_adaptation = 0;
 }
 
 // ---- standalone device primitives (no program needed) ----
@@ -1161,6 +1222,14 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
                     const size_t lds_r = e->lds_score * wpb;
                     if (lds_r > 150 * 1024 || S > FG_SMC_HIST) { fg_set_error("SMC rejuvenation: tile does not fit LDS"); cleanup(); SC.free_all(); return FG_E_LIMIT; }
                     const unsigned nblk = (unsigned)((N + (long long)e->tw * wpb - 1) / ((long long)e->tw * wpb));
+                    if (cfg->sequential_adaptation) {               // the reference's order: one wave, particle by particle (k_smc_rejuv_seq)
+                        const uint32_t mv0 = (uint32_t)((steps - 1) * cfg->rejuvenation_steps);
+#define SMC_SEQ(SC_) do { SMC_TRY(set_lds(k_smc_rejuv_seq<SC_>, std::max<size_t>(e->lds_score, 64 * 1024 + 1))); \
+                          hipLaunchKernelGGL(k_smc_rejuv_seq<SC_>, dim3(1), dim3(FG_WAVE), e->lds_score, s, e->P, e->X, M, (const FgSmcScalars *)st, mv0, cfg->rejuvenation_steps); } while (0)
+                        if (score == 0) SMC_SEQ(0); else if (score == 3) SMC_SEQ(3); else if (score == 2) SMC_SEQ(2); else SMC_SEQ(-1);
+#undef SMC_SEQ
+                        n_runs += 2 * N * cfg->rejuvenation_steps;
+                    } else
                     for (int r = 0; r < cfg->rejuvenation_steps; ++r) {
                         const uint32_t mv = (uint32_t)((steps - 1) * cfg->rejuvenation_steps + r);
 #define SMC_REJUV(SC_) do { SMC_TRY(set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))); \

@@ -41,7 +41,7 @@ class fg_mh_stats(C.Structure):
 
 
 class fg_smc_config(C.Structure):
-    _fields_ = [("resampling_method", C.c_int32), ("ess_threshold", C.c_double), ("rejuvenation_steps", C.c_int32)]
+    _fields_ = [("resampling_method", C.c_int32), ("ess_threshold", C.c_double), ("rejuvenation_steps", C.c_int32), ("sequential_adaptation", C.c_int32)]
 
 
 class fg_smc_result(C.Structure):
@@ -567,11 +567,11 @@ class Engine:
         return a
 
     # ---- SMC ----------------------------------------------------------------------------
-    def smc_run(self, resampling_method=RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=0, max_betas=10000, download=True):
+    def smc_run(self, resampling_method=RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=0, max_betas=10000, download=True, sequential_adaptation=False):
         """`adaptive_smc` (/root/reference/src/inference/smc.rs:455-581) over this engine's chains as particles.
         download=False leaves particles and weights in HBM (engine values / fg_smc_run's device state): only the
         evidence, the ladder and the counters come back."""
-        cfg = fg_smc_config(int(resampling_method), float(ess_threshold), int(rejuvenation_steps))
+        cfg = fg_smc_config(int(resampling_method), float(ess_threshold), int(rejuvenation_steps), 1 if sequential_adaptation else 0)
         res = fg_smc_result()
         betas = np.zeros(max_betas)
         log_w, w = (np.zeros(self.C), np.zeros(self.C)) if download else (None, None)

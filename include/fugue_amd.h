@@ -271,6 +271,12 @@ typedef struct fg_smc_config {      /* SMCConfig, smc.rs:172-189 (same defaults)
     int32_t resampling_method;      /* systematic */
     double  ess_threshold;          /* 0.5 */
     int32_t rejuvenation_steps;     /* 0 */
+    int32_t sequential_adaptation;  /* 0: every particle of a rejuvenation sweep uses the scales from the sweep's start and the shared
+                                     * DiminishingAdaptation is updated once per sweep from per-site counts (the many-particle form);
+                                     * 1: the reference's own order (smc.rs:482,544-553,698-713) -- particle-major, the one adaptation
+                                     * updated after EVERY move -- walked by one wave, sequential by construction (a few us per move:
+                                     * for checking parity with the reference's semantics, not for speed).  (Sits in what was padding:
+                                     * the struct's size and the other fields' offsets are unchanged.) */
 } fg_smc_config;
 typedef struct fg_smc_result {      /* SMCResult minus the particles (smc.rs:361-366) */
     double  log_evidence;

@@ -340,7 +340,7 @@ SMCResult adaptive_smc(uint64_t seed, size_t num_particles, F model_fn, SMCConfi
     auto prog = flatten<A>(model_fn);
     Engine eng(*prog, (int64_t)num_particles, seed, device);
     const size_t S = (size_t)prog->n_sites();
-    fg_smc_config c{(int32_t)config.resampling_method, config.ess_threshold, (int32_t)config.rejuvenation_steps};
+    fg_smc_config c{(int32_t)config.resampling_method, config.ess_threshold, (int32_t)config.rejuvenation_steps, 0};
     fg_smc_result r{};
     out.n_particles = num_particles; out.weights.resize(num_particles); out.log_weights.resize(num_particles); out.betas.resize(10000);
     check(fg_smc_run(eng.raw(), &c, out.log_weights.data(), out.weights.data(), &r, out.betas.data(), (int)out.betas.size()), "adaptive_smc");

@@ -149,7 +149,8 @@ impl GpuBackend {
         let (sites, vtypes) = Self::sorted_sites(&prog);
         let (s, n) = (sites.len(), num_particles);
         let cfg = fg_smc_config { resampling_method: match config.resampling_method { ResamplingMethod::Multinomial => 0, ResamplingMethod::Systematic => 1, ResamplingMethod::Stratified => 2 },
-                                  ess_threshold: config.ess_threshold, rejuvenation_steps: config.rejuvenation_steps as i32 };
+                                  ess_threshold: config.ess_threshold, rejuvenation_steps: config.rejuvenation_steps as i32,
+                                  sequential_adaptation: 0 /* 1 = the reference's particle-by-particle adaptation, sequential by construction */ };
         let (mut lw, mut w) = (vec![0f64; n], vec![0f64; n]);
         let mut res = fg_smc_result::default();
         check(unsafe { fg_smc_run(eng.0, &cfg, lw.as_mut_ptr(), w.as_mut_ptr(), &mut res, std::ptr::null_mut(), 0) })?;

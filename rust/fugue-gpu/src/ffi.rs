@@ -45,7 +45,7 @@ pub struct fg_site_proposal { pub kind: i32, pub lower: f64, pub upper: f64 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct fg_mh_stats { pub accept_rate: f64, pub n_steps: i64 }
 #[repr(C)] #[derive(Clone, Copy, Debug)]
-pub struct fg_smc_config { pub resampling_method: i32, pub ess_threshold: f64, pub rejuvenation_steps: i32 }
+pub struct fg_smc_config { pub resampling_method: i32, pub ess_threshold: f64, pub rejuvenation_steps: i32, pub sequential_adaptation: i32 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct fg_smc_result { pub log_evidence: f64, pub n_steps: i32, pub n_model_runs: i64 }
 

@@ -74,8 +74,9 @@ def test_resample_large_population_properties():
 def _smc_pair(oracle, prog, n, seed, **kw):
     cp, om = E.compile_model(prog), oracle.OracleModel(prog)
     eng = E.Engine(cp, n, seed=seed)
-    got = eng.smc_run(rejuvenation_steps=kw.get("R", 0), ess_threshold=kw.get("thr", 0.5), resampling_method=kw.get("method", 1))
-    exp = om.smc_run(n, seed, method=kw.get("method", 1), ess_threshold=kw.get("thr", 0.5), rejuvenation_steps=kw.get("R", 0), batched=1)
+    seq = kw.get("sequential", False)
+    got = eng.smc_run(rejuvenation_steps=kw.get("R", 0), ess_threshold=kw.get("thr", 0.5), resampling_method=kw.get("method", 1), sequential_adaptation=seq)
+    exp = om.smc_run(n, seed, method=kw.get("method", 1), ess_threshold=kw.get("thr", 0.5), rejuvenation_steps=kw.get("R", 0), batched=0 if seq else 1)
     return cp, got, exp
 
 
@@ -100,6 +101,28 @@ def test_smc_tempered_matches_oracle(oracle, method):
     assert bad.sum() <= 3, bad.sum()                   # a knife-edge accept / resample boundary
     np.testing.assert_allclose(got["weights"][~bad], exp["weights"][~bad], rtol=1e-8)
     assert got["n_model_runs"] == exp["n_model_evals"]
+
+
+@pytest.mark.parametrize("name", ["smc_normal", "refmodel8"])
+def test_smc_sequential_adaptation_is_the_references_order(oracle, name):
+    """fg_smc_config.sequential_adaptation: particle-major moves with ONE DiminishingAdaptation updated after every move
+    (smc.rs:482,544-553,698-713) -- the reference's own semantics, against the oracle's unbatched form: the beta ladder, the
+    evidence, every particle and weight.  (The default, batched per sweep, is the documented deviation; this mode closes it.)"""
+    from tests.models import ZOO
+    prog = W.smc_normal() if name == "smc_normal" else ZOO[name]()
+    cp, got, exp = _smc_pair(oracle, prog, 1500, seed=42, R=3, sequential=True)
+    np.testing.assert_allclose(got["betas"], exp["betas"], rtol=1e-9)
+    assert got["log_evidence"] == pytest.approx(exp["log_evidence"], rel=1e-9)
+    bad = np.zeros(1500, dtype=bool)
+    for j in range(cp.S):
+        bad |= ~np.isclose(got["values"].view(np.float64)[j], exp["values"].view(np.float64)[j], rtol=1e-9, atol=1e-12)
+    # an accept on a knife edge changes that particle AND, through the shared adaptation, every later scale by ~1e-4: the comparison is
+    # exact or it visibly is not
+    assert bad.sum() == 0, bad.sum()
+    np.testing.assert_allclose(got["weights"], exp["weights"], rtol=1e-8)
+    assert got["n_model_runs"] == exp["n_model_evals"]
+    _, got_b, _ = _smc_pair(oracle, prog, 1500, seed=42, R=3)
+    assert not np.array_equal(got_b["values"], got["values"])            # ... and it is not the batched form
 
 
 def test_smc_multisite_model_matches_oracle(oracle):
