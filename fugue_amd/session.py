@@ -153,21 +153,20 @@ class HmcSession:
     def site_names(self) -> List[str]:
         return list(self._names)
 
-    def step(self, n: int) -> int:                               # hmc.rs:104-115: post-warmup states are kept
+    def step(self, n: int) -> int:                               # hmc.rs:104-115: the state after EVERY transition is kept, warmup included (push_history)
         n = int(n)
-        before = self.eng.hmc_iterations()
         if n > 0:
-            buf = self.eng.device_alloc(max(1, n * self.d * self.C) * 8)
-            self.eng.hmc_step(n, buf)
-            kept = max(0, before + n - max(before, self.n_warmup))
-            if kept > 0 and self.d > 0:
-                self.hist.append(self.eng.download(buf, (kept, self.d, self.C), dtype=np.int64))
-            self.eng.device_free(buf)
+            pos, _ = self.eng.hmc_step_info(n)                   # [n][d][C]: each transition's state (fg_hmc_step_info)
+            if self.d > 0:
+                self.hist.append(np.ascontiguousarray(pos).view(np.int64))
         return self.eng.hmc_iterations()
 
-    def step_recorded(self, chain: int = 0):                     # hmc.rs:83-101: the next transition's leapfrog path of one chain
+    def step_recorded(self, chain: int = 0):                     # hmc.rs:83-101: the next transition's leapfrog path of one chain; its state joins the history
         L = int(self.cfg.n_leapfrog)
         traj, ham, npts = self.eng.hmc_step_recorded([int(chain)], L)
+        if self.d > 0:
+            cells = self.eng.get_values()
+            self.hist.append(np.ascontiguousarray(cells[self.cp.f64_sites])[None, :, :])
         return dict(positions=traj[0, :npts[0]], hamiltonians=ham[0, :npts[0]], n_points=int(npts[0]))
 
     def set_step_size(self, eps: float):                         # hmc.rs:118-121: pins the step size and ends the warmup (hmc.rs:741-747)
@@ -184,7 +183,7 @@ class HmcSession:
     def step_size(self) -> np.ndarray:                           # hmc.rs:133-136 (one per chain)
         return self.eng.hmc_step_sizes()
 
-    def values(self, site: str) -> np.ndarray:                   # hmc.rs:138-146: [retained draws][chains]
+    def values(self, site: str) -> np.ndarray:                   # hmc.rs:138-146: [retained states][chains], every transition since the session began
         if site not in self._names:
             return np.zeros((0, self.C))
         return np.ascontiguousarray(self.hist.buf[:, self._names.index(site), :]).view(np.float64)

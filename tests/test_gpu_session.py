@@ -58,15 +58,17 @@ def test_mh_session_matches_a_plain_run_of_the_same_steps():
 def test_hmc_session_protocol():
     s = HmcSession(MODEL, n_chains=128, seed=3, n_warmup=50, n_leapfrog=8)
     assert s.site_names() == ["mu"] and s.is_warming_up()
-    assert s.step(30) == 30 and s.values("mu").shape == (0, 128) and s.is_warming_up()
-    assert s.step(40) == 70 and not s.is_warming_up() and s.values("mu").shape == (20, 128)      # states are kept once the warmup is over
+    assert s.step(30) == 30 and s.values("mu").shape == (30, 128) and s.is_warming_up()          # every transition's state is kept, warmup included (hmc.rs:104-115, 159-164)
+    assert s.step(40) == 70 and not s.is_warming_up() and s.values("mu").shape == (70, 128)
+    assert np.array_equal(s.values("mu")[-1], s.eng.get_values()[0].view(np.float64))             # the last kept state is the chains' current one
     rec = s.step_recorded(chain=5)
     assert rec["n_points"] == 9 and rec["positions"].shape == (9, 1) and np.isfinite(rec["hamiltonians"]).all()
-    assert s.values("mu").shape == (20, 128)                    # the recorded transition advanced the chains but is not part of the kept history
+    assert s.values("mu").shape == (71, 128)                    # the recorded transition's state joins the history (hmc.rs:83-101)
+    assert np.array_equal(s.values("mu")[-1], s.eng.get_values()[0].view(np.float64))
     s.set_n_leapfrog(12)
     s.step(200)
-    x = s.values("mu")
-    assert x.shape == (220, 128) and abs(x.mean() - 2.0) < 0.05 and s.ess("mu") > 1000
+    x = s.values("mu")[71:]
+    assert x.shape == (200, 128) and abs(x.mean() - 2.0) < 0.05 and s.ess("mu") > 1000
     assert (s.step_size() > 0.0).all()
     s.close()
 
