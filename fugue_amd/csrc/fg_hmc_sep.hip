@@ -246,6 +246,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         // its kinetic term, the whole trajectory in registers, the endpoint's kinetic and score terms
         bool bad = false;
         double zb = 0.0;
+        FgD2 zzh = {0.0, 0.0}; bool zh_next = false;                 // half tiles: the pair a lane half generated, and whether the upper half's is the next pair
         const double *termsE = terms;                                // rows of the endpoint's score terms
         if (DENSE) {
             for (int i = k0; i < k1; ++i) {                          // p0 ~ N(0, M), its kinetic term, the start position
@@ -328,7 +329,21 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             const bool on = !HALF || i + half < d;                   // odd d: the upper half idles on the last pair
             const int ci = HALF ? (on ? i + half : i) : i;           // the lane's coordinate
             double z;
-            if (HALF) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = (half && on) ? zz.b : zz.a; }   // an idle upper half repeats the lower half's coordinate: the same values to the same cells
+            if (HALF) {
+                // Both lane halves carry the same chains, so generating a pair in both would double the Philox + Box-Muller work per
+                // chain.  Instead a wave takes its pairs two at a time: the lower half generates this pair, the upper half the wave's
+                // NEXT pair, and each hands the other the component it needs (one cross-half exchange per pair).  An idle upper half
+                // (odd d, last pair) repeats the lower half's coordinate: the same values to the same cells.
+                if (!(((i - k0) >> 1) & 1)) {
+                    zh_next = i + 2 < k1;
+                    zzh = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1) + ((half && zh_next) ? 1u : 0u), (uint32_t)iter, FG_RNG_HMC);
+                    const double ob = __shfl_xor(zzh.b, 32, 64);       // this pair's second component, from the lower half
+                    z = half ? (on ? (zh_next ? ob : zzh.b) : zzh.a) : zzh.a;
+                } else {
+                    const double oa = __shfl_xor(zzh.a, 32, 64);       // the next pair's first component, from the upper half
+                    z = half ? (on ? zzh.b : zzh.a) : oa;
+                }
+            }
             else if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
             else z = zb;
             double p = MASS ? z * ms[(long long)ci * X.C] : z;
@@ -483,7 +498,7 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     int W = e->mw_override > 0 ? e->mw_override : 1;
     if (e->mw_override <= 0) {
         const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
-        while (W < FG_SEP_WMAX && resident * W < 16 && (half ? pairs >= 2 * W : e->d >= 4 * W)) W *= 2;
+        while (W < FG_SEP_WMAX && resident * W < 16 && (half ? pairs >= 2 * W : e->d >= 4 * W)) W *= 2;     // (a half tile with a pair per wave beats two pairs per wave sharing their random numbers: 1.31e10 against 1.25e10 at 8 192 chains)
     }
     while (W > 1 && 2 * (W - 1) >= e->d + 1) W /= 2;             // no empty waves
     FgSegSep seg;
