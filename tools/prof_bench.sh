@@ -1,9 +1,7 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats of the default bench command (what BENCH_rNN.json is measured with, minus the CPU baseline and extras)
+# kernel-trace + --stats of the default bench command (CPU baselines skipped: they only add host time) -> gpurun_out/r3prof_bench
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- python3 $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof_bench.log
-cd $R && head -4 gpurun_out/prof_bench/*/*kernel_stats.csv | cut -c1-220 && python3 -c "
-import json
-j = json.loads(open('gpurun_out/prof_bench.json').read().strip().splitlines()[-1]); print('bench under the profiler: avg_launch_ms', j['roofline']['avg_launch_ms'], 'value', j['value'])"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3prof_bench; rm -rf $O; mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
+cd $R && python3 tools/prof_bench_region.py $O/trace $O/bench.json $O/round3_hmc_timed_region.txt
+cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/round3_bench_kernel_stats.csv

@@ -60,7 +60,7 @@ def main(key):
         eng.synchronize()
     elif key == "smc|c4|1048576":
         eng = E.Engine(E.compile_model(W.smc_normal()), 1 << 20, seed=42)
-        for _ in range(2):                           # two identical runs: the collector halves the totals
+        for _ in range(3):                           # the collector keeps the last run (from its k_prior_init on)
             r = eng.smc_run(rejuvenation_steps=3, download=False)
         print(key, len(r["betas"]), "tempering steps")
     else:

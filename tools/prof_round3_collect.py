@@ -11,21 +11,27 @@ os.makedirs(S, exist_ok=True)
 KIB = 1024.0
 
 
-def counters(d):
-    """kernel base name -> counter -> values in dispatch order"""
+def counters(d, last_run_from=None):
+    """kernel base name -> counter -> values in dispatch order (last_run_from: only the dispatches from the LAST dispatch of that kernel on)"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r.get("Dispatch_Id", 0)))
+        if last_run_from:
+            starts = [int(r["Dispatch_Id"]) for r in rows if last_run_from in r["Kernel_Name"]]
+            rows = [r for r in rows if starts and int(r["Dispatch_Id"]) >= max(starts)]
         for r in rows:
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
 
-def trace(d):
+def trace(d, last_run_from=None):
     """kernel name -> list of durations (ns) in dispatch order"""
     out = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+        if last_run_from:
+            starts = [int(r["Start_Timestamp"]) for r in rows if last_run_from in r["Kernel_Name"]]
+            rows = [r for r in rows if starts and int(r["Start_Timestamp"]) >= max(starts)]
         for r in rows:
             out[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return out
@@ -41,7 +47,8 @@ for kd in sorted(glob.glob(os.path.join(O, "*", "key.txt"))):
     match, units, keep, unit = CONFIGS[key]
     ent = {"unit": unit, "units_per_dispatch": units, "dispatches_kept": keep}
     lines = [f"== {key}  (unit = {unit}; {units} per dispatch)"]
-    tr = trace(os.path.join(D, "stats"))
+    whole = "k_prior_init" if not match else None          # a whole run (SMC): the LAST run of the driver, which starts with its prior draw
+    tr = trace(os.path.join(D, "stats"), whole)
     if match:
         names = [k for k in tr if match in k]
         durs = [v for k in names for v in tr[k]][-keep:] if keep else []
@@ -49,17 +56,17 @@ for kd in sorted(glob.glob(os.path.join(O, "*", "key.txt"))):
         if durs:
             ent["kernel_trace_avg_ms_per_dispatch"] = sum(durs) / len(durs) / 1e6
             lines.append(f"kernel {ent['kernel']}: {len(durs)} dispatches kept, average {ent['kernel_trace_avg_ms_per_dispatch']:.4f} ms (min {min(durs) / 1e6:.4f}, max {max(durs) / 1e6:.4f})")
-    else:                                              # whole run (SMC): every kernel, two identical runs -> halve
+    else:                                              # whole run (SMC): every kernel and copy of the driver's last run
         tot = sum(sum(v) for v in tr.values())
-        ent["kernel_time_ms_per_unit"] = tot / 2 / 1e6
-        ent["launches_per_unit"] = sum(len(v) for v in tr.values()) / 2
+        ent["kernel_time_ms_per_unit"] = tot / 1e6
+        ent["launches_per_unit"] = sum(len(v) for v in tr.values())
         rows = sorted(((sum(v), len(v), k.split("(")[0]) for k, v in tr.items()), reverse=True)
-        lines.append(f"kernel time per run {ent['kernel_time_ms_per_unit']:.4f} ms over {ent['launches_per_unit']:.0f} launches")
-        for s_, n_, k_ in rows[:14]:
-            lines.append(f"   {k_[:60]:60s} {n_ / 2:6.1f} launches {s_ / 2 / 1e3:9.1f} us  avg {s_ / n_ / 1e3:7.2f} us")
+        lines.append(f"kernel time of the run {ent['kernel_time_ms_per_unit']:.4f} ms over {ent['launches_per_unit']:.0f} launches (summed durations; the host-timed run is in bench.py's smc leg)")
+        for s_, n_, k_ in rows[:16]:
+            lines.append(f"   {k_[:60]:60s} {n_:4d} launches {s_ / 1e3:9.1f} us  avg {s_ / n_ / 1e3:7.2f} us")
     cpu = {}
     for p in ("pmc1", "pmc2", "pmc3", "fetch", "write"):
-        acc = counters(os.path.join(D, p))
+        acc = counters(os.path.join(D, p), whole)
         for kname, cs in acc.items():
             if match and match not in kname:
                 continue
@@ -68,7 +75,7 @@ for kd in sorted(glob.glob(os.path.join(O, "*", "key.txt"))):
                     vv = v[-keep:]
                     cpu[c] = cpu.get(c, 0.0) + sum(vv) / len(vv) / units
                 else:
-                    cpu[c] = cpu.get(c, 0.0) + sum(v) / 2.0
+                    cpu[c] = cpu.get(c, 0.0) + sum(v)
     if "FETCH_SIZE" in cpu:
         ent["fetch_bytes_per_unit"] = cpu.pop("FETCH_SIZE") * KIB
     if "WRITE_SIZE" in cpu:
