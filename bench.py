@@ -419,14 +419,17 @@ def run_rank(args):
     # its own draws to chain sums on its GPU; the library all-reduces 6 d + 2 d doubles (+ 32 d per chunk of lags) over RCCL / xGMI
     # (fg_diag_rhat_ess; communicator created from an id that rank 0 obtains and torch.distributed's store hands out).
     t_diag = time.perf_counter()
-    diag_path, comm, failed, exch = "library (single GPU)", None, False, 0
+    diag_path, comm, failed, exch, fallback_note = "library (single GPU)", None, False, 0, ""
     r_ = None
     if world == 1:
         r_ = eng.diag_rhat_ess(last.data_ptr(), K, d, None)
-    elif not one_device or os.environ.get("FG_BENCH_FORCE_NATIVE_RCCL") == "1":    # (forced in the rehearsal mode: exercises the failure path)
+    elif not one_device or os.environ.get("FG_BENCH_FORCE_NATIVE_RCCL") == "1":    # (forced in the rehearsal mode: exercises the error path)
+        native_err = None
         try:
             ids = [E.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
+            if os.environ.get("FG_BENCH_FAKE_RCCL_HANG") == "1":     # rehearsal of the watchdog: a communicator that never forms
+                call_with_timeout(lambda: time.sleep(3600), 2.0)
             # under a watchdog: a communicator that cannot form must cost a bounded wait, not the run
             comm = call_with_timeout(lambda: eng.comm_init(world, rank, ids[0]), NATIVE_RCCL_TIMEOUT_S)
             r_ = call_with_timeout(lambda: eng.diag_rhat_ess(last.data_ptr(), K, d, comm), NATIVE_RCCL_TIMEOUT_S)
@@ -434,18 +437,37 @@ def run_rank(args):
             diag_path = "library: ncclAllReduce of chain sums (6 d + 2 d + 32 d per lag chunk doubles)"
             exch = r_["exchange_bytes"]
         except BaseException as ex:                              # noqa: BLE001
-            # No torch.distributed collective from here on: a thread may still sit inside RCCL on this device.  The line is
-            # finished from this rank's own chains and the process exits non-zero (main).
-            sys.stderr.write(f"rank {rank}: the library's RCCL exchange failed ({ex!r}); finishing from rank-local data, exit code {EXIT_DIAGNOSTICS_FAILED}\n")
+            native_err, r_ = ex, None
+        # Two kinds of failure.  A call that did NOT RETURN (watchdog): a thread of this process still sits inside RCCL on this
+        # device, so no further collective of any kind -- the line is finished from this rank's own chains and the process exits
+        # non-zero (main).  A call that RETURNED an error (the library could not bind / initialise RCCL): nothing is stuck, the
+        # ranks agree on it through torch.distributed (itself under the watchdog: a peer that hung never joins) and take the
+        # same O(d) exchange through torch.distributed's all-reduce instead; the line says so and the exit code stays 0.
+        hung = bool(ABANDONED)
+        if not hung:
+            try:
+                ok = torch.tensor([0 if native_err is not None else 1], dtype=torch.int32, device="cpu" if one_device else coll_dev)
+                call_with_timeout(lambda: (dist.all_reduce(ok, op=dist.ReduceOp.MIN), ok.cpu()), NATIVE_RCCL_TIMEOUT_S)
+                if int(ok.cpu()[0]) == 0:
+                    r_ = None
+                    if native_err is None:
+                        native_err = RuntimeError("another rank's library exchange returned an error")
+            except BaseException as ex:                          # noqa: BLE001
+                hung, native_err = True, native_err or ex
+        if hung:
+            sys.stderr.write(f"rank {rank}: the library's RCCL exchange did not return ({native_err!r}); finishing from rank-local data, exit code {EXIT_DIAGNOSTICS_FAILED}\n")
             failed, r_ = True, None
-            diag_path = f"failed ({type(ex).__name__}: {ex}); R-hat / ESS below are of THIS rank's chains only"
-    if r_ is None and not failed and world > 1:                  # one-device rehearsal: the same reduce exchange over torch.distributed (gloo)
+            diag_path = f"failed ({type(native_err).__name__}: {native_err}); R-hat / ESS below are of THIS rank's chains only"
+        elif native_err is not None:
+            sys.stderr.write(f"rank {rank}: the library's RCCL exchange returned an error ({native_err!r}); taking the same exchange through torch.distributed\n")
+            fallback_note = f" (the library's own RCCL exchange returned an error: {type(native_err).__name__}: {native_err})"
+    if r_ is None and not failed and world > 1:                  # the same reduce exchange over torch.distributed (one-device rehearsal: gloo)
         prov = D.EngineMoments(eng, last.data_ptr(), K, d)
         cd = D.ChainDiagnostics(prov, device=None if one_device else coll_dev)
         r_ = dict(r_hat=cd.split_rhat(), ess=cd.ess(), chains=cd.m)
         exch = cd.exchange_bytes
         prov.close()
-        diag_path = "torch.distributed all-reduce of chain sums + library combination (rehearsal mode)"
+        diag_path = "torch.distributed all-reduce of chain sums + library combination" + (fallback_note or " (rehearsal mode)")
     if r_ is None:                                               # failure path: rank-local statistics, no collective
         r_ = eng.diag_rhat_ess(last.data_ptr(), K, d, None)
     rhat, ess, n_chains_diag = r_["r_hat"], (r_["ess"] if K >= 4 else np.full(d, float("nan"))), r_["chains"]

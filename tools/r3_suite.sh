@@ -6,6 +6,7 @@ tail -4 gpurun_out/r3_gpu_suite.log
 grep -q "suite rc 0" gpurun_out/r3_gpu_suite.log || exit 1
 timeout -k 10 600 bash tools/rehearse_ranks.sh > gpurun_out/r3_rehearse.log 2>&1; echo "rehearse rc $?" | tee -a gpurun_out/r3_rehearse.log
 tail -6 gpurun_out/r3_rehearse.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout -k 10 900 python bench.py > gpurun_out/r3_bench_a.json 2> gpurun_out/r3_bench_a.err; echo "bench rc $?"
 tail -12 gpurun_out/r3_bench_a.err
 python - <<'PY'

@@ -2,9 +2,10 @@
 # Rehearsal of the N > 1 bench path on a ONE-GPU box (not a measurement): two ranks drive cuda:0, collectives over gloo.
 #   pass 1: every leg (HMC, MH, SMC, extras, validity) -- catches rank-asymmetric collectives (a rank-0-only leg that enters an
 #           all-gather deadlocks here exactly as it would on 8 GPUs);
-#   pass 2: the library's RCCL path forced on -- RCCL refuses two ranks on one device, so this exercises the failure path: a bounded
-#           wait, then every rank finishes from its own chains WITHOUT another collective, rank 0 still prints its line (marked
-#           failed) and the run exits non-zero.
+#   pass 2: the library's RCCL path forced on -- RCCL refuses two ranks on one device and RETURNS an error: the ranks agree on it
+#           and take the same O(d) exchange through torch.distributed; complete line, all chains in R-hat, exit code 0;
+#   pass 3: a communicator that never forms (FG_BENCH_FAKE_RCCL_HANG): a bounded wait, then every rank finishes from its own
+#           chains WITHOUT another collective, rank 0 still prints its line (marked failed) and the run exits non-zero.
 R=${GRAFT_REPO_ROOT:-.}
 cd $R
 mkdir -p gpurun_out
@@ -13,8 +14,12 @@ timeout -k 10 240 python bench.py --gpus 2 --chains 16384 --steps 100 --warmup 5
 grep "bench rank" gpurun_out/rehearse_all.err
 FG_BENCH_FORCE_NATIVE_RCCL=1 FG_BENCH_RCCL_TIMEOUT=25 timeout -k 10 240 python bench.py --gpus 2 --chains 16384 --steps 100 --warmup 50 --no-extras > gpurun_out/rehearse_rccl.out 2> gpurun_out/rehearse_rccl.err
 RC2=$?
-echo "pass 2 exit code $RC2 (a failed exchange must exit non-zero)"
-[ $RC2 -ne 0 ] || { echo "pass 2 FAILED: a hung / refused RCCL path exited 0"; exit 1; }
+echo "pass 2 exit code $RC2 (an exchange that returned an error falls back to torch.distributed: 0)"
+FG_BENCH_FORCE_NATIVE_RCCL=1 FG_BENCH_FAKE_RCCL_HANG=1 FG_BENCH_RCCL_TIMEOUT=25 timeout -k 10 240 python bench.py --gpus 2 --chains 16384 --steps 100 --warmup 50 --no-extras > gpurun_out/rehearse_hang.out 2> gpurun_out/rehearse_hang.err
+RC3=$?
+echo "pass 3 exit code $RC3 (an exchange that did not return must exit non-zero)"
+[ $RC3 -ne 0 ] || { echo "pass 3 FAILED: a hung RCCL path exited 0"; exit 1; }
+export RC2
 python - <<'PY'
 import json
 j = json.loads(open("gpurun_out/rehearse_all.out").read().strip().splitlines()[-1])
@@ -23,7 +28,15 @@ assert 0 < j["check"]["diagnostics_exchange_bytes_per_rank"] < 1 << 20, j["check
 print("pass 1 ok:", j["check"]["diagnostics_path"], "| exchanged", j["check"]["diagnostics_exchange_bytes_per_rank"], "B per rank")
 for leg in ("mh", "smc", "c3", "c5", "hmc_fd_dense", "validity"):
     assert leg in j, leg
+import os
 j = json.loads(open("gpurun_out/rehearse_rccl.out").read().strip().splitlines()[-1])
+p = j["check"]["diagnostics_path"]
+if os.environ["RC2"] == "0":
+    assert "returned an error" in p and j["check"]["chains_in_rhat"] == 2 * 16384, j["check"]
+else:                                                  # this RCCL build hung instead of refusing: the watchdog path, as in pass 3
+    assert p.startswith("failed") and j["check"]["chains_in_rhat"] == 16384, j["check"]
+print("pass 2 ok:", p[:140])
+j = json.loads(open("gpurun_out/rehearse_hang.out").read().strip().splitlines()[-1])
 assert j["check"]["diagnostics_path"].startswith("failed") and j["check"]["chains_in_rhat"] == 16384 and "mh" not in j, j["check"]
-print("pass 2 ok:", j["check"]["diagnostics_path"][:90])
+print("pass 3 ok:", j["check"]["diagnostics_path"][:90])
 PY
