@@ -743,6 +743,7 @@ fg_engine *fg_engine_new(const fg_program *p, int64_t n_chains, uint64_t seed, u
     if (const char *mw = std::getenv("FG_HMC_WAVES")) { const int w = std::atoi(mw); if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) e->mw_override = w; }
     if (const char *sp = std::getenv("FG_HMC_SEP")) e->sep_disabled = std::atoi(sp) == 0;
     if (const char *sp = std::getenv("FG_HMC_LIN")) e->lin_disabled = std::atoi(sp) == 0;
+    if (const char *sp = std::getenv("FG_HMC_INTERP_MW")) e->interp_mw_disabled = std::atoi(sp) == 0;
     if (const char *sp = std::getenv("FG_MH_MW")) e->mh_mw_disabled = std::atoi(sp) == 0;
     // LDS tile of 64 chains: the score / prior / MH / SMC kernels need the slot rows only, the HMC kernels also the
     // momentum and the multi-wave exchange rows.  A model whose slots alone exceed the 160 KB of a CU cannot run at all;
@@ -805,7 +806,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
     if (e->smc_arena) hipFree(e->smc_arena);
-    void *ptrs[] = { e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_mwi_order, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -1053,6 +1054,10 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         HIPCHK(hipGetLastError());
         e->last_hmc_kernel = std::string(dense_stream ? "k_hmc_stream_steps (dense stream) W=" : "k_hmc_stream_steps W=") + std::to_string(W);
         return FG_OK;
+    }
+    {   // interpreter programs: the tile shared by W waves, each on its own copy of the slots (fg_hmc_interp.hip)
+        const int rc = fg_hmc_interp_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+        if (rc != FG_E_UNSUPPORTED) return rc;
     }
     e->last_hmc_kernel = "k_hmc_steps W=1";
     FG_LAUNCH_GT(e, k_hmc_steps, dim3(tiles), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, iter0, n,

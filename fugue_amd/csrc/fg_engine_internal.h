@@ -122,6 +122,8 @@ struct fg_engine {
     int diag_mode = 0;         // FG_DIAG_REDUCE / FG_DIAG_GATHER: how fg_diag_rhat_ess exchanges chain statistics between ranks
     long long diag_bytes = 0;  // bytes this rank put into collectives during the last fg_diag_rhat_ess
     std::string last_hmc_kernel;   // kernel (and waves per tile) the last fg_hmc_step launch ran (fg_hmc_last_kernel)
+    bool interp_mw_disabled = false;   // FG_HMC_INTERP_MW=0: keep interpreter programs on the one-wave-per-tile HMC kernel (A/B tests)
+    int *d_mwi_order = nullptr; std::vector<int> mwi_off; int mwi_W = 0, mwi_sparse = -1;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
 
@@ -188,6 +190,9 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
 
 // fg_hmc_lin.hip: observation-major finite-difference gradient for dense regressions (FG_E_UNSUPPORTED: not applicable)
 int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
+
+// fg_hmc_interp.hip: interpreter programs with a tile shared by W waves (FG_E_UNSUPPORTED: not applicable)
+int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
 
 // fg_engine.hip internals used by fg_state.hip
 extern "C" {

@@ -57,11 +57,22 @@ __device__ __forceinline__ double fg_dbl(uint32_t lo, uint32_t hi) { return __hi
 #define FG_I_IMM(r, k) fg_dbl(FG_I_DW(r, 6 + 2 * (k)), FG_I_DW(r, 7 + 2 * (k)))
 __device__ __forceinline__ double fg_ins_h(const FgInsRegs &r, int k) { return fg_dbl(FG_I_DW(r, 14 + 2 * k), FG_I_DW(r, 15 + 2 * k)); }
 
-__device__ __forceinline__ double fg_operand(uint32_t w, double imm, const double *slots, const double *pool, int tw) {
+// Row remapping of the multi-wave interpreter kernel (fg_hmc_interp.hip): the tile's SITE rows [0, n_shared) are shared by the
+// waves of a workgroup, every row above (expression temporaries, Categorical tables, select options, the zero slot) is private to
+// the wave -- row k of the program is row k + woff of the tile -- and reads of the coordinate under perturbation (`pi`) go to the
+// wave's private row `pert` instead of the shared one.  All scalar arithmetic (the program counter is wave-uniform).
+struct FgRemap { uint32_t pi, n_shared, woff, pert; };
+template <bool RM>
+__device__ __forceinline__ uint32_t fg_row(const FgRemap *rm, uint32_t idx) {
+    if (!RM) return idx;
+    return idx == rm->pi ? rm->pert : (idx < rm->n_shared ? idx : idx + rm->woff);
+}
+template <bool RM = false>
+__device__ __forceinline__ double fg_operand(uint32_t w, double imm, const double *slots, const double *pool, int tw, const FgRemap *rm = nullptr) {
     const uint32_t kind = FG_OPND_KIND(w), idx = FG_OPND_IDX(w);
     if (kind == FG_OPND_IMM) return imm;
-    if (kind == FG_OPND_SLOT_F) return slots[idx * tw];
-    if (kind == FG_OPND_SLOT_I) return (double)fg_as_i64(slots[idx * tw]);
+    if (kind == FG_OPND_SLOT_F) return slots[fg_row<RM>(rm, idx) * tw];
+    if (kind == FG_OPND_SLOT_I) return (double)fg_as_i64(slots[fg_row<RM>(rm, idx) * tw]);
     return pool[idx];
 }
 
@@ -143,9 +154,11 @@ __device__ __forceinline__ void fg_mh_walk_proposal(FgMhCtx &mh, uint32_t vtype,
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have two readable instructions past `n` (the host pads the arrays).
 // logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
-template <int MODE, bool WITH_LOGP>
+template <int MODE, bool WITH_LOGP, bool RM = false>
 __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, int tw, FgAcc3 &A,
-                                        FgStream *rng, double *logp_out, long long logp_stride, bool live, FgMhCtx *mh = nullptr) {
+                                        FgStream *rng, double *logp_out, long long logp_stride, bool live, FgMhCtx *mh = nullptr,
+                                        const FgRemap *rm = nullptr) {
+    static_assert(!RM || MODE == FG_MODE_SCORE, "row remapping: scoring runs only");
     double acc = 0.0;
     FgInsRegs I = fg_fetch_ins(prog, 0), Inext = fg_fetch_ins(prog, 1);
     for (int pc = 0; pc < n; ++pc) {
@@ -156,8 +169,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             // Normal, constant sigma (distribution.rs:189-208): operands are `imm + slot` (the zero slot for
             // constants), ln(sigma) hoisted, (x-mu)/sigma an exact multiply when sigma = 2^k.  A non-finite x or
             // mu makes z NaN or +-inf: NaN -> -inf by the guard, +-inf -> -inf by the formula itself.
-            const double xv = FG_I_IMM(I, 0) + slots[FG_I_OPND(I, 0) * tw];
-            const double mv = FG_I_IMM(I, 1) + slots[FG_I_OPND(I, 1) * tw];
+            const double xv = FG_I_IMM(I, 0) + slots[fg_row<RM>(rm, FG_I_OPND(I, 0)) * tw];
+            const double mv = FG_I_IMM(I, 1) + slots[fg_row<RM>(rm, FG_I_OPND(I, 1)) * tw];
             const double dl = xv - mv;
             double z = dl * fg_ins_h(I, 4);                                        // exact quotient when sigma = 2^k
             if (!(op & FG_F_POW2SCALE)) z = (op & FG_F_RCPSCALE) ? fg_div_const(dl, FG_I_IMM(I, 2), fg_ins_h(I, 4)) : dl / FG_I_IMM(I, 2);
@@ -179,8 +192,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             if (code == 3u) {                            // Categorical: distribution.rs:771-791
                 const uint32_t bw = FG_I_OPND(I, 1);
                 const int K = (int)FG_I_OPND(I, 2);
-                const uint32_t base = FG_OPND_IDX(bw);
                 const bool in_pool = FG_OPND_KIND(bw) == FG_OPND_POOL;
+                const uint32_t base = in_pool ? FG_OPND_IDX(bw) : fg_row<RM>(rm, FG_OPND_IDX(bw));   // a table in slots is a run of temporaries
                 long long xi;
                 if (MODE == FG_MODE_PRIOR && !observe) {
                     // first i with cumulative[i] >= u, clamped to K-1 (partition_point(c < u))
@@ -194,7 +207,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                     xi = idx < K - 1 ? idx : K - 1;
                     slots[aux * tw] = fg_as_double(xi);
                 } else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) {
-                    xi = fg_as_i64(slots[FG_OPND_IDX(xw) * tw]);
+                    xi = fg_as_i64(slots[fg_row<RM>(rm, FG_OPND_IDX(xw)) * tw]);
                     if (MODE == FG_MODE_MH && !observe) {
                         // usize target: resample from the site's prior; lqf/lqr = prior log-probs (mh.rs:516-530)
                         const bool is_t = ((int)aux == mh->target);
@@ -222,15 +235,15 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                         }
                     }
                 } else {
-                    xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw), vtype);
+                    xi = fg_int_of(fg_operand<RM>(xw, FG_I_IMM(I, 0), slots, pool, tw, rm), vtype);
                 }
                 if ((op & FG_F_INVALID) != 0u || xi < 0 || xi >= (long long)K) lp = FG_NEG_INF;
                 else if (in_pool) lp = pool[base + K + (int)xi];          // precomputed ln p (or -inf)
                 else { const double p = slots[(base + (int)xi) * tw]; lp = p > 0.0 ? log(p) : FG_NEG_INF; }
             } else {
-                const double p0 = fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw);
-                const double p1 = fg_operand(FG_I_OPND(I, 2), FG_I_IMM(I, 2), slots, pool, tw);
-                const double p2 = fg_operand(FG_I_OPND(I, 3), FG_I_IMM(I, 3), slots, pool, tw);
+                const double p0 = fg_operand<RM>(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw, rm);
+                const double p1 = fg_operand<RM>(FG_I_OPND(I, 2), FG_I_IMM(I, 2), slots, pool, tw, rm);
+                const double p2 = fg_operand<RM>(FG_I_OPND(I, 3), FG_I_IMM(I, 3), slots, pool, tw, rm);
                 if (MODE == FG_MODE_PRIOR && !observe) {
                     const long long cell = fg_sample_cold(code, hoisted, p0, p1, p2, rng);
                     slots[aux * tw] = fg_as_double(cell);
@@ -273,9 +286,9 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                     }
                 }
                 double xf = 0.0; long long xi = 0;
-                if (vtype == 0u) xf = fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw);
-                else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xi = fg_as_i64(slots[FG_OPND_IDX(xw) * tw]);
-                else xi = fg_int_of(fg_operand(xw, FG_I_IMM(I, 0), slots, pool, tw), vtype);
+                if (vtype == 0u) xf = fg_operand<RM>(xw, FG_I_IMM(I, 0), slots, pool, tw, rm);
+                else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xi = fg_as_i64(slots[fg_row<RM>(rm, FG_OPND_IDX(xw)) * tw]);
+                else xi = fg_int_of(fg_operand<RM>(xw, FG_I_IMM(I, 0), slots, pool, tw, rm), vtype);
                 if ((op & FG_F_INVALID) != 0u) lp = FG_NEG_INF;
                 else if (code == 12u && hoisted) {
                     // Normal with constant parameters -- the hot case (distribution.rs:189-208):
@@ -297,7 +310,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)aux * logp_stride] = lp; }
             }
         } else {
-            const double x0 = fg_operand(FG_I_OPND(I, 0), FG_I_IMM(I, 0), slots, pool, tw);
+            const double x0 = fg_operand<RM>(FG_I_OPND(I, 0), FG_I_IMM(I, 0), slots, pool, tw, rm);
             switch (code) {
             case FG_OP_FACTOR: A.fac += x0; break;       // Handler::on_factor
             case FG_OP_LOAD: acc = x0; break;
@@ -320,14 +333,14 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             case FG_OP_RPOW: acc = pow(x0, acc); break;
             case FG_OP_MIN: acc = fmin(acc, x0); break;
             case FG_OP_MAX: acc = fmax(acc, x0); break;
-            case FG_OP_CLAMP: acc = fg_clamp(acc, x0, fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw)); break;
-            case FG_OP_MAC: { const double t = x0 * fg_operand(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw);
+            case FG_OP_CLAMP: acc = fg_clamp(acc, x0, fg_operand<RM>(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw, rm)); break;
+            case FG_OP_MAC: { const double t = x0 * fg_operand<RM>(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw, rm);
                               acc = acc + t; break; }
-            case FG_OP_STORE: slots[FG_I_AUX(I) * tw] = acc; break;
+            case FG_OP_STORE: slots[fg_row<RM>(rm, FG_I_AUX(I)) * tw] = acc; break;
             case FG_OP_GATHER: { const int k = (int)FG_I_OPND(I, 1);
                                  const bool ok = (acc >= 0.0) && (acc < (double)k) && (acc == floor(acc));
                                  const int j = ok ? (int)acc : 0;
-                                 const double v = slots[(FG_I_AUX(I) + j) * tw];
+                                 const double v = slots[(fg_row<RM>(rm, FG_I_AUX(I)) + j) * tw];     // the options are a run of temporaries
                                  acc = ok ? v : NAN; break; }
             case FG_OP_CONSTLIK: A.lik += FG_I_IMM(I, 0); break;
             case FG_OP_DOT: {                             // n MACs (slot x constant), terms fetched 4 at a time by scalar loads
@@ -336,7 +349,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 int t = 0;
                 for (; t + 4 <= n; t += 4) {
                     const fg_u32x16 q = *(const FG_AS4 fg_u32x16 *)(tb + 16 * t);
-                    const double v0 = slots[q[0] * tw], v1 = slots[q[4] * tw], v2 = slots[q[8] * tw], v3 = slots[q[12] * tw];
+                    const double v0 = slots[fg_row<RM>(rm, q[0]) * tw], v1 = slots[fg_row<RM>(rm, q[4]) * tw], v2 = slots[fg_row<RM>(rm, q[8]) * tw], v3 = slots[fg_row<RM>(rm, q[12]) * tw];
                     acc = acc + v0 * fg_dbl(q[2], q[3]);
                     acc = acc + v1 * fg_dbl(q[6], q[7]);
                     acc = acc + v2 * fg_dbl(q[10], q[11]);
@@ -344,7 +357,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 }
                 for (; t < n; ++t) {
                     const fg_u32x4 q = *(const FG_AS4 fg_u32x4 *)(tb + 16 * t);
-                    acc = acc + slots[q[0] * tw] * fg_dbl(q[2], q[3]);
+                    acc = acc + slots[fg_row<RM>(rm, q[0]) * tw] * fg_dbl(q[2], q[3]);
                 }
                 break; }
             default: break;

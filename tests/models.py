@@ -178,6 +178,38 @@ def indep_uniform5() -> M.Program:
 ZOO["indep_uniform5"] = indep_uniform5
 
 
+def poisson_glm(n: int = 12) -> M.Program:
+    """A log-link count regression: the Poisson rate is exp(linear predictor) -- an expression parameter, so every coordinate's
+    finite difference runs through the interpreter (no record stream)."""
+    rng = np.random.default_rng(12)
+    P = M.Program()
+    b = [P.sample(M.addr("b", j), M.Normal(0.0, 1.0 if j else 2.0)) for j in range(4)]
+    X = rng.normal(0.0, 0.6, (n, 3))
+    for i in range(n):
+        eta = b[0] + b[1] * float(X[i, 0]) + b[2] * float(X[i, 1]) + b[3] * float(X[i, 2])
+        P.observe(M.addr("y", i), M.Poisson(M.exp(eta)), int(rng.poisson(np.exp(0.4 + 0.5 * X[i, 0] - 0.3 * X[i, 1]))))
+    return P
+
+
+def hier_logsigma(groups: int = 5) -> M.Program:
+    """A hierarchical model in the usual unconstrained form: the group scale is exp(log_sigma) and the observation scale a
+    sqrt of a site -- expression parameters on both levels."""
+    rng = np.random.default_rng(13)
+    P = M.Program()
+    mu = P.sample(M.addr("mu"), M.Normal(0.0, 5.0))
+    ls = P.sample(M.addr("log_sigma"), M.Normal(0.0, 1.0))
+    v = P.sample(M.addr("v"), M.Gamma(3.0, 2.0))
+    for g in range(groups):
+        x = P.sample(M.addr("x", g), M.Normal(mu, M.exp(ls)))
+        for j in range(2):
+            P.observe(M.addr("y", 2 * g + j), M.Normal(x, M.sqrt(v)), float(rng.normal(0.5 * g, 1.0)))
+    return P
+
+
+ZOO["poisson_glm"] = poisson_glm
+ZOO["hier_logsigma"] = hier_logsigma
+
+
 # random programs (tests/random_models.py): every ZOO-wide test (site tables, log-joint, prior draws vs the oracle) covers them too
 from tests.random_models import random_program  # noqa: E402
 

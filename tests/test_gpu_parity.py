@@ -347,6 +347,39 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
 
 
+@pytest.mark.parametrize("name,adapt_mass,mode", [("alldists", True, E.GRAD_FD_SPARSE), ("alldists", False, E.GRAD_FD_DENSE),
+                                                  ("poisson_glm", True, E.GRAD_FD_SPARSE), ("hier_logsigma", False, E.GRAD_FD_SPARSE),
+                                                  ("hier_logsigma", True, E.GRAD_FD_DENSE), ("mixture", False, E.GRAD_FD_DENSE),
+                                                  ("hier_scale", True, E.GRAD_FD_DENSE), ("rand3", False, E.GRAD_FD_DENSE)])
+def test_hmc_interp_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
+    """Programs without a gradient stream (expression parameters, selects, guards ...) share a tile between W waves, each on its
+    own copy of the slots (k_hmc_interp_mw_steps, fg_hmc_interp.hip): per coordinate the same operations in the same order as
+    the one-wave kernel, so draws, step sizes, mass matrix, log-joint and values agree BIT FOR BIT for every W."""
+    cp = E.compile_model(ZOO[name]())
+    if cp.d < 2:
+        pytest.skip("one coordinate: nothing to split")
+    C, nw, ns = 150, 30, 20
+    out, kernels = [], []
+    for mw, W, occ in [(0, 0, 3), (1, 2, 3), (1, 3, 2), (1, 4, 4), (1, 8, 2), (1, 12, 3), (1, 0, 3)]:
+        monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
+        monkeypatch.setenv("FG_HMC_INTERP_OCC", str(occ))
+        if W: monkeypatch.setenv("FG_HMC_INTERP_WAVES", str(W))
+        else: monkeypatch.delenv("FG_HMC_INTERP_WAVES", raising=False)
+        eng = E.Engine(cp, C, seed=23, chain_offset=9)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=5, adapt_mass=adapt_mass), ns, nw, d)
+        kernels.append(eng.hmc_last_kernel())
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
+                    eng.hmc_mass() if adapt_mass else None))
+    assert kernels[0] == "k_hmc_steps W=1" and all(k.startswith("k_hmc_interp_mw_steps W=") for k in kernels[1:]), kernels
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert np.isfinite(out[0][0]).all()
+
+
 @pytest.mark.parametrize("mode", [E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE, E.GRAD_ANALYTIC])
 @pytest.mark.parametrize("name,adapt_mass", [("normal32", False), ("normal32", True), ("readme", False), ("indep_mixed", True), ("indep_mixed", False),
                                              ("indep_uniform5", True)])

@@ -16,6 +16,10 @@ CONFIGS = {
     "mh|refmodel20|65536": ("k_mh_mw_steps", 100, 6, "chain step of every chain"),
     "mh|c5|262144": ("k_mh_mw_steps", 100, 2, "chain step of every chain"),
     "smc|c4|1048576": ("", 1, 0, "run"),
+    "hmc|zoo:alldists|65536|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
+    "hmc|zoo:alldists|8192|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
+    "hmc|zoo:hier_logsigma|65536|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
+    "hmc|zoo:poisson_glm|65536|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
 }
 
 
@@ -31,6 +35,17 @@ def main(key):
         eng.hmc_step(25 if mode == E.GRAD_FD_SPARSE else 10)
         for _ in range(n):
             eng.hmc_step(25, d)                      # sampling launches: draw rows written, as in the bench's timed region
+        eng.synchronize()
+        print(key, eng.hmc_last_kernel())
+    elif parts[0] == "hmc" and parts[1].startswith("zoo:"):
+        from tests.models import ZOO
+        C = int(parts[2])
+        cp = E.compile_model(ZOO[parts[1][4:]]())
+        eng = E.Engine(cp, C, seed=2)
+        eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=16), 10)
+        eng.hmc_step(10)                                 # adaptation
+        for _ in range(CONFIGS[key][2]):
+            eng.hmc_step(5)
         eng.synchronize()
         print(key, eng.hmc_last_kernel())
     elif parts[0] == "hmc" and parts[1] == "c3":
