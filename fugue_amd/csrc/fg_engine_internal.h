@@ -123,7 +123,7 @@ struct fg_engine {
     long long diag_bytes = 0;  // bytes this rank put into collectives during the last fg_diag_rhat_ess
     std::string last_hmc_kernel;   // kernel (and waves per tile) the last fg_hmc_step launch ran (fg_hmc_last_kernel)
     bool interp_mw_disabled = false;   // FG_HMC_INTERP_MW=0: keep interpreter programs on the one-wave-per-tile HMC kernel (A/B tests)
-    int *d_mwi_order = nullptr; std::vector<int> mwi_off; int mwi_W = 0, mwi_sparse = -1;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
+    int *d_mwi_order = nullptr; long long *d_mwi_prof = nullptr; std::vector<int> mwi_off; std::vector<long long> mwi_cost; int mwi_W = 0, mwi_sparse = -1, mwi_calibrated = 0;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
 

@@ -111,7 +111,7 @@ __device__ __forceinline__ void fg_lin_mu_dual(const fg_u32x16 &r, const double 
 __device__ __forceinline__ void fg_gen_lp(const fg_u32x16 &r, double xs, const double *slots, int tw, double h, int n_signs, double *lp_out) {
     const uint32_t fl = r[2], kind = (fl >> 16) & 0xffu, ci = r[3];
     if (fl & FG_G_GEN_INVALID) { lp_out[0] = FG_NEG_INF; lp_out[1] = FG_NEG_INF; return; }
-    const bool xint = (fl & FG_G_GEN_XINT) != 0u, hoisted = (fl & FG_G_GEN_HOISTED) != 0u, sh = (fl & FG_G_GEN_SH) != 0u;
+    const bool xint = (fl & FG_G_GEN_XINT) != 0u, hoisted = (fl & FG_G_GEN_HOISTED) != 0u, sh = (fl & FG_G_GEN_SH) != 0u, xh = (fl & FG_G_GEN_XH) != 0u;
     const double xv = (fl & FG_G_X_CONST) ? fg_dbl(r[4], r[5]) : xs;
     const long long xi = xint ? fg_as_i64(xv) : 0;
     const double xf = xint ? 0.0 : xv;
@@ -128,11 +128,11 @@ __device__ __forceinline__ void fg_gen_lp(const fg_u32x16 &r, double xs, const d
     for (int s = 0; s < n_signs; ++s) {                      // the perturbed operand holds orig +- h (hmc.rs:317-319)
         const double hs = dual ? (s == 0 ? h : -h) : 0.0;
 #ifdef FG_GEN_INLINE_LOGPDF
-        const double hh5[5] = { hh[0], hh[1], 0.0, 0.0, 0.0 };
-        lp_out[s] = fg_logpdf(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1], pp[2] ? p[2] + hs : p[2], hh5, sh);
+        const double hh5[5] = { hh[0], hh[1], 0.0, xh ? hh[1] : 0.0, 0.0 };
+        lp_out[s] = fg_logpdf(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1], pp[2] ? p[2] + hs : p[2], hh5, sh, xh);
 #else
         lp_out[s] = fg_logpdf_cold(kind, hoisted, false, px ? xf + hs : xf, xi, pp[0] ? p[0] + hs : p[0], pp[1] ? p[1] + hs : p[1],
-                                   pp[2] ? p[2] + hs : p[2], hh[0], hh[1], 0.0, 0.0, 0.0, sh);   // out of line: the 17 densities stay out of the stream loops' registers
+                                   pp[2] ? p[2] + hs : p[2], hh[0], hh[1], 0.0, xh ? hh[1] : 0.0, 0.0, sh, xh);   // out of line: the 17 densities stay out of the stream loops' registers
 #endif
     }
 }

@@ -4,23 +4,25 @@
 // k_hmc_steps gives such a program ONE wave per tile: at 65 536 chains that is one wave per SIMD, so every instruction fetch, LDS
 // round trip, scalar branch and out-of-line density call of the interpreter sits exposed between its f64 instructions (a lone
 // wave issues a dependent f64 op every ~6 cycles, two or more one per ~4.4: profiles/round1_f64_issue_microbench.txt), and at 8 192
-// chains seven SIMDs in eight are idle.  The finite-difference gradient (hmc.rs:304-329) is d independent pairs of model runs:
-// here wave w evaluates the pairs of ITS coordinates (a host-side longest-processing-time split by sub-program cost).  The site
-// rows of the tile are shared and read-only inside a gradient; what an evaluation writes -- the perturbed coordinate, expression
+// chains seven SIMDs in eight are idle.  The finite-difference gradient (hmc.rs:304-329) is 2 d independent model runs: here
+// wave w evaluates ITS (coordinate, sign) tasks -- a host-side longest-processing-time split by sub-program cost.  The site rows
+// of the tile are shared and read-only inside a gradient; what an evaluation writes -- the perturbed coordinate, expression
 // temporaries, Categorical tables, select options -- lives in a small block of rows private to the wave (FgRemap, fg_interp.h:
 // the interpreter redirects reads of slot i to the wave's `pert` row and offsets every row above the sites), so a tile costs
-// S + W (temporaries + 2) rows of LDS, not W copies.  Each wave kicks its p_i in the shared momentum rows; after a workgroup
-// barrier the drift of coordinate k is applied by wave k mod W, and a second barrier publishes it.  The sequential parts (Hamiltonians, the endpoint score
-// in program order, accept, dual averaging) run on wave 0 exactly as in k_hmc_stream_steps.  Per coordinate the operations and
-// their order are those of fg_trajectory (fg_engine.hip), so the kernel is bit-identical to k_hmc_steps for every W
-// (tests/test_gpu_parity.py::test_hmc_interp_multiwave_is_bit_identical).
+// S + W (temporaries + 2) rows of LDS, not W copies.  Every evaluation leaves its log-joint in an LDS row; after a workgroup
+// barrier wave k mod W forms g_k, kicks p_k and drifts q_k, and a second barrier publishes it.  The sequential parts
+// (Hamiltonians, the endpoint score in program order, accept, dual averaging) run on wave 0 exactly as in k_hmc_stream_steps.
+// Per coordinate the operations and their order are those of fg_trajectory (fg_engine.hip), so the kernel is bit-identical to
+// k_hmc_steps for every W (tests/test_gpu_parity.py::test_hmc_interp_multiwave_is_bit_identical).
 #include "fg_engine_internal.h"
 #include "fg_cold.h"
 
 #define FG_MWI_MAX 16         /* waves per tile */
 
-struct FgMwi { int off[FG_MWI_MAX + 1]; const int *order; };   // wave w owns coordinates order[off[w] .. off[w + 1])
+struct FgMwi { int off[FG_MWI_MAX + 1]; const int *order; long long *prof; int n_sub_ins, n_fast_ins; };   // wave w owns the tasks order[off[w] .. off[w + 1]): 2 i + sign = evaluate at q_i + h / q_i - h;
+                                                                                  // prof: [2 d] cycles of each task (tile 0, first gradient of the launch) or null
 
+template <bool PL>
 __device__ __forceinline__ void fg_hmc_interp_mw_body(const FgProgramDev &P, const FgChainCtx &X, const FgHmcDev &H, const FgMwi &seg, int iter0, int n_steps,
                                                       int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                       double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
@@ -36,7 +38,17 @@ __device__ __forceinline__ void fg_hmc_interp_mw_body(const FgProgramDev &P, con
     const int np = P.n_slots - P.S + 1;                                              // private rows of a wave: temporaries, zero slot, perturbed coordinate
     double *slots = lds + lane;                                                      // site rows [0, S), shared
     double *pl = lds + (long long)(P.S + W * np) * tw + lane;                        // momentum rows, shared
-    double *xch = lds + ((long long)(P.S + W * np) + d) * tw + lane;                 // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    double *ev_lp = lds + ((long long)(P.S + W * np) + d) * tw + lane;               // log-joint of evaluation (coordinate i, sign): row 2 i + sign
+    double *xch = lds + ((long long)(P.S + W * np) + 3 * d) * tw + lane;             // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    // PL: the sub-programs and the whole program, staged in LDS behind the rows (instruction fetch = ds_read_b32)
+    const FgIns *l_sub = P.sub, *l_fast = P.ins_fast;
+    if (PL) {
+        uint32_t *dst = (uint32_t *)(lds + ((long long)(P.S + W * np) + 3 * d + 2 + W) * tw);
+        const int n_sub_dw = seg.n_sub_ins * 24, n_fast_dw = seg.n_fast_ins * 24;
+        for (int k = (int)threadIdx.x; k < n_sub_dw; k += (int)blockDim.x) dst[k] = ((const uint32_t *)P.sub)[k];
+        for (int k = (int)threadIdx.x; k < n_fast_dw; k += (int)blockDim.x) dst[n_sub_dw + k] = ((const uint32_t *)P.ins_fast)[k];
+        l_sub = (const FgIns *)dst; l_fast = (const FgIns *)(dst + n_sub_dw);
+    }
     FgRemap rm;
     rm.pi = 0xffffffffu; rm.n_shared = (uint32_t)P.S; rm.woff = (uint32_t)(wv * np); rm.pert = (uint32_t)(P.n_slots + wv * np);
     const int j0 = seg.off[wv], j1 = seg.off[wv + 1];
@@ -83,45 +95,51 @@ __device__ __forceinline__ void fg_hmc_interp_mw_body(const FgProgramDev &P, con
         __syncthreads();
         const double e = xch[0], hk = 0.5 * e;
         // leapfrog (hmc.rs:353-407) + endpoint score (hmc.rs:283-299) as one flat loop of model evaluations around the interpreter's
-        // single call site: this wave's coordinates at +h then -h for gradients 0 .. L, then (wave 0) the whole program
-        const int n_evals = (L + 1) * 2 * (j1 - j0) + (wv == 0 ? 1 : 0);
+        // single call site: this wave's (coordinate, sign) tasks for gradients 0 .. L, then (wave 0) the whole program.  An evaluation
+        // leaves its log-joint in row 2 i + sign of `ev_lp`; behind the barrier wave k mod W forms g_k, kicks p_k and drifts q_k.
+        const int n_evals = (L + 1) * (j1 - j0) + (wv == 0 ? 1 : 0);
         bool bad = false;
-        int s = 0, jj = j0, i = 0, slot = 0;
-        FgCoord cd = {0, 0, 0, 0};
-        double orig = 0.0, lp_plus = 0.0, lj_new = FG_NEG_INF;
+        int s = 0, jj = j0;
+        double lj_new = FG_NEG_INF;
         for (int ev = 0; ev < n_evals; ++ev) {
             const bool is_final = (wv == 0) && (ev == n_evals - 1);
-            const bool minus = (ev & 1) != 0;
-            const FgIns *prog = P.ins_fast;
-            int n = P.n_ins;
+            const FgIns *prog = l_fast;
+            int n = P.n_ins, task = 0;
+            rm.pi = 0xffffffffu;
             if (!is_final) {
                 // the perturbed value goes to the wave's private row; the shared q_i is only read (hmc.rs:317-319 restores it: here it never changes)
-                if (!minus) { i = seg.order[jj]; cd = P.coord[i]; slot = cd.slot; orig = slots[slot * tw]; slots[rm.pert * tw] = orig + h; }
-                else slots[rm.pert * tw] = orig - h;
-                if (sparse) { prog = P.sub + cd.sub_off; n = cd.sub_n; }
+                task = seg.order[jj];
+                const FgCoord cd = P.coord[task >> 1];
+                const double orig = slots[cd.slot * tw];
+                slots[rm.pert * tw] = (task & 1) ? orig - h : orig + h;
+                rm.pi = (uint32_t)cd.slot;
+                if (sparse) { prog = l_sub + cd.sub_off; n = cd.sub_n; }
             }
-            rm.pi = is_final ? 0xffffffffu : (uint32_t)slot;
+            const bool clocked = seg.prof != nullptr && blockIdx.x == 0 && t == 0 && s == 0 && !is_final;
+            long long t0 = 0;
+            if (clocked) t0 = (long long)clock64();
             FgAcc3 A = {0.0, 0.0, 0.0};
-            fg_exec<FG_MODE_SCORE, false, true>(prog, n, P.pool, slots, tw, A, nullptr, nullptr, 0, false, nullptr, &rm);
+            fg_exec<FG_MODE_SCORE, false, true, PL>(prog, n, P.pool, slots, tw, A, nullptr, nullptr, 0, false, nullptr, &rm);
             const double tot = fg_total(A);
             if (is_final) { lj_new = tot; break; }
-            if (!minus) { lp_plus = tot; continue; }
-            const double g = (lp_plus - tot) / (2.0 * h);            // hmc.rs:322
-            bad = bad || !fg_finite(g);
-            double p = pl[i * tw];
-            p += hk * g;                                              // hmc.rs:389 / :400
-            if (s > 0 && s < L) p += hk * g;                          // trailing kick of step s + leading kick of s + 1
-            pl[i * tw] = p;
+            ev_lp[task * tw] = tot;
+            if (clocked && lane == 0) seg.prof[task] = (long long)clock64() - t0;
             if (++jj == j1) {
                 jj = j0;
-                __syncthreads();                                      // every p kicked, every read of q done
-                if (s < L) {                                          // q += eps * M^-1 p   (hmc.rs:391-393): coordinate k by wave k mod W
-                    for (int k = wv; k < d; k += W) {
+                __syncthreads();                                      // every evaluation of this gradient done, every read of q done
+                for (int k = wv; k < d; k += W) {
+                    const double g = (ev_lp[2 * k * tw] - ev_lp[(2 * k + 1) * tw]) / (2.0 * h);    // hmc.rs:322
+                    bad = bad || !fg_finite(g);
+                    double p = pl[k * tw];
+                    p += hk * g;                                      // hmc.rs:389 / :400
+                    if (s > 0 && s < L) p += hk * g;                  // trailing kick of step s + leading kick of s + 1
+                    pl[k * tw] = p;
+                    if (s < L) {                                      // q += eps * M^-1 p   (hmc.rs:391-393)
                         const double mk = mi ? mi[(long long)k * X.C] : 1.0;
-                        slots[k * tw] += e * mk * pl[k * tw];
+                        slots[k * tw] += e * mk * p;
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
                 ++s;
             }
         }
@@ -184,15 +202,17 @@ __device__ __forceinline__ void fg_hmc_interp_mw_body(const FgProgramDev &P, con
     }
 }
 
-// OCC = waves per SIMD the register budget allows (2: 256 VGPRs, no spills; 3: 168; 4: 128 with the interpreter's cold paths spilling)
-#define FG_MWI_KERNEL(OCC) \
+// OCC = waves per SIMD the register budget allows (2: 256 VGPRs, no spills; 4: 128 with the interpreter's cold paths spilling -- the
+// faster one wherever enough waves exist: tools/bench_interp_mw.py); PL: program staged in LDS
+#define FG_MWI_KERNEL(OCC, PL, NAME) \
 __global__ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) __launch_bounds__(FG_WAVE * 4 * OCC) \
-void k_hmc_interp_mw_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgMwi seg, int iter0, int n_steps, int n_warmup, int welford_on, double *draws, \
-                                    int first_sample_t, double *pos_all, double *info) { \
-    fg_hmc_interp_mw_body(P, X, H, seg, iter0, n_steps, n_warmup, welford_on, draws, first_sample_t, pos_all, info); }
-FG_MWI_KERNEL(2)
-FG_MWI_KERNEL(3)
-FG_MWI_KERNEL(4)
+void NAME(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgMwi seg, int iter0, int n_steps, int n_warmup, int welford_on, double *draws, \
+          int first_sample_t, double *pos_all, double *info) { \
+    fg_hmc_interp_mw_body<PL>(P, X, H, seg, iter0, n_steps, n_warmup, welford_on, draws, first_sample_t, pos_all, info); }
+FG_MWI_KERNEL(2, false, k_hmc_interp_mw_steps_occ2)
+FG_MWI_KERNEL(4, false, k_hmc_interp_mw_steps_occ4)
+FG_MWI_KERNEL(2, true, k_hmc_interp_mw_steps_lds_occ2)
+FG_MWI_KERNEL(4, true, k_hmc_interp_mw_steps_lds_occ4)
 
 // cost of one interpreted instruction in the split (relative: an out-of-line density with its logs / lgammas against an add)
 static long long mwi_ins_cost(const FgIns &in) {
@@ -208,77 +228,104 @@ static long long mwi_ins_cost(const FgIns &in) {
     }
 }
 
+// longest-processing-time split of the 2 d tasks (task 2 k + sign costs cost[k]) over W waves; returns the makespan
+static long long mwi_split(const std::vector<long long> &cost, int W, std::vector<std::vector<int>> *bins_out) {
+    const int n_tasks = 2 * (int)cost.size();
+    std::vector<int> by(n_tasks);
+    for (int k = 0; k < n_tasks; ++k) by[k] = k;
+    std::stable_sort(by.begin(), by.end(), [&](int a, int b) { return cost[a >> 1] > cost[b >> 1]; });
+    std::vector<std::vector<int>> bins(W);
+    std::vector<long long> load(W, 0);
+    for (int k : by) {
+        int best = 0;
+        for (int w = 1; w < W; ++w) if (load[w] < load[best]) best = w;
+        bins[best].push_back(k); load[best] += cost[k >> 1];
+    }
+    int lightest = 0;                                           // wave 0 also runs the endpoint score: it gets the lightest bin
+    for (int w = 1; w < W; ++w) if (load[w] < load[lightest]) lightest = w;
+    std::swap(bins[0], bins[lightest]);
+    if (bins_out) *bins_out = bins;
+    return *std::max_element(load.begin(), load.end());
+}
+
 int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
     if (e->interp_mw_disabled || e->gt || e->tw != FG_WAVE || e->d < 2) return FG_E_UNSUPPORTED;
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
     const bool sparse = e->cfg.grad_mode != FG_GRAD_FD_DENSE;
     for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;    // site rows first, the private rows above them
     for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
-    auto lds_for = [&](int W) { return (size_t)((long long)e->S + (long long)W * (e->n_slots - e->S + 1) + e->d + 2 + W) * FG_WAVE * sizeof(double); };
+    // the program in LDS (instruction fetch by ds_read_b32: -5 ... -10 % time) when that does not cost a resident tile: with two or more
+    // tiles per CU the workgroup must stay under half the LDS, a CU's only tile may take all of it
+    const size_t prog_bytes = (e->prog->sub.size() + e->prog->ins_fast.size()) * sizeof(FgIns);
+    const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
+    auto rows_for = [&](int W) { return (size_t)((long long)e->S + (long long)W * (e->n_slots - e->S + 1) + 3LL * e->d + 2 + W) * FG_WAVE * sizeof(double); };
+    auto lds_for = rows_for;
     int occ = 4;                                               // measured (tools/bench_interp_mw.py): 128 VGPRs with the cold paths spilling beats 168 and 198 -- the waves hide more than the spills cost
-    if (const char *sp = std::getenv("FG_HMC_INTERP_OCC")) occ = std::min(4, std::max(2, std::atoi(sp)));
+    if (const char *sp = std::getenv("FG_HMC_INTERP_OCC")) occ = std::atoi(sp) <= 2 ? 2 : 4;
     const int wmax = 4 * occ;                                  // a workgroup's waves must fit one CU at that occupancy
-    const int wcap = std::min(wmax, e->d);
-    int W;
+    const int wcap = std::min(wmax, 2 * e->d);
+    const int n_tasks = 2 * e->d;
     int forced = e->mw_override;
     if (const char *sp = std::getenv("FG_HMC_INTERP_WAVES")) forced = std::atoi(sp);
-    if (forced > 0) W = std::max(2, std::min(forced, wcap));
-    else {
-        // the fewest waves per tile that fill the CU's 4 x occ wave slots with the tiles it gets (each tile's LDS = W copies of the slots):
-        // many tiles -> few waves each, more coordinates per wave and a better balance; few tiles -> the tile is all its CU has
-        const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
-        for (W = 2; W < wcap; ++W) {
-            const long long resident = std::min<long long>(per_cu, (160 * 1024) / (long long)lds_for(W));
-            if (resident * W >= 4 * occ) break;
-        }
+    if (!e->d_mwi_order) {
+        HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)n_tasks * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
+        HIPCHK(hipMemsetAsync(e->d_mwi_prof, 0, (size_t)n_tasks * sizeof(long long), e->stream));
     }
-    while (W > 1 && lds_for(W) > 160 * 1024) --W;
-    if (W < 2) return FG_E_UNSUPPORTED;
-    if (e->mwi_W != W || e->mwi_sparse != (int)sparse || !e->d_mwi_order) {     // the split: longest processing time first
-        std::vector<long long> cost(e->d, 1);
+    const bool debug = std::getenv("FG_HMC_INTERP_DEBUG") != nullptr;
+    if (debug && e->mwi_calibrated == 1) {                      // FG_HMC_INTERP_DEBUG: the cycles the previous launch clocked per task, beside the static costs
+        std::vector<long long> prof(n_tasks, 0);
+        HIPCHK(hipMemcpyAsync(prof.data(), e->d_mwi_prof, (size_t)n_tasks * sizeof(long long), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (int k = 0; k < e->d; ++k) fprintf(stderr, "coord %d static %lld measured %lld %lld sub_n %d\n", k, e->mwi_cost[k], prof[2 * k], prof[2 * k + 1], e->prog->coord[k].sub_n);
+        e->mwi_calibrated = 2;
+    }
+    if (e->mwi_sparse != (int)sparse || e->mwi_cost.empty() || e->mwi_W <= 0) {
+        // task costs: static weights per interpreted instruction (they track the measured cycles within ~30 %: FG_HMC_INTERP_DEBUG)
+        e->mwi_cost.assign(e->d, 1);
         if (sparse)
             for (int k = 0; k < e->d; ++k) {
                 long long cs = 0;
                 for (int q = 0; q < e->prog->coord[k].sub_n; ++q) cs += mwi_ins_cost(e->prog->sub[e->prog->coord[k].sub_off + q]);
-                cost[k] = std::max(1LL, cs);
+                e->mwi_cost[k] = std::max(1LL, cs);
             }
-        std::vector<int> by(e->d);
-        for (int k = 0; k < e->d; ++k) by[k] = k;
-        std::stable_sort(by.begin(), by.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-        std::vector<std::vector<int>> bins(W);
-        std::vector<long long> load(W, 0);
-        for (int k : by) {
-            int best = 0;
-            for (int w = 1; w < W; ++w) if (load[w] < load[best]) best = w;
-            bins[best].push_back(k); load[best] += cost[k];
-        }
-        // wave 0 also runs the endpoint score: give it the lightest bin
-        int lightest = 0;
-        for (int w = 1; w < W; ++w) if (load[w] < load[lightest]) lightest = w;
-        std::swap(bins[0], bins[lightest]);
+        // waves per tile: eight (two tiles fill a CU's sixteen wave slots, one tile still gives every SIMD two waves), a power of two
+        // (measured: 6 and 12 lose to 4 and 8 on every model), never more than the 2 d tasks
+        int W = 2;
+        if (forced > 0) W = std::max(2, std::min(forced, wcap));
+        else while (2 * W <= std::min(8, wcap) && lds_for(2 * W) <= 160 * 1024) W *= 2;
+        while (W > 1 && lds_for(W) > 160 * 1024) --W;
+        if (W < 2) return FG_E_UNSUPPORTED;
+        std::vector<std::vector<int>> bins;
+        mwi_split(e->mwi_cost, W, &bins);
         std::vector<int> order;
-        e->mwi_off.assign(FG_MWI_MAX + 1, e->d);
+        e->mwi_off.assign(FG_MWI_MAX + 1, n_tasks);
         for (int w = 0; w < W; ++w) {
             e->mwi_off[w] = (int)order.size();
             std::sort(bins[w].begin(), bins[w].end());
             order.insert(order.end(), bins[w].begin(), bins[w].end());
         }
-        for (int w = W; w <= FG_MWI_MAX; ++w) e->mwi_off[w] = e->d;
-        if (!e->d_mwi_order) HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)e->d * sizeof(int)));
-        HIPCHK(hipMemcpyAsync(e->d_mwi_order, order.data(), (size_t)e->d * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(e->d_mwi_order, order.data(), (size_t)n_tasks * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));                // `order` is a local
-        e->mwi_W = W; e->mwi_sparse = (int)sparse;
+        e->mwi_W = W; e->mwi_sparse = (int)sparse; e->mwi_calibrated = 0;
     }
+    const int W = e->mwi_W;
     FgMwi seg;
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
     seg.order = e->d_mwi_order;
-    const size_t lds = lds_for(W);
-#define FG_MWI_LAUNCH(OCC) do { if (int rc = set_lds(k_hmc_interp_mw_steps_occ##OCC, lds)) return rc; \
-    hipLaunchKernelGGL(k_hmc_interp_mw_steps_occ##OCC, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, e->n_warmup, welford_on, \
+    seg.prof = (debug && e->mwi_calibrated == 0) ? e->d_mwi_prof : nullptr;
+    if (debug && e->mwi_calibrated == 0) e->mwi_calibrated = 1;
+    seg.n_sub_ins = (int)e->prog->sub.size(); seg.n_fast_ins = (int)e->prog->ins_fast.size();
+    bool pl = rows_for(W) + prog_bytes <= (size_t)(per_cu >= 2 ? 80 : 160) * 1024;
+    if (const char *sp = std::getenv("FG_HMC_INTERP_LDSPROG")) pl = std::atoi(sp) != 0 && rows_for(W) + prog_bytes <= 160 * 1024;
+    const size_t lds = rows_for(W) + (pl ? prog_bytes : 0);
+#define FG_MWI_LAUNCH(K) do { if (int rc = set_lds(K, lds)) return rc; \
+    hipLaunchKernelGGL(K, dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->H, seg, iter0, n, e->n_warmup, welford_on, \
                        draws, first_sample_t, pos_all, info); } while (0)
-    if (occ == 4) FG_MWI_LAUNCH(4); else if (occ == 3) FG_MWI_LAUNCH(3); else FG_MWI_LAUNCH(2);
+    if (pl) { if (occ == 4) FG_MWI_LAUNCH(k_hmc_interp_mw_steps_lds_occ4); else FG_MWI_LAUNCH(k_hmc_interp_mw_steps_lds_occ2); }
+    else { if (occ == 4) FG_MWI_LAUNCH(k_hmc_interp_mw_steps_occ4); else FG_MWI_LAUNCH(k_hmc_interp_mw_steps_occ2); }
 #undef FG_MWI_LAUNCH
     HIPCHK(hipGetLastError());
-    e->last_hmc_kernel = "k_hmc_interp_mw_steps W=" + std::to_string(W) + (occ != 2 ? " occ=" + std::to_string(occ) : std::string());
+    e->last_hmc_kernel = "k_hmc_interp_mw_steps W=" + std::to_string(W) + (occ != 4 ? " occ=" + std::to_string(occ) : std::string()) + (pl ? std::string() : std::string(" (program in global memory)"));
     return FG_OK;
 }

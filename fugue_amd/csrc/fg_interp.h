@@ -41,11 +41,16 @@ enum { FG_MODE_SCORE = 0, FG_MODE_PRIOR = 1, FG_MODE_MH = 2 };
 // instruction is waited for at that instruction's first operand read and every interpreted instruction exposes a
 // scalar-cache round trip (PMC: 45-63 % of the wave's cycles in s_waitcnt).  Vector loads return in order on their
 // own counter (vmcnt), so instructions are fetched two ahead and the wait is usually free.
+// PL: the program was staged in LDS by the kernel (fg_hmc_interp.hip): the fetch is one ds_read_b32 -- ~100 cycles and in order on
+// lgkmcnt like the operand reads around it -- instead of a vector-memory round trip (measured ~1 000 cycles per interpreted
+// instruction with the two-ahead global fetch, whatever the instruction did: tools/mb_interp_costs.py).
 struct FgInsRegs { uint32_t w; };
+template <bool PL = false>
 __device__ __forceinline__ FgInsRegs fg_fetch_ins(const FgIns *prog, int pc) {
     const int l = (int)(threadIdx.x & (FG_WAVE - 1));
     FgInsRegs r;
-    r.w = ((const uint32_t *)(prog + pc))[l < 24 ? l : 23];
+    if (PL) r.w = ((const __attribute__((address_space(3))) uint32_t *)(prog + pc))[l < 24 ? l : 23];
+    else r.w = ((const uint32_t *)(prog + pc))[l < 24 ? l : 23];
     return r;
 }
 __device__ __forceinline__ double fg_dbl(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
@@ -99,9 +104,9 @@ struct FgMhCtx {
 };
 // rare paths kept out of line so the interpreter stays small
 __device__ __noinline__ double fg_logpdf_cold(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1,
-                                              double p2, double h0, double h1, double h2, double h3, double h4, bool sh) {
+                                              double p2, double h0, double h1, double h2, double h3, double h4, bool sh, bool xh = false) {
     const double hh[5] = { h0, h1, h2, h3, h4 };
-    return fg_logpdf(kind, hoisted, pow2, xf, xi, p0, p1, p2, hh, sh);
+    return fg_logpdf(kind, hoisted, pow2, xf, xi, p0, p1, p2, hh, sh, xh);
 }
 __device__ __noinline__ long long fg_sample_cold(uint32_t kind, bool hoisted, double p0, double p1, double p2, FgStream *s) {
     return fg_sample_dist(kind, hoisted, p0, p1, p2, *s);
@@ -154,15 +159,15 @@ __device__ __forceinline__ void fg_mh_walk_proposal(FgMhCtx &mh, uint32_t vtype,
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have two readable instructions past `n` (the host pads the arrays).
 // logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
-template <int MODE, bool WITH_LOGP, bool RM = false>
+template <int MODE, bool WITH_LOGP, bool RM = false, bool PL = false>
 __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, int tw, FgAcc3 &A,
                                         FgStream *rng, double *logp_out, long long logp_stride, bool live, FgMhCtx *mh = nullptr,
                                         const FgRemap *rm = nullptr) {
     static_assert(!RM || MODE == FG_MODE_SCORE, "row remapping: scoring runs only");
     double acc = 0.0;
-    FgInsRegs I = fg_fetch_ins(prog, 0), Inext = fg_fetch_ins(prog, 1);
+    FgInsRegs I = fg_fetch_ins<PL>(prog, 0), Inext = fg_fetch_ins<PL>(prog, 1);
     for (int pc = 0; pc < n; ++pc) {
-        const FgInsRegs Inext2 = fg_fetch_ins(prog, pc + 2);     // two ahead, in order on vmcnt
+        const FgInsRegs Inext2 = fg_fetch_ins<PL>(prog, pc + 2);     // two ahead, in order on vmcnt (PL: lgkmcnt)
         const uint32_t op = FG_I_OP(I);
         const uint32_t code = FG_INS_OPCODE(op);
         if (MODE == FG_MODE_SCORE && code == FG_OP_NORMAL_FAST) {
@@ -301,7 +306,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 } else {
                     // out of line: the other sixteen densities (lgamma, log1p, pow ...) stay out of the interpreter loop's registers
                     lp = fg_logpdf_cold(code, hoisted, (op & FG_F_POW2SCALE) != 0u, xf, xi, p0, p1, p2, fg_ins_h(I, 0), fg_ins_h(I, 1), fg_ins_h(I, 2),
-                                        fg_ins_h(I, 3), fg_ins_h(I, 4), (op & FG_F_SCALEHOIST) != 0u);
+                                        fg_ins_h(I, 3), fg_ins_h(I, 4), (op & FG_F_SCALEHOIST) != 0u, (op & FG_F_XHOIST) != 0u);
                 }
             }
             if (observe) A.lik += lp;                    // interpreters.rs:76-83

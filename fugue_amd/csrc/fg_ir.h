@@ -41,8 +41,10 @@ enum : uint32_t {
     FG_F_POW2SCALE = 1u << 11,     // hoisted scale is 2^k: h[4] = 1/scale, (x-loc)/scale == (x-loc)*h[4] exactly
     FG_F_VTYPE_SHIFT = 12,         // 3 bits: FG_F64..FG_I64
     FG_F_RCPSCALE = 1u << 16,      // h[4] = RN(1/scale) and fg_div_const_ok(scale): (x - loc) / scale via fg_div_const (same bits)
-    FG_F_SCALEHOIST = 1u << 15     // location-scale family with a constant valid scale but a varying location:
+    FG_F_SCALEHOIST = 1u << 15,    // location-scale family with a constant valid scale but a varying location:
                                    // h[0] = the scale-only term (ln sigma, ...), h[4] = 1/scale when FG_F_POW2SCALE
+    FG_F_XHOIST = 1u << 17         // observed COUNT is a constant while the parameters vary: h[3] = the term of the value alone --
+                                   // Poisson ln k!, Binomial (constant n) ln C(n, k) -- one lgamma chain per evaluation less (count regressions)
 };
 #define FG_INS_OPCODE(op) ((op) & 0xffu)
 #define FG_INS_VTYPE(op) (((op) >> FG_F_VTYPE_SHIFT) & 7u)
@@ -73,6 +75,7 @@ enum : uint32_t { FG_S_OBS = 1u,      // score stream: the record is an observe 
                   FG_G_CATC = 1u << 28,   // Categorical site with a constant table (score stream only): xi = its slot, mimm dwords = {pool base, K}
                   FG_G_GEN = 1024u,    // any of the 17 distributions with leaf operands (fg_logpdf): layout below, kind in flags >> 16
                   FG_G_GEN_HOISTED = 2048u, FG_G_GEN_SH = 4096u, FG_G_GEN_INVALID = 8192u, FG_G_GEN_XINT = 16384u,
+                  FG_G_GEN_XH = 32768u,   // FG_F_XHOIST of the statement: the value-only term sits in h1 (a record with varying parameters has no other use for it)
                   FG_G_GEN_P0SLOT = 1u << 24, FG_G_GEN_P1SLOT = 1u << 25, FG_G_GEN_P2SLOT = 1u << 26,
                   FG_G_LIN = 256u,     // mu = mimm + sum_t slot[s_t] c_t: maskx = pool offset of the terms {u32 s, u32 0, f64 c},
                                        //   maskm = their number, flags >> 16 = first term that reads the record's coordinate

@@ -113,7 +113,8 @@ FG_HD double fg_du_logp(long long lo, long long hi) {
 // wave-uniform on the device.
 // ---------------------------------------------------------------------------------------
 FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1, double p2,
-                       const double *h, bool sh = false /* scale-only hoisting: sigma guards done on the host, h[0] valid */) {
+                       const double *h, bool sh = false /* scale-only hoisting: sigma guards done on the host, h[0] valid */,
+                       bool xh = false /* constant observed count: h[3] = its own term (FG_F_XHOIST) */) {
     switch (kind) {
     case 12: { /* Normal: distribution.rs:189-208 */
         if (!hoisted && ((!sh && (p1 <= 0.0 || !fg_finite(p1))) || !fg_finite(p0))) return FG_NEG_INF;
@@ -172,8 +173,10 @@ FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long l
         if (k > n) return FG_NEG_INF;
         if (p1 == 0.0) return (k == 0) ? 0.0 : FG_NEG_INF;
         if (p1 == 1.0) return (k == n) ? 0.0 : FG_NEG_INF;
-        double lgn = hoisted ? h[0] : fg_lgamma((double)n + 1.0);
-        double lbc = lgn - fg_lgamma((double)k + 1.0) - fg_lgamma((double)(n - k) + 1.0);
+        double lbc;
+        if (xh) lbc = h[3];
+        else { double lgn = hoisted ? h[0] : fg_lgamma((double)n + 1.0);
+               lbc = lgn - fg_lgamma((double)k + 1.0) - fg_lgamma((double)(n - k) + 1.0); }
         double lp = hoisted ? h[1] : log(p1);
         double lq = hoisted ? h[2] : log(1.0 - p1);
         return lbc + ((double)k) * lp + ((double)(n - k)) * lq; }
@@ -183,7 +186,7 @@ FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long l
         if (p0 > 700.0 && xi == 0) return -p0;
         double kf = (double)xi;
         double ll = hoisted ? h[0] : log(p0);
-        double lf = fg_lgamma(kf + 1.0);
+        double lf = xh ? h[3] : fg_lgamma(kf + 1.0);
         return kf * ll - p0 - lf; }
     case 14: { /* StudentT(df, loc, scale): :1362-1381 */
         if (!hoisted && (p0 <= 0.0 || p2 <= 0.0 || !fg_finite(p0) || !fg_finite(p2) || !fg_finite(p1))) return FG_NEG_INF;

@@ -336,6 +336,16 @@ void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &tem
         I.opnd[0] = FG_OPND(s.vtype == FG_F64 ? FG_OPND_SLOT_F : FG_OPND_SLOT_I, site_slot[s.sorted]);
     } else {
         G.operand(s.value, I.opnd[0], I.imm[0]);
+        // a constant observed count under varying parameters (a count regression): its own term -- ln k!, ln C(n, k) -- once, here
+        if (!params_const && nodes[s.value].is_const && s.vtype != FG_F64 && s.vtype != FG_BOOL && (s.dist == FG_POISSON || s.dist == FG_BINOMIAL)) {
+            const double v = nodes[s.value].cval;
+            const long long xi = std::isfinite(v) ? (long long)v : 0LL;                 // fg_int_of (fg_interp.h)
+            if (s.dist == FG_POISSON && xi >= 0) { I.op |= FG_F_XHOIST; I.h[3] = fg_lgamma((double)xi + 1.0); }
+            if (s.dist == FG_BINOMIAL && nodes[s.params[0]].is_const && xi >= 0) {
+                const unsigned long long n = (unsigned long long)nodes[s.params[0]].cval, k = (unsigned long long)xi;
+                if (k <= n) { I.op |= FG_F_XHOIST; I.h[3] = fg_lgamma((double)n + 1.0) - fg_lgamma((double)k + 1.0) - fg_lgamma((double)(n - k) + 1.0); }
+            }
+        }
     }
     out.push_back(I);
     temp_max = std::max(temp_max, G.temp_max);
@@ -544,7 +554,8 @@ int fg_program::finalize() {
             g.xi = kx == FG_OPND_IMM ? (uint32_t)zero_slot : FG_OPND_IDX(F.opnd[0]);
             g.mi = (uint32_t)zero_slot;
             g.flags = FG_G_GEN | (FG_INS_OPCODE(F.op) << 16) | (kx == FG_OPND_IMM ? FG_G_X_CONST : 0u) | (vt != (uint32_t)FG_F64 ? FG_G_GEN_XINT : 0u) |
-                      ((F.op & FG_F_HOISTED) ? FG_G_GEN_HOISTED : 0u) | ((F.op & FG_F_SCALEHOIST) ? FG_G_GEN_SH : 0u) | ((F.op & FG_F_INVALID) ? FG_G_GEN_INVALID : 0u);
+                      ((F.op & FG_F_HOISTED) ? FG_G_GEN_HOISTED : 0u) | ((F.op & FG_F_SCALEHOIST) ? FG_G_GEN_SH : 0u) | ((F.op & FG_F_INVALID) ? FG_G_GEN_INVALID : 0u) |
+                      ((F.op & FG_F_XHOIST) ? FG_G_GEN_XH : 0u);
             // an observed constant of a discrete distribution is its integer value (fg_int_of, fg_interp.h)
             if (kx == FG_OPND_IMM) g.x = vt == (uint32_t)FG_F64 ? F.imm[0]
                                         : fg_as_double(vt == (uint32_t)FG_BOOL ? (long long)(F.imm[0] != 0.0) : (std::isfinite(F.imm[0]) ? (long long)F.imm[0] : 0LL));
@@ -552,7 +563,7 @@ int fg_program::finalize() {
                 if (FG_OPND_KIND(F.opnd[1 + q]) == FG_OPND_SLOT_F) { g.flags |= FG_G_GEN_P0SLOT << q; g.p[q] = fg_as_double((long long)FG_OPND_IDX(F.opnd[1 + q])); }
                 else g.p[q] = F.imm[1 + q];
             }
-            g.h[0] = F.h[0]; g.h[1] = F.h[1];
+            g.h[0] = F.h[0]; g.h[1] = (F.op & FG_F_XHOIST) ? F.h[3] : F.h[1];
             if (coord_k >= 0) g.coord = (uint32_t)coord_k;
             std::memcpy(&r, &g, sizeof(r));
             return r;

@@ -360,9 +360,10 @@ def test_hmc_interp_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypat
         pytest.skip("one coordinate: nothing to split")
     C, nw, ns = 150, 30, 20
     out, kernels = [], []
-    for mw, W, occ in [(0, 0, 3), (1, 2, 3), (1, 3, 2), (1, 4, 4), (1, 8, 2), (1, 12, 3), (1, 0, 3)]:
+    for mw, W, occ, pl in [(0, 0, 4, 1), (1, 2, 4, 1), (1, 3, 2, 1), (1, 4, 4, 0), (1, 8, 2, 0), (1, 12, 4, 1), (1, 16, 4, 1), (1, 0, 4, 1)]:
         monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
         monkeypatch.setenv("FG_HMC_INTERP_OCC", str(occ))
+        monkeypatch.setenv("FG_HMC_INTERP_LDSPROG", str(pl))           # sub-programs staged in LDS / fetched from global memory
         if W: monkeypatch.setenv("FG_HMC_INTERP_WAVES", str(W))
         else: monkeypatch.delenv("FG_HMC_INTERP_WAVES", raising=False)
         eng = E.Engine(cp, C, seed=23, chain_offset=9)

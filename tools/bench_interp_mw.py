@@ -9,7 +9,7 @@ L = 16
 for name in sys.argv[1:] or ["alldists", "poisson_glm", "hier_logsigma"]:
     cp = E.compile_model(ZOO[name]())
     for C in (65536, 8192):
-        for mw, occ, W in [(0, 2, 0), (1, 2, 0), (1, 2, 2), (1, 2, 4), (1, 3, 0), (1, 3, 3), (1, 3, 4), (1, 3, 6), (1, 3, 12), (1, 4, 0), (1, 4, 4), (1, 4, 8)]:
+        for mw, occ, W in [(0, 4, 0), (1, 4, 0), (1, 4, 4), (1, 4, 8), (1, 4, 16)]:
             os.environ["FG_HMC_INTERP_MW"] = str(mw)
             os.environ["FG_HMC_INTERP_OCC"] = str(occ)
             if W: os.environ["FG_HMC_INTERP_WAVES"] = str(W)
