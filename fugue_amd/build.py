@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.environ.get("FG_LIB_PATH") or os.path.join(LIB_DIR, "libfugue_amd.so")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
-SOURCES = ["fg_program.cpp", "fg_dsl.cpp", "fg_diag_host.cpp", "fg_engine.hip", "fg_hmc_sep.hip", "fg_hmc_lin.hip", "fg_hmc_interp.hip", "fg_mh.hip", "fg_smc.hip", "fg_diag.hip", "fg_state.hip"]
+SOURCES = ["fg_program.cpp", "fg_dsl.cpp", "fg_diag_host.cpp", "fg_engine.hip", "fg_hmc_sep.hip", "fg_hmc_lin.hip", "fg_hmc_interp.hip", "fg_mh.hip", "fg_mh_interp.hip", "fg_smc.hip", "fg_diag.hip", "fg_state.hip"]
 HEADERS = ["fg_ir.h", "fg_math.h", "fg_interp.h", "fg_program.h", "fg_engine_internal.h", "fg_gradstream.h", "fg_cold.h",
            os.path.join("..", "..", "include", "fugue_amd.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-DFG_BUILD", "-Wall",

@@ -159,11 +159,15 @@ __device__ __forceinline__ void fg_mh_walk_proposal(FgMhCtx &mh, uint32_t vtype,
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have two readable instructions past `n` (the host pads the arrays).
 // logp_out: optional global column pointer (stride logp_stride) for per-site log-densities.
-template <int MODE, bool WITH_LOGP, bool RM = false, bool PL = false>
+// TM: instead of adding to the accumulators, statement k of the run leaves its term in row k of `terms` (the caller adds the rows
+// in program order: fg_mh_interp.hip splits a scoring run between waves and still forms the reference's in-order sums).
+template <int MODE, bool WITH_LOGP, bool RM = false, bool PL = false, bool TM = false>
 __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *pool, double *slots, int tw, FgAcc3 &A,
                                         FgStream *rng, double *logp_out, long long logp_stride, bool live, FgMhCtx *mh = nullptr,
-                                        const FgRemap *rm = nullptr) {
+                                        const FgRemap *rm = nullptr, double *terms = nullptr) {
     static_assert(!RM || MODE == FG_MODE_SCORE, "row remapping: scoring runs only");
+    static_assert(!TM || MODE == FG_MODE_SCORE, "term rows: scoring runs only");
+    int tk = 0;
     double acc = 0.0;
     FgInsRegs I = fg_fetch_ins<PL>(prog, 0), Inext = fg_fetch_ins<PL>(prog, 1);
     for (int pc = 0; pc < n; ++pc) {
@@ -181,7 +185,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             if (!(op & FG_F_POW2SCALE)) z = (op & FG_F_RCPSCALE) ? fg_div_const(dl, FG_I_IMM(I, 2), fg_ins_h(I, 4)) : dl / FG_I_IMM(I, 2);
             double lp = -0.5 * z * z - fg_ins_h(I, 0) - 0.5 * FG_LN_2PI;
             lp = (z != z) ? FG_NEG_INF : lp;
-            if (op & FG_F_OBSERVE) A.lik += lp;
+            if (TM) { terms[tk * tw] = lp; ++tk; }
+            else if (op & FG_F_OBSERVE) A.lik += lp;
             else {
                 A.prior += lp;
                 if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)FG_I_AUX(I) * logp_stride] = lp; }
@@ -309,7 +314,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                         fg_ins_h(I, 3), fg_ins_h(I, 4), (op & FG_F_SCALEHOIST) != 0u, (op & FG_F_XHOIST) != 0u);
                 }
             }
-            if (observe) A.lik += lp;                    // interpreters.rs:76-83
+            if (TM) { terms[tk * tw] = lp; ++tk; }
+            else if (observe) A.lik += lp;               // interpreters.rs:76-83
             else {
                 A.prior += lp;                           // interpreters.rs:150-158
                 if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)aux * logp_stride] = lp; }
@@ -317,7 +323,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
         } else {
             const double x0 = fg_operand<RM>(FG_I_OPND(I, 0), FG_I_IMM(I, 0), slots, pool, tw, rm);
             switch (code) {
-            case FG_OP_FACTOR: A.fac += x0; break;       // Handler::on_factor
+            case FG_OP_FACTOR: if (TM) { terms[tk * tw] = x0; ++tk; } else A.fac += x0; break;       // Handler::on_factor
             case FG_OP_LOAD: acc = x0; break;
             case FG_OP_ADD: acc = acc + x0; break;
             case FG_OP_SUB: acc = acc - x0; break;
@@ -347,7 +353,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                  const int j = ok ? (int)acc : 0;
                                  const double v = slots[(fg_row<RM>(rm, FG_I_AUX(I)) + j) * tw];     // the options are a run of temporaries
                                  acc = ok ? v : NAN; break; }
-            case FG_OP_CONSTLIK: A.lik += FG_I_IMM(I, 0); break;
+            case FG_OP_CONSTLIK: if (TM) { terms[tk * tw] = FG_I_IMM(I, 0); ++tk; } else A.lik += FG_I_IMM(I, 0); break;
             case FG_OP_DOT: {                             // n MACs (slot x constant), terms fetched 4 at a time by scalar loads
                 const int n = (int)FG_I_OPND(I, 1);
                 const FG_AS4 char *tb = (const FG_AS4 char *)(uintptr_t)(pool + FG_I_AUX(I));

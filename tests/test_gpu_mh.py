@@ -148,3 +148,36 @@ def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypat
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize("name,with_overrides", [("alldists", False), ("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("coin", False)])
+def test_mh_interp_multiwave_is_bit_identical(name, with_overrides, monkeypatch):
+    """Programs without a score stream split a step's scoring run between W waves (k_mh_interp_mw_steps, fg_mh_interp.hip: each
+    statement's term in an LDS row, the three accumulators added in program order by wave 0); steps whose proposal needs the model
+    (undecided kinds during the first steps, PriorResample overrides) run k_mh_steps' propose-and-score path on wave 0.  Recorded
+    draws, final state, adapted scales, log-weights and accept counts equal the one-wave kernel's for every W."""
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 150, 100, 40
+    rec = list(range(cp.S))
+    ov = None
+    if with_overrides:
+        ov = [None] * cp.S
+        f64 = [j for j in range(cp.S) if cp.site_vtypes[j] == 0]
+        ov[f64[0]] = (E.PROP_PRIOR_RESAMPLE, 0.0, 0.0)           # needs the model at that site: the general path whenever a lane picks it
+        ov[f64[1]] = (E.PROP_GAUSSIAN, 0.0, 0.0)
+    out = []
+    for mw, W in ((0, 0), (1, 2), (1, 3), (1, 4), (1, 8), (1, 0)):
+        monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
+        if W: monkeypatch.setenv("FG_MH_INTERP_WAVES", str(W))
+        else: monkeypatch.delenv("FG_MH_INTERP_WAVES", raising=False)
+        eng = E.Engine(cp, C, seed=17, chain_offset=4)
+        d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
+        st = eng.mh_run(ns, nw, ov, rec, d)
+        draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
+        eng.device_free(d)
+        out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
+        eng.close()
+    assert 0.0 < out[0][4] < 1.0
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
