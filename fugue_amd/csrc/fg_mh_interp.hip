@@ -8,9 +8,10 @@
 // run of statements (host split by instruction cost) and leaves each statement's term in an LDS row (fg_exec's TM mode); wave 0
 // adds the rows in program order into log_prior / log_likelihood / log_factors -- the reference's in-order sums, bit for bit --
 // and finishes the step (accept, DiminishingAdaptation, recording).  Site rows are shared; expression temporaries, Categorical
-// tables and select options are private to the wave (FgRemap, fg_interp.h).  When some lane's proposal needs the model
-// (undecided kinds, prior-resample kinds, computed Categorical tables) the step takes k_mh_steps' propose-and-score path on wave 0
-// alone.  Identical to k_mh_steps for every W (tests/test_gpu_mh.py::test_mh_interp_multiwave_is_bit_identical).
+// tables and select options are private to the wave (FgRemap, fg_interp.h).  A lane whose proposal needs the model (an undecided
+// kind, PriorResample, a Categorical site with a computed table) gets it from its target's own statement, run in the
+// propose-and-score mode on wave 0 before the scoring run -- not from a whole propose-and-score run of the program, which is what
+// k_mh_steps falls back to as soon as ONE lane of the wave needs it.  Identical to k_mh_steps for every W (tests/test_gpu_mh.py::test_mh_interp_multiwave_is_bit_identical).
 #include "fg_engine_internal.h"
 #include "fg_cold.h"
 
@@ -20,6 +21,7 @@ struct FgMhi {
     int ins_off[FG_MHI_MAX + 1];     // wave w interprets instructions [ins_off[w], ins_off[w + 1]) of ins_fast ...
     int stmt_off[FG_MHI_MAX + 1];    // ... which hold statements [stmt_off[w], stmt_off[w + 1])
     const unsigned char *stmt_acc;   // [n_stmt] accumulator of each statement: 0 log_prior, 1 log_likelihood, 2 log_factors
+    const int *site_ins;             // [S][2] {first instruction, count} of each site's own sample statement in P.ins (generic opcodes)
     int n_stmt;
 };
 
@@ -28,6 +30,46 @@ static __device__ __noinline__ FgAcc3 fg_mhi_cold_mh_exec(const FgIns *ins, int 
     FgAcc3 A = {0.0, 0.0, 0.0};
     fg_exec<FG_MODE_MH, false>(ins, n_ins, pool, slots, tw, A, nullptr, nullptr, 0, live, mh);
     return A;
+}
+
+// A step in which some lane's proposal needs the model (an undecided kind, PriorResample, a Categorical site with a computed table),
+// out of line (the step loop keeps its registers).  Such a lane gets its proposal from its target's OWN statement, interpreted in
+// the propose-and-score mode (SingleSiteProposalHandler, mh.rs:298-570) ahead of the scoring run: the statement's parameters read
+// only other sites, which hold the chain's current values, so the proposed value, log q(x'|x), log q(x|x'), the decided kind and the
+// accept uniform's block are those of a whole propose-and-score run.  One pass per distinct such target in the wave (the other
+// lanes see no target there); the remaining lanes make their model-independent proposals as in the usual step.
+struct FgMhiPre { double lqf, lqr; int kind, next_block; };
+static __device__ __noinline__ FgMhiPre fg_mhi_mixed_proposals(const FgIns *ins, const int *site_ins, const double *pool, double *slots, bool live, bool walk, int target,
+                                                               int tv, int kind_eff, int cat_base, int cat_K, FgMhCtx mh) {
+    constexpr int tw = FG_WAVE;
+    const int tslot = mh.target;
+    FgMhCtx pre = mh;
+    pre.target = walk ? -1 : tslot;
+    unsigned long long todo = __ballot(!walk);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int tl = __builtin_amdgcn_readlane(target, leader);
+        const unsigned long long same = __ballot(!walk && target == tl);
+        (void)fg_mhi_cold_mh_exec(ins + site_ins[2 * tl], site_ins[2 * tl + 1], pool, slots, tw, live, &pre);
+        todo &= ~same;
+    }
+    if (walk) {
+        if (tv == 3) {                                        // usize target: resample from the constant prior table (mh.rs:516-530)
+            FgStream s1 = mh.rng;
+            const double uu = fg_rng_u01(s1);
+            double cum = 0.0; int idx = cat_K;
+            for (int i = 0; i < cat_K; ++i) { cum += pool[cat_base + i]; if (idx == cat_K && !(cum < uu)) idx = i; }
+            const long long prop = idx < cat_K - 1 ? idx : cat_K - 1;
+            const long long cur = fg_as_i64(mh.old_cell);
+            mh.lqf += pool[cat_base + cat_K + (int)prop];
+            mh.lqr += (cur < 0 || cur >= (long long)cat_K) ? FG_NEG_INF : pool[cat_base + cat_K + (int)cur];
+            mh.next_block = (int)s1.c1;
+            slots[tslot * tw] = fg_as_double(prop);
+        } else fg_mh_walk_proposal(mh, (uint32_t)tv, kind_eff, tslot, slots, tw);
+    }
+    FgMhiPre r;
+    r.lqf = walk ? mh.lqf : pre.lqf; r.lqr = walk ? mh.lqr : pre.lqr; r.kind = walk ? mh.kind : pre.kind; r.next_block = walk ? mh.next_block : pre.next_block;
+    return r;
 }
 
 __global__ __launch_bounds__(FG_WAVE * FG_MHI_MAX, 1) void k_mh_interp_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps,
@@ -44,7 +86,6 @@ __global__ __launch_bounds__(FG_WAVE * FG_MHI_MAX, 1) void k_mh_interp_mw_steps(
     double *slots = lds + lane;                                                      // site rows [0, S) shared; wave 0's private block follows, so
                                                                                      // wave 0 may also run the program WITHOUT the remap (the general path)
     double *terms = lds + (long long)(P.S + W * np) * tw + lane;                     // one row per statement
-    double *xch = lds + (long long)(P.S + W * np + seg.n_stmt) * tw + lane;          // row 0: every lane's proposal is model-independent
     FgRemap rm;
     rm.pi = 0xffffffffu; rm.n_shared = (uint32_t)P.S; rm.woff = (uint32_t)(wv * np); rm.pert = (uint32_t)(P.n_slots + wv * np);
     for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
@@ -59,7 +100,6 @@ __global__ __launch_bounds__(FG_WAVE * FG_MHI_MAX, 1) void k_mh_interp_mw_steps(
         const bool adapt = iter < n_warmup;
         FgMhCtx mh;
         long long g = 0; int tslot = 0, kind0 = 0;
-        bool walk_all = false;
         mh.lqf = 0.0; mh.lqr = 0.0; mh.scale = 0.0; mh.kind = 0; mh.next_block = 2; mh.old_cell = 0.0; mh.target = 0; mh.z = 0.0;
         if (wv == 0) {                                       // the proposal: k_mh_steps' code (fg_engine.hip)
             FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, (uint32_t)iter, FG_RNG_MH);
@@ -83,8 +123,12 @@ __global__ __launch_bounds__(FG_WAVE * FG_MHI_MAX, 1) void k_mh_interp_mw_steps(
             const int cat_base = P.site_cat[2 * target], cat_K = P.site_cat[2 * target + 1];
             const bool walk = tv == 0u ? (kind_eff == FG_PROP_GAUSSIAN || kind_eff == FG_PROP_LOGSPACE || kind_eff == FG_PROP_REFLECT)
                                        : (tv == 1u || tv == 2u || tv == 4u || (tv == 3u && cat_K > 0));
-            walk_all = __all(walk);
-            if (walk_all) {
+            // A lane whose proposal needs the model (an undecided kind, PriorResample, a Categorical site with a computed table) gets it from
+            // its target's OWN statement, interpreted in the propose-and-score mode (SingleSiteProposalHandler, mh.rs:298-570) ahead of the
+            // scoring run: the statement's parameters read only other sites, which hold the chain's current values, so the proposal,
+            // log q(x'|x), log q(x|x'), the decided kind and the accept uniform's block are those of a whole propose-and-score run.  One
+            // pass per distinct such target in the wave; the other lanes see no target there (target = -1).
+            if (__all(walk)) {                                   // the usual step: every lane's proposal is model-independent
                 if (tv == 3u) {                                   // usize target: resample from the constant prior table (mh.rs:516-530)
                     FgStream s1 = mh.rng;
                     const double uu = fg_rng_u01(s1);
@@ -97,17 +141,16 @@ __global__ __launch_bounds__(FG_WAVE * FG_MHI_MAX, 1) void k_mh_interp_mw_steps(
                     mh.next_block = (int)s1.c1;
                     slots[tslot * tw] = fg_as_double(prop);
                 } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+            } else {
+                const FgMhiPre r = fg_mhi_mixed_proposals(P.ins, seg.site_ins, P.pool, slots, live, walk, target, (int)tv, kind_eff, cat_base, cat_K, mh);
+                mh.lqf = r.lqf; mh.lqr = r.lqr; mh.kind = r.kind; mh.next_block = r.next_block;
             }
-            xch[0] = walk_all ? 1.0 : 0.0;
         }
         __syncthreads();                                     // the proposed values are in the site rows
-        const bool scored_by_all = xch[0] != 0.0;
         FgAcc3 A = {0.0, 0.0, 0.0};
-        if (scored_by_all) {
-            fg_exec<FG_MODE_SCORE, false, true, false, true>(P.ins_fast + i0, i1 - i0, P.pool, slots, tw, A, nullptr, nullptr, 0, false, nullptr, &rm, terms + (long long)s0 * tw);
-        } else if (wv == 0) A = fg_mhi_cold_mh_exec(P.ins, P.n_ins, P.pool, slots, tw, live, &mh);   // propose_and_score, on wave 0 alone
-        __syncthreads();                                     // every statement's term is in its row (and row 0 of xch has been read)
-        if (scored_by_all && wv == 0)
+        fg_exec<FG_MODE_SCORE, false, true, false, true>(P.ins_fast + i0, i1 - i0, P.pool, slots, tw, A, nullptr, nullptr, 0, false, nullptr, &rm, terms + (long long)s0 * tw);
+        __syncthreads();                                     // every statement's term is in its row
+        if (wv == 0)
             for (int k = 0; k < seg.n_stmt; ++k) {           // the three accumulators, each in program order (trace.rs:168-177)
                 const double v = terms[k * tw];
                 const int a = (int)seg.stmt_acc[k];
@@ -174,7 +217,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         }
         const int n_stmt = (int)stmt_end.size();
         if (n_stmt < 4 || stmt_end.back() != n_ins) return FG_E_UNSUPPORTED;
-        auto lds_for = [&](int W) { return (size_t)((long long)e->S + (long long)W * (e->n_slots - e->S + 1) + n_stmt + 2) * FG_WAVE * sizeof(double); };
+        auto lds_for = [&](int W) { return (size_t)((long long)e->S + (long long)W * (e->n_slots - e->S + 1) + n_stmt) * FG_WAVE * sizeof(double); };
         int W = 2;
         int forced = 0;
         if (const char *sp = std::getenv("FG_MH_INTERP_WAVES")) forced = std::atoi(sp);
@@ -200,11 +243,24 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         }
         HIPCHK(hipMalloc((void **)&e->d_mhi_acc, (size_t)n_stmt));
         HIPCHK(hipMemcpy(e->d_mhi_acc, acc.data(), (size_t)n_stmt, hipMemcpyHostToDevice));
+        // every site's own sample statement in the generic program: from the instruction after the previous statement's last to its distribution
+        std::vector<int> site_ins((size_t)2 * e->S, -1);
+        const std::vector<FgIns> &gen = e->prog->ins;
+        for (int k = 0, begin = 0; k < n_ins; ++k) {
+            const uint32_t code = FG_INS_OPCODE(gen[k].op);
+            const bool ends = code < 17u || code == FG_OP_FACTOR || code == FG_OP_CONSTLIK;
+            if (!ends) continue;
+            if (code < 17u && !(gen[k].op & FG_F_OBSERVE))
+                for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] == (int)gen[k].aux) { site_ins[2 * j] = begin; site_ins[2 * j + 1] = k + 1 - begin; }
+            begin = k + 1;
+        }
+        for (int j = 0; j < e->S; ++j) if (site_ins[2 * j] < 0) { fg_set_error("fg_mh_interp: a site without a sample statement"); return FG_E_STATE; }
+        if (dev_upload(&e->d_mhi_site_ins, site_ins)) return FG_E_HIP;
         e->mhi_W = W; e->mhi_n_stmt = n_stmt; e->mhi_lds = lds_for(W);
     }
     FgMhi seg;
     for (int w = 0; w <= FG_MHI_MAX; ++w) { seg.ins_off[w] = e->mhi_ins_off[w]; seg.stmt_off[w] = e->mhi_stmt_off[w]; }
-    seg.stmt_acc = e->d_mhi_acc; seg.n_stmt = e->mhi_n_stmt;
+    seg.stmt_acc = e->d_mhi_acc; seg.n_stmt = e->mhi_n_stmt; seg.site_ins = e->d_mhi_site_ins;
     if (int rc = set_lds(k_mh_interp_mw_steps, e->mhi_lds)) return rc;
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
     hipLaunchKernelGGL(k_mh_interp_mw_steps, dim3(tiles), dim3(FG_WAVE * e->mhi_W), e->mhi_lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup,
