@@ -102,6 +102,15 @@ struct FgMhCtx {
     const int *ov_kind;         // [S] per-site overrides (SiteProposal, mh.rs:145-161) or null
     const double *ov_lo, *ov_hi;
 };
+// the transcendental opcodes out of line: inlined, ocml's polynomial coefficients are hoisted out of the interpreter loop into
+// registers and, at the 128-VGPR budget of the multi-wave kernels, spilled -- every log then reloads them from scratch one dependent
+// round trip at a time (six per log in k_hmc_interp_mw_steps).  Behind a call they are literals of the callee.
+__device__ __noinline__ double fg_op_exp(double x) { return exp(x); }
+__device__ __noinline__ double fg_op_log(double x) { return log(x); }
+__device__ __noinline__ double fg_op_sin(double x) { return sin(x); }
+__device__ __noinline__ double fg_op_cos(double x) { return cos(x); }
+__device__ __noinline__ double fg_op_tanh(double x) { return tanh(x); }
+__device__ __noinline__ double fg_op_pow(double x, double y) { return pow(x, y); }
 // rare paths kept out of line so the interpreter stays small
 __device__ __noinline__ double fg_logpdf_cold(uint32_t kind, bool hoisted, bool pow2, double xf, long long xi, double p0, double p1,
                                               double p2, double h0, double h1, double h2, double h3, double h4, bool sh, bool xh = false) {
@@ -332,16 +341,16 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             case FG_OP_RSUB: acc = x0 - acc; break;
             case FG_OP_RDIV: acc = x0 / acc; break;
             case FG_OP_NEG: acc = -acc; break;
-            case FG_OP_EXP: acc = exp(acc); break;
-            case FG_OP_LN: acc = log(acc); break;
+            case FG_OP_EXP: acc = fg_op_exp(acc); break;
+            case FG_OP_LN: acc = fg_op_log(acc); break;
             case FG_OP_SQRT: acc = sqrt(acc); break;
             case FG_OP_ABS: acc = fabs(acc); break;
             case FG_OP_FLOOR: acc = floor(acc); break;
-            case FG_OP_SIN: acc = sin(acc); break;
-            case FG_OP_COS: acc = cos(acc); break;
-            case FG_OP_TANH: acc = tanh(acc); break;
-            case FG_OP_POW: acc = pow(acc, x0); break;
-            case FG_OP_RPOW: acc = pow(x0, acc); break;
+            case FG_OP_SIN: acc = fg_op_sin(acc); break;
+            case FG_OP_COS: acc = fg_op_cos(acc); break;
+            case FG_OP_TANH: acc = fg_op_tanh(acc); break;
+            case FG_OP_POW: acc = fg_op_pow(acc, x0); break;
+            case FG_OP_RPOW: acc = fg_op_pow(x0, acc); break;
             case FG_OP_MIN: acc = fmin(acc, x0); break;
             case FG_OP_MAX: acc = fmax(acc, x0); break;
             case FG_OP_CLAMP: acc = fg_clamp(acc, x0, fg_operand<RM>(FG_I_OPND(I, 1), FG_I_IMM(I, 1), slots, pool, tw, rm)); break;

@@ -72,7 +72,10 @@ static __device__ __noinline__ FgMhiPre fg_mhi_mixed_proposals(const FgIns *ins,
     return r;
 }
 
-__global__ __launch_bounds__(FG_WAVE * FG_MHI_MAX, 1) void k_mh_interp_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps,
+#ifndef FG_MHI_OCC
+#define FG_MHI_OCC 2
+#endif
+__global__ __attribute__((amdgpu_waves_per_eu(FG_MHI_OCC, FG_MHI_OCC))) __launch_bounds__(FG_WAVE * FG_MHI_MAX) void k_mh_interp_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps,
                                                                                  int n_warmup, long long *draws, int first_sample_t) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;
@@ -227,7 +230,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
             // the kernel's 256 VGPRs leave a CU eight wave slots: W = 8 / (tiles a CU gets), so that all of its tiles are resident --
             // 65 536 chains: 2 (+50 % over one wave per tile); 16 384 and fewer: 8 (x 3)   [tools/bench_mh_interp.py]
             const long long n_cu = std::max(1, e->n_simd / 4), tiles = (e->C + FG_WAVE - 1) / FG_WAVE, per_cu = (tiles + n_cu - 1) / n_cu;
-            while (2 * W <= wcap && 2 * W * per_cu <= 8 && lds_for(2 * W) * (size_t)per_cu <= 160 * 1024) W *= 2;
+            while (2 * W <= wcap && 2 * W * per_cu <= 4 * FG_MHI_OCC && lds_for(2 * W) * (size_t)per_cu <= 160 * 1024) W *= 2;
         }
         while (W > 1 && lds_for(W) > 160 * 1024) --W;
         if (W < 2) return FG_E_UNSUPPORTED;
