@@ -44,6 +44,10 @@ enum { FG_MODE_SCORE = 0, FG_MODE_PRIOR = 1, FG_MODE_MH = 2 };
 // PL: the program was staged in LDS by the kernel (fg_hmc_interp.hip): the fetch is one ds_read_b32 -- ~100 cycles and in order on
 // lgkmcnt like the operand reads around it -- instead of a vector-memory round trip (measured ~1 000 cycles per interpreted
 // instruction with the two-ahead global fetch, whatever the instruction did: tools/mb_interp_costs.py).
+// HAZARD: the VGPR is an ordinary per-lane value to the compiler.  If it is spilled and reloaded inside DIVERGENT control flow, the
+// lanes that were inactive there hold garbage, and a field read (v_readlane of a fixed lane) returns it -- seen at the 128 / 168 VGPR
+// budgets as proposal kinds decided from a garbage density.  Every field is therefore read where all lanes are active, before any
+// per-lane branch that uses it.
 struct FgInsRegs { uint32_t w; };
 template <bool PL = false>
 __device__ __forceinline__ FgInsRegs fg_fetch_ins(const FgIns *prog, int pc) {
@@ -198,7 +202,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
             else if (op & FG_F_OBSERVE) A.lik += lp;
             else {
                 A.prior += lp;
-                if (WITH_LOGP) { if (live && logp_out) logp_out[(long long)FG_I_AUX(I) * logp_stride] = lp; }
+                if (WITH_LOGP) { const uint32_t aux_f = FG_I_AUX(I); if (live && logp_out) logp_out[(long long)aux_f * logp_stride] = lp; }   // the field is read outside the divergent branch (see FG_I_DW)
             }
         } else if (code < 17u) {
             // ---------------- sample / observe site: dist.log_prob(x) ----------------
@@ -270,6 +274,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 if (MODE == FG_MODE_MH && !observe) {
                     const bool is_t = ((int)aux == mh->target);
                     if (__any(is_t)) {
+                        // instruction fields are read HERE, where every lane is active (FG_I_DW)
+                        const double hq0 = fg_ins_h(I, 0), hq1 = fg_ins_h(I, 1), hq2 = fg_ins_h(I, 2), hq3 = fg_ins_h(I, 3), hq4 = fg_ins_h(I, 4);
                         if (is_t) {
                             const double curd = slots[aux * tw];
                             const bool p2s = (op & FG_F_POW2SCALE) != 0u;
@@ -279,8 +285,7 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                     kind = mh->kind;
                                     if (kind == FG_PROP_AUTO) {
                                         const double probe = ((op & FG_F_INVALID) != 0u) ? FG_NEG_INF
-                                            : fg_logpdf_cold(code, hoisted, p2s, -1.0, 0, p0, p1, p2, fg_ins_h(I, 0), fg_ins_h(I, 1),
-                                                             fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), (op & FG_F_SCALEHOIST) != 0u);
+                                            : fg_logpdf_cold(code, hoisted, p2s, -1.0, 0, p0, p1, p2, hq0, hq1, hq2, hq3, hq4, (op & FG_F_SCALEHOIST) != 0u);
                                         kind = (curd > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN;
                                         mh->kind = kind;
                                     }
@@ -293,10 +298,8 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                                     mh->next_block = (int)s1.c1;
                                     const bool inv = (op & FG_F_INVALID) != 0u;
                                     const bool shf = (op & FG_F_SCALEHOIST) != 0u;
-                                    const double f = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, prop, 0, p0, p1, p2, fg_ins_h(I, 0),
-                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), shf);
-                                    const double r = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, curd, 0, p0, p1, p2, fg_ins_h(I, 0),
-                                                                          fg_ins_h(I, 1), fg_ins_h(I, 2), fg_ins_h(I, 3), fg_ins_h(I, 4), shf);
+                                    const double f = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, prop, 0, p0, p1, p2, hq0, hq1, hq2, hq3, hq4, shf);
+                                    const double r = inv ? FG_NEG_INF : fg_logpdf_cold(code, hoisted, p2s, curd, 0, p0, p1, p2, hq0, hq1, hq2, hq3, hq4, shf);
                                     mh->lqf += f; mh->lqr += r;
                                     slots[aux * tw] = prop;
                                 }
@@ -312,10 +315,11 @@ __device__ __forceinline__ void fg_exec(const FgIns *prog, int n, const double *
                 else if (code == 12u && hoisted) {
                     // Normal with constant parameters -- the hot case (distribution.rs:189-208):
                     // ln(sigma) hoisted; (x-mu)/sigma as an exact multiply when sigma = 2^k.
+                    const double hn0 = fg_ins_h(I, 0), hn4 = fg_ins_h(I, 4);     // read where every lane is active (FG_I_DW)
                     if (!fg_finite(xf)) lp = FG_NEG_INF;
                     else {
-                        const double z = (op & FG_F_POW2SCALE) ? (xf - p0) * fg_ins_h(I, 4) : (xf - p0) / p1;
-                        lp = -0.5 * z * z - fg_ins_h(I, 0) - 0.5 * FG_LN_2PI;
+                        const double z = (op & FG_F_POW2SCALE) ? (xf - p0) * hn4 : (xf - p0) / p1;
+                        lp = -0.5 * z * z - hn0 - 0.5 * FG_LN_2PI;
                     }
                 } else {
                     // out of line: the other sixteen densities (lgamma, log1p, pow ...) stay out of the interpreter loop's registers

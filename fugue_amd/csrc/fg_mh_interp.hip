@@ -72,11 +72,9 @@ static __device__ __noinline__ FgMhiPre fg_mhi_mixed_proposals(const FgIns *ins,
     return r;
 }
 
-#ifndef FG_MHI_OCC
-#define FG_MHI_OCC 2
-#endif
-__global__ __attribute__((amdgpu_waves_per_eu(FG_MHI_OCC, FG_MHI_OCC))) __launch_bounds__(FG_WAVE * FG_MHI_MAX) void k_mh_interp_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps,
-                                                                                 int n_warmup, long long *draws, int first_sample_t) {
+template <int OCC_UNUSED>
+__device__ __forceinline__ void fg_mh_interp_mw_body(const FgProgramDev &P, const FgChainCtx &X, const FgMhDev &M, const FgMhi &seg, int iter0, int n_steps,
+                                                     int n_warmup, long long *draws, int first_sample_t) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1);
@@ -190,6 +188,15 @@ __global__ __attribute__((amdgpu_waves_per_eu(FG_MHI_OCC, FG_MHI_OCC))) __launch
     if (wv == 0 && live) { M.lw[c] = lw; M.n_acc[c] += nacc; }
 }
 
+// OCC = waves per SIMD the register budget allows: 2 (256 VGPRs) when LDS holds a CU to eight waves anyway, 4 (128 VGPRs, more of the
+// cold propose-and-score path spilled) when more tiles fit -- poisson_glm 2.7e9 -> 3.8e9 chain-steps/s at 65 536 chains
+#define FG_MHI_KERNEL(OCC) \
+__global__ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) __launch_bounds__(FG_WAVE * FG_MHI_MAX) \
+void k_mh_interp_mw_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps, int n_warmup, long long *draws, int first_sample_t) { \
+    fg_mh_interp_mw_body<OCC>(P, X, M, seg, iter0, n_steps, n_warmup, draws, first_sample_t); }
+FG_MHI_KERNEL(2)
+FG_MHI_KERNEL(4)
+
 static long long mhi_ins_cost(const FgIns &in) {       // the weights of fg_hmc_interp.hip's split
     const uint32_t code = FG_INS_OPCODE(in.op);
     if (code == FG_OP_NORMAL_FAST) return 3;
@@ -227,10 +234,10 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         const int wcap = std::min(FG_MHI_MAX, n_stmt / 2);
         if (forced > 0) W = std::max(2, std::min(forced, wcap));
         else {
-            // the kernel's 256 VGPRs leave a CU eight wave slots: W = 8 / (tiles a CU gets), so that all of its tiles are resident --
-            // 65 536 chains: 2 (+50 % over one wave per tile); 16 384 and fewer: 8 (x 3)   [tools/bench_mh_interp.py]
+            // W = (a CU's sixteen wave slots) / (tiles it gets), as far as LDS keeps all of its tiles resident: 65 536 chains -> 4 for
+            // short programs, 2 for alldists (its tile is 46 KB at W = 4); 16 384 and fewer -> 8   [tools/bench_mh_interp.py]
             const long long n_cu = std::max(1, e->n_simd / 4), tiles = (e->C + FG_WAVE - 1) / FG_WAVE, per_cu = (tiles + n_cu - 1) / n_cu;
-            while (2 * W <= wcap && 2 * W * per_cu <= 4 * FG_MHI_OCC && lds_for(2 * W) * (size_t)per_cu <= 160 * 1024) W *= 2;
+            while (2 * W <= wcap && 2 * W * per_cu <= 16 && lds_for(2 * W) * (size_t)per_cu <= 160 * 1024) W *= 2;
         }
         while (W > 1 && lds_for(W) > 160 * 1024) --W;
         if (W < 2) return FG_E_UNSUPPORTED;
@@ -260,14 +267,21 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         for (int j = 0; j < e->S; ++j) if (site_ins[2 * j] < 0) { fg_set_error("fg_mh_interp: a site without a sample statement"); return FG_E_STATE; }
         if (dev_upload(&e->d_mhi_site_ins, site_ins)) return FG_E_HIP;
         e->mhi_W = W; e->mhi_n_stmt = n_stmt; e->mhi_lds = lds_for(W);
+        {   // more than eight waves on a CU need the 128-VGPR build
+            const long long n_cu = std::max(1, e->n_simd / 4), tiles = (e->C + FG_WAVE - 1) / FG_WAVE, per_cu = (tiles + n_cu - 1) / n_cu;
+            const long long resident = std::min<long long>(per_cu, (160 * 1024) / (long long)e->mhi_lds);
+            e->mhi_occ = resident * W > 8 ? 4 : 2;
+            if (const char *sp = std::getenv("FG_MH_INTERP_OCC")) e->mhi_occ = std::atoi(sp) <= 2 ? 2 : 4;
+        }
     }
     FgMhi seg;
     for (int w = 0; w <= FG_MHI_MAX; ++w) { seg.ins_off[w] = e->mhi_ins_off[w]; seg.stmt_off[w] = e->mhi_stmt_off[w]; }
     seg.stmt_acc = e->d_mhi_acc; seg.n_stmt = e->mhi_n_stmt; seg.site_ins = e->d_mhi_site_ins;
-    if (int rc = set_lds(k_mh_interp_mw_steps, e->mhi_lds)) return rc;
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
-    hipLaunchKernelGGL(k_mh_interp_mw_steps, dim3(tiles), dim3(FG_WAVE * e->mhi_W), e->mhi_lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup,
-                       draws, first_sample_t);
+#define FG_MHI_LAUNCH(K) do { if (int rc = set_lds(K, e->mhi_lds)) return rc; \
+    hipLaunchKernelGGL(K, dim3(tiles), dim3(FG_WAVE * e->mhi_W), e->mhi_lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t); } while (0)
+    if (e->mhi_occ == 4) FG_MHI_LAUNCH(k_mh_interp_mw_steps_occ4); else FG_MHI_LAUNCH(k_mh_interp_mw_steps_occ2);
+#undef FG_MHI_LAUNCH
     HIPCHK(hipGetLastError());
     return FG_OK;
 }
