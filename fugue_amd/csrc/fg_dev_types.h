@@ -1,0 +1,38 @@
+// fg_dev_types.h -- kernel-argument structs and small device helpers shared by the engine's translation units AND the run-time
+// compiled model kernels (fg_jit.cpp embeds this header's text: keep it free of host-only includes).
+#pragma once
+#include "fg_ir.h"
+
+struct FgChainCtx {
+    long long C;          // chains in this engine
+    uint32_t chain0;      // global id of chain 0 (RNG stream key)
+    unsigned long long seed;
+    long long *values;    // [S][C]
+    double *gtile;        // global-memory tiles [tiles][gtile_rows][64] of the one-wave kernels, or null (tiles in LDS)
+    int gtile_rows;
+};
+
+
+struct FgHmcDev {
+    double *lj, *eps, *frozen, *da_mu, *da_leb, *da_hbar;
+    unsigned long long *da_m;
+    double *m_inv, *mass_sqrt, *w_mean, *w_m2;     // [d][C] or null
+    unsigned long long *w_n;
+    double *alpha_sum; unsigned long long *n_div;
+    double *p0_scratch;                             // [d][C] (eps search / injected momentum)
+    int L; double h, target; int grad_mode; int use_mass;
+};
+
+
+// in-order kinetic energy and momentum draw shared by the HMC kernels
+__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, int tw, const double *m_inv, long long C) {
+    double s = 0.0;
+    if (m_inv) {
+        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; }
+    } else {                                              // identity mass: p*p*1.0 == p*p exactly
+#pragma unroll 8
+        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p; }
+    }
+    return 0.5 * s;
+}
+

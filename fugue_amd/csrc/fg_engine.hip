@@ -806,6 +806,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
     if (e->smc_arena) hipFree(e->smc_arena);
+    if (e->jit_mod) (void)hipModuleUnload(e->jit_mod);
     void *ptrs[] = { e->d_mhi_acc, e->d_mhi_site_ins, e->d_mwi_order, e->d_mwi_prof, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
@@ -1054,6 +1055,10 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         HIPCHK(hipGetLastError());
         e->last_hmc_kernel = std::string(dense_stream ? "k_hmc_stream_steps (dense stream) W=" : "k_hmc_stream_steps W=") + std::to_string(W);
         return FG_OK;
+    }
+    {   // programs without a record stream, compiled at run time (fg_jit.cpp)
+        const int rc = fg_hmc_jit_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+        if (rc != FG_E_UNSUPPORTED) return rc;
     }
     {   // interpreter programs: the tile shared by W waves, each on its own copy of the slots (fg_hmc_interp.hip)
         const int rc = fg_hmc_interp_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);

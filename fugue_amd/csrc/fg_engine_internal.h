@@ -13,6 +13,7 @@
 
 #include "fg_interp.h"
 #include "fg_program.h"
+#include "fg_dev_types.h"
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     fg_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return FG_E_HIP; } } while (0)
@@ -20,15 +21,6 @@
 // ======================================================================================
 // kernels
 // ======================================================================================
-struct FgChainCtx {
-    long long C;          // chains in this engine
-    uint32_t chain0;      // global id of chain 0 (RNG stream key)
-    unsigned long long seed;
-    long long *values;    // [S][C]
-    double *gtile;        // global-memory tiles [tiles][gtile_rows][64] of the one-wave kernels, or null (tiles in LDS)
-    int gtile_rows;
-};
-
 __device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
     for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
     slots[(P.n_slots - 1) * tw] = 0.0;                   // the always-zero slot (constant operands of fast opcodes)
@@ -42,16 +34,6 @@ static __global__ void k_fill(double *p, long long n, double v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-
-struct FgHmcDev {
-    double *lj, *eps, *frozen, *da_mu, *da_leb, *da_hbar;
-    unsigned long long *da_m;
-    double *m_inv, *mass_sqrt, *w_mean, *w_m2;     // [d][C] or null
-    unsigned long long *w_n;
-    double *alpha_sum; unsigned long long *n_div;
-    double *p0_scratch;                             // [d][C] (eps search / injected momentum)
-    int L; double h, target; int grad_mode; int use_mass;
-};
 
 // DiminishingAdaptation's state of one (site, chain) (mcmc_utils.rs:40-62) + the decided proposal kind, as two 16-byte groups:
 // what a proposal reads {scale, kind} and what an update reads and writes {log_scale, total, accepted} are one 16-byte access each
@@ -125,20 +107,10 @@ struct fg_engine {
     bool interp_mw_disabled = false;   // FG_HMC_INTERP_MW=0: keep interpreter programs on the one-wave-per-tile HMC kernel (A/B tests)
     int *d_mwi_order = nullptr; long long *d_mwi_prof = nullptr; std::vector<int> mwi_off; std::vector<long long> mwi_cost; int mwi_W = 0, mwi_sparse = -1, mwi_calibrated = 0;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
     int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
+    int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)
+    hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr; std::string jit_log;
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
-
-// in-order kinetic energy and momentum draw shared by the HMC kernels
-__device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double *pl, int tw, const double *m_inv, long long C) {
-    double s = 0.0;
-    if (m_inv) {
-        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p * m_inv[(long long)i * C]; }
-    } else {                                              // identity mass: p*p*1.0 == p*p exactly
-#pragma unroll 8
-        for (int i = 0; i < P.d; ++i) { const double p = pl[i * tw]; s += p * p; }
-    }
-    return 0.5 * s;
-}
 
 // p0 ~ N(0, M): hmc.rs:436-441.  Box-Muller pairs from the chain's (iteration) stream.
 __device__ __forceinline__ void fg_draw_momentum(const FgProgramDev &P, FgStream &rng, double *pl, int tw, const double *mass_sqrt,
@@ -192,6 +164,8 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
 // fg_hmc_lin.hip: observation-major finite-difference gradient for dense regressions (FG_E_UNSUPPORTED: not applicable)
 int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
 
+// fg_hmc_interp.hip: the program compiled at run time (fg_jit.cpp) behind the same multi-wave kernel (FG_E_UNSUPPORTED: not applicable)
+int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
 // fg_hmc_interp.hip: interpreter programs with a tile shared by W waves (FG_E_UNSUPPORTED: not applicable)
 int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info);
 

@@ -16,6 +16,7 @@
 // k_hmc_steps for every W (tests/test_gpu_parity.py::test_hmc_interp_multiwave_is_bit_identical).
 #include "fg_engine_internal.h"
 #include "fg_cold.h"
+#include "fg_jit.h"
 
 #define FG_MWI_MAX 16         /* waves per tile */
 
@@ -327,5 +328,77 @@ int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double 
 #undef FG_MWI_LAUNCH
     HIPCHK(hipGetLastError());
     e->last_hmc_kernel = "k_hmc_interp_mw_steps W=" + std::to_string(W) + (occ != 4 ? " occ=" + std::to_string(occ) : std::string()) + (pl ? std::string() : std::string(" (program in global memory)"));
+    return FG_OK;
+}
+
+// ---- the same kernel around a model compiled at run time (fg_jit.cpp, fg_hmc_jit_body.h) --------------------------------------
+struct FgJitSeg { int off[FG_MWI_MAX + 1]; const int *order; };
+
+int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
+    if (e->jit_state < 0 || e->gt || e->tw != FG_WAVE || e->d < 1 || e->cfg.grad_mode == FG_GRAD_FD_DENSE) return FG_E_UNSUPPORTED;
+    if (e->jit_state == 0) {
+        e->jit_state = -1;
+        if (const char *sp = std::getenv("FG_JIT")) if (std::atoi(sp) == 0) return FG_E_UNSUPPORTED;
+        for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;
+        for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
+        if (e->prog->sub.size() + e->prog->ins_fast.size() > 20000) return FG_E_UNSUPPORTED;        // straight-line code: keep the compilation short
+        const std::string src = fg_jit_hmc_source(e->prog);
+        if (src.empty()) return FG_E_UNSUPPORTED;
+        std::vector<char> code;
+        const int rc = fg_jit_get_code(src, code, e->jit_log);
+        if (rc != FG_OK) {
+            if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: run-time compilation unavailable (%s): the interpreter kernels take this program\n", e->jit_log.c_str());
+            return FG_E_UNSUPPORTED;
+        }
+        if (hipModuleLoadData(&e->jit_mod, code.data()) != hipSuccess || hipModuleGetFunction(&e->jit_fn, e->jit_mod, "k_hmc_jit_steps") != hipSuccess) {
+            e->jit_log = "hipModuleLoadData / hipModuleGetFunction failed"; (void)hipGetLastError();
+            return FG_E_UNSUPPORTED;
+        }
+        e->jit_state = 1;
+    }
+    const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
+    const int n_tasks = 2 * e->d;
+    auto lds_for = [&](int W) { return (size_t)((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * sizeof(double); };
+    if (lds_for(FG_MWI_MAX) > 64 * 1024) return FG_E_UNSUPPORTED;
+    if (!e->d_mwi_order) {
+        HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)n_tasks * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
+    }
+    if (e->mwi_sparse != 2 || e->mwi_W <= 0) {             // (2: the split of the compiled kernel)
+        e->mwi_cost.assign(e->d, 1);
+        for (int k = 0; k < e->d; ++k) {
+            long long cs = 0;
+            for (int q = 0; q < e->prog->coord[k].sub_n; ++q) cs += mwi_ins_cost(e->prog->sub[e->prog->coord[k].sub_off + q]);
+            e->mwi_cost[k] = std::max(1LL, cs);
+        }
+        int forced = e->mw_override;
+        if (const char *sp = std::getenv("FG_HMC_INTERP_WAVES")) forced = std::atoi(sp);
+        const int wcap = std::min(FG_MWI_MAX, n_tasks);
+        int W = 1;
+        const long long n_cu = std::max(1, e->n_simd / 4);
+        if (forced > 0) W = std::max(1, std::min(forced, wcap));
+        else if ((long long)tiles <= n_cu) W = wcap;             // a CU has at most one tile: a wave per task (logistic regression, 8 192 chains: W = 6 beats 4 by 45 %)
+        else while (2 * W <= std::min(8, wcap)) W *= 2;         // several tiles per CU: a power of two up to eight (measured on four models)
+        std::vector<std::vector<int>> bins;
+        mwi_split(e->mwi_cost, W, &bins);
+        std::vector<int> order;
+        e->mwi_off.assign(FG_MWI_MAX + 1, n_tasks);
+        for (int w = 0; w < W; ++w) {
+            e->mwi_off[w] = (int)order.size();
+            std::sort(bins[w].begin(), bins[w].end());
+            order.insert(order.end(), bins[w].begin(), bins[w].end());
+        }
+        HIPCHK(hipMemcpyAsync(e->d_mwi_order, order.data(), (size_t)n_tasks * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->mwi_W = W; e->mwi_sparse = 2;
+    }
+    const int W = e->mwi_W;
+    FgJitSeg seg;
+    for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
+    seg.order = e->d_mwi_order;
+    int n_warmup = e->n_warmup;
+    void *args[] = { &e->P, &e->X, &e->H, &seg, &iter0, &n, &n_warmup, &welford_on, &draws, &first_sample_t, &pos_all, &info };
+    HIPCHK(hipModuleLaunchKernel(e->jit_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds_for(W), e->stream, args, nullptr));
+    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + " (compiled at run time)";
     return FG_OK;
 }

@@ -1,0 +1,156 @@
+// fg_hmc_jit_body.h -- HmcSession::step (hmc.rs:819-919) around a model compiled at run time (fg_jit.cpp).
+//
+// This text is compiled by hiprtc, behind the generated functions of ONE model:
+//     double fg_jit_task(int k, double pert, const double *slots)   log-joint terms that read coordinate k, with q_k replaced by `pert`
+//                                                                  -- the straight-line form of the sparse finite difference's sub-program k
+//     void   fg_jit_score(const double *slots, double &pr, double &lk, double &fc)   the whole program (score_full, hmc.rs:283-299)
+// Both perform the interpreter's operations in the interpreter's order (fg_interp.h: one C++ statement per FgIns), with expression
+// temporaries in registers instead of LDS rows and every instruction field a literal.  The kernel is fg_hmc_interp.hip's: a tile of 64
+// chains shared by W waves, (coordinate, sign) tasks split over the waves, kick + drift by wave k mod W behind a barrier, the
+// sequential parts on wave 0 -- so its results are bit-identical to k_hmc_interp_mw_steps and k_hmc_steps
+// (tests/test_gpu_jit.py).  LDS: S site rows + d momentum rows + 2 d evaluation rows + 2 + W exchange rows.
+#define FG_JIT_WMAX 16
+struct FgJitSeg { int off[FG_JIT_WMAX + 1]; const int *order; };   // wave w owns tasks order[off[w] .. off[w + 1]): 2 k + sign
+
+extern "C" __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(FG_WAVE * FG_JIT_WMAX)
+void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int iter0, int n_steps, int n_warmup, int welford_on, double *draws,
+                     int first_sample_t, double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const long long chain = (long long)blockIdx.x * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    const int d = P.d, L = H.L;
+    double *slots = lds + lane;                                                      // site rows [0, S)
+    double *pl = lds + (long long)P.S * tw + lane;                                   // momentum rows
+    double *ev_lp = lds + (long long)(P.S + d) * tw + lane;                          // log-joint of evaluation (coordinate k, sign): row 2 k + sign
+    double *xch = lds + (long long)(P.S + 3 * d) * tw + lane;                        // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    const int j0 = seg.off[wv], j1 = seg.off[wv + 1];
+    const double *mi = H.use_mass ? H.m_inv + c : nullptr;
+    const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    const double h = H.h;
+    for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
+    unsigned long long da_m = 0, ndiv = 0;
+    if (wv == 0) {
+        lj = H.lj[c]; eps = H.eps[c]; frozen = H.frozen[c];
+        da_mu = H.da_mu[c]; da_leb = H.da_leb[c]; da_hbar = H.da_hbar[c]; da_m = H.da_m[c];
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const int iter = iter0 + t;
+        const bool warming = iter < n_warmup;
+        double h0 = 0.0, u = 0.0;
+        const int n_pairs = (d + 1) >> 1;
+        for (int j = wv; j < n_pairs; j += W) {              // p0 ~ N(0, M) (hmc.rs:436-441): Box-Muller pair j = Philox block j
+            const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)j, (uint32_t)iter, FG_RNG_HMC);
+            const int i = 2 * j;
+            pl[i * tw] = zz.a * (ms ? ms[(long long)i * X.C] : 1.0);
+            if (i + 1 < d) pl[(i + 1) * tw] = zz.b * (ms ? ms[(long long)(i + 1) * X.C] : 1.0);
+        }
+        if (wv == 0) {
+            double e;
+            if (warming) e = eps;
+            else {                                             // frozen_or_current: hmc.rs:789-798
+                if (frozen == frozen) e = frozen;
+                else if (n_warmup > 0) e = fg_cold_exp(da_leb);
+                else e = eps;
+                frozen = e;
+            }
+            u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)n_pairs, (uint32_t)iter, FG_RNG_HMC).a;
+            xch[0] = e;
+        }
+        __syncthreads();
+        if (wv == 0) h0 = -lj + fg_kinetic(P, pl, tw, mi, X.C);  // hmc.rs:442-443 (all of p0, before any kick)
+        __syncthreads();
+        const double e = xch[0], hk = 0.5 * e;
+        bool bad = false;
+        for (int s = 0; s <= L; ++s) {                        // gradients 0 .. L of the leapfrog (hmc.rs:353-407)
+            for (int jj = j0; jj < j1; ++jj) {
+                const int task = seg.order[jj];
+                const int k = task >> 1;
+                const double orig = slots[k * tw];
+                ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, slots);      // hmc.rs:317-321
+            }
+            __syncthreads();                                  // every evaluation of this gradient done, every read of q done
+            for (int k = wv; k < d; k += W) {
+                const double g = (ev_lp[2 * k * tw] - ev_lp[(2 * k + 1) * tw]) / (2.0 * h);    // hmc.rs:322
+                bad = bad || !fg_finite(g);
+                double p = pl[k * tw];
+                p += hk * g;                                  // hmc.rs:389 / :400
+                if (s > 0 && s < L) p += hk * g;              // trailing kick of step s + leading kick of s + 1
+                pl[k * tw] = p;
+                if (s < L) {                                  // q += eps * M^-1 p   (hmc.rs:391-393)
+                    const double mk = mi ? mi[(long long)k * X.C] : 1.0;
+                    slots[k * tw] += e * mk * p;
+                }
+            }
+            __syncthreads();
+        }
+        double lj_new = FG_NEG_INF;
+        if (wv == 0) {
+            double pr = 0.0, lk = 0.0, fc = 0.0;
+            fg_jit_score(slots, pr, lk, fc);
+            lj_new = pr + lk + fc;                            // total_log_weight (trace.rs:198-200)
+        }
+        xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
+        __syncthreads();
+        if (wv == 0) {
+            bool div = false;
+            for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
+            div = div || !fg_finite(lj_new);
+            double ap = 0.0; bool acc = false;
+            if (!div) {
+                const double h_new = -lj_new + fg_kinetic(P, pl, tw, mi, X.C);
+                ap = fg_cold_accept_prob(h0, h_new);             // hmc.rs:460
+                acc = u < ap;                                    // hmc.rs:461
+            }
+            if (acc) lj = lj_new;
+            xch[tw] = acc ? 1.0 : 0.0;
+            asum += ap; ndiv += div ? 1ull : 0ull;
+            if (live && info) {                                  // HmcStepInfo: hmc.rs:587-602
+                double *r = info + (long long)t * 4 * X.C + c;
+                r[0] = acc ? 1.0 : 0.0; r[X.C] = div ? 1.0 : 0.0; r[2 * X.C] = ap; r[3 * X.C] = e;
+            }
+            if (warming) {                                       // DualAveraging::update: hmc.rs:168-178
+                da_m += 1ull;
+                const FgD3 r = fg_cold_da_update(da_hbar, da_leb, (double)da_m, da_mu, H.target, ap);
+                eps = r.a; da_hbar = r.b; da_leb = r.c;
+            }
+        }
+        __syncthreads();
+        const bool acc = xch[tw] != 0.0;
+        unsigned long long wn = 0;
+        if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
+        for (int k = wv; k < d; k += W) {                         // commit or roll back: coordinate k by wave k mod W
+            const long long g = (long long)P.f64_site[k] * X.C + c;
+            if (acc) { if (live) X.values[g] = fg_as_i64(slots[k * tw]); }
+            else slots[k * tw] = fg_as_double(X.values[g]);
+            const double x = slots[k * tw];
+            if (live && pos_all) pos_all[((long long)t * d + k) * X.C + c] = x;
+            if (warming) {
+                if (welford_on) {                                 // Welford::push: hmc.rs:202-211
+                    const long long gi = (long long)k * X.C + c;
+                    const double n = (double)wn;
+                    double mean = H.w_mean[gi];
+                    const double delta = x - mean;
+                    mean += delta / n;
+                    const double delta2 = x - mean;
+                    if (live) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
+                }
+            } else if (draws && live) draws[((long long)(t - first_sample_t) * d + k) * X.C + c] = x;   // hmc.rs:577-582
+        }
+        if (warming && welford_on) {
+            __syncthreads();                                      // all waves hold the old count
+            if (wv == 0 && live) H.w_n[c] = wn;
+        }
+    }
+    if (wv == 0 && live) {
+        H.lj[c] = lj; H.eps[c] = eps; H.frozen[c] = frozen;
+        H.da_mu[c] = da_mu; H.da_leb[c] = da_leb; H.da_hbar[c] = da_hbar; H.da_m[c] = da_m;
+        H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
+    }
+}

@@ -1,0 +1,349 @@
+// fg_jit.cpp -- models compiled at run time: straight-line HIP for the programs the record streams do not cover.
+//
+// A program with an expression parameter (a GLM's link function, exp(log_sigma), a select ...) has no gradient / score stream and runs
+// on the interpreter (fg_interp.h), which spends ~100 issue slots decoding each FgIns -- most of a step for models whose arithmetic
+// is light (logistic regression: a leapfrog step costs 7x its f64 instructions; tools/mb_interp_costs.py).  The interpreter's input
+// is already a flat list of FgIns per sub-program, so each becomes ONE C++ statement here -- the same operation on the same
+// operands in the same order, fields as literals, expression temporaries as locals instead of LDS rows -- and hiprtc compiles the
+// result for gfx950 behind fg_hmc_jit_body.h (the multi-wave HMC kernel of fg_hmc_interp.hip around two generated functions).
+// Results are bit-identical to the interpreter kernels (tests/test_gpu_jit.py); when hiprtc is missing, the program is too long or
+// the compilation fails the engine stays on them (FG_JIT=0 forces that).  Nothing here runs on the CPU at sampling time.
+#include <dlfcn.h>
+
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "fg_program.h"
+#include "fg_jit.h"
+#include "_fg_jit_embed.inc"      // FG_JIT_EMBED: fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h and fg_hmc_jit_body.h as text (fugue_amd/build.py)
+
+namespace {
+
+std::string lit(double v) {                      // a double literal with exactly these bits
+    char b[64];
+    if (std::isfinite(v)) { std::snprintf(b, sizeof b, "%a", v); return std::string("(") + b + ")"; }
+    long long bits; std::memcpy(&bits, &v, 8);
+    std::snprintf(b, sizeof b, "fg_as_double((long long)0x%016llxULL)", (unsigned long long)bits);
+    return b;
+}
+
+struct Gen {
+    const fg_program &p;
+    int pert_slot = -1;                          // slot whose reads become `pert` (a finite-difference task) or -1
+    std::string body;
+    std::set<int> temps;
+    std::map<std::string, std::string> *lp_fns;  // signature -> definition of the per-signature density wrappers
+    std::vector<std::string> *tables;            // file-scope constant tables
+    bool ok = true;
+
+    std::string slot(uint32_t idx) {
+        if ((int)idx == p.n_slots - 1) return "0.0";                        // the always-zero slot
+        if ((int)idx < (int)p.site_vtype.size()) return (int)idx == pert_slot ? std::string("pert") : "slots[" + std::to_string(idx) + " * FG_WAVE]";
+        temps.insert((int)idx);
+        return "t" + std::to_string(idx);
+    }
+    std::string opnd(uint32_t w, double imm) {
+        const uint32_t kind = FG_OPND_KIND(w), idx = FG_OPND_IDX(w);
+        if (kind == FG_OPND_IMM) return lit(imm);
+        if (kind == FG_OPND_SLOT_F) return slot(idx);
+        if (kind == FG_OPND_SLOT_I) return "(double)fg_as_i64(" + slot(idx) + ")";
+        return lit(p.pool[idx]);
+    }
+    // per-lane choice among consecutive temporaries t[base .. base + K): v = t[base + j]
+    std::string pick(int base, int K, const std::string &j, const std::string &out) {
+        std::string s = "double " + out + " = " + slot((uint32_t)base) + "; ";
+        for (int q = 1; q < K; ++q) s += out + " = (" + j + " == " + std::to_string(q) + ") ? " + slot((uint32_t)(base + q)) + " : " + out + "; ";
+        return s;
+    }
+    void add(const std::string &s) { body += "    " + s + "\n"; }
+
+    void ins(const FgIns &I) {
+        const uint32_t op = I.op, code = FG_INS_OPCODE(op);
+        const bool observe = (op & FG_F_OBSERVE) != 0u;
+        const std::string accum = observe ? "lk += lp;" : "pr += lp;";
+        if (code == FG_OP_NORMAL_FAST) {                                     // fg_interp.h: the fast Normal of score-only programs
+            std::string z;
+            if (op & FG_F_POW2SCALE) z = "double z = dl * " + lit(I.h[4]) + ";";
+            else if (op & FG_F_RCPSCALE) z = "double z = fg_div_const(dl, " + lit(I.imm[2]) + ", " + lit(I.h[4]) + ");";
+            else z = "double z = dl / " + lit(I.imm[2]) + ";";
+            add("{ const double xv = " + lit(I.imm[0]) + " + " + slot(I.opnd[0]) + "; const double mv = " + lit(I.imm[1]) + " + " + slot(I.opnd[1]) +
+                "; const double dl = xv - mv; " + z + " double lp = -0.5 * z * z - " + lit(I.h[0]) + " - 0.5 * FG_LN_2PI; lp = (z != z) ? FG_NEG_INF : lp; " + accum + " }");
+            return;
+        }
+        if (code < 17u) {
+            const bool hoisted = (op & FG_F_HOISTED) != 0u, invalid = (op & FG_F_INVALID) != 0u;
+            const uint32_t vtype = FG_INS_VTYPE(op), xw = I.opnd[0];
+            if (code == 3u) {                                                 // Categorical: distribution.rs:771-791
+                const uint32_t bw = I.opnd[1]; const int K = (int)I.opnd[2];
+                const bool in_pool = FG_OPND_KIND(bw) == FG_OPND_POOL; const int base = (int)FG_OPND_IDX(bw);
+                std::string xi = FG_OPND_KIND(xw) == FG_OPND_SLOT_I ? "fg_as_i64(" + slot(FG_OPND_IDX(xw)) + ")"
+                                                                      : "fg_jit_int_of(" + opnd(xw, I.imm[0]) + ", " + std::to_string(vtype) + "u)";
+                if (invalid) { add("{ double lp = FG_NEG_INF; " + accum + " }"); return; }
+                if (in_pool) {
+                    std::string tn = "fg_jit_tab" + std::to_string(tables->size());
+                    std::string t = "static __device__ const double " + tn + "[" + std::to_string(K) + "] = {";
+                    for (int q = 0; q < K; ++q) t += (q ? ", " : "") + lit(p.pool[(size_t)base + K + q]);
+                    tables->push_back(t + "};");
+                    add("{ const long long xi = " + xi + "; double lp = (xi < 0 || xi >= " + std::to_string(K) + "LL) ? FG_NEG_INF : " + tn + "[(xi < 0 || xi >= " +
+                        std::to_string(K) + "LL) ? 0 : (int)xi]; " + accum + " }");
+                } else {
+                    add("{ const long long xi = " + xi + "; const bool oob = xi < 0 || xi >= " + std::to_string(K) + "LL; const int j = oob ? 0 : (int)xi; " +
+                        pick(base, K, "j", "pv") + "double lp = oob ? FG_NEG_INF : (pv > 0.0 ? log(pv) : FG_NEG_INF); " + accum + " }");
+                }
+                return;
+            }
+            const std::string p0 = opnd(I.opnd[1], I.imm[1]), p1 = opnd(I.opnd[2], I.imm[2]), p2 = opnd(I.opnd[3], I.imm[3]);
+            std::string xs;
+            if (vtype == 0u) xs = "const double xf = " + opnd(xw, I.imm[0]) + "; const long long xi = 0;";
+            else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xs = "const double xf = 0.0; const long long xi = fg_as_i64(" + slot(FG_OPND_IDX(xw)) + ");";
+            else xs = "const double xf = 0.0; const long long xi = fg_jit_int_of(" + opnd(xw, I.imm[0]) + ", " + std::to_string(vtype) + "u);";
+            if (invalid) { add("{ double lp = FG_NEG_INF; " + accum + " }"); return; }
+            if (code == 12u && hoisted) {                                     // Normal with constant parameters, inline as in fg_interp.h
+                const std::string z = (op & FG_F_POW2SCALE) ? "(xf - p0) * " + lit(I.h[4]) : std::string("(xf - p0) / p1");
+                add("{ " + xs + " const double p0 = " + p0 + ", p1 = " + p1 + "; (void)p1; (void)xi; double lp; if (!fg_finite(xf)) lp = FG_NEG_INF; else { const double z = " + z +
+                    "; lp = -0.5 * z * z - " + lit(I.h[0]) + " - 0.5 * FG_LN_2PI; } " + accum + " }");
+                return;
+            }
+            const bool pow2 = (op & FG_F_POW2SCALE) != 0u, sh = (op & FG_F_SCALEHOIST) != 0u, xh = (op & FG_F_XHOIST) != 0u;
+            char sig[96];
+            std::snprintf(sig, sizeof sig, "fg_jit_lp_%u_%d%d%d%d", code, (int)hoisted, (int)pow2, (int)sh, (int)xh);
+            if (!lp_fns->count(sig)) {
+                char def[640];
+                std::snprintf(def, sizeof def,
+                              "static __device__ __noinline__ double %s(double xf, long long xi, double p0, double p1, double p2, double h0, double h1, double h2, double h3, double h4) {\n"
+                              "    const double hh[5] = { h0, h1, h2, h3, h4 };\n    return fg_logpdf(%uu, %s, %s, xf, xi, p0, p1, p2, hh, %s, %s);\n}\n",
+                              sig, code, hoisted ? "true" : "false", pow2 ? "true" : "false", sh ? "true" : "false", xh ? "true" : "false");
+                (*lp_fns)[sig] = def;
+            }
+            add("{ " + xs + " double lp = " + sig + "(xf, xi, " + p0 + ", " + p1 + ", " + p2 + ", " + lit(I.h[0]) + ", " + lit(I.h[1]) + ", " + lit(I.h[2]) + ", " + lit(I.h[3]) + ", " +
+                lit(I.h[4]) + "); " + accum + " }");
+            return;
+        }
+        const std::string x0 = opnd(I.opnd[0], I.imm[0]);
+        switch (code) {
+        case FG_OP_FACTOR: add("fc += " + x0 + ";"); break;
+        case FG_OP_LOAD: add("acc = " + x0 + ";"); break;
+        case FG_OP_ADD: add("acc = acc + " + x0 + ";"); break;
+        case FG_OP_SUB: add("acc = acc - " + x0 + ";"); break;
+        case FG_OP_MUL: add("acc = acc * " + x0 + ";"); break;
+        case FG_OP_DIV: add("acc = acc / " + x0 + ";"); break;
+        case FG_OP_RSUB: add("acc = " + x0 + " - acc;"); break;
+        case FG_OP_RDIV: add("acc = " + x0 + " / acc;"); break;
+        case FG_OP_NEG: add("acc = -acc;"); break;
+        case FG_OP_EXP: add("acc = fg_jit_exp(acc);"); break;
+        case FG_OP_LN: add("acc = fg_jit_log(acc);"); break;
+        case FG_OP_SQRT: add("acc = sqrt(acc);"); break;
+        case FG_OP_ABS: add("acc = fabs(acc);"); break;
+        case FG_OP_FLOOR: add("acc = floor(acc);"); break;
+        case FG_OP_SIN: add("acc = fg_jit_sin(acc);"); break;
+        case FG_OP_COS: add("acc = fg_jit_cos(acc);"); break;
+        case FG_OP_TANH: add("acc = fg_jit_tanh(acc);"); break;
+        case FG_OP_POW: add("acc = fg_jit_pow(acc, " + x0 + ");"); break;
+        case FG_OP_RPOW: add("acc = fg_jit_pow(" + x0 + ", acc);"); break;
+        case FG_OP_MIN: add("acc = fmin(acc, " + x0 + ");"); break;
+        case FG_OP_MAX: add("acc = fmax(acc, " + x0 + ");"); break;
+        case FG_OP_CLAMP: add("acc = fg_clamp(acc, " + x0 + ", " + opnd(I.opnd[1], I.imm[1]) + ");"); break;
+        case FG_OP_MAC: add("{ const double t_ = " + x0 + " * " + opnd(I.opnd[1], I.imm[1]) + "; acc = acc + t_; }"); break;
+        case FG_OP_STORE: { const std::string t = slot(I.aux); if (t == "0.0" || t == "pert" || t[0] == 's') { ok = false; break; } add(t + " = acc;"); break; }
+        case FG_OP_GATHER: {
+            const int K = (int)I.opnd[1];
+            add("{ const bool ok_ = (acc >= 0.0) && (acc < " + lit((double)K) + ") && (acc == floor(acc)); const int j = ok_ ? (int)acc : 0; " + pick((int)I.aux, K, "j", "gv") +
+                "acc = ok_ ? gv : NAN; }");
+            break; }
+        case FG_OP_CONSTLIK: add("lk += " + lit(I.imm[0]) + ";"); break;
+        case FG_OP_DOT: {                                                    // acc = (..((acc + s_0 c_0) + s_1 c_1)..): one product, one sum per term
+            const int n = (int)I.opnd[1];
+            for (int t = 0; t < n; ++t) {
+                long long sb; std::memcpy(&sb, &p.pool[(size_t)I.aux + 2 * t], 8);
+                add("acc = acc + " + slot((uint32_t)sb) + " * " + lit(p.pool[(size_t)I.aux + 2 * t + 1]) + ";");
+            }
+            break; }
+        default: ok = false; break;
+        }
+    }
+    std::string decls() const {
+        std::string s = "    double acc = 0.0, pr = 0.0, lk = 0.0, fc = 0.0;\n";
+        for (int t : temps) s += "    double t" + std::to_string(t) + " = 0.0;\n";
+        return s;
+    }
+};
+
+// ---- hiprtc, bound at run time ---------------------------------------------------------------------------------------------
+struct Rtc {
+    void *h = nullptr;
+    int (*create)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*compile)(void *, int, const char **) = nullptr;
+    int (*log_size)(void *, size_t *) = nullptr;
+    int (*log)(void *, char *) = nullptr;
+    int (*code_size)(void *, size_t *) = nullptr;
+    int (*code)(void *, char *) = nullptr;
+    int (*destroy)(void **) = nullptr;
+    bool ok = false;
+};
+Rtc &rtc() {
+    static Rtc R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr((void *)hipGetDeviceCount, &di) && di.dli_fname) {       // the copy beside the HIP runtime this library runs on
+            std::string d(di.dli_fname); const size_t s = d.rfind('/');
+            if (s != std::string::npos) { names.push_back(d.substr(0, s + 1) + "libhiprtc.so"); names.push_back(d.substr(0, s + 1) + "libhiprtc.so.7"); }
+        }
+        names.push_back("libhiprtc.so"); names.push_back("/opt/rocm/lib/libhiprtc.so");
+        for (const std::string &nm : names) { R.h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (R.h) break; }
+        if (!R.h) return;
+        R.create = (decltype(R.create))dlsym(R.h, "hiprtcCreateProgram");
+        R.compile = (decltype(R.compile))dlsym(R.h, "hiprtcCompileProgram");
+        R.log_size = (decltype(R.log_size))dlsym(R.h, "hiprtcGetProgramLogSize");
+        R.log = (decltype(R.log))dlsym(R.h, "hiprtcGetProgramLog");
+        R.code_size = (decltype(R.code_size))dlsym(R.h, "hiprtcGetCodeSize");
+        R.code = (decltype(R.code))dlsym(R.h, "hiprtcGetCode");
+        R.destroy = (decltype(R.destroy))dlsym(R.h, "hiprtcDestroyProgram");
+        R.ok = R.create && R.compile && R.log_size && R.log && R.code_size && R.code && R.destroy;
+    });
+    return R;
+}
+
+const char *PROLOGUE = R"FGJ(
+#define FG_BUILD 1
+#define FG_JIT_RTC 1
+#define FG_WAVE 64
+#ifndef INFINITY
+#define INFINITY __builtin_huge_val()
+#endif
+#ifndef NAN
+#define NAN __builtin_nan("")
+#endif
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#define FG_HD __device__ __forceinline__
+typedef unsigned int uint32_t;
+typedef int int32_t;
+typedef unsigned long long uint64_t;
+typedef long long int64_t;
+typedef unsigned long uintptr_t;
+)FGJ";
+
+const char *HELPERS = R"FGJ(
+// the transcendental opcodes behind calls, as in fg_interp.h (same ocml functions: same bits)
+static __device__ __noinline__ double fg_jit_exp(double x) { return exp(x); }
+static __device__ __noinline__ double fg_jit_log(double x) { return log(x); }
+static __device__ __noinline__ double fg_jit_sin(double x) { return sin(x); }
+static __device__ __noinline__ double fg_jit_cos(double x) { return cos(x); }
+static __device__ __noinline__ double fg_jit_tanh(double x) { return tanh(x); }
+static __device__ __noinline__ double fg_jit_pow(double x, double y) { return pow(x, y); }
+// fg_int_of (fg_interp.h): the integer value of an observed expression
+static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vtype) { if (vtype == 1u) return v != 0.0; return fg_finite(v) ? (long long)v : 0; }
+)FGJ";
+
+}  // namespace
+
+// The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
+std::string fg_jit_hmc_source(const fg_program *p) {
+    std::map<std::string, std::string> lp_fns;
+    std::vector<std::string> tables;
+    std::string fns;
+    const int d = (int)p->coord.size();
+    for (int k = 0; k < d; ++k) {
+        Gen g{*p}; g.pert_slot = p->coord[k].slot; g.lp_fns = &lp_fns; g.tables = &tables;
+        for (int q = 0; q < p->coord[k].sub_n; ++q) g.ins(p->sub[(size_t)p->coord[k].sub_off + q]);
+        if (!g.ok) return "";
+        fns += "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const double *slots) {\n" + g.decls() + g.body +
+               "    (void)acc;\n    return pr + lk + fc;\n}\n";
+    }
+    fns += "static __device__ __forceinline__ double fg_jit_task(int k, double pert, const double *slots) {\n    switch (k) {\n";
+    for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_sub_" + std::to_string(k) + "(pert, slots);\n";
+    fns += "    default: return 0.0;\n    }\n}\n";
+    {
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables;
+        for (int q = 0; q < p->n_ins; ++q) g.ins(p->ins_fast[(size_t)q]);
+        if (!g.ok) return "";
+        fns += "static __device__ __noinline__ void fg_jit_score(const double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+               "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
+    }
+    std::string src = PROLOGUE;
+    src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
+    src += HELPERS;
+    for (const std::string &t : tables) src += t + "\n";
+    for (const auto &kv : lp_fns) src += kv.second;
+    src += fns;
+    src += FG_JIT_EMBED_HMC_BODY;                // fg_hmc_jit_body.h
+    return src;
+}
+
+// Compiles `src` for gfx950; on success `code` holds the code object.  `log` receives the compiler's messages.
+int fg_jit_compile(const std::string &src, std::vector<char> &code, std::string &log) {
+    Rtc &R = rtc();
+    if (!R.ok) { log = "hiprtc not available"; return FG_E_UNSUPPORTED; }
+    void *prog = nullptr;
+    if (R.create(&prog, src.c_str(), "fg_model.hip", 0, nullptr, nullptr) != 0) { log = "hiprtcCreateProgram failed"; return FG_E_HIP; }
+    const char *opts[] = { "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-variable", "-Wno-unused-but-set-variable" };
+    const int rc = R.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    size_t n = 0;
+    if (R.log_size(prog, &n) == 0 && n > 1) { log.resize(n); R.log(prog, &log[0]); }
+    if (rc != 0) { R.destroy(&prog); return FG_E_HIP; }
+    if (R.code_size(prog, &n) != 0 || n == 0) { R.destroy(&prog); log += " (no code)"; return FG_E_HIP; }
+    code.resize(n);
+    R.code(prog, code.data());
+    R.destroy(&prog);
+    return FG_OK;
+}
+
+// ---- compiled code objects: per process by source text, and on disk (FG_JIT_CACHE, default /tmp/fugue_amd_jit_<uid>) by its hash -----------
+#include <sys/stat.h>
+#include <unistd.h>
+
+int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string &log) {
+    static std::mutex mu;
+    static std::map<std::string, std::vector<char>> mem;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = mem.find(src);
+    if (it != mem.end()) { code = it->second; return FG_OK; }
+    unsigned long long hsh = 1469598103934665603ULL;                     // FNV-1a of the source text
+    for (unsigned char ch : src) { hsh ^= ch; hsh *= 1099511628211ULL; }
+    std::string dir = std::getenv("FG_JIT_CACHE") ? std::getenv("FG_JIT_CACHE") : "/tmp/fugue_amd_jit_" + std::to_string((long long)getuid());
+    char name[64]; std::snprintf(name, sizeof name, "/%016llx_%zu.hsaco", hsh, src.size());
+    const std::string path = dir + name;
+    if (FILE *f = std::fopen(path.c_str(), "rb")) {
+        std::fseek(f, 0, SEEK_END); const long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+        if (n > 0) { code.resize((size_t)n); if (std::fread(code.data(), 1, (size_t)n, f) == (size_t)n) { std::fclose(f); mem[src] = code; return FG_OK; } }
+        std::fclose(f);
+    }
+    const int rc = fg_jit_compile(src, code, log);
+    if (rc != FG_OK) return rc;
+    mem[src] = code;
+    (void)mkdir(dir.c_str(), 0700);
+    const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
+    if (FILE *f = std::fopen(tmp.c_str(), "wb")) {
+        const bool okw = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+        std::fclose(f);
+        if (okw) (void)std::rename(tmp.c_str(), path.c_str()); else (void)std::remove(tmp.c_str());
+    }
+    return FG_OK;
+}
+
+// test hook (no GPU needed: hiprtc cross-compiles): generated source and compiler log of a program's HMC kernel
+extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long long src_cap, char *log_out, long long log_cap, long long *code_bytes) {
+    if (!p) return FG_E_BAD_ARG;
+    const std::string src = fg_jit_hmc_source(p);
+    if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
+    if (code_bytes) *code_bytes = 0;
+    if (src.empty()) return FG_E_UNSUPPORTED;
+    std::vector<char> code; std::string log;
+    const int rc = fg_jit_compile(src, code, log);
+    if (log_out && log_cap > 0) std::snprintf(log_out, (size_t)log_cap, "%s", log.c_str());
+    if (code_bytes) *code_bytes = (long long)code.size();
+    return rc;
+}

@@ -9,11 +9,13 @@
 #include <stdint.h>
 #include "fg_ir.h"
 
+#ifndef FG_HD                     /* the run-time compiled kernels (fg_jit.cpp) define it themselves */
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define FG_HD __host__ __device__ __forceinline__
 #else
 #define FG_HD inline
+#endif
 #endif
 
 #define FG_LN_2PI 1.8378770664093456   /* distribution.rs:206 */

@@ -67,6 +67,33 @@ def ridge_regression(X: np.ndarray, y: np.ndarray, sigma: float = 0.5, lam: floa
     return P
 
 
+def logistic_regression(X: np.ndarray, labels: np.ndarray) -> Program:
+    """/root/reference/examples/classification.rs:104-135 (run there with adaptive_mcmc_chain, :159): beta#j ~ N(0, 2);
+    linear_pred = 0.0 + sum_j beta#j x_ij in feature order; prob = 1 / (1 + exp(-linear_pred)) clamped to [1e-10, 1 - 1e-10];
+    y#i ~ Bernoulli(prob) observed.  Every observe statement's parameter is an expression of the coefficients: no record stream, the
+    model runs on the interpreter kernels (fg_hmc_interp.hip, fg_mh_interp.hip)."""
+    from .model import Bernoulli, as_expr, exp
+    n, p = X.shape
+    P = Program()
+    betas = [P.sample(addr("beta", j), Normal(0.0, 2.0)) for j in range(p)]
+    for i in range(n):
+        lp = as_expr(0.0)
+        for j in range(p):
+            lp = lp + betas[j] * float(X[i, j])
+        prob = (1.0 / (1.0 + exp(-lp))).clamp(1e-10, 1.0 - 1e-10)
+        P.observe(addr("y", i), Bernoulli(prob), bool(labels[i]))
+    return P
+
+
+def classification_data(n: int = 100, seed: int = 42):
+    """The shape of classification.rs:36-60's generator: features [1, x1, x2], x ~ N(0, 1), true coefficients (-1.0, 2.0, -1.5)."""
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([np.ones(n), rng.standard_normal(n), rng.standard_normal(n)])
+    beta = np.array([-1.0, 2.0, -1.5])
+    labels = rng.random(n) < 1.0 / (1.0 + np.exp(-(X @ beta)))
+    return X, labels, beta
+
+
 def ridge_data(n: int = 1024, p: int = 32, sigma: float = 0.5, seed_x: int = 7, seed_b: int = 8):
     X = np.random.default_rng(seed_x).standard_normal((n, p))
     beta = np.random.default_rng(seed_b).standard_normal(p)

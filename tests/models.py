@@ -206,6 +206,7 @@ def hier_logsigma(groups: int = 5) -> M.Program:
     return P
 
 
+ZOO["logistic"] = lambda: W.logistic_regression(*W.classification_data(14)[:2])     # the reference's classification example, small
 ZOO["poisson_glm"] = poisson_glm
 ZOO["hier_logsigma"] = hier_logsigma
 

@@ -110,3 +110,17 @@ def test_stream_records_report_what_the_compiler_could_build():
             "mixture": (44, 24, 2), "alldists": (0, 0, 0), "coin": (0, 0, 0)}
     for name, rec in want.items():
         assert E.compile_model(ZOO[name]()).stream_records == rec, name
+
+
+@pytest.mark.parametrize("name", ["alldists", "poisson_glm", "hier_logsigma", "logistic", "mixture", "coin"])
+def test_jit_source_compiles_for_gfx950(name):
+    """fg_jit.cpp: the generated translation unit of a program's HMC kernel (one C++ statement per interpreter instruction behind
+    fg_hmc_jit_body.h) goes through hiprtc for gfx950 -- no GPU needed to compile."""
+    lib = E.lib()
+    lib.fg_debug_jit_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    cp = E.compile_model(ZOO[name]())
+    src = ctypes.create_string_buffer(8 << 20); log = ctypes.create_string_buffer(1 << 20); n = ctypes.c_longlong()
+    rc = lib.fg_debug_jit_compile(cp.h, src, len(src), log, len(log), ctypes.byref(n))
+    assert rc == 0 and n.value > 0, log.value.decode()[:2000]
+    text = src.value.decode()
+    assert "fg_jit_task" in text and "fg_jit_score" in text and "k_hmc_jit_steps" in text

@@ -1,0 +1,50 @@
+"""Models compiled at run time (fg_jit.cpp: one C++ statement per interpreter instruction, hiprtc, the multi-wave HMC kernel around
+the generated functions) against the interpreter kernels: the same operations in the same order, so draws, step sizes, mass
+matrix, log-joint, values and statistics agree BIT FOR BIT -- and against the oracle like every other path."""
+import numpy as np
+import pytest
+
+from fugue_amd import engine as E
+from tests.models import ZOO
+
+pytestmark = pytest.mark.gpu
+
+INTERP_MODELS = ["alldists", "poisson_glm", "hier_logsigma", "logistic", "coin"]
+
+
+@pytest.mark.parametrize("name,adapt_mass", [("alldists", True), ("alldists", False), ("poisson_glm", True), ("hier_logsigma", False), ("logistic", True), ("coin", False)])
+def test_jit_hmc_is_bit_identical_to_the_interpreter(name, adapt_mass, monkeypatch):
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 150, 30, 20
+    out, kernels = [], []
+    for jit, W in [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 16)]:
+        monkeypatch.setenv("FG_JIT", str(jit))
+        if W: monkeypatch.setenv("FG_HMC_INTERP_WAVES", str(W))
+        else: monkeypatch.delenv("FG_HMC_INTERP_WAVES", raising=False)
+        eng = E.Engine(cp, C, seed=29, chain_offset=11)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(n_leapfrog=5, adapt_mass=adapt_mass), ns, nw, d)
+        kernels.append(eng.hmc_last_kernel())
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
+                    eng.hmc_mass() if adapt_mass else None))
+        eng.close()
+    assert not kernels[0].startswith("k_hmc_jit_steps") and all(k.startswith("k_hmc_jit_steps W=") for k in kernels[1:]), kernels
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert np.isfinite(out[0][0]).all()
+
+
+def test_jit_is_not_used_where_a_record_stream_exists(monkeypatch):
+    """Programs with a gradient stream keep their hand-written kernels; the dense mode (the reference's whole-program finite
+    difference) keeps the interpreter."""
+    monkeypatch.setenv("FG_JIT", "1")
+    for name, mode in [("refmodel8", E.GRAD_FD_SPARSE), ("normal32", E.GRAD_FD_SPARSE), ("poisson_glm", E.GRAD_FD_DENSE)]:
+        cp = E.compile_model(ZOO[name]())
+        eng = E.Engine(cp, 64, seed=1)
+        eng.hmc_init(E.hmc_config(grad_mode=mode, n_leapfrog=3), 2)
+        eng.hmc_step(2)
+        assert not eng.hmc_last_kernel().startswith("k_hmc_jit_steps"), (name, eng.hmc_last_kernel())
+        eng.close()

@@ -37,7 +37,7 @@ def _compare(cp, draws, odraws, max_bad_chains=0):
     return bad
 
 
-@pytest.mark.parametrize("name", ["readme", "coin", "refmodel8", "mixture", "alldists", "normal32", "hier_scale", "ridge7", "linreg"])
+@pytest.mark.parametrize("name", ["readme", "coin", "refmodel8", "mixture", "alldists", "normal32", "hier_scale", "ridge7", "linreg", "logistic", "poisson_glm", "hier_logsigma"])
 def test_mh_chain_matches_oracle(oracle, name):
     prog = ZOO[name]()
     cp, eng, st, draws, odraws, ofinal, oscales, ost = _run_both(oracle, prog, C=96, nw=150, ns=60, seed=13, chain0=3)
@@ -150,7 +150,7 @@ def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypat
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
-@pytest.mark.parametrize("name,with_overrides", [("alldists", False), ("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("coin", False)])
+@pytest.mark.parametrize("name,with_overrides", [("alldists", False), ("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("coin", False), ("logistic", False)])
 def test_mh_interp_multiwave_is_bit_identical(name, with_overrides, monkeypatch):
     """Programs without a score stream split a step's scoring run between W waves (k_mh_interp_mw_steps, fg_mh_interp.hip: each
     statement's term in an LDS row, the three accumulators added in program order by wave 0); steps whose proposal needs the model

@@ -96,7 +96,7 @@ def test_fd_gradient_matches_oracle(oracle, name):
         _close(g_sparse[fin, c], og[fin], 1e-7, tol)
 
 
-@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "ridge", "alldists", "hier_scale", "mixture"])
+@pytest.mark.parametrize("name", ["readme", "normal32", "refmodel8", "ridge", "alldists", "hier_scale", "mixture", "logistic", "poisson_glm", "hier_logsigma"])
 @pytest.mark.parametrize("mode", [E.GRAD_FD_DENSE, E.GRAD_FD_SPARSE])
 def test_hmc_transition_injected(oracle, name, mode):
     """hmc_transition (hmc.rs:419-473) under injected momentum and uniform: accept decision,
@@ -348,7 +348,7 @@ def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("name,adapt_mass,mode", [("alldists", True, E.GRAD_FD_SPARSE), ("alldists", False, E.GRAD_FD_DENSE),
-                                                  ("poisson_glm", True, E.GRAD_FD_SPARSE), ("hier_logsigma", False, E.GRAD_FD_SPARSE),
+                                                  ("poisson_glm", True, E.GRAD_FD_SPARSE), ("hier_logsigma", False, E.GRAD_FD_SPARSE), ("logistic", True, E.GRAD_FD_SPARSE),
                                                   ("hier_logsigma", True, E.GRAD_FD_DENSE), ("mixture", False, E.GRAD_FD_DENSE),
                                                   ("hier_scale", True, E.GRAD_FD_DENSE), ("rand3", False, E.GRAD_FD_DENSE)])
 def test_hmc_interp_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
@@ -360,6 +360,7 @@ def test_hmc_interp_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypat
         pytest.skip("one coordinate: nothing to split")
     C, nw, ns = 150, 30, 20
     out, kernels = [], []
+    monkeypatch.setenv("FG_JIT", "0")                                      # the interpreter kernels themselves (tests/test_gpu_jit.py covers the compiled form)
     for mw, W, occ, pl in [(0, 0, 4, 1), (1, 2, 4, 1), (1, 3, 2, 1), (1, 4, 4, 0), (1, 8, 2, 0), (1, 12, 4, 1), (1, 16, 4, 1), (1, 0, 4, 1)]:
         monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
         monkeypatch.setenv("FG_HMC_INTERP_OCC", str(occ))

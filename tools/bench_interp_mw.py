@@ -6,10 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fugue_amd import engine as E
 from tests.models import ZOO
 L = 16
-for name in sys.argv[1:] or ["alldists", "poisson_glm", "hier_logsigma"]:
-    cp = E.compile_model(ZOO[name]())
+for name in sys.argv[1:] or ["alldists", "poisson_glm", "hier_logsigma", "logistic100"]:
+    from fugue_amd import workloads as W
+    cp = E.compile_model(W.logistic_regression(*W.classification_data(100)[:2]) if name == "logistic100" else ZOO[name]())
     for C in (65536, 8192):
-        for mw, occ, W in [(0, 4, 0), (1, 4, 0), (1, 4, 4), (1, 4, 8), (1, 4, 16)]:
+        for jit, mw, occ, W in [(0, 0, 4, 0), (0, 1, 4, 0), (1, 1, 4, 0), (1, 1, 4, 2), (1, 1, 4, 4), (1, 1, 4, 16)]:
+            os.environ["FG_JIT"] = str(jit)                  # 1: the model compiled at run time (fg_jit.cpp)
             os.environ["FG_HMC_INTERP_MW"] = str(mw)
             os.environ["FG_HMC_INTERP_OCC"] = str(occ)
             if W: os.environ["FG_HMC_INTERP_WAVES"] = str(W)
