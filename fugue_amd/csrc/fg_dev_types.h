@@ -36,3 +36,21 @@ __device__ __forceinline__ double fg_kinetic(const FgProgramDev &P, const double
     return 0.5 * s;
 }
 
+
+// DiminishingAdaptation's state of one (site, chain) (mcmc_utils.rs:40-62) + the decided proposal kind, as two 16-byte groups:
+// what a proposal reads {scale, kind} and what an update reads and writes {log_scale, total, accepted} are one 16-byte access each
+// (lanes hold different sites: every access of a wave touches 64 different lines, so the NUMBER of accesses is the cost).
+struct alignas(16) FgMhAdapt { double scale; int32_t kind, pad; double log_scale; uint32_t tot, acc; };
+static_assert(sizeof(FgMhAdapt) == 32, "FgMhAdapt is two 16-byte groups");
+
+struct FgMhDev {
+    double *lw;
+    FgMhAdapt *ad;                                       // [S][C]
+    const int *ov_kind; const double *ov_lo, *ov_hi;    // [S] overrides or null
+    unsigned long long *n_acc;                           // [C] accepted proposals
+    const int *rec;                                      // [n_rec] recorded sites
+    int n_rec;
+    int rec_all;                                         // record during adaptation too (fg_mh_set_recording: incremental sessions)
+    const double *step_tab; uint32_t step_n;             // 1 / n^0.7 for n < step_n (DiminishingAdaptation's step, mcmc_utils.rs:118)
+};
+

@@ -807,6 +807,7 @@ void fg_engine_free(fg_engine *e) {
     if (e->d_rec) hipFree(e->d_rec);
     if (e->smc_arena) hipFree(e->smc_arena);
     if (e->jit_mod) (void)hipModuleUnload(e->jit_mod);
+    if (e->jit_mh_mod) (void)hipModuleUnload(e->jit_mh_mod);
     void *ptrs[] = { e->d_mhi_acc, e->d_mhi_site_ins, e->d_mwi_order, e->d_mwi_prof, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
@@ -1201,6 +1202,7 @@ int fg_hmc_set_n_leapfrog(fg_engine *e, int n_leapfrog) {     // hmc.rs:751-753
     return FG_OK;
 }
 const char *fg_hmc_last_kernel(const fg_engine *e) { return e ? e->last_hmc_kernel.c_str() : ""; }
+const char *fg_mh_last_kernel(const fg_engine *e) { return e ? e->last_mh_kernel.c_str() : ""; }
 int fg_hmc_is_warming_up(const fg_engine *e) { return (e && e->hmc_ready && e->iter < e->n_warmup) ? 1 : 0; }   // hmc.rs:780-782
 int64_t fg_hmc_iterations(const fg_engine *e) { return (e && e->hmc_ready) ? (int64_t)e->iter : 0; }             // hmc.rs:785-787
 
@@ -1368,12 +1370,13 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
     const int first_sample_t = e->M.rec_all ? 0 : std::max(iter, e->mh_warmup) - iter;
     if (n_steps > 0) {                                                  // multi-wave tiles when every statement has a score-stream record
         const int rc = fg_mh_mw_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
-        if (rc == FG_OK) { e->mh_iter += n_steps; return FG_OK; }
+        if (rc == FG_OK) { e->mh_iter += n_steps; e->last_mh_kernel = "k_mh_mw_steps"; return FG_OK; }
         if (rc != FG_E_UNSUPPORTED) return rc;
         const int rc2 = fg_mh_interp_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);   // interpreter programs: statements split over waves
         if (rc2 == FG_OK) { e->mh_iter += n_steps; return FG_OK; }
         if (rc2 != FG_E_UNSUPPORTED) return rc2;
     }
+    e->last_mh_kernel = "k_mh_steps W=1";
     FG_LAUNCH_GT(e, k_mh_steps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->M,
                        iter, n_steps, e->mh_warmup, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
     HIPCHK(hipGetLastError());

@@ -35,23 +35,6 @@ static __global__ void k_fill(double *p, long long n, double v) {
     if (i < n) p[i] = v;
 }
 
-// DiminishingAdaptation's state of one (site, chain) (mcmc_utils.rs:40-62) + the decided proposal kind, as two 16-byte groups:
-// what a proposal reads {scale, kind} and what an update reads and writes {log_scale, total, accepted} are one 16-byte access each
-// (lanes hold different sites: every access of a wave touches 64 different lines, so the NUMBER of accesses is the cost).
-struct alignas(16) FgMhAdapt { double scale; int32_t kind, pad; double log_scale; uint32_t tot, acc; };
-static_assert(sizeof(FgMhAdapt) == 32, "FgMhAdapt is two 16-byte groups");
-
-struct FgMhDev {
-    double *lw;
-    FgMhAdapt *ad;                                       // [S][C]
-    const int *ov_kind; const double *ov_lo, *ov_hi;    // [S] overrides or null
-    unsigned long long *n_acc;                           // [C] accepted proposals
-    const int *rec;                                      // [n_rec] recorded sites
-    int n_rec;
-    int rec_all;                                         // record during adaptation too (fg_mh_set_recording: incremental sessions)
-    const double *step_tab; uint32_t step_n;             // 1 / n^0.7 for n < step_n (DiminishingAdaptation's step, mcmc_utils.rs:118)
-};
-
 struct fg_engine {
     const fg_program *prog = nullptr;
     int device = 0;
@@ -109,6 +92,8 @@ struct fg_engine {
     int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
     int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)
     hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr; std::string jit_log;
+    int jit_mh_state = 0; hipModule_t jit_mh_mod = nullptr; hipFunction_t jit_mh_fn[2] = {nullptr, nullptr};   // ... and its MH kernel (128- and 256-VGPR builds)
+    std::string last_mh_kernel;  // kernel the last fg_mh_step launch ran (fg_mh_last_kernel)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
 };
 

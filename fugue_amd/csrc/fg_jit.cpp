@@ -45,6 +45,7 @@ struct Gen {
     std::map<std::string, std::string> *lp_fns;  // signature -> definition of the per-signature density wrappers
     std::vector<std::string> *tables;            // file-scope constant tables
     bool ok = true;
+    int term = -1;                               // >= 0: a scoring run for MH -- statement k leaves its term in row k of `terms` (fg_exec's TM mode)
 
     std::string slot(uint32_t idx) {
         if ((int)idx == p.n_slots - 1) return "0.0";                        // the always-zero slot
@@ -70,7 +71,8 @@ struct Gen {
     void ins(const FgIns &I) {
         const uint32_t op = I.op, code = FG_INS_OPCODE(op);
         const bool observe = (op & FG_F_OBSERVE) != 0u;
-        const std::string accum = observe ? "lk += lp;" : "pr += lp;";
+        const bool ends = code == FG_OP_NORMAL_FAST || code < 17u;
+        const std::string accum = (term >= 0 && ends) ? "terms[" + std::to_string(term++) + " * FG_WAVE] = lp;" : (observe ? "lk += lp;" : "pr += lp;");
         if (code == FG_OP_NORMAL_FAST) {                                     // fg_interp.h: the fast Normal of score-only programs
             std::string z;
             if (op & FG_F_POW2SCALE) z = "double z = dl * " + lit(I.h[4]) + ";";
@@ -131,7 +133,7 @@ struct Gen {
         }
         const std::string x0 = opnd(I.opnd[0], I.imm[0]);
         switch (code) {
-        case FG_OP_FACTOR: add("fc += " + x0 + ";"); break;
+        case FG_OP_FACTOR: add(term >= 0 ? "terms[" + std::to_string(term++) + " * FG_WAVE] = " + x0 + ";" : "fc += " + x0 + ";"); break;
         case FG_OP_LOAD: add("acc = " + x0 + ";"); break;
         case FG_OP_ADD: add("acc = acc + " + x0 + ";"); break;
         case FG_OP_SUB: add("acc = acc - " + x0 + ";"); break;
@@ -160,7 +162,7 @@ struct Gen {
             add("{ const bool ok_ = (acc >= 0.0) && (acc < " + lit((double)K) + ") && (acc == floor(acc)); const int j = ok_ ? (int)acc : 0; " + pick((int)I.aux, K, "j", "gv") +
                 "acc = ok_ ? gv : NAN; }");
             break; }
-        case FG_OP_CONSTLIK: add("lk += " + lit(I.imm[0]) + ";"); break;
+        case FG_OP_CONSTLIK: add(term >= 0 ? "terms[" + std::to_string(term++) + " * FG_WAVE] = " + lit(I.imm[0]) + ";" : "lk += " + lit(I.imm[0]) + ";"); break;
         case FG_OP_DOT: {                                                    // acc = (..((acc + s_0 c_0) + s_1 c_1)..): one product, one sum per term
             const int n = (int)I.opnd[1];
             for (int t = 0; t < n; ++t) {
@@ -234,6 +236,7 @@ typedef int int32_t;
 typedef unsigned long long uint64_t;
 typedef long long int64_t;
 typedef unsigned long uintptr_t;
+typedef unsigned long size_t;
 )FGJ";
 
 const char *HELPERS = R"FGJ(
@@ -280,6 +283,60 @@ std::string fg_jit_hmc_source(const fg_program *p) {
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += FG_JIT_EMBED_HMC_BODY;                // fg_hmc_jit_body.h
+    return src;
+}
+
+// The generated translation unit of one program's MH kernel: the scoring run as FG_JIT_NSEG statement segments (contiguous, balanced by
+// instruction cost at generation time) that the waves of a tile share, behind fg_mh_interp_body.h; the interpreter itself is part
+// of the unit for the propose-and-score pass of model-dependent proposals.
+std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost) {
+    constexpr int NSEG = 8;
+    std::map<std::string, std::string> lp_fns;
+    std::vector<std::string> tables;
+    std::vector<int> stmt_end;
+    for (int k = 0; k < p->n_ins; ++k) {
+        const uint32_t code = FG_INS_OPCODE(p->ins_fast[(size_t)k].op);
+        if (code == FG_OP_NORMAL_FAST || code < 17u || code == FG_OP_FACTOR || code == FG_OP_CONSTLIK) stmt_end.push_back(k + 1);
+    }
+    const int n_stmt = (int)stmt_end.size();
+    if (n_stmt < 1 || stmt_end.back() != p->n_ins) return "";
+    std::vector<long long> cum((size_t)n_stmt + 1, 0);
+    for (int k = 0, i = 0; k < n_stmt; ++k) { long long cs = 0; for (; i < stmt_end[k]; ++i) cs += ins_cost[(size_t)i]; cum[(size_t)k + 1] = cum[(size_t)k] + cs; }
+    std::string fns;
+    int s_at = 0;
+    for (int sg = 0; sg < NSEG; ++sg) {
+        int s_to = n_stmt;
+        if (sg + 1 < NSEG) { const long long target = cum[(size_t)n_stmt] * (sg + 1) / NSEG; s_to = s_at; while (s_to < n_stmt && cum[(size_t)s_to] < target) ++s_to; }
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.term = s_at;
+        for (int q = s_at > 0 ? stmt_end[(size_t)s_at - 1] : 0; q < (s_to > 0 ? stmt_end[(size_t)s_to - 1] : 0); ++q) g.ins(p->ins_fast[(size_t)q]);
+        if (!g.ok) return "";
+        fns += "static __device__ __noinline__ void fg_jit_seg_" + std::to_string(sg) + "(const double *slots, double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+               "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
+        s_at = s_to;
+    }
+    fns += "static __device__ __forceinline__ void fg_jit_terms(int sg, const double *slots, double *terms) {\n    switch (sg) {\n";
+    for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_seg_" + std::to_string(sg) + "(slots, terms); break;\n";
+    fns += "    default: break;\n    }\n}\n";
+    std::string src = PROLOGUE;
+    src += FG_JIT_EMBED_API;                     // include/fugue_amd.h (proposal kinds, error codes)
+    src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
+    src += FG_JIT_EMBED_INTERP;                  // fg_interp.h: the propose-and-score mode for model-dependent proposals
+    src += HELPERS;
+    for (const std::string &t : tables) src += t + "\n";
+    for (const auto &kv : lp_fns) src += kv.second;
+    src += fns;
+    src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
+           "#define FG_MHI_SCORE() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_terms(sg_, slots, terms); (void)i0; (void)i1; (void)s0; } while (0)\n"
+           "#define FG_MHI_PRIV_BLOCKS(W) 1\n";
+    src += FG_JIT_EMBED_MH_BODY;                 // fg_mh_interp_body.h
+    src += R"FGJ(
+#define FG_MH_JIT_KERNEL(OCC) \
+extern "C" __global__ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) __launch_bounds__(FG_WAVE * FG_MHI_MAX) \
+void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps, int n_warmup, long long *draws, int first_sample_t) { \
+    fg_mh_interp_mw_body<OCC>(P, X, M, seg, iter0, n_steps, n_warmup, draws, first_sample_t); }
+FG_MH_JIT_KERNEL(2)
+FG_MH_JIT_KERNEL(4)
+)FGJ";
     return src;
 }
 
@@ -337,7 +394,8 @@ int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string
 // test hook (no GPU needed: hiprtc cross-compiles): generated source and compiler log of a program's HMC kernel
 extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long long src_cap, char *log_out, long long log_cap, long long *code_bytes) {
     if (!p) return FG_E_BAD_ARG;
-    const std::string src = fg_jit_hmc_source(p);
+    const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
+    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1)) : fg_jit_hmc_source(p);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;
     if (src.empty()) return FG_E_UNSUPPORTED;

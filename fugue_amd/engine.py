@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "fg_mh_get_log_weight", "fg_smc_config_default", "fg_smc_run", "fg_smc_prior_particles", "fg_smc_normalize", "fg_smc_ess", "fg_smc_resample", "fg_smc_rejuvenate",
     "fg_smc_get_weights", "fg_smc_set_log_weights", "fg_device_log_sum_exp", "fg_device_next_beta",
     "fg_device_resample_indices", "fg_diag_chain_moments", "fg_diag_autocov_sums", "fg_diag_rhat_ess", "fg_diag_combine", "fg_diag_geweke",
-    "fg_diag_combine_reduced", "fg_diag_set_exchange", "fg_diag_exchange_bytes", "fg_hmc_last_kernel", "fg_diag_quantiles",
+    "fg_diag_combine_reduced", "fg_diag_set_exchange", "fg_diag_exchange_bytes", "fg_hmc_last_kernel", "fg_mh_last_kernel", "fg_diag_quantiles",
     "fg_comm_unique_id", "fg_comm_init", "fg_comm_destroy", "fg_device_alloc", "fg_device_free", "fg_device_download", "fg_device_upload",
     "fg_dsl_compile", "fg_dsl_warning_count", "fg_dsl_warning",
 ]
@@ -193,6 +193,8 @@ def lib():
     L.fg_diag_exchange_bytes.argtypes = [vp]
     L.fg_hmc_last_kernel.restype = C.c_char_p
     L.fg_hmc_last_kernel.argtypes = [vp]
+    L.fg_mh_last_kernel.restype = C.c_char_p
+    L.fg_mh_last_kernel.argtypes = [vp]
     L.fg_comm_unique_id.argtypes = [vp]
     L.fg_comm_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.fg_comm_destroy.argtypes = [vp]
@@ -651,6 +653,10 @@ class Engine:
     def hmc_last_kernel(self) -> str:
         """Kernel (and waves per tile) the engine's last HMC launch ran."""
         return (lib().fg_hmc_last_kernel(self.h) or b"").decode()
+
+    def mh_last_kernel(self) -> str:
+        """Kernel the engine's last MH launch ran."""
+        return (lib().fg_mh_last_kernel(self.h) or b"").decode()
 
     def comm_init(self, world_size: int, rank: int, unique_id: bytes) -> int:
         out = C.c_void_p()

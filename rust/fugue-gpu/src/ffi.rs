@@ -100,6 +100,7 @@ extern "C" {
     pub fn fg_hmc_is_warming_up(e: *const fg_engine) -> c_int;
     pub fn fg_hmc_iterations(e: *const fg_engine) -> i64;
     pub fn fg_hmc_last_kernel(e: *const fg_engine) -> *const c_char;
+    pub fn fg_mh_last_kernel(e: *const fg_engine) -> *const c_char;
     // ---- single-site MH (mh.rs:921-1014)
     pub fn fg_mh_init(e: *mut fg_engine, n_warmup: c_int, overrides: *const fg_site_proposal) -> c_int;
     pub fn fg_mh_step(e: *mut fg_engine, n: c_int, rec_sites: *const i32, n_rec: c_int, d_draws: *mut c_void) -> c_int;

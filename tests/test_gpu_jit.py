@@ -48,3 +48,37 @@ def test_jit_is_not_used_where_a_record_stream_exists(monkeypatch):
         eng.hmc_step(2)
         assert not eng.hmc_last_kernel().startswith("k_hmc_jit_steps"), (name, eng.hmc_last_kernel())
         eng.close()
+
+
+@pytest.mark.parametrize("name,with_overrides", [("alldists", False), ("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("logistic", False), ("coin", False)])
+def test_jit_mh_is_bit_identical_to_the_interpreter(name, with_overrides, monkeypatch):
+    """adaptive_mcmc_chain with the scoring run compiled at run time (eight generated statement segments shared by the waves of a
+    tile, k_mh_jit_steps) against the one-wave interpreter kernel: recorded draws, final state, adapted scales, log-weights and accept
+    counts, including steps whose proposal needs the model (undecided kinds, PriorResample overrides, computed Categorical tables)."""
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 150, 100, 40
+    rec = list(range(cp.S))
+    ov = None
+    if with_overrides:
+        ov = [None] * cp.S
+        f64 = [j for j in range(cp.S) if cp.site_vtypes[j] == 0]
+        ov[f64[0]] = (E.PROP_PRIOR_RESAMPLE, 0.0, 0.0)
+        ov[f64[1]] = (E.PROP_GAUSSIAN, 0.0, 0.0)
+    out, kernels = [], []
+    for jit, mw, W, occ in ((0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 2), (1, 1, 2, 4), (1, 1, 4, 2), (1, 1, 8, 4)):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
+        if W: monkeypatch.setenv("FG_MH_INTERP_WAVES", str(W)); monkeypatch.setenv("FG_MH_INTERP_OCC", str(occ))
+        else: monkeypatch.delenv("FG_MH_INTERP_WAVES", raising=False); monkeypatch.delenv("FG_MH_INTERP_OCC", raising=False)
+        eng = E.Engine(cp, C, seed=17, chain_offset=4)
+        d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
+        st = eng.mh_run(ns, nw, ov, rec, d)
+        kernels.append(eng.mh_last_kernel())
+        draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
+        eng.device_free(d)
+        out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
+        eng.close()
+    assert kernels[0] == "k_mh_steps W=1" and all(k.startswith("k_mh_jit_steps W=") for k in kernels[1:]), kernels
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)

@@ -166,6 +166,7 @@ def test_mh_interp_multiwave_is_bit_identical(name, with_overrides, monkeypatch)
         ov[f64[0]] = (E.PROP_PRIOR_RESAMPLE, 0.0, 0.0)           # needs the model at that site: the general path whenever a lane picks it
         ov[f64[1]] = (E.PROP_GAUSSIAN, 0.0, 0.0)
     out = []
+    monkeypatch.setenv("FG_JIT", "0")                                      # the interpreter kernels themselves (tests/test_gpu_jit.py covers the compiled form)
     for mw, W in ((0, 0), (1, 2), (1, 3), (1, 4), (1, 8), (1, 0)):
         monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
         if W: monkeypatch.setenv("FG_MH_INTERP_WAVES", str(W))
