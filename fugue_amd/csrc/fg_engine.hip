@@ -1006,6 +1006,20 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         const int rc = fg_hmc_lin_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
         if (rc != FG_E_UNSUPPORTED) return rc;
     }
+    if (e->cfg.grad_mode == FG_GRAD_FD_SPARSE && e->P.gstream && e->jit_state >= 0) {
+        // Gradient-stream programs: the program compiled at run time (fg_jit.cpp) is faster than the stream kernel wherever records are more
+        // than fast Normals (linear predictors, general distributions, option selects: hier_scale 1.2e9 -> 3.7e9, linreg 2.8e9 -> 2.0e10
+        // leapfrog-steps/s, bit-identical -- tools/bench_jit_vs_stream.py), and for fast-Normal programs when the tiles do not fill the GPU
+        // (reference_model(8) at 8 192 chains: 3.6e9 -> 6.2e9; at 65 536 chains the stream kernel keeps 13 %).  FG_JIT=2 forces it.
+        int rkj = 0;
+        const std::vector<FgGradRec> &gsj = e->prog->gstream;
+        for (int k = 0; k < e->prog->n_gstream && rkj < 2; ++k) rkj = std::max(rkj, (gsj[k].flags & (FG_G_GEN | FG_G_NSEL | FG_G_CATC)) ? 2 : ((gsj[k].flags & FG_G_LIN) ? 1 : 0));
+        const bool forced = std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2;
+        if (forced || rkj >= 1 || (long long)tiles <= std::max(1, e->n_simd / 4)) {
+            const int rc = fg_hmc_jit_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+            if (rc != FG_E_UNSUPPORTED) return rc;
+        }
+    }
     if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE && !e->gt) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing
@@ -1368,6 +1382,11 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
     e->M.rec = e->d_rec; e->M.n_rec = n_rec;
     const int iter = e->mh_iter;
     const int first_sample_t = e->M.rec_all ? 0 : std::max(iter, e->mh_warmup) - iter;
+    if (n_steps > 0 && std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2) {
+        const int rc2 = fg_mh_interp_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
+        if (rc2 == FG_OK) { e->mh_iter += n_steps; return FG_OK; }
+        if (rc2 != FG_E_UNSUPPORTED) return rc2;
+    }
     if (n_steps > 0) {                                                  // multi-wave tiles when every statement has a score-stream record
         const int rc = fg_mh_mw_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
         if (rc == FG_OK) { e->mh_iter += n_steps; e->last_mh_kernel = "k_mh_mw_steps"; return FG_OK; }

@@ -41,7 +41,8 @@ static long long mhi_ins_cost(const FgIns &in) {       // the weights of fg_hmc_
 }
 
 int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
-    if (e->interp_mw_disabled || e->gt || e->tw != FG_WAVE || e->P.sstream != nullptr) return FG_E_UNSUPPORTED;
+    const bool force_jit = std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2;      // experiments: the compiled form even where a stream kernel exists
+    if (e->interp_mw_disabled || e->gt || e->tw != FG_WAVE || (e->P.sstream != nullptr && !force_jit)) return FG_E_UNSUPPORTED;
     for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;
     const std::vector<FgIns> &ins = e->prog->ins_fast;
     const int n_ins = e->prog->n_ins;

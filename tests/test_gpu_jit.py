@@ -37,11 +37,35 @@ def test_jit_hmc_is_bit_identical_to_the_interpreter(name, adapt_mass, monkeypat
     assert np.isfinite(out[0][0]).all()
 
 
-def test_jit_is_not_used_where_a_record_stream_exists(monkeypatch):
-    """Programs with a gradient stream keep their hand-written kernels; the dense mode (the reference's whole-program finite
-    difference) keeps the interpreter."""
-    monkeypatch.setenv("FG_JIT", "1")
-    for name, mode in [("refmodel8", E.GRAD_FD_SPARSE), ("normal32", E.GRAD_FD_SPARSE), ("poisson_glm", E.GRAD_FD_DENSE)]:
+@pytest.mark.parametrize("name,adapt_mass", [("hier_scale", True), ("mixture", False), ("linreg", True), ("refmodel8", False), ("hier", True), ("ridge7", False),
+                                             ("rand1", False), ("rand3", True), ("rand4", False)])
+def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkeypatch):
+    """Gradient-stream programs: the compiled form (the engine's choice for linear-predictor / general / option-select records and for
+    small chain counts) against k_hmc_stream_steps -- the same arithmetic per coordinate, so every bit agrees."""
+    cp = E.compile_model(ZOO[name]())
+    assert cp.stream_records[0] > 0
+    C, nw, ns = 150, 30, 20
+    out, kernels = [], []
+    for jit in (0, 2):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        eng = E.Engine(cp, C, seed=31, chain_offset=2)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(n_leapfrog=6, adapt_mass=adapt_mass), ns, nw, d)
+        kernels.append(eng.hmc_last_kernel())
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent, eng.hmc_mass() if adapt_mass else None))
+        eng.close()
+    assert kernels[0].startswith("k_hmc_stream_steps") and kernels[1].startswith("k_hmc_jit_steps"), kernels
+    for a, b in zip(out[0], out[1]):
+        assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_jit_is_not_used_where_a_faster_kernel_exists(monkeypatch):
+    """Independent-sites programs and dense regressions keep their hand-written kernels (whole trajectories in registers, the
+    observation-major gradient); the dense mode (the reference's whole-program finite difference) keeps the interpreter."""
+    monkeypatch.delenv("FG_JIT", raising=False)
+    for name, mode in [("normal32", E.GRAD_FD_SPARSE), ("ridge8", E.GRAD_FD_SPARSE), ("poisson_glm", E.GRAD_FD_DENSE)]:
         cp = E.compile_model(ZOO[name]())
         eng = E.Engine(cp, 64, seed=1)
         eng.hmc_init(E.hmc_config(grad_mode=mode, n_leapfrog=3), 2)

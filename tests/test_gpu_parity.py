@@ -329,6 +329,7 @@ def test_hmc_posterior_closed_form():
 def test_hmc_multiwave_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     """k_hmc_stream_steps splits a tile's coordinates over 1 ... 16 waves; the per-coordinate operations and
     their order are the same, so draws, step sizes, mass matrix and log-joint must agree BIT FOR BIT."""
+    monkeypatch.setenv("FG_JIT", "0")          # the hand-written kernels themselves; the compiled form is compared with them in tests/test_gpu_jit.py
     cp = E.compile_model(ZOO[name]())
     C, nw, ns = 192, 40, 25
     out = []
@@ -391,6 +392,7 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     gradient-stream kernel's, so draws, step sizes, mass matrix, log-joint and statistics agree BIT FOR BIT with it -- in the
     dependency-aware mode and in the dense mode (grad_log_joint verbatim: whole log-joints at q +- h e_i, formed from term rows with
     the coordinate's own terms substituted, against the dense stream that re-evaluates every statement)."""
+    monkeypatch.setenv("FG_JIT", "0")          # the hand-written kernels themselves; the compiled form is compared with them in tests/test_gpu_jit.py
     cp = E.compile_model(ZOO[name]())
     assert cp.stream_records[0] > 0 and lib_sep_records(cp) > 0
     C, nw, ns = 150, 40, 25
@@ -427,6 +429,7 @@ def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
     (coordinate, observation, sign) the additions and multiplications are the gradient stream's in the same order, so draws,
     step sizes, mass matrix, log-joint, statistics and per-transition info agree BIT FOR BIT with k_hmc_stream_steps -- for
     both waves-per-tile layouts, on full (64-chain) and half (32-chain) tiles."""
+    monkeypatch.setenv("FG_JIT", "0")          # the hand-written kernels themselves; the compiled form is compared with them in tests/test_gpu_jit.py
     cp = E.compile_model(ZOO[name]())
     assert E.lib().fg_program_stream_records(cp.h, 4) > 0
     C, nw, ns = 150, 40, 25
@@ -512,6 +515,7 @@ def test_analytic_mode_is_refused_where_unavailable():
 def test_issue_priorities_change_no_result(monkeypatch):
     """s_setprio only reorders the waves of a SIMD: the register-resident HMC kernel (waves taking turns, 8 waves per tile) and the
     multi-wave MH kernel (control wave, phase B) give the same bits with the priorities switched off."""
+    monkeypatch.setenv("FG_JIT", "0")          # the hand-written kernels themselves; the compiled form is compared with them in tests/test_gpu_jit.py
     out = {}
     for prio in ("1", "0"):
         monkeypatch.setenv("FG_HMC_PRIO", prio)
