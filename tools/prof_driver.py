@@ -16,10 +16,12 @@ CONFIGS = {
     "mh|refmodel20|65536": ("k_mh_mw_steps", 100, 6, "chain step of every chain"),
     "mh|c5|262144": ("k_mh_mw_steps", 100, 2, "chain step of every chain"),
     "smc|c4|1048576": ("", 1, 0, "run"),
-    "hmc|zoo:alldists|65536|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
-    "hmc|zoo:alldists|8192|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
-    "hmc|zoo:hier_logsigma|65536|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
-    "hmc|zoo:poisson_glm|65536|fd_sparse|L16": ("k_hmc_interp_mw_steps", 5, 2, "transition"),
+    # programs without a record stream: compiled at run time (k_hmc_jit_steps); with FG_JIT=0 in the environment the interpreter kernel
+    "hmc|zoo:alldists|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    "hmc|zoo:alldists|8192|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    "hmc|zoo:hier_logsigma|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    "hmc|zoo:poisson_glm|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    "hmc|zoo:logistic100|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
 }
 
 
@@ -40,7 +42,7 @@ def main(key):
     elif parts[0] == "hmc" and parts[1].startswith("zoo:"):
         from tests.models import ZOO
         C = int(parts[2])
-        cp = E.compile_model(ZOO[parts[1][4:]]())
+        cp = E.compile_model(W.logistic_regression(*W.classification_data(100)[:2]) if parts[1] == "zoo:logistic100" else ZOO[parts[1][4:]]())
         eng = E.Engine(cp, C, seed=2)
         eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_FD_SPARSE, n_leapfrog=16), 10)
         eng.hmc_step(10)                                 # adaptation
