@@ -341,9 +341,9 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
         if (const char *sp = std::getenv("FG_JIT")) if (std::atoi(sp) == 0) return FG_E_UNSUPPORTED;
         for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;
         for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
-        if (e->prog->sub.size() + e->prog->ins_fast.size() > 20000) return FG_E_UNSUPPORTED;        // straight-line code: keep the compilation short
+        if (e->prog->sub.size() + e->prog->ins_fast.size() > 4000000) return FG_E_UNSUPPORTED;
         const std::string src = fg_jit_hmc_source(e->prog);
-        if (src.empty()) return FG_E_UNSUPPORTED;
+        if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
         if (rc != FG_OK) {

@@ -46,6 +46,17 @@ struct Gen {
     std::vector<std::string> *tables;            // file-scope constant tables
     bool ok = true;
     int term = -1;                               // >= 0: a scoring run for MH -- statement k leaves its term in row k of `terms` (fg_exec's TM mode)
+    // Rolled runs: >= 4 consecutive statements that differ only in their constants (a plate of observations) become ONE loop over a
+    // constant table -- the same statements in the same order, the constants read from memory instead of the instruction stream.
+    std::vector<double> *cvec = nullptr;         // non-null: constants go here and the code says c[j]
+    bool rolled_term = false;                    // ... and a term row is (term + r)
+    std::map<std::string, std::string> *ctabs = nullptr;   // table text -> name: identical tables (the d sub-programs of a regression) are emitted once
+
+    std::string lit(double v) {
+        if (!cvec) return ::lit(v);
+        cvec->push_back(v);
+        return "c[" + std::to_string(cvec->size() - 1) + "]";
+    }
 
     std::string slot(uint32_t idx) {
         if ((int)idx == p.n_slots - 1) return "0.0";                        // the always-zero slot
@@ -67,12 +78,91 @@ struct Gen {
         return s;
     }
     void add(const std::string &s) { body += "    " + s + "\n"; }
+    std::string term_row() {                     // the LDS row of the statement being emitted (TM mode); a rolled run emits ONE statement for R rows
+        if (rolled_term) return "terms[(" + std::to_string(term) + " + r) * FG_WAVE]";
+        return "terms[" + std::to_string(term++) + " * FG_WAVE]";
+    }
+    static bool ends_statement(const FgIns &I) {
+        const uint32_t code = FG_INS_OPCODE(I.op);
+        return code == FG_OP_NORMAL_FAST || code < 17u || code == FG_OP_FACTOR || code == FG_OP_CONSTLIK;
+    }
+    // everything of an instruction that shapes the generated code, i.e. all but the values of its constants
+    std::string shape(const FgIns &I) const {
+        const uint32_t code = FG_INS_OPCODE(I.op);
+        if (code == 3u) return "";                                            // Categorical: a table of its own -- never rolled
+        char b[128];
+        std::snprintf(b, sizeof b, "%x:%x:%x:%x:%x:%x;", I.op, I.opnd[0], I.opnd[1], I.opnd[2], I.opnd[3], I.aux);
+        std::string k = b;
+        if (code == FG_OP_DOT) {                                              // its terms' slots shape the code, its coefficients are constants
+            k = "dot" + std::to_string(I.opnd[1]) + ":";
+            for (int t = 0; t < (int)I.opnd[1]; ++t) { long long sb; std::memcpy(&sb, &p.pool[(size_t)I.aux + 2 * t], 8); k += std::to_string(sb) + ","; }
+            k += ";";
+        }
+        // an operand that reads the constant pool is a constant too
+        for (int q = 0; q < 4; ++q) if (FG_OPND_KIND(I.opnd[q]) == FG_OPND_POOL && code != 3u) { k += "P"; }
+        return k;
+    }
+    // instructions [b, e) of v: statement by statement, rolling runs of isomorphic statements
+    void emit(const std::vector<FgIns> &v, size_t b, size_t e) {
+        struct St { size_t b, e; std::string key; };
+        std::vector<St> st;
+        for (size_t q = b, s0 = b; q < e; ++q)
+            if (ends_statement(v[q]) || q + 1 == e) {
+                St x{s0, q + 1, ""};
+                bool rollable = true;
+                for (size_t i = s0; i <= q; ++i) { const std::string k = shape(v[i]); if (k.empty()) rollable = false; x.key += k; }
+                if (!rollable) x.key = "#" + std::to_string(st.size());       // unique: never equal to a neighbour's
+                st.push_back(x); s0 = q + 1;
+            }
+        for (size_t i = 0; i < st.size();) {
+            size_t j = i + 1;
+            while (j < st.size() && st[j].key == st[i].key && st[i].key[0] != '#') ++j;
+            const size_t R = j - i;
+            if (R < 4 || !ctabs) { for (size_t q = st[i].b; q < st[i].e; ++q) ins(v[q]); i += 1; continue; }
+            // one statement's code with its constants as c[0 .. K); every statement's constants into the table, in the same order
+            std::vector<double> first; std::string code;
+            {
+                const std::string keep = body; body.clear();
+                cvec = &first; rolled_term = term >= 0;
+                for (size_t q = st[i].b; q < st[i].e; ++q) ins(v[q]);
+                code = body; body = keep;
+            }
+            const size_t K = first.size();
+            std::vector<double> tab = first;
+            bool same_k = true;
+            for (size_t s = i + 1; s < j && same_k; ++s) {
+                std::vector<double> row; std::string scratch_body = body; std::set<int> scratch_temps = temps;
+                body.clear(); cvec = &row;
+                for (size_t q = st[s].b; q < st[s].e; ++q) ins(v[q]);
+                body = scratch_body; temps = scratch_temps;
+                if (row.size() != K) same_k = false;
+                tab.insert(tab.end(), row.begin(), row.end());
+            }
+            cvec = nullptr; rolled_term = false;
+            if (!same_k || !ok || K == 0) {                                   // (cannot happen for equal shapes; stay safe: emit them one by one)
+                for (size_t s = i; s < j; ++s) for (size_t q = st[s].b; q < st[s].e; ++q) ins(v[q]);
+                i = j; continue;
+            }
+            std::string text;
+            text.reserve(tab.size() * 24);
+            for (size_t q = 0; q < tab.size(); ++q) { text += ::lit(tab[q]); text += (q + 1 < tab.size()) ? "," : ""; if ((q + 1) % 8 == 0) text += "\n"; }
+            auto it = ctabs->find(text);
+            std::string name;
+            if (it == ctabs->end()) { name = "fg_jit_ctab" + std::to_string(ctabs->size()); (*ctabs)[text] = name; } else name = it->second;
+            add("#pragma unroll 2");
+            add("for (int r = 0; r < " + std::to_string(R) + "; ++r) { const double *c = " + name + " + (size_t)r * " + std::to_string(K) + ";");
+            body += code;
+            add("}");
+            if (term >= 0) term += (int)R;
+            i = j;
+        }
+    }
 
     void ins(const FgIns &I) {
         const uint32_t op = I.op, code = FG_INS_OPCODE(op);
         const bool observe = (op & FG_F_OBSERVE) != 0u;
         const bool ends = code == FG_OP_NORMAL_FAST || code < 17u;
-        const std::string accum = (term >= 0 && ends) ? "terms[" + std::to_string(term++) + " * FG_WAVE] = lp;" : (observe ? "lk += lp;" : "pr += lp;");
+        const std::string accum = (term >= 0 && ends) ? term_row() + " = lp;" : (observe ? "lk += lp;" : "pr += lp;");
         if (code == FG_OP_NORMAL_FAST) {                                     // fg_interp.h: the fast Normal of score-only programs
             std::string z;
             if (op & FG_F_POW2SCALE) z = "double z = dl * " + lit(I.h[4]) + ";";
@@ -133,7 +223,7 @@ struct Gen {
         }
         const std::string x0 = opnd(I.opnd[0], I.imm[0]);
         switch (code) {
-        case FG_OP_FACTOR: add(term >= 0 ? "terms[" + std::to_string(term++) + " * FG_WAVE] = " + x0 + ";" : "fc += " + x0 + ";"); break;
+        case FG_OP_FACTOR: add(term >= 0 ? term_row() + " = " + x0 + ";" : "fc += " + x0 + ";"); break;
         case FG_OP_LOAD: add("acc = " + x0 + ";"); break;
         case FG_OP_ADD: add("acc = acc + " + x0 + ";"); break;
         case FG_OP_SUB: add("acc = acc - " + x0 + ";"); break;
@@ -162,7 +252,7 @@ struct Gen {
             add("{ const bool ok_ = (acc >= 0.0) && (acc < " + lit((double)K) + ") && (acc == floor(acc)); const int j = ok_ ? (int)acc : 0; " + pick((int)I.aux, K, "j", "gv") +
                 "acc = ok_ ? gv : NAN; }");
             break; }
-        case FG_OP_CONSTLIK: add(term >= 0 ? "terms[" + std::to_string(term++) + " * FG_WAVE] = " + lit(I.imm[0]) + ";" : "lk += " + lit(I.imm[0]) + ";"); break;
+        case FG_OP_CONSTLIK: { const std::string v = lit(I.imm[0]); add(term >= 0 ? term_row() + " = " + v + ";" : "lk += " + v + ";"); break; }
         case FG_OP_DOT: {                                                    // acc = (..((acc + s_0 c_0) + s_1 c_1)..): one product, one sum per term
             const int n = (int)I.opnd[1];
             for (int t = 0; t < n; ++t) {
@@ -254,14 +344,21 @@ static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vty
 }  // namespace
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
+static std::string ctab_text(const std::map<std::string, std::string> &ctabs) {
+    std::string s;
+    for (const auto &kv : ctabs) s += "static __device__ const double " + kv.second + "[] = {\n" + kv.first + "};\n";
+    return s;
+}
+
 std::string fg_jit_hmc_source(const fg_program *p) {
-    std::map<std::string, std::string> lp_fns;
+    std::map<std::string, std::string> lp_fns, ctabs;
     std::vector<std::string> tables;
     std::string fns;
     const int d = (int)p->coord.size();
     for (int k = 0; k < d; ++k) {
         Gen g{*p}; g.pert_slot = p->coord[k].slot; g.lp_fns = &lp_fns; g.tables = &tables;
-        for (int q = 0; q < p->coord[k].sub_n; ++q) g.ins(p->sub[(size_t)p->coord[k].sub_off + q]);
+        g.ctabs = &ctabs;
+        g.emit(p->sub, (size_t)p->coord[k].sub_off, (size_t)p->coord[k].sub_off + (size_t)p->coord[k].sub_n);
         if (!g.ok) return "";
         fns += "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const double *slots) {\n" + g.decls() + g.body +
                "    (void)acc;\n    return pr + lk + fc;\n}\n";
@@ -271,7 +368,8 @@ std::string fg_jit_hmc_source(const fg_program *p) {
     fns += "    default: return 0.0;\n    }\n}\n";
     {
         Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables;
-        for (int q = 0; q < p->n_ins; ++q) g.ins(p->ins_fast[(size_t)q]);
+        g.ctabs = &ctabs;
+        g.emit(p->ins_fast, 0, (size_t)p->n_ins);
         if (!g.ok) return "";
         fns += "static __device__ __noinline__ void fg_jit_score(const double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
@@ -280,6 +378,7 @@ std::string fg_jit_hmc_source(const fg_program *p) {
     src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
     src += HELPERS;
     for (const std::string &t : tables) src += t + "\n";
+    src += ctab_text(ctabs);
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += FG_JIT_EMBED_HMC_BODY;                // fg_hmc_jit_body.h
@@ -291,7 +390,7 @@ std::string fg_jit_hmc_source(const fg_program *p) {
 // of the unit for the propose-and-score pass of model-dependent proposals.
 std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost) {
     constexpr int NSEG = 8;
-    std::map<std::string, std::string> lp_fns;
+    std::map<std::string, std::string> lp_fns, ctabs;
     std::vector<std::string> tables;
     std::vector<int> stmt_end;
     for (int k = 0; k < p->n_ins; ++k) {
@@ -308,11 +407,19 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
         int s_to = n_stmt;
         if (sg + 1 < NSEG) { const long long target = cum[(size_t)n_stmt] * (sg + 1) / NSEG; s_to = s_at; while (s_to < n_stmt && cum[(size_t)s_to] < target) ++s_to; }
         Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.term = s_at;
-        for (int q = s_at > 0 ? stmt_end[(size_t)s_at - 1] : 0; q < (s_to > 0 ? stmt_end[(size_t)s_to - 1] : 0); ++q) g.ins(p->ins_fast[(size_t)q]);
+        g.ctabs = &ctabs;
+        g.emit(p->ins_fast, (size_t)(s_at > 0 ? stmt_end[(size_t)s_at - 1] : 0), (size_t)(s_to > 0 ? stmt_end[(size_t)s_to - 1] : 0));
         if (!g.ok) return "";
         fns += "static __device__ __noinline__ void fg_jit_seg_" + std::to_string(sg) + "(const double *slots, double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
         s_at = s_to;
+    }
+    {   // the whole program with the accumulators themselves: the direct mode of programs with more statements than LDS has rows
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.ctabs = &ctabs;
+        g.emit(p->ins_fast, 0, (size_t)p->n_ins);
+        if (!g.ok) return "";
+        fns += "static __device__ __noinline__ void fg_jit_score(const double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+               "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
     fns += "static __device__ __forceinline__ void fg_jit_terms(int sg, const double *slots, double *terms) {\n    switch (sg) {\n";
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_seg_" + std::to_string(sg) + "(slots, terms); break;\n";
@@ -323,10 +430,12 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
     src += FG_JIT_EMBED_INTERP;                  // fg_interp.h: the propose-and-score mode for model-dependent proposals
     src += HELPERS;
     for (const std::string &t : tables) src += t + "\n";
+    src += ctab_text(ctabs);
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
            "#define FG_MHI_SCORE() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_terms(sg_, slots, terms); (void)i0; (void)i1; (void)s0; } while (0)\n"
+           "#define FG_MHI_DIRECT_SCORE() fg_jit_score(slots, A.prior, A.lik, A.fac)\n"
            "#define FG_MHI_PRIV_BLOCKS(W) 1\n";
     src += FG_JIT_EMBED_MH_BODY;                 // fg_mh_interp_body.h
     src += R"FGJ(

@@ -46,7 +46,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
     for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;
     const std::vector<FgIns> &ins = e->prog->ins_fast;
     const int n_ins = e->prog->n_ins;
-    if (e->mhi_W <= 0) {
+    if (!e->mhi_setup_done) {
         // statements: an instruction that ends one adds a term (a distribution, FACTOR, CONSTLIK)
         std::vector<int> stmt_end;                           // index past the last instruction of each statement
         std::vector<unsigned char> acc;
@@ -75,7 +75,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
                 while (2 * W <= wcap && lds_for(2 * W) <= 160 * 1024 && waves_on_cu(2 * W) <= 16 && waves_on_cu(2 * W) >= waves_on_cu(W)) W *= 2;
         }
         while (W > 1 && lds_for(W) > 160 * 1024) --W;
-        if (W < 2) return FG_E_UNSUPPORTED;
+        if (W < 2) W = 0;                                    // more statements than LDS has term rows: only the compiled kernel's direct mode below can take it
         std::vector<long long> cum(n_stmt + 1, 0);           // work before statement k
         for (int k = 0, i = 0; k < n_stmt; ++k) { long long cs = 0; for (; i < stmt_end[k]; ++i) cs += mhi_ins_cost(ins[i]); cum[k + 1] = cum[k] + cs; }
         e->mhi_ins_off.assign(FG_MHI_MAX + 1, n_ins); e->mhi_stmt_off.assign(FG_MHI_MAX + 1, n_stmt);
@@ -101,10 +101,10 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         }
         for (int j = 0; j < e->S; ++j) if (site_ins[2 * j] < 0) { fg_set_error("fg_mh_interp: a site without a sample statement"); return FG_E_STATE; }
         if (dev_upload(&e->d_mhi_site_ins, site_ins)) return FG_E_HIP;
-        e->mhi_W = W; e->mhi_n_stmt = n_stmt; e->mhi_lds = lds_for(W);
+        e->mhi_W = W; e->mhi_n_stmt = n_stmt; e->mhi_lds = lds_for(std::max(W, 1)); e->mhi_setup_done = true;
         {   // more than eight waves on a CU need the 128-VGPR build
             const long long n_cu = std::max(1, e->n_simd / 4), tiles = (e->C + FG_WAVE - 1) / FG_WAVE, per_cu = (tiles + n_cu - 1) / n_cu;
-            const long long resident = std::min<long long>(per_cu, (160 * 1024) / (long long)e->mhi_lds);
+            const long long resident = std::min<long long>(per_cu, std::max<long long>(1, (160 * 1024) / (long long)e->mhi_lds));
             e->mhi_occ = resident * W > 8 ? 4 : 2;
             if (const char *sp = std::getenv("FG_MH_INTERP_OCC")) e->mhi_occ = std::atoi(sp) <= 2 ? 2 : 4;
         }
@@ -117,20 +117,25 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
     if (e->jit_mh_state == 0) {
         e->jit_mh_state = -1;
         const char *sp = std::getenv("FG_JIT");
-        if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 20000) {
+        if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 4000000) {
             std::vector<long long> cost((size_t)e->prog->n_ins);
             for (int k = 0; k < e->prog->n_ins; ++k) cost[(size_t)k] = mhi_ins_cost(e->prog->ins_fast[(size_t)k]);
             const std::string src = fg_jit_mh_source(e->prog, cost);
             std::vector<char> code;
-            if (!src.empty() && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
+            if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mh_mod, code.data()) == hipSuccess &&
                 hipModuleGetFunction(&e->jit_mh_fn[0], e->jit_mh_mod, "k_mh_jit_steps_occ2") == hipSuccess &&
                 hipModuleGetFunction(&e->jit_mh_fn[1], e->jit_mh_mod, "k_mh_jit_steps_occ4") == hipSuccess) e->jit_mh_state = 1;
             else { (void)hipGetLastError(); if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: MH kernel not compiled at run time (%s)\n", e->jit_log.c_str()); }
         }
     }
+    seg.direct = 0;
     if (e->jit_mh_state == 1) {
-        const size_t lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1) + e->mhi_n_stmt) * FG_WAVE * sizeof(double);    // site rows, wave 0's temporaries, term rows
+        size_t lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1) + e->mhi_n_stmt) * FG_WAVE * sizeof(double);    // site rows, wave 0's temporaries, term rows
+        if (lds > 64 * 1024) {                               // too many statements for term rows: one wave, the accumulators themselves
+            lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1)) * FG_WAVE * sizeof(double);
+            seg.direct = 1;
+        }
         if (lds <= 64 * 1024) {
             const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
             int W = 1;
@@ -139,15 +144,17 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
             if (forced > 0) { while (2 * W <= std::min(forced, 8)) W *= 2; }
             const long long resident = std::max<long long>(1, std::min<long long>(per_cu, (160 * 1024) / (long long)lds));    // tiles a CU holds at once
             if (forced <= 0) while (2 * W <= 8 && 2 * W * resident <= 16) W *= 2;
+            if (seg.direct) W = 1;
             int occ = resident * W > 8 ? 4 : 2;
             if (const char *sp = std::getenv("FG_MH_INTERP_OCC")) occ = std::atoi(sp) <= 2 ? 2 : 4;
             int n_warmup = e->mh_warmup;
             void *args[] = { &e->P, &e->X, &e->M, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t };
             HIPCHK(hipModuleLaunchKernel(e->jit_mh_fn[occ == 4 ? 1 : 0], tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
-            e->last_mh_kernel = "k_mh_jit_steps W=" + std::to_string(W) + " (compiled at run time)";
+            e->last_mh_kernel = "k_mh_jit_steps W=" + std::to_string(W) + (seg.direct ? " (compiled at run time; in-order accumulators on one wave)" : " (compiled at run time)");
             return FG_OK;
         }
     }
+    if (e->mhi_W < 2) return FG_E_UNSUPPORTED;
     e->last_mh_kernel = "k_mh_interp_mw_steps W=" + std::to_string(e->mhi_W);
 #define FG_MHI_LAUNCH(K) do { if (int rc = set_lds(K, e->mhi_lds)) return rc; \
     hipLaunchKernelGGL(K, dim3(tiles), dim3(FG_WAVE * e->mhi_W), e->mhi_lds, e->stream, e->P, e->X, e->M, seg, iter0, n_steps, e->mh_warmup, draws, first_sample_t); } while (0)

@@ -15,6 +15,8 @@ struct FgMhi {
     const unsigned char *stmt_acc;   // [n_stmt] accumulator of each statement: 0 log_prior, 1 log_likelihood, 2 log_factors
     const int *site_ins;             // [S][2] {first instruction, count} of each site's own sample statement in P.ins (generic opcodes)
     int n_stmt;
+    int direct;                      // compiled kernels only: 1 = the program has more statements than LDS has term rows -- ONE wave scores it with
+                                     // the in-order accumulators themselves (no rows, no second barrier)
 };
 
 // propose_and_score (SingleSiteProposalHandler, mh.rs:298-570) behind a call, as in fg_engine.hip
@@ -78,7 +80,7 @@ __device__ __forceinline__ void fg_mh_interp_mw_body(const FgProgramDev &P, cons
     const int np = P.n_slots - P.S + 1;                                              // private rows of a wave (temporaries, zero slot, one spare: FgRemap's layout)
     double *slots = lds + lane;                                                      // site rows [0, S) shared; wave 0's private block follows, so
                                                                                      // wave 0 may also run the program WITHOUT the remap (the general path)
-    double *terms = lds + (long long)(P.S + FG_MHI_PRIV_BLOCKS(W) * np) * tw + lane;                     // one row per statement
+    double *terms = lds + (long long)(P.S + FG_MHI_PRIV_BLOCKS(W) * np) * tw + lane;                     // one row per statement (none in the direct mode)                     // one row per statement
     FgRemap rm;
     rm.pi = 0xffffffffu; rm.n_shared = (uint32_t)P.S; rm.woff = (uint32_t)(wv * np); rm.pert = (uint32_t)(P.n_slots + wv * np);
     for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
@@ -141,9 +143,13 @@ __device__ __forceinline__ void fg_mh_interp_mw_body(const FgProgramDev &P, cons
         }
         __syncthreads();                                     // the proposed values are in the site rows
         FgAcc3 A = {0.0, 0.0, 0.0};
-        FG_MHI_SCORE();
+#ifdef FG_MHI_DIRECT_SCORE
+        if (seg.direct) { if (wv == 0) FG_MHI_DIRECT_SCORE(); }
+        else
+#endif
+        { FG_MHI_SCORE(); }
         __syncthreads();                                     // every statement's term is in its row
-        if (wv == 0)
+        if (wv == 0 && !seg.direct)
             for (int k = 0; k < seg.n_stmt; ++k) {           // the three accumulators, each in program order (trace.rs:168-177)
                 const double v = terms[k * tw];
                 const int a = (int)seg.stmt_acc[k];

@@ -106,3 +106,29 @@ def test_jit_mh_is_bit_identical_to_the_interpreter(name, with_overrides, monkey
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_jit_rolls_plates_and_scores_long_programs_directly(monkeypatch):
+    """A plate of observations (statements that differ only in their constants) becomes one loop over a constant table in the
+    generated code; a program with more statements than LDS has term rows runs MH with the in-order accumulators on one wave
+    (k_mh_jit_steps' direct mode).  Logistic regression with 300 observations: HMC and MH against the interpreter kernels, bit for bit."""
+    from fugue_amd import workloads as W
+    cp = E.compile_model(W.logistic_regression(*W.classification_data(300)[:2]))
+    C = 130
+    out = []
+    for jit in (0, 1):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        eng = E.Engine(cp, C, seed=5)
+        eng.hmc_init(E.hmc_config(n_leapfrog=4, init_step_size=0.02), 6)
+        eng.hmc_step(10)
+        kh = eng.hmc_last_kernel()
+        v = eng.get_values(); lj = eng.hmc_log_joint(); eps = eng.hmc_step_sizes()
+        eng.mh_init(30)
+        eng.mh_step(50)
+        km = eng.mh_last_kernel()
+        out.append((v, lj, eps, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), kh, km))
+        eng.close()
+    assert out[1][6].startswith("k_hmc_jit_steps") and "in-order accumulators" in out[1][7], out[1][6:]
+    assert not out[0][6].startswith("k_hmc_jit") and not out[0][7].startswith("k_mh_jit"), out[0][6:]
+    for a, b in zip(out[0][:6], out[1][:6]):
+        assert np.array_equal(a, b, equal_nan=True)
