@@ -802,16 +802,17 @@ def extras(X):
     cpl = E.compile_model(W.logistic_regression(Xc, yc))
     for Cl in (C, 8192):
         eng = E.Engine(cpl, Cl, seed=1, device=dev)
-        eng.mh_init(100); eng.mh_step(100); eng.synchronize()
-        t0 = time.perf_counter(); eng.mh_step(200); eng.synchronize(); dt = time.perf_counter() - t0
-        out[f"interpreter_logistic_regression_mh_chain_steps_per_sec_{Cl}_chains"] = Cl * 200 / dt
+        eng.mh_init(100); eng.mh_step(200); eng.synchronize()
+        t0 = time.perf_counter(); eng.mh_step(400); eng.synchronize(); dt = time.perf_counter() - t0
+        out[f"interpreter_logistic_regression_mh_chain_steps_per_sec_{Cl}_chains"] = Cl * 400 / dt
         eng.hmc_init(E.hmc_config(), 5); eng.hmc_step(5); eng.synchronize()
         t0 = time.perf_counter(); eng.hmc_step(10); eng.synchronize(); dt = time.perf_counter() - t0
         out[f"interpreter_logistic_regression_hmc_leapfrog_steps_per_sec_{Cl}_chains"] = Cl * 10 * 16 / dt
-        out["interpreter_hmc_kernel"] = eng.hmc_last_kernel()
+        out[f"interpreter_kernels_{Cl}_chains"] = [eng.mh_last_kernel(), eng.hmc_last_kernel()]
         eng.close()
-    out["interpreter_note"] = ("examples/classification.rs logistic regression (S = 3, O = 100; prob = clamp(1 / (1 + exp(-x.beta)))): no record stream, "
-                               "k_mh_interp_mw_steps / k_hmc_interp_mw_steps (a tile shared by W waves) -- side measurement, never `value`")
+    out["interpreter_note"] = ("examples/classification.rs logistic regression (S = 3, O = 100; prob = clamp(1 / (1 + exp(-x.beta)))): no record stream -- the "
+                               "program is compiled at run time (k_mh_jit_steps / k_hmc_jit_steps; hiprtc, cached on disk), or runs on the multi-wave "
+                               "interpreter kernels when hiprtc is absent; side measurement, never `value`")
     # C2 as BASELINE.json words it: the README model (d = 1), 65 536 chains x 1 000 steps after 200 warmup transitions
     cp1 = E.compile_model(W.readme_normal())
     eng = E.Engine(cp1, CHAINS_PER_GPU, seed=1, device=dev)
