@@ -132,3 +132,29 @@ def test_jit_rolls_plates_and_scores_long_programs_directly(monkeypatch):
     assert not out[0][6].startswith("k_hmc_jit") and not out[0][7].startswith("k_mh_jit"), out[0][6:]
     for a, b in zip(out[0][:6], out[1][:6]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_jit_matches_the_interpreter_on_random_expression_programs(seed, monkeypatch):
+    """tests/random_models.py::random_expression_program: random expression trees over every interpreter opcode and distribution
+    family, plates, selects, factors -- HMC and MH through the compiled kernels and through the interpreter kernels, bit for bit
+    (NaN and -inf included: chains that leave a family's support must do so identically)."""
+    from tests.random_models import random_expression_program
+    cp = E.compile_model(random_expression_program(seed))
+    C = 100
+    out = []
+    for jit in (0, 1):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        eng = E.Engine(cp, C, seed=40 + seed)
+        eng.prior_init()
+        eng.hmc_init(E.hmc_config(n_leapfrog=4, init_step_size=0.01), 5)
+        eng.hmc_step(10)
+        kh = eng.hmc_last_kernel()
+        v = eng.get_values(); lj = eng.hmc_log_joint(); eps = eng.hmc_step_sizes()
+        eng.mh_init(20)
+        eng.mh_step(40)
+        out.append((v, lj, eps, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), kh, eng.mh_last_kernel()))
+        eng.close()
+    assert out[1][6].startswith("k_hmc_jit_steps") and out[1][7].startswith("k_mh_jit_steps"), out[1][6:]
+    for a, b in zip(out[0][:6], out[1][:6]):
+        assert np.array_equal(a, b, equal_nan=True)
