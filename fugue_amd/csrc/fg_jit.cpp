@@ -388,7 +388,7 @@ std::string fg_jit_hmc_source(const fg_program *p) {
 // The generated translation unit of one program's MH kernel: the scoring run as FG_JIT_NSEG statement segments (contiguous, balanced by
 // instruction cost at generation time) that the waves of a tile share, behind fg_mh_interp_body.h; the interpreter itself is part
 // of the unit for the propose-and-score pass of model-dependent proposals.
-std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost) {
+std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost, int occ) {
     constexpr int NSEG = 8;
     std::map<std::string, std::string> lp_fns, ctabs;
     std::vector<std::string> tables;
@@ -443,9 +443,8 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
 extern "C" __global__ __attribute__((amdgpu_waves_per_eu(OCC, OCC))) __launch_bounds__(FG_WAVE * FG_MHI_MAX) \
 void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg, int iter0, int n_steps, int n_warmup, long long *draws, int first_sample_t) { \
     fg_mh_interp_mw_body<OCC>(P, X, M, seg, iter0, n_steps, n_warmup, draws, first_sample_t); }
-FG_MH_JIT_KERNEL(2)
-FG_MH_JIT_KERNEL(4)
 )FGJ";
+    src += occ == 4 ? "FG_MH_JIT_KERNEL(4)\n" : "FG_MH_JIT_KERNEL(2)\n";     // one register budget per unit (the launch site knows which: halves the compilation)
     return src;
 }
 
@@ -504,7 +503,7 @@ int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string
 extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long long src_cap, char *log_out, long long log_cap, long long *code_bytes) {
     if (!p) return FG_E_BAD_ARG;
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
-    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1)) : fg_jit_hmc_source(p);
+    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4) : fg_jit_hmc_source(p);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;
     if (src.empty()) return FG_E_UNSUPPORTED;

@@ -117,42 +117,42 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
     if (e->jit_mh_state == 0) {
         e->jit_mh_state = -1;
         const char *sp = std::getenv("FG_JIT");
-        if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 4000000) {
+        // launch shape first (the unit is compiled for ONE register budget): LDS, direct mode, waves per tile, waves per SIMD
+        size_t lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1) + e->mhi_n_stmt) * FG_WAVE * sizeof(double);    // site rows, wave 0's temporaries, term rows
+        int direct = 0;
+        if (lds > 64 * 1024) {                               // too many statements for term rows: one wave, the accumulators themselves
+            lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1)) * FG_WAVE * sizeof(double);
+            direct = 1;
+        }
+        const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
+        const long long resident = std::max<long long>(1, std::min<long long>(per_cu, (160 * 1024) / (long long)lds));    // tiles a CU holds at once
+        int W = 1, forced = 0;
+        if (const char *fw = std::getenv("FG_MH_INTERP_WAVES")) forced = std::atoi(fw);
+        if (forced > 0) { while (2 * W <= std::min(forced, 8)) W *= 2; }
+        else while (2 * W <= 8 && 2 * W * resident <= 16) W *= 2;
+        if (direct) W = 1;
+        int occ = resident * W > 8 ? 4 : 2;
+        if (const char *fo = std::getenv("FG_MH_INTERP_OCC")) occ = std::atoi(fo) <= 2 ? 2 : 4;
+        if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 4000000 && lds <= 64 * 1024) {
             std::vector<long long> cost((size_t)e->prog->n_ins);
             for (int k = 0; k < e->prog->n_ins; ++k) cost[(size_t)k] = mhi_ins_cost(e->prog->ins_fast[(size_t)k]);
-            const std::string src = fg_jit_mh_source(e->prog, cost);
+            const std::string src = fg_jit_mh_source(e->prog, cost, occ);
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mh_mod, code.data()) == hipSuccess &&
-                hipModuleGetFunction(&e->jit_mh_fn[0], e->jit_mh_mod, "k_mh_jit_steps_occ2") == hipSuccess &&
-                hipModuleGetFunction(&e->jit_mh_fn[1], e->jit_mh_mod, "k_mh_jit_steps_occ4") == hipSuccess) e->jit_mh_state = 1;
-            else { (void)hipGetLastError(); if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: MH kernel not compiled at run time (%s)\n", e->jit_log.c_str()); }
+                hipModuleGetFunction(&e->jit_mh_fn[0], e->jit_mh_mod, occ == 4 ? "k_mh_jit_steps_occ4" : "k_mh_jit_steps_occ2") == hipSuccess) {
+                e->jit_mh_state = 1; e->jit_mh_W = W; e->jit_mh_lds = lds; e->jit_mh_direct = direct;
+            } else { (void)hipGetLastError(); if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: MH kernel not compiled at run time (%s)\n", e->jit_log.c_str()); }
         }
     }
     seg.direct = 0;
     if (e->jit_mh_state == 1) {
-        size_t lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1) + e->mhi_n_stmt) * FG_WAVE * sizeof(double);    // site rows, wave 0's temporaries, term rows
-        if (lds > 64 * 1024) {                               // too many statements for term rows: one wave, the accumulators themselves
-            lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1)) * FG_WAVE * sizeof(double);
-            seg.direct = 1;
-        }
-        if (lds <= 64 * 1024) {
-            const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
-            int W = 1;
-            int forced = 0;
-            if (const char *sp = std::getenv("FG_MH_INTERP_WAVES")) forced = std::atoi(sp);
-            if (forced > 0) { while (2 * W <= std::min(forced, 8)) W *= 2; }
-            const long long resident = std::max<long long>(1, std::min<long long>(per_cu, (160 * 1024) / (long long)lds));    // tiles a CU holds at once
-            if (forced <= 0) while (2 * W <= 8 && 2 * W * resident <= 16) W *= 2;
-            if (seg.direct) W = 1;
-            int occ = resident * W > 8 ? 4 : 2;
-            if (const char *sp = std::getenv("FG_MH_INTERP_OCC")) occ = std::atoi(sp) <= 2 ? 2 : 4;
-            int n_warmup = e->mh_warmup;
-            void *args[] = { &e->P, &e->X, &e->M, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t };
-            HIPCHK(hipModuleLaunchKernel(e->jit_mh_fn[occ == 4 ? 1 : 0], tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
-            e->last_mh_kernel = "k_mh_jit_steps W=" + std::to_string(W) + (seg.direct ? " (compiled at run time; in-order accumulators on one wave)" : " (compiled at run time)");
-            return FG_OK;
-        }
+        seg.direct = e->jit_mh_direct;
+        int n_warmup = e->mh_warmup;
+        void *args[] = { &e->P, &e->X, &e->M, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t };
+        HIPCHK(hipModuleLaunchKernel(e->jit_mh_fn[0], tiles, 1, 1, FG_WAVE * e->jit_mh_W, 1, 1, (unsigned)e->jit_mh_lds, e->stream, args, nullptr));
+        e->last_mh_kernel = "k_mh_jit_steps W=" + std::to_string(e->jit_mh_W) + (seg.direct ? " (compiled at run time; in-order accumulators on one wave)" : " (compiled at run time)");
+        return FG_OK;
     }
     if (e->mhi_W < 2) return FG_E_UNSUPPORTED;
     e->last_mh_kernel = "k_mh_interp_mw_steps W=" + std::to_string(e->mhi_W);
