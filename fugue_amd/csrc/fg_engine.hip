@@ -938,7 +938,27 @@ void fg_internal_hmc_set_cfg(fg_engine *e, const fg_hmc_config *cfg) {
     e->H.grad_mode = cfg->grad_mode;
 }
 
+// does fg_hmc_step run this program through the kernel compiled at run time (hmc_launch_steps' order: independent sites, dense regressions,
+// then the compiled form where it is the faster one, the stream kernel, the compiled form, the interpreter)?
+static bool hmc_jit_preferred(const fg_engine *e) {
+    if (e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->jit_state < 0) return false;
+    if (!e->P.gstream) return true;
+    if (e->gt || e->tw != FG_WAVE) return false;
+    if (e->P.sep && !e->sep_disabled && e->d >= 1) return false;                                     // fg_hmc_sep_launch takes it
+    if (e->P.lin_tab && !e->lin_disabled && (e->d == 8 || e->d == 16 || e->d == 32)) return false;   // fg_hmc_lin_launch takes it
+    const bool forced = std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2;
+    int rkj = 0;
+    const std::vector<FgGradRec> &gsj = e->prog->gstream;
+    for (int k = 0; k < e->prog->n_gstream && rkj < 2; ++k) rkj = std::max(rkj, (gsj[k].flags & (FG_G_GEN | FG_G_NSEL | FG_G_CATC)) ? 2 : ((gsj[k].flags & FG_G_LIN) ? 1 : 0));
+    const long long tiles = (e->C + e->tw - 1) / e->tw;
+    return forced || rkj >= 1 || tiles <= std::max(1, e->n_simd / 4);
+}
+
 static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
+    if (hmc_jit_preferred(e)) {                              // the step-size search on the compiled kernel too (k_hmc_jit_find_eps)
+        const int rc = fg_hmc_jit_find_eps(e, instance, injected, d_eps_out);
+        if (rc != FG_E_UNSUPPORTED) return rc;
+    }
     FG_LAUNCH_GT(e, k_hmc_find_eps, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_bytes, e->stream, e->P, e->X, e->H, instance,
                        injected, d_eps_out);
     HIPCHK(hipGetLastError());
@@ -1011,11 +1031,7 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
         // than fast Normals (linear predictors, general distributions, option selects: hier_scale 1.2e9 -> 3.7e9, linreg 2.8e9 -> 2.0e10
         // leapfrog-steps/s, bit-identical -- tools/bench_jit_vs_stream.py), and for fast-Normal programs when the tiles do not fill the GPU
         // (reference_model(8) at 8 192 chains: 3.6e9 -> 6.2e9; at 65 536 chains the stream kernel keeps 13 %).  FG_JIT=2 forces it.
-        int rkj = 0;
-        const std::vector<FgGradRec> &gsj = e->prog->gstream;
-        for (int k = 0; k < e->prog->n_gstream && rkj < 2; ++k) rkj = std::max(rkj, (gsj[k].flags & (FG_G_GEN | FG_G_NSEL | FG_G_CATC)) ? 2 : ((gsj[k].flags & FG_G_LIN) ? 1 : 0));
-        const bool forced = std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2;
-        if (forced || rkj >= 1 || (long long)tiles <= std::max(1, e->n_simd / 4)) {
+        if (hmc_jit_preferred(e)) {
             const int rc = fg_hmc_jit_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
             if (rc != FG_E_UNSUPPORTED) return rc;
         }

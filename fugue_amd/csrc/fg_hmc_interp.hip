@@ -334,7 +334,8 @@ int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double 
 // ---- the same kernel around a model compiled at run time (fg_jit.cpp, fg_hmc_jit_body.h) --------------------------------------
 struct FgJitSeg { int off[FG_MWI_MAX + 1]; const int *order; };
 
-int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
+// the program's compiled HMC module (once per engine) and the task split of its kernels; FG_E_UNSUPPORTED when there is none
+static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
     if (e->jit_state < 0 || e->gt || e->tw != FG_WAVE || e->d < 1 || e->cfg.grad_mode == FG_GRAD_FD_DENSE) return FG_E_UNSUPPORTED;
     if (e->jit_state == 0) {
         e->jit_state = -1;
@@ -350,16 +351,15 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
             if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: run-time compilation unavailable (%s): the interpreter kernels take this program\n", e->jit_log.c_str());
             return FG_E_UNSUPPORTED;
         }
-        if (hipModuleLoadData(&e->jit_mod, code.data()) != hipSuccess || hipModuleGetFunction(&e->jit_fn, e->jit_mod, "k_hmc_jit_steps") != hipSuccess) {
+        if (hipModuleLoadData(&e->jit_mod, code.data()) != hipSuccess || hipModuleGetFunction(&e->jit_fn, e->jit_mod, "k_hmc_jit_steps") != hipSuccess ||
+            hipModuleGetFunction(&e->jit_fn_eps, e->jit_mod, "k_hmc_jit_find_eps") != hipSuccess) {
             e->jit_log = "hipModuleLoadData / hipModuleGetFunction failed"; (void)hipGetLastError();
             return FG_E_UNSUPPORTED;
         }
         e->jit_state = 1;
     }
-    const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
     const int n_tasks = 2 * e->d;
-    auto lds_for = [&](int W) { return (size_t)((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * sizeof(double); };
-    if (lds_for(FG_MWI_MAX) > 64 * 1024) return FG_E_UNSUPPORTED;
+    if ((size_t)((long long)e->S + 3LL * e->d + 2 + FG_MWI_MAX) * FG_WAVE * sizeof(double) > 64 * 1024) return FG_E_UNSUPPORTED;
     if (!e->d_mwi_order) {
         HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)n_tasks * sizeof(int)));
         HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
@@ -392,6 +392,28 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
         HIPCHK(hipStreamSynchronize(e->stream));
         e->mwi_W = W; e->mwi_sparse = 2;
     }
+    return FG_OK;
+}
+
+// find_reasonable_epsilon through the compiled kernel (k_hmc_jit_find_eps)
+int fg_hmc_jit_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
+    const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
+    // the choice of kernel must be the one fg_hmc_step will make: only programs the compiled form takes by default or by force
+    if (int rc = jit_hmc_prepare(e, tiles)) return rc;
+    const int W = e->mwi_W;
+    FgJitSeg seg;
+    for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
+    seg.order = e->d_mwi_order;
+    const size_t lds = (size_t)((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * sizeof(double);
+    void *args[] = { &e->P, &e->X, &e->H, &seg, &instance, &injected, &d_eps_out };
+    HIPCHK(hipModuleLaunchKernel(e->jit_fn_eps, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
+    return FG_OK;
+}
+
+int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
+    const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
+    if (int rc = jit_hmc_prepare(e, tiles)) return rc;
+    auto lds_for = [&](int W) { return (size_t)((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * sizeof(double); };
     const int W = e->mwi_W;
     FgJitSeg seg;
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];

@@ -154,3 +154,105 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         H.alpha_sum[c] += asum; H.n_div[c] += ndiv;
     }
 }
+
+// find_reasonable_epsilon (hmc.rs:479-535) around the same generated functions: the doubling / halving search of k_hmc_find_eps
+// (fg_engine.hip), one leapfrog step per trial, the two gradients of a trial split over the waves like a transition's.  Every wave
+// carries the per-lane search state (it is a function of the trial's log-ratio, which wave 0 publishes), so the loop condition is
+// the same on all of them.
+extern "C" __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(FG_WAVE * FG_JIT_WMAX)
+void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, uint32_t instance, int injected, double *eps_out) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = (int)(blockDim.x >> 6);
+    const long long chain = (long long)blockIdx.x * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    const int d = P.d;
+    double *slots = lds + lane;
+    double *pl = lds + (long long)P.S * tw + lane;
+    double *ev_lp = lds + (long long)(P.S + d) * tw + lane;
+    double *xch = lds + (long long)(P.S + 3 * d) * tw + lane;                        // rows: 0 the trial's log-ratio, 2.. per-wave divergence flags
+    const int j0 = seg.off[wv], j1 = seg.off[wv + 1];
+    const double *mi = H.use_mass ? H.m_inv + c : nullptr;
+    const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    const double h = H.h;
+    for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    const int n_pairs = (d + 1) >> 1;
+    if (!injected) {                                          // p0 from the chain's (instance) EPS stream: pair j = Philox block j
+        for (int j = wv; j < n_pairs; j += W) {
+            const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)j, instance, FG_RNG_EPS);
+            const int i = 2 * j;
+            const double a0 = zz.a * (ms ? ms[(long long)i * X.C] : 1.0);
+            pl[i * tw] = a0;
+            if (live) H.p0_scratch[(long long)i * X.C + c] = a0;
+            if (i + 1 < d) { const double a1 = zz.b * (ms ? ms[(long long)(i + 1) * X.C] : 1.0); pl[(i + 1) * tw] = a1; if (live) H.p0_scratch[(long long)(i + 1) * X.C + c] = a1; }
+        }
+    } else for (int j = wv; j < n_pairs; j += W) for (int i = 2 * j; i < 2 * j + 2 && i < d; ++i) pl[i * tw] = H.p0_scratch[(long long)i * X.C + c];
+    __syncthreads();
+    double h0 = 0.0;
+    if (wv == 0) h0 = -H.lj[c] + fg_kinetic(P, pl, tw, mi, X.C);
+    // p0 of a dead lane: the pair its mirror chain drew (the same counter), so the restore below reads what the lane itself would have written
+    const double ln_half = log(0.5), ln2 = log(2.0);            // folded at compile time, as in k_hmc_find_eps
+    double eps = 1.0, lr = 0.0, a = 1.0;
+    bool active = true, first = true;
+    unsigned iters = 0;
+    __syncthreads();
+    while (__any(active)) {
+        const double eps_try = first ? 1.0 : eps * ((a > 0.0) ? 2.0 : 0.5);   // eps * 2^a
+        const double hk = 0.5 * eps_try;
+        bool bad = false;
+        for (int s = 0; s <= 1; ++s) {                        // one leapfrog step (hmc.rs:500-511): two gradients
+            for (int jj = j0; jj < j1; ++jj) {
+                const int task = seg.order[jj];
+                const int k = task >> 1;
+                const double orig = slots[k * tw];
+                ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, slots);
+            }
+            __syncthreads();
+            for (int k = wv; k < d; k += W) {
+                const double g = (ev_lp[2 * k * tw] - ev_lp[(2 * k + 1) * tw]) / (2.0 * h);
+                bad = bad || !fg_finite(g);
+                double p = pl[k * tw];
+                p += hk * g;
+                pl[k * tw] = p;
+                if (s < 1) { const double mk = mi ? mi[(long long)k * X.C] : 1.0; slots[k * tw] += eps_try * mk * p; }
+            }
+            __syncthreads();
+        }
+        xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
+        __syncthreads();
+        if (wv == 0) {
+            double pr = 0.0, lk = 0.0, fc = 0.0;
+            fg_jit_score(slots, pr, lk, fc);
+            const double lj1 = pr + lk + fc;
+            bool div = !fg_finite(lj1);
+            for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
+            double lr_try = FG_NEG_INF;
+            if (!div) lr_try = h0 - (-lj1 + fg_kinetic(P, pl, tw, mi, X.C));
+            xch[0] = lr_try;
+        }
+        __syncthreads();
+        const double lr_try = xch[0];
+        for (int j = wv; j < n_pairs; j += W)                 // restore (q, p0) for the next trial: the pairs this wave drew
+            for (int i = 2 * j; i < 2 * j + 2 && i < d; ++i) {
+                slots[i * tw] = fg_as_double(X.values[(long long)P.f64_site[i] * X.C + c]);
+                pl[i * tw] = H.p0_scratch[(long long)i * X.C + c];
+            }
+        __syncthreads();
+        if (first) {
+            lr = lr_try;
+            a = (lr > ln_half) ? 1.0 : -1.0;
+            active = a * lr > -a * ln2;
+            first = false;
+        } else if (active) {
+            eps = eps_try; lr = lr_try; iters += 1;
+            if (iters > 100 || !(eps >= 1e-12 && eps <= 1e12)) active = false;
+            else if (a > 0.0 && lr == FG_NEG_INF) { eps /= 2.0; active = false; }
+            else active = a * lr > -a * ln2;
+        }
+    }
+    if (wv == 0 && live) eps_out[c] = fmin(fmax(eps, 1e-6), 1e3);
+}
