@@ -359,7 +359,15 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         e->jit_state = 1;
     }
     const int n_tasks = 2 * e->d;
-    if ((size_t)((long long)e->S + 3LL * e->d + 2 + FG_MWI_MAX) * FG_WAVE * sizeof(double) > 64 * 1024) return FG_E_UNSUPPORTED;
+    {   // LDS: S site rows + d momentum rows + 2 d evaluation rows + exchange rows; beyond 64 KB the module's functions need the attribute
+        const size_t lds_max = (size_t)((long long)e->S + 3LL * e->d + 2 + FG_MWI_MAX) * FG_WAVE * sizeof(double);
+        if (lds_max > 160 * 1024) return FG_E_UNSUPPORTED;
+        if (lds_max > 64 * 1024 && !e->jit_lds_attr) {
+            if (hipFuncSetAttribute((const void *)e->jit_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void *)e->jit_fn_eps, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); e->jit_state = -1; return FG_E_UNSUPPORTED; }
+            e->jit_lds_attr = true;
+        }
+    }
     if (!e->d_mwi_order) {
         HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)n_tasks * sizeof(int)));
         HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
