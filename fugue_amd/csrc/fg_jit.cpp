@@ -21,7 +21,9 @@
 #include <string>
 #include <vector>
 
+#ifndef FG_JIT_NO_HIP             /* host-only builds (sanitizer tests of the generator): no hiprtc binding */
 #include <hip/hip_runtime.h>
+#endif
 
 #include "fg_program.h"
 #include "fg_jit.h"
@@ -284,6 +286,7 @@ struct Rtc {
 };
 Rtc &rtc() {
     static Rtc R;
+#ifndef FG_JIT_NO_HIP
     static std::once_flag once;
     std::call_once(once, [] {
         std::vector<std::string> names;
@@ -304,6 +307,7 @@ Rtc &rtc() {
         R.destroy = (decltype(R.destroy))dlsym(R.h, "hiprtcDestroyProgram");
         R.ok = R.create && R.compile && R.log_size && R.log && R.code_size && R.code && R.destroy;
     });
+#endif
     return R;
 }
 

@@ -17,6 +17,15 @@
 #include <vector>
 
 #include "../../include/fugue_amd.h"
+#include "../../fugue_amd/csrc/fg_jit.h"
+#include "../../fugue_amd/csrc/fg_program.h"
+
+// the run-time code generator (fg_jit.cpp, host-only build: FG_JIT_NO_HIP) over a finalized program: both translation units
+static size_t jit_sources(const fg_program *p) {
+    const std::string a = fg_jit_hmc_source(p);
+    const std::string b = fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4);
+    return a.size() + b.size();
+}
 
 static int run_dsl(const char *path) {
     std::ifstream f(path);
@@ -34,6 +43,7 @@ static int run_dsl(const char *path) {
                 for (int j = 0; j < fg_program_n_sites(p); ++j) fg_program_site_name(p, j, buf, sizeof buf);
                 for (int w = 0; w < fg_dsl_warning_count(p); ++w) (void)std::strlen(fg_dsl_warning(p, w));
                 for (int k = 0; k < 5; ++k) (void)fg_program_stream_records(p, k);
+                (void)jit_sources(p);
                 std::printf("ok %d sites %d observes %d instructions\n", fg_program_n_sites(p), fg_program_n_observe(p), fg_program_n_instructions(p));
                 fg_program_free(p);
             } else std::printf("error %s\n", fg_last_error());
@@ -118,7 +128,7 @@ static int run_program(unsigned seed) {
             else { std::vector<fg_tok> v; rnd_expr(v, 1); rc = fg_program_observe(p, addr, dist, toks.data(), plen.data(), np, v.data(), (int)v.size()); }
             if (rc < 0) ok = false;
         }
-        if (ok && fg_program_finalize(p) == 0) { ++built; for (int k = 0; k < 5; ++k) (void)fg_program_stream_records(p, k); (void)fg_program_n_slots(p); }
+        if (ok && fg_program_finalize(p) == 0) { ++built; for (int k = 0; k < 5; ++k) (void)fg_program_stream_records(p, k); (void)fg_program_n_slots(p); (void)jit_sources(p); }
         else ++refused;
         fg_program_free(p);
     }

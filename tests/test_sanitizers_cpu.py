@@ -1,5 +1,6 @@
 """Host-side sanitizer runs (CPU only; GPU AddressSanitizer is not available on the pool): the model-language parser, the program
-builder / compiler and the diagnostics combination built with -fsanitize=address,undefined and driven through the C ABI with the
+builder / compiler, the run-time code generator (fg_jit.cpp: both generated translation units of every program that compiles) and
+the diagnostics combination built with -fsanitize=address,undefined and driven through the C ABI with the
 DSL sources of tests/dsl_models.py, malformed / truncated / mutated variants of them and random token streams; the oracle's
 known-answer tests on its `make asan` build."""
 import json
@@ -21,9 +22,12 @@ def driver(tmp_path_factory):
     if not shutil.which("g++"):
         pytest.skip("g++ not available")
     out = tmp_path_factory.mktemp("san") / "san_driver"
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-DFG_BUILD",
+    sys.path.insert(0, ROOT)
+    from fugue_amd import build as B
+    B._write_jit_embed()                                       # fg_jit.cpp's embedded header text (a generated file)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-DFG_BUILD", "-DFG_JIT_NO_HIP",
            "-Wno-unknown-pragmas", os.path.join(ROOT, "tests", "cpp", "san_driver.cpp")] + \
-          [os.path.join(CSRC, f) for f in ("fg_program.cpp", "fg_dsl.cpp", "fg_diag_host.cpp")] + ["-o", str(out)]
+          [os.path.join(CSRC, f) for f in ("fg_program.cpp", "fg_dsl.cpp", "fg_diag_host.cpp", "fg_jit.cpp")] + ["-ldl", "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     return str(out)
