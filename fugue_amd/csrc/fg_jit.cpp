@@ -53,6 +53,12 @@ struct Gen {
     std::vector<double> *cvec = nullptr;         // non-null: constants go here and the code says c[j]
     bool rolled_term = false;                    // ... and a term row is (term + r)
     std::map<std::string, std::string> *ctabs = nullptr;   // table text -> name: identical tables (the d sub-programs of a regression) are emitted once
+    // Cooperative scoring (the MH kernel's direct mode): the function is entered by ALL waves of the tile.  The statements of a plate are
+    // shared by the waves -- statement r0 + rr of a chunk by wave rr mod W, its term into row rr of one half of a ring of LDS rows --
+    // and wave 0 adds each chunk's rows to the accumulator IN ORDER behind a barrier (the other half of the ring is being filled
+    // meanwhile); everything that is not a plate runs on wave 0 alone.  The accumulators are wave 0's.
+    bool coop = false;
+    bool ring_term = false;                      // the statement being emitted writes its term to ring row (buf * CH + rr)
 
     std::string lit(double v) {
         if (!cvec) return ::lit(v);
@@ -81,6 +87,7 @@ struct Gen {
     }
     void add(const std::string &s) { body += "    " + s + "\n"; }
     std::string term_row() {                     // the LDS row of the statement being emitted (TM mode); a rolled run emits ONE statement for R rows
+        if (ring_term) return "ring[(buf * FG_JIT_CH + rr) * FG_WAVE]";
         if (rolled_term) return "terms[(" + std::to_string(term) + " + r) * FG_WAVE]";
         return "terms[" + std::to_string(term++) + " * FG_WAVE]";
     }
@@ -120,12 +127,18 @@ struct Gen {
             size_t j = i + 1;
             while (j < st.size() && st[j].key == st[i].key && st[i].key[0] != '#') ++j;
             const size_t R = j - i;
-            if (R < 4 || !ctabs) { for (size_t q = st[i].b; q < st[i].e; ++q) ins(v[q]); i += 1; continue; }
+            if (R < 4 || !ctabs) {
+                if (coop) add("if (wv == 0) {");
+                for (size_t q = st[i].b; q < st[i].e; ++q) ins(v[q]);
+                if (coop) add("}");
+                i += 1; continue;
+            }
+            const bool share = coop && R >= 16;                               // a plate long enough to share between the waves
             // one statement's code with its constants as c[0 .. K); every statement's constants into the table, in the same order
             std::vector<double> first; std::string code;
             {
                 const std::string keep = body; body.clear();
-                cvec = &first; rolled_term = term >= 0;
+                cvec = &first; rolled_term = term >= 0; ring_term = share;
                 for (size_t q = st[i].b; q < st[i].e; ++q) ins(v[q]);
                 code = body; body = keep;
             }
@@ -140,7 +153,7 @@ struct Gen {
                 if (row.size() != K) same_k = false;
                 tab.insert(tab.end(), row.begin(), row.end());
             }
-            cvec = nullptr; rolled_term = false;
+            cvec = nullptr; rolled_term = false; ring_term = false;
             if (!same_k || !ok || K == 0) {                                   // (cannot happen for equal shapes; stay safe: emit them one by one)
                 for (size_t s = i; s < j; ++s) for (size_t q = st[s].b; q < st[s].e; ++q) ins(v[q]);
                 i = j; continue;
@@ -151,10 +164,27 @@ struct Gen {
             auto it = ctabs->find(text);
             std::string name;
             if (it == ctabs->end()) { name = "fg_jit_ctab" + std::to_string(ctabs->size()); (*ctabs)[text] = name; } else name = it->second;
-            add("#pragma unroll 2");
-            add("for (int r = 0; r < " + std::to_string(R) + "; ++r) { const double *c = " + name + " + (size_t)r * " + std::to_string(K) + ";");
-            body += code;
-            add("}");
+            if (share) {
+                const FgIns &last = v[st[i].e - 1];
+                const uint32_t lc = FG_INS_OPCODE(last.op);
+                const char *accn = lc == FG_OP_FACTOR ? "fc" : ((lc == FG_OP_CONSTLIK || (last.op & FG_F_OBSERVE)) ? "lk" : "pr");
+                add("{ int buf = 0;");
+                add("for (int r0 = 0; r0 < " + std::to_string(R) + "; r0 += FG_JIT_CH, buf ^= 1) { const int rn = (" + std::to_string(R) + " - r0) < FG_JIT_CH ? (" + std::to_string(R) + " - r0) : FG_JIT_CH;");
+                add("for (int rr = wv; rr < rn; rr += W) { const double *c = " + name + " + (size_t)(r0 + rr) * " + std::to_string(K) + ";");
+                body += code;
+                add("}");
+                add("__syncthreads();");
+                add(std::string("if (wv == 0) for (int rr = 0; rr < rn; ++rr) ") + accn + " += ring[(buf * FG_JIT_CH + rr) * FG_WAVE];");
+                add("}");
+                add("__syncthreads(); }");
+            } else {
+                if (coop) add("if (wv == 0) {");
+                add("#pragma unroll 2");
+                add("for (int r = 0; r < " + std::to_string(R) + "; ++r) { const double *c = " + name + " + (size_t)r * " + std::to_string(K) + ";");
+                body += code;
+                add("}");
+                if (coop) add("}");
+            }
             if (term >= 0) term += (int)R;
             i = j;
         }
@@ -164,7 +194,7 @@ struct Gen {
         const uint32_t op = I.op, code = FG_INS_OPCODE(op);
         const bool observe = (op & FG_F_OBSERVE) != 0u;
         const bool ends = code == FG_OP_NORMAL_FAST || code < 17u;
-        const std::string accum = (term >= 0 && ends) ? term_row() + " = lp;" : (observe ? "lk += lp;" : "pr += lp;");
+        const std::string accum = ((term >= 0 || ring_term) && ends) ? term_row() + " = lp;" : (observe ? "lk += lp;" : "pr += lp;");
         if (code == FG_OP_NORMAL_FAST) {                                     // fg_interp.h: the fast Normal of score-only programs
             std::string z;
             if (op & FG_F_POW2SCALE) z = "double z = dl * " + lit(I.h[4]) + ";";
@@ -225,7 +255,7 @@ struct Gen {
         }
         const std::string x0 = opnd(I.opnd[0], I.imm[0]);
         switch (code) {
-        case FG_OP_FACTOR: add(term >= 0 ? term_row() + " = " + x0 + ";" : "fc += " + x0 + ";"); break;
+        case FG_OP_FACTOR: add((term >= 0 || ring_term) ? term_row() + " = " + x0 + ";" : "fc += " + x0 + ";"); break;
         case FG_OP_LOAD: add("acc = " + x0 + ";"); break;
         case FG_OP_ADD: add("acc = acc + " + x0 + ";"); break;
         case FG_OP_SUB: add("acc = acc - " + x0 + ";"); break;
@@ -254,7 +284,7 @@ struct Gen {
             add("{ const bool ok_ = (acc >= 0.0) && (acc < " + lit((double)K) + ") && (acc == floor(acc)); const int j = ok_ ? (int)acc : 0; " + pick((int)I.aux, K, "j", "gv") +
                 "acc = ok_ ? gv : NAN; }");
             break; }
-        case FG_OP_CONSTLIK: { const std::string v = lit(I.imm[0]); add(term >= 0 ? term_row() + " = " + v + ";" : "lk += " + v + ";"); break; }
+        case FG_OP_CONSTLIK: { const std::string v = lit(I.imm[0]); add((term >= 0 || ring_term) ? term_row() + " = " + v + ";" : "lk += " + v + ";"); break; }
         case FG_OP_DOT: {                                                    // acc = (..((acc + s_0 c_0) + s_1 c_1)..): one product, one sum per term
             const int n = (int)I.opnd[1];
             for (int t = 0; t < n; ++t) {
@@ -418,12 +448,13 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
         s_at = s_to;
     }
-    {   // the whole program with the accumulators themselves: the direct mode of programs with more statements than LDS has rows
-        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.ctabs = &ctabs;
+    {   // the whole program with the accumulators themselves, entered by every wave: the direct mode of programs with more statements than
+        // LDS has term rows (plates shared between the waves through a ring of 2 x FG_JIT_CH rows, everything else on wave 0)
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.ctabs = &ctabs; g.coop = true;
         g.emit(p->ins_fast, 0, (size_t)p->n_ins);
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ void fg_jit_score(const double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
-               "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
+        fns += "#define FG_JIT_CH 32\nstatic __device__ __noinline__ void fg_jit_score_coop(const double *slots, double *ring, int wv, int W, double &pr_out, double &lk_out, double &fc_out) {\n"
+               "    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body + "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
     fns += "static __device__ __forceinline__ void fg_jit_terms(int sg, const double *slots, double *terms) {\n    switch (sg) {\n";
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_seg_" + std::to_string(sg) + "(slots, terms); break;\n";
@@ -439,7 +470,7 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
     src += fns;
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
            "#define FG_MHI_SCORE() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_terms(sg_, slots, terms); (void)i0; (void)i1; (void)s0; } while (0)\n"
-           "#define FG_MHI_DIRECT_SCORE() fg_jit_score(slots, A.prior, A.lik, A.fac)\n"
+           "#define FG_MHI_DIRECT_SCORE() fg_jit_score_coop(slots, terms, wv, W, A.prior, A.lik, A.fac)\n"
            "#define FG_MHI_PRIV_BLOCKS(W) 1\n";
     src += FG_JIT_EMBED_MH_BODY;                 // fg_mh_interp_body.h
     src += R"FGJ(

@@ -120,8 +120,8 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         // launch shape first (the unit is compiled for ONE register budget): LDS, direct mode, waves per tile, waves per SIMD
         size_t lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1) + e->mhi_n_stmt) * FG_WAVE * sizeof(double);    // site rows, wave 0's temporaries, term rows
         int direct = 0;
-        if (lds > 64 * 1024) {                               // too many statements for term rows: one wave, the accumulators themselves
-            lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1)) * FG_WAVE * sizeof(double);
+        if (lds > 64 * 1024) {                               // too many statements for term rows: the accumulators themselves, plates through a ring of 2 x 32 rows
+            lds = (size_t)((long long)e->S + (e->n_slots - e->S + 1) + 64) * FG_WAVE * sizeof(double);
             direct = 1;
         }
         const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
@@ -130,7 +130,6 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         if (const char *fw = std::getenv("FG_MH_INTERP_WAVES")) forced = std::atoi(fw);
         if (forced > 0) { while (2 * W <= std::min(forced, 8)) W *= 2; }
         else while (2 * W <= 8 && 2 * W * resident <= 16) W *= 2;
-        if (direct) W = 1;
         int occ = resident * W > 8 ? 4 : 2;
         if (const char *fo = std::getenv("FG_MH_INTERP_OCC")) occ = std::atoi(fo) <= 2 ? 2 : 4;
         if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 4000000 && lds <= 64 * 1024) {
@@ -151,7 +150,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         int n_warmup = e->mh_warmup;
         void *args[] = { &e->P, &e->X, &e->M, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t };
         HIPCHK(hipModuleLaunchKernel(e->jit_mh_fn[0], tiles, 1, 1, FG_WAVE * e->jit_mh_W, 1, 1, (unsigned)e->jit_mh_lds, e->stream, args, nullptr));
-        e->last_mh_kernel = "k_mh_jit_steps W=" + std::to_string(e->jit_mh_W) + (seg.direct ? " (compiled at run time; in-order accumulators on one wave)" : " (compiled at run time)");
+        e->last_mh_kernel = "k_mh_jit_steps W=" + std::to_string(e->jit_mh_W) + (seg.direct ? " (compiled at run time; in-order accumulators, plates shared through an LDS ring)" : " (compiled at run time)");
         return FG_OK;
     }
     if (e->mhi_W < 2) return FG_E_UNSUPPORTED;

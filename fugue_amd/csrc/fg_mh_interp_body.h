@@ -15,8 +15,9 @@ struct FgMhi {
     const unsigned char *stmt_acc;   // [n_stmt] accumulator of each statement: 0 log_prior, 1 log_likelihood, 2 log_factors
     const int *site_ins;             // [S][2] {first instruction, count} of each site's own sample statement in P.ins (generic opcodes)
     int n_stmt;
-    int direct;                      // compiled kernels only: 1 = the program has more statements than LDS has term rows -- ONE wave scores it with
-                                     // the in-order accumulators themselves (no rows, no second barrier)
+    int direct;                      // compiled kernels only: 1 = the program has more statements than LDS has term rows -- it is scored with the
+                                     // in-order accumulators themselves on wave 0, the statements of its plates shared by the waves through a ring
+                                     // of 2 x 32 LDS rows (fg_jit.cpp: fg_jit_score_coop)
 };
 
 // propose_and_score (SingleSiteProposalHandler, mh.rs:298-570) behind a call, as in fg_engine.hip
@@ -144,7 +145,7 @@ __device__ __forceinline__ void fg_mh_interp_mw_body(const FgProgramDev &P, cons
         __syncthreads();                                     // the proposed values are in the site rows
         FgAcc3 A = {0.0, 0.0, 0.0};
 #ifdef FG_MHI_DIRECT_SCORE
-        if (seg.direct) { if (wv == 0) FG_MHI_DIRECT_SCORE(); }
+        if (seg.direct) { FG_MHI_DIRECT_SCORE(); }             // every wave: plates are shared through a ring of LDS rows, the rest is wave 0's
         else
 #endif
         { FG_MHI_SCORE(); }
