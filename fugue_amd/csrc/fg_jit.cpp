@@ -416,6 +416,7 @@ std::string fg_jit_hmc_source(const fg_program *p) {
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += FG_JIT_EMBED_HMC_BODY;                // fg_hmc_jit_body.h
+    if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
     return src;
 }
 
@@ -480,6 +481,7 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
     fg_mh_interp_mw_body<OCC>(P, X, M, seg, iter0, n_steps, n_warmup, draws, first_sample_t); }
 )FGJ";
     src += occ == 4 ? "FG_MH_JIT_KERNEL(4)\n" : "FG_MH_JIT_KERNEL(2)\n";     // one register budget per unit (the launch site knows which: halves the compilation)
+    if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
     return src;
 }
 

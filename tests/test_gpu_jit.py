@@ -158,3 +158,23 @@ def test_jit_matches_the_interpreter_on_random_expression_programs(seed, monkeyp
     assert out[1][6].startswith("k_hmc_jit_steps") and out[1][7].startswith("k_mh_jit_steps"), out[1][6:]
     for a, b in zip(out[0][:6], out[1][:6]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_a_failed_compilation_falls_back_to_the_interpreter_kernels(monkeypatch, tmp_path):
+    """When hiprtc refuses the generated unit (FG_JIT_BREAK appends an #error; the same path as a missing libhiprtc), the engine stays on
+    the interpreter kernels -- on the GPU, with the same results -- and says which kernel ran."""
+    cp = E.compile_model(ZOO["poisson_glm"]())
+    monkeypatch.setenv("FG_JIT_CACHE", str(tmp_path))                    # an empty cache: nothing compiled earlier can be picked up
+    out = []
+    for broken in (False, True):
+        if broken: monkeypatch.setenv("FG_JIT_BREAK", "1")
+        eng = E.Engine(cp, 100, seed=3)
+        eng.hmc_init(E.hmc_config(n_leapfrog=4), 5); eng.hmc_step(8)
+        kh = eng.hmc_last_kernel(); v = eng.get_values()
+        eng.mh_init(10); eng.mh_step(20)
+        out.append((v, eng.get_values(), eng.mh_scales(), kh, eng.mh_last_kernel()))
+        eng.close()
+    assert out[0][3].startswith("k_hmc_jit_steps") and out[0][4].startswith("k_mh_jit_steps"), out[0][3:]
+    assert out[1][3].startswith("k_hmc_interp_mw_steps") and out[1][4].startswith("k_mh_interp_mw_steps"), out[1][3:]
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, b, equal_nan=True)
