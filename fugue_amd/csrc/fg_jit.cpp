@@ -518,10 +518,22 @@ int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string
     std::string dir = std::getenv("FG_JIT_CACHE") ? std::getenv("FG_JIT_CACHE") : "/tmp/fugue_amd_jit_" + std::to_string((long long)getuid());
     char name[64]; std::snprintf(name, sizeof name, "/%016llx_%zu.hsaco", hsh, src.size());
     const std::string path = dir + name;
+    // a cache file is {magic, source length, source text, code object}: the text is compared in full, so a hash collision or a truncated
+    // file can never hand back another program's code
+    static const char MAGIC[8] = { 'F', 'G', 'J', 'I', 'T', '0', '1', '\n' };
     if (FILE *f = std::fopen(path.c_str(), "rb")) {
         std::fseek(f, 0, SEEK_END); const long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
-        if (n > 0) { code.resize((size_t)n); if (std::fread(code.data(), 1, (size_t)n, f) == (size_t)n) { std::fclose(f); mem[src] = code; return FG_OK; } }
+        std::vector<char> buf;
+        if (n > (long)(sizeof MAGIC + 8)) { buf.resize((size_t)n); if (std::fread(buf.data(), 1, (size_t)n, f) != (size_t)n) buf.clear(); }
         std::fclose(f);
+        unsigned long long sl = 0;
+        if (!buf.empty() && !std::memcmp(buf.data(), MAGIC, sizeof MAGIC)) std::memcpy(&sl, buf.data() + sizeof MAGIC, 8);
+        const size_t head = sizeof MAGIC + 8;
+        if (!buf.empty() && sl == src.size() && buf.size() > head + sl && !std::memcmp(buf.data() + head, src.data(), sl)) {
+            code.assign(buf.begin() + (long)(head + sl), buf.end());
+            mem[src] = code;
+            return FG_OK;
+        }
     }
     const int rc = fg_jit_compile(src, code, log);
     if (rc != FG_OK) return rc;
@@ -529,7 +541,9 @@ int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string
     (void)mkdir(dir.c_str(), 0700);
     const std::string tmp = path + ".tmp." + std::to_string((long long)getpid());
     if (FILE *f = std::fopen(tmp.c_str(), "wb")) {
-        const bool okw = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+        const unsigned long long sl = src.size();
+        const bool okw = std::fwrite(MAGIC, 1, sizeof MAGIC, f) == sizeof MAGIC && std::fwrite(&sl, 1, 8, f) == 8 && std::fwrite(src.data(), 1, src.size(), f) == src.size() &&
+                         std::fwrite(code.data(), 1, code.size(), f) == code.size();
         std::fclose(f);
         if (okw) (void)std::rename(tmp.c_str(), path.c_str()); else (void)std::remove(tmp.c_str());
     }

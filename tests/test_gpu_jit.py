@@ -178,3 +178,44 @@ def test_a_failed_compilation_falls_back_to_the_interpreter_kernels(monkeypatch,
     assert out[1][3].startswith("k_hmc_interp_mw_steps") and out[1][4].startswith("k_mh_interp_mw_steps"), out[1][3:]
     for a, b in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_code_objects_are_cached_on_disk_and_verified(tmp_path):
+    """FG_JIT_CACHE: a second process finds the compiled code object of the same program (no second compilation: the run is faster),
+    and a cache file that was truncated or belongs to another source text is ignored, not trusted."""
+    import glob, os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(f"""
+import sys, time
+sys.path.insert(0, {root!r})
+from fugue_amd import engine as E
+from tests.models import ZOO
+cp = E.compile_model(ZOO["poisson_glm"]())
+eng = E.Engine(cp, 64, seed=1)
+t0 = time.perf_counter()
+eng.hmc_init(E.hmc_config(n_leapfrog=3), 2); eng.hmc_step(3); eng.synchronize()
+print(eng.hmc_last_kernel(), "|", time.perf_counter() - t0, "|", eng.get_values().tobytes().hex()[:64])
+""")
+    env = dict(os.environ, FG_JIT_CACHE=str(tmp_path / "cache"), FG_JIT="1")
+
+    def run():
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        k, t, v = [x.strip() for x in r.stdout.strip().splitlines()[-1].split("|")]
+        assert k.startswith("k_hmc_jit_steps"), k
+        return float(t), v
+    t1, v1 = run()
+    files = glob.glob(str(tmp_path / "cache" / "*.hsaco"))
+    assert len(files) == 1
+    t2, v2 = run()
+    assert v2 == v1 and t2 < t1                                   # found on disk: no compilation
+    size = os.path.getsize(files[0])
+    with open(files[0], "r+b") as f:                              # damage the file: cut its tail off, then flip a byte of the stored source text
+        f.truncate(size // 2)
+    t3, v3 = run()
+    assert v3 == v1 and os.path.getsize(files[0]) == size         # ignored, recompiled, rewritten
+    with open(files[0], "r+b") as f:
+        f.seek(100); b = f.read(1); f.seek(100); f.write(bytes([b[0] ^ 1]))
+    t4, v4 = run()
+    assert v4 == v1
