@@ -545,8 +545,9 @@ def run_rank(args):
         progress(rank, "c5 leg done")
         if rank == 0:
             out["hmc_fd_dense"] = leg_dense(X)
+            progress(rank, "dense leg done")
             out["extras"] = extras(X)
-            progress(rank, "dense + extras done")
+            progress(rank, "extras done")
             out["validity"] = validity(E, W, D, local_rank)
             progress(rank, "validity leg done")
     if rank == 0:
@@ -796,20 +797,25 @@ def extras(X):
     out["hmc_analytic_leapfrog_steps_per_sec"] = C * 100 * 16 / dt
     out["hmc_analytic_note"] = "closed-form derivative of the Normal force terms: NOT the reference's arithmetic, opt-in, never `value`"
     eng.close()
+    progress(X.rank, "extras: analytic gradient done")
     # a model the record streams do not cover (expression parameters -> the interpreter kernels): the reference's own logistic
     # regression example (examples/classification.rs:104-135: 100 observations, 3 coefficients, run there with adaptive_mcmc_chain)
     Xc, yc, _ = W.classification_data(100)
     cpl = E.compile_model(W.logistic_regression(Xc, yc))
     for Cl in (C, 8192):
-        eng = E.Engine(cpl, Cl, seed=1, device=dev)
-        eng.mh_init(100); eng.mh_step(200); eng.synchronize()
-        t0 = time.perf_counter(); eng.mh_step(400); eng.synchronize(); dt = time.perf_counter() - t0
-        out[f"interpreter_logistic_regression_mh_chain_steps_per_sec_{Cl}_chains"] = Cl * 400 / dt
-        eng.hmc_init(E.hmc_config(), 5); eng.hmc_step(5); eng.synchronize()
-        t0 = time.perf_counter(); eng.hmc_step(10); eng.synchronize(); dt = time.perf_counter() - t0
-        out[f"interpreter_logistic_regression_hmc_leapfrog_steps_per_sec_{Cl}_chains"] = Cl * 10 * 16 / dt
-        out[f"interpreter_kernels_{Cl}_chains"] = [eng.mh_last_kernel(), eng.hmc_last_kernel()]
-        eng.close()
+        try:                                                # a side measurement must not cost the run its line
+            eng = E.Engine(cpl, Cl, seed=1, device=dev)
+            eng.mh_init(100); eng.mh_step(200); eng.synchronize()
+            t0 = time.perf_counter(); eng.mh_step(400); eng.synchronize(); dt = time.perf_counter() - t0
+            out[f"interpreter_logistic_regression_mh_chain_steps_per_sec_{Cl}_chains"] = Cl * 400 / dt
+            eng.hmc_init(E.hmc_config(), 5); eng.hmc_step(5); eng.synchronize()
+            t0 = time.perf_counter(); eng.hmc_step(10); eng.synchronize(); dt = time.perf_counter() - t0
+            out[f"interpreter_logistic_regression_hmc_leapfrog_steps_per_sec_{Cl}_chains"] = Cl * 10 * 16 / dt
+            out[f"interpreter_kernels_{Cl}_chains"] = [eng.mh_last_kernel(), eng.hmc_last_kernel()]
+            eng.close()
+        except E.EngineError as ex:
+            out[f"interpreter_error_{Cl}_chains"] = str(ex)
+        progress(X.rank, f"extras: logistic regression at {Cl} chains done")
     out["interpreter_note"] = ("examples/classification.rs logistic regression (S = 3, O = 100; prob = clamp(1 / (1 + exp(-x.beta)))): no record stream -- the "
                                "program is compiled at run time (k_mh_jit_steps / k_hmc_jit_steps; hiprtc, cached on disk), or runs on the multi-wave "
                                "interpreter kernels when hiprtc is absent; side measurement, never `value`")

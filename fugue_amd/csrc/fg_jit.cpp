@@ -9,6 +9,9 @@
 // Results are bit-identical to the interpreter kernels (tests/test_gpu_jit.py); when hiprtc is missing, the program is too long or
 // the compilation fails the engine stays on them (FG_JIT=0 forces that).  Nothing here runs on the CPU at sampling time.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <cerrno>
+#include <functional>
 
 #include <cinttypes>
 #include <cmath>
@@ -244,7 +247,7 @@ struct Gen {
             if (!lp_fns->count(sig)) {
                 char def[640];
                 std::snprintf(def, sizeof def,
-                              "static __device__ __noinline__ double %s(double xf, long long xi, double p0, double p1, double p2, double h0, double h1, double h2, double h3, double h4) {\n"
+                              "static __device__ FG_JIT_CALL double %s(double xf, long long xi, double p0, double p1, double p2, double h0, double h1, double h2, double h3, double h4) {\n"
                               "    const double hh[5] = { h0, h1, h2, h3, h4 };\n    return fg_logpdf(%uu, %s, %s, xf, xi, p0, p1, p2, hh, %s, %s);\n}\n",
                               sig, code, hoisted ? "true" : "false", pow2 ? "true" : "false", sh ? "true" : "false", xh ? "true" : "false");
                 (*lp_fns)[sig] = def;
@@ -355,22 +358,30 @@ const char *PROLOGUE = R"FGJ(
 #define M_PI 3.14159265358979323846
 #endif
 #define FG_HD __device__ __forceinline__
+#ifdef __HIPCC_RTC__              /* hiprtc: no standard headers; under hipcc the HIP wrapper headers bring these */
 typedef unsigned int uint32_t;
 typedef int int32_t;
 typedef unsigned long long uint64_t;
 typedef long long int64_t;
 typedef unsigned long uintptr_t;
 typedef unsigned long size_t;
+#else
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#endif
 )FGJ";
 
 const char *HELPERS = R"FGJ(
 // the transcendental opcodes behind calls, as in fg_interp.h (same ocml functions: same bits)
-static __device__ __noinline__ double fg_jit_exp(double x) { return exp(x); }
-static __device__ __noinline__ double fg_jit_log(double x) { return log(x); }
-static __device__ __noinline__ double fg_jit_sin(double x) { return sin(x); }
-static __device__ __noinline__ double fg_jit_cos(double x) { return cos(x); }
-static __device__ __noinline__ double fg_jit_tanh(double x) { return tanh(x); }
-static __device__ __noinline__ double fg_jit_pow(double x, double y) { return pow(x, y); }
+#ifndef FG_JIT_CALL
+#define FG_JIT_CALL __noinline__
+#endif
+static __device__ FG_JIT_CALL double fg_jit_exp(double x) { return exp(x); }
+static __device__ FG_JIT_CALL double fg_jit_log(double x) { return log(x); }
+static __device__ FG_JIT_CALL double fg_jit_sin(double x) { return sin(x); }
+static __device__ FG_JIT_CALL double fg_jit_cos(double x) { return cos(x); }
+static __device__ FG_JIT_CALL double fg_jit_tanh(double x) { return tanh(x); }
+static __device__ FG_JIT_CALL double fg_jit_pow(double x, double y) { return pow(x, y); }
 // fg_int_of (fg_interp.h): the integer value of an observed expression
 static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vtype) { if (vtype == 1u) return v != 0.0; return fg_finite(v) ? (long long)v : 0; }
 )FGJ";
@@ -409,6 +420,7 @@ std::string fg_jit_hmc_source(const fg_program *p) {
                "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
     std::string src = PROLOGUE;
+    if (std::getenv("FG_JIT_INLINE")) src += "#define FG_JIT_CALL __forceinline__\n";       // experiments: densities and transcendentals inlined into the statements
     src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
     src += HELPERS;
     for (const std::string &t : tables) src += t + "\n";
@@ -485,8 +497,86 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
     return src;
 }
 
+// ---- the compiler -----------------------------------------------------------------------------------------------------------
+// Two ways to the same code object.  In-process: hiprtc, bound with dlopen beside the HIP runtime in use.  Out-of-process: `hipcc --genco`
+// of the system ROCm as a child process with a clean environment.  The second exists because a host process may run on a HIP runtime
+// that is NOT a ROCm installation's -- PyTorch wheels bundle their own libamdhip64 / libhiprtc / libamd_comgr, and the code objects that
+// bundle's hiprtc produced for these units did not run ("invalid kernel file" / HSA_STATUS_ERROR_INVALID_ISA on MI355X, ROCm 7.0 bundle
+// inside a ROCm 7.2 image), while everything the system toolchain compiles -- this library included -- runs on either runtime.  So:
+// hiprtc only when the runtime in use sits in a ROCm installation (a bin/hipcc beside its lib directory), else hipcc, else nothing
+// (the interpreter kernels).  FG_JIT_COMPILER=hiprtc / hipcc forces one.
+#ifndef FG_JIT_NO_HIP
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+extern char **environ;
+
+static std::string runtime_dir() {                           // directory of the libamdhip64 this process runs on
+    Dl_info di;
+    if (dladdr((void *)hipGetDeviceCount, &di) && di.dli_fname) { std::string d(di.dli_fname); const size_t s = d.rfind('/'); if (s != std::string::npos) return d.substr(0, s); }
+    return "";
+}
+static bool is_file(const std::string &p) { struct stat st; return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+static std::string find_hipcc() {
+    std::vector<std::string> c;
+    if (const char *h = std::getenv("HIPCC")) c.push_back(h);
+    if (const char *r = std::getenv("ROCM_PATH")) c.push_back(std::string(r) + "/bin/hipcc");
+    c.push_back("/opt/rocm/bin/hipcc");
+    for (const std::string &p : c) if (is_file(p) && ::access(p.c_str(), X_OK) == 0) return p;
+    return "";
+}
+static int compile_with_hipcc(const std::string &hipcc, const std::string &src, std::vector<char> &code, std::string &log) {
+    std::string dir = std::getenv("FG_JIT_CACHE") ? std::getenv("FG_JIT_CACHE") : "/tmp/fugue_amd_jit_" + std::to_string((long long)getuid());
+    (void)mkdir(dir.c_str(), 0700);
+    const std::string base = dir + "/build_" + std::to_string((long long)getpid()) + "_" + std::to_string((long long)std::hash<std::string>{}(src) & 0xffffff);
+    const std::string in = base + ".hip", out = base + ".hsaco", err = base + ".log";
+    { FILE *f = std::fopen(in.c_str(), "wb"); if (!f) { log = "cannot write " + in; return FG_E_HIP; }
+      const bool okw = std::fwrite(src.data(), 1, src.size(), f) == src.size(); if (std::fclose(f) != 0 || !okw) { log = "cannot write " + in; return FG_E_HIP; } }
+    std::vector<std::string> av = { hipcc, "--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-w", "-x", "hip", in, "-o", out };
+    std::vector<char *> argv; for (std::string &a : av) argv.push_back(&a[0]); argv.push_back(nullptr);
+    // the child's environment: this process's, without what a profiler or a Python wheel put there for THIS process
+    std::vector<std::string> ev; std::vector<char *> envp;
+    for (char **e = environ; e && *e; ++e) {
+        const std::string kv(*e);
+        if (!kv.compare(0, 11, "LD_PRELOAD=") || !kv.compare(0, 16, "LD_LIBRARY_PATH=") || !kv.compare(0, 5, "ROCP_") || !kv.compare(0, 12, "ROCPROFILER_") || !kv.compare(0, 10, "HSA_TOOLS_")) continue;
+        ev.push_back(kv);
+    }
+    for (std::string &e : ev) envp.push_back(&e[0]); envp.push_back(nullptr);
+    posix_spawn_file_actions_t fa; posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, err.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = 0;
+    const int sp = posix_spawn(&pid, hipcc.c_str(), &fa, nullptr, argv.data(), envp.data());
+    posix_spawn_file_actions_destroy(&fa);
+    int status = -1;
+    if (sp == 0) { while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} }
+    { std::FILE *f = std::fopen(err.c_str(), "rb"); if (f) { char b[4096]; size_t n; while ((n = std::fread(b, 1, sizeof b, f)) > 0) log.append(b, n); std::fclose(f); } }
+    int rc = FG_E_HIP;
+    if (sp == 0 && WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+        if (FILE *f = std::fopen(out.c_str(), "rb")) {
+            std::fseek(f, 0, SEEK_END); const long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+            if (n > 0) { code.resize((size_t)n); if (std::fread(code.data(), 1, (size_t)n, f) == (size_t)n) rc = FG_OK; }
+            std::fclose(f);
+        }
+    } else if (sp != 0) log += " (posix_spawn of " + hipcc + " failed)";
+    (void)std::remove(in.c_str()); (void)std::remove(out.c_str()); (void)std::remove(err.c_str());
+    return rc;
+}
+#endif
+
 // Compiles `src` for gfx950; on success `code` holds the code object.  `log` receives the compiler's messages.
 int fg_jit_compile(const std::string &src, std::vector<char> &code, std::string &log) {
+#ifndef FG_JIT_NO_HIP
+    const char *force = std::getenv("FG_JIT_COMPILER");
+    const std::string rt = runtime_dir(), hipcc = find_hipcc();
+    const bool rocm_install = !rt.empty() && is_file(rt + "/../bin/hipcc") && is_file(rt + "/libhiprtc.so");
+    const bool use_rtc = force ? !std::strcmp(force, "hiprtc") : rocm_install;
+    if (!use_rtc) {
+        if (hipcc.empty()) { log = "no compiler: the HIP runtime in use is not part of a ROCm installation and no hipcc was found"; return FG_E_UNSUPPORTED; }
+        return compile_with_hipcc(hipcc, src, code, log);
+    }
+#endif
     Rtc &R = rtc();
     if (!R.ok) { log = "hiprtc not available"; return FG_E_UNSUPPORTED; }
     void *prog = nullptr;

@@ -219,3 +219,36 @@ print(eng.hmc_last_kernel(), "|", time.perf_counter() - t0, "|", eng.get_values(
         f.seek(100); b = f.read(1); f.seek(100); f.write(bytes([b[0] ^ 1]))
     t4, v4 = run()
     assert v4 == v1
+
+
+def test_compilation_inside_a_process_that_runs_on_a_bundled_hip_runtime(tmp_path):
+    """A host process that imported PyTorch runs on the wheel's own libamdhip64 / libhiprtc / libamd_comgr, whose hiprtc produced code
+    objects that did not run for these units ("invalid kernel file").  There the library compiles with the system ROCm's hipcc in a
+    child process instead: same results as the interpreter, in a fresh cache directory."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text(f"""
+import sys, os
+import torch                                   # first: the process binds the wheel's HIP runtime
+sys.path.insert(0, {root!r})
+from fugue_amd import engine as E
+from tests.models import ZOO
+cp = E.compile_model(ZOO["hier_logsigma"]())
+out = []
+for jit in ("0", "1"):
+    os.environ["FG_JIT"] = jit
+    eng = E.Engine(cp, 100, seed=1)
+    eng.hmc_init(E.hmc_config(n_leapfrog=3), 3); eng.hmc_step(5)
+    kh = eng.hmc_last_kernel(); v = eng.get_values().tobytes()
+    eng.mh_init(10); eng.mh_step(20); eng.synchronize()
+    out.append((kh, eng.mh_last_kernel(), v, eng.get_values().tobytes()))
+    eng.close()
+assert out[1][0].startswith("k_hmc_jit_steps") and out[1][1].startswith("k_mh_jit_steps"), out[1][:2]
+assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
+print("ok")
+""")
+    env = dict(os.environ, FG_JIT_CACHE=str(tmp_path / "cache"))
+    env.pop("FG_JIT_COMPILER", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
