@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 3: full GPU suite, the two-rank rehearsal, the default bench line
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
+ulimit -c 0; export HSA_ENABLE_COREDUMP=0      # a faulting kernel must not write a core dump of the GPU (tens of GB)
 timeout -k 10 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r3_gpu_suite.log 2>&1; echo "suite rc $?" | tee -a gpurun_out/r3_gpu_suite.log
 tail -4 gpurun_out/r3_gpu_suite.log
 grep -q "suite rc 0" gpurun_out/r3_gpu_suite.log || exit 1
