@@ -252,3 +252,24 @@ print("ok")
     env.pop("FG_JIT_COMPILER", None)
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_jit_mh_segments_with_rolled_plates(monkeypatch):
+    """Sixty observations: each of the eight statement segments of the compiled MH kernel holds a run of isomorphic statements long
+    enough to roll into a loop whose iteration r writes term row (base + r) -- against the interpreter kernels, bit for bit."""
+    from fugue_amd import workloads as W
+    cp = E.compile_model(W.logistic_regression(*W.classification_data(60)[:2]))
+    out = []
+    for jit, W_ in ((0, 0), (1, 1), (1, 2), (1, 8)):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        if W_: monkeypatch.setenv("FG_MH_INTERP_WAVES", str(W_))
+        else: monkeypatch.delenv("FG_MH_INTERP_WAVES", raising=False)
+        eng = E.Engine(cp, 140, seed=9)
+        eng.prior_init()
+        eng.mh_init(40); eng.mh_step(80)
+        out.append((eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), eng.mh_last_kernel()))
+        eng.close()
+    assert all(o[3].startswith("k_mh_jit_steps W=") and "in-order" not in o[3] for o in out[1:]), [o[3] for o in out]
+    for o in out[1:]:
+        for a, b in zip(out[0][:3], o[:3]):
+            assert np.array_equal(a, b, equal_nan=True)
