@@ -91,7 +91,7 @@ struct fg_engine {
     int *d_mwi_order = nullptr; long long *d_mwi_prof = nullptr; std::vector<int> mwi_off; std::vector<long long> mwi_cost; int mwi_W = 0, mwi_sparse = -1, mwi_calibrated = 0;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
     int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; bool mhi_setup_done = false; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
     int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)
-    hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr; std::string jit_log; bool jit_lds_attr = false;
+    hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr; std::string jit_log; bool jit_lds_attr = false; double *d_jit_tab = nullptr, *d_jit_mh_tab = nullptr;   // the modules' constant tables (fg_jit_bind_tables)
     int jit_mh_state = 0, jit_mh_W = 1, jit_mh_direct = 0; size_t jit_mh_lds = 0; hipModule_t jit_mh_mod = nullptr; hipFunction_t jit_mh_fn[2] = {nullptr, nullptr};   // ... and its MH kernel (128- and 256-VGPR builds)
     std::string last_mh_kernel;  // kernel the last fg_mh_step launch ran (fg_mh_last_kernel)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)

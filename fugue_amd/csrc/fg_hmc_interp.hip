@@ -343,7 +343,8 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;
         for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
         if (e->prog->sub.size() + e->prog->ins_fast.size() > 4000000) return FG_E_UNSUPPORTED;
-        const std::string src = fg_jit_hmc_source(e->prog);
+        std::vector<double> ctab;
+        const std::string src = fg_jit_hmc_source(e->prog, &ctab);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
@@ -352,8 +353,9 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
             return FG_E_UNSUPPORTED;
         }
         if (hipModuleLoadData(&e->jit_mod, code.data()) != hipSuccess || hipModuleGetFunction(&e->jit_fn, e->jit_mod, "k_hmc_jit_steps") != hipSuccess ||
-            hipModuleGetFunction(&e->jit_fn_eps, e->jit_mod, "k_hmc_jit_find_eps") != hipSuccess) {
-            e->jit_log = "hipModuleLoadData / hipModuleGetFunction failed"; (void)hipGetLastError();
+            hipModuleGetFunction(&e->jit_fn_eps, e->jit_mod, "k_hmc_jit_find_eps") != hipSuccess ||
+            fg_jit_bind_tables(e->jit_mod, ctab, &e->d_jit_tab, e->stream) != FG_OK) {
+            e->jit_log = "hipModuleLoadData / hipModuleGetFunction / table upload failed"; (void)hipGetLastError();
             return FG_E_UNSUPPORTED;
         }
         e->jit_state = 1;

@@ -42,6 +42,24 @@ std::string lit(double v) {                      // a double literal with exactl
     return b;
 }
 
+// The constants of the rolled runs of one module.  They live in ONE device buffer whose address the engine writes into the module's
+// global `fg_jit_ctab_ptr` after loading it -- not in the source text: the generated unit then depends on the STRUCTURE of a program,
+// not on its data (a regression on another data set of the same shape finds its code object in the cache), and its size does not
+// grow with the number of observations.  The code reads them through the constant address space (uniform addresses: scalar loads).
+struct FgJitTabs {
+    std::vector<double> data;
+    std::map<std::string, size_t> index;         // table bytes -> offset (in doubles)
+    size_t add(const std::vector<double> &t) {
+        const std::string key((const char *)t.data(), t.size() * sizeof(double));
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        const size_t off = data.size();
+        data.insert(data.end(), t.begin(), t.end());
+        index[key] = off;
+        return off;
+    }
+};
+
 struct Gen {
     const fg_program &p;
     int pert_slot = -1;                          // slot whose reads become `pert` (a finite-difference task) or -1
@@ -55,7 +73,8 @@ struct Gen {
     // constant table -- the same statements in the same order, the constants read from memory instead of the instruction stream.
     std::vector<double> *cvec = nullptr;         // non-null: constants go here and the code says c[j]
     bool rolled_term = false;                    // ... and a term row is (term + r)
-    std::map<std::string, std::string> *ctabs = nullptr;   // table text -> name: identical tables (the d sub-programs of a regression) are emitted once
+    FgJitTabs *ctabs = nullptr;                  // the constants of rolled runs: ONE device buffer per module, identical tables (the d sub-programs of a
+                                                 // regression hold the same observations) stored once
     // Cooperative scoring (the MH kernel's direct mode): the function is entered by ALL waves of the tile.  The statements of a plate are
     // shared by the waves -- statement r0 + rr of a chunk by wave rr mod W, its term into row rr of one half of a ring of LDS rows --
     // and wave 0 adds each chunk's rows to the accumulator IN ORDER behind a barrier (the other half of the ring is being filled
@@ -161,19 +180,14 @@ struct Gen {
                 for (size_t s = i; s < j; ++s) for (size_t q = st[s].b; q < st[s].e; ++q) ins(v[q]);
                 i = j; continue;
             }
-            std::string text;
-            text.reserve(tab.size() * 24);
-            for (size_t q = 0; q < tab.size(); ++q) { text += ::lit(tab[q]); text += (q + 1 < tab.size()) ? "," : ""; if ((q + 1) % 8 == 0) text += "\n"; }
-            auto it = ctabs->find(text);
-            std::string name;
-            if (it == ctabs->end()) { name = "fg_jit_ctab" + std::to_string(ctabs->size()); (*ctabs)[text] = name; } else name = it->second;
+            const std::string name = "(fg_jit_ctab() + " + std::to_string(ctabs->add(tab)) + ")";
             if (share) {
                 const FgIns &last = v[st[i].e - 1];
                 const uint32_t lc = FG_INS_OPCODE(last.op);
                 const char *accn = lc == FG_OP_FACTOR ? "fc" : ((lc == FG_OP_CONSTLIK || (last.op & FG_F_OBSERVE)) ? "lk" : "pr");
                 add("{ int buf = 0;");
                 add("for (int r0 = 0; r0 < " + std::to_string(R) + "; r0 += FG_JIT_CH, buf ^= 1) { const int rn = (" + std::to_string(R) + " - r0) < FG_JIT_CH ? (" + std::to_string(R) + " - r0) : FG_JIT_CH;");
-                add("for (int rr = wv; rr < rn; rr += W) { const double *c = " + name + " + (size_t)(r0 + rr) * " + std::to_string(K) + ";");
+                add("for (int rr = wv; rr < rn; rr += W) { const FG_JIT_AS4 double *c = " + name + " + (size_t)(r0 + rr) * " + std::to_string(K) + ";");
                 body += code;
                 add("}");
                 add("__syncthreads();");
@@ -183,7 +197,7 @@ struct Gen {
             } else {
                 if (coop) add("if (wv == 0) {");
                 add("#pragma unroll 2");
-                add("for (int r = 0; r < " + std::to_string(R) + "; ++r) { const double *c = " + name + " + (size_t)r * " + std::to_string(K) + ";");
+                add("for (int r = 0; r < " + std::to_string(R) + "; ++r) { const FG_JIT_AS4 double *c = " + name + " + (size_t)r * " + std::to_string(K) + ";");
                 body += code;
                 add("}");
                 if (coop) add("}");
@@ -382,6 +396,10 @@ static __device__ FG_JIT_CALL double fg_jit_sin(double x) { return sin(x); }
 static __device__ FG_JIT_CALL double fg_jit_cos(double x) { return cos(x); }
 static __device__ FG_JIT_CALL double fg_jit_tanh(double x) { return tanh(x); }
 static __device__ FG_JIT_CALL double fg_jit_pow(double x, double y) { return pow(x, y); }
+// the module's constant tables (FgJitTabs): one device buffer, its address stored here by the engine after hipModuleLoadData
+#define FG_JIT_AS4 __attribute__((address_space(4)))
+__device__ const double *fg_jit_ctab_ptr = nullptr;
+static __device__ __forceinline__ const FG_JIT_AS4 double *fg_jit_ctab() { return (const FG_JIT_AS4 double *)(unsigned long)fg_jit_ctab_ptr; }
 // fg_int_of (fg_interp.h): the integer value of an observed expression
 static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vtype) { if (vtype == 1u) return v != 0.0; return fg_finite(v) ? (long long)v : 0; }
 )FGJ";
@@ -389,14 +407,9 @@ static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vty
 }  // namespace
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
-static std::string ctab_text(const std::map<std::string, std::string> &ctabs) {
-    std::string s;
-    for (const auto &kv : ctabs) s += "static __device__ const double " + kv.second + "[] = {\n" + kv.first + "};\n";
-    return s;
-}
-
-std::string fg_jit_hmc_source(const fg_program *p) {
-    std::map<std::string, std::string> lp_fns, ctabs;
+std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out) {
+    std::map<std::string, std::string> lp_fns;
+    FgJitTabs ctabs;
     std::vector<std::string> tables;
     std::string fns;
     const int d = (int)p->coord.size();
@@ -424,20 +437,21 @@ std::string fg_jit_hmc_source(const fg_program *p) {
     src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
     src += HELPERS;
     for (const std::string &t : tables) src += t + "\n";
-    src += ctab_text(ctabs);
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += FG_JIT_EMBED_HMC_BODY;                // fg_hmc_jit_body.h
     if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
+    if (ctab_out) *ctab_out = ctabs.data;
     return src;
 }
 
 // The generated translation unit of one program's MH kernel: the scoring run as FG_JIT_NSEG statement segments (contiguous, balanced by
 // instruction cost at generation time) that the waves of a tile share, behind fg_mh_interp_body.h; the interpreter itself is part
 // of the unit for the propose-and-score pass of model-dependent proposals.
-std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost, int occ) {
+std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost, int occ, std::vector<double> *ctab_out) {
     constexpr int NSEG = 8;
-    std::map<std::string, std::string> lp_fns, ctabs;
+    std::map<std::string, std::string> lp_fns;
+    FgJitTabs ctabs;
     std::vector<std::string> tables;
     std::vector<int> stmt_end;
     for (int k = 0; k < p->n_ins; ++k) {
@@ -478,7 +492,6 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
     src += FG_JIT_EMBED_INTERP;                  // fg_interp.h: the propose-and-score mode for model-dependent proposals
     src += HELPERS;
     for (const std::string &t : tables) src += t + "\n";
-    src += ctab_text(ctabs);
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
@@ -494,6 +507,7 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
 )FGJ";
     src += occ == 4 ? "FG_MH_JIT_KERNEL(4)\n" : "FG_MH_JIT_KERNEL(2)\n";     // one register budget per unit (the launch site knows which: halves the compilation)
     if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
+    if (ctab_out) *ctab_out = ctabs.data;
     return src;
 }
 
@@ -644,7 +658,7 @@ int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string
 extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long long src_cap, char *log_out, long long log_cap, long long *code_bytes) {
     if (!p) return FG_E_BAD_ARG;
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
-    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4) : fg_jit_hmc_source(p);
+    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;
     if (src.empty()) return FG_E_UNSUPPORTED;
@@ -654,3 +668,18 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     if (code_bytes) *code_bytes = (long long)code.size();
     return rc;
 }
+
+#ifndef FG_JIT_NO_HIP
+// Uploads a module's constant tables and writes their device address into its global `fg_jit_ctab_ptr`.  *d_tab receives the
+// allocation (the caller frees it with the engine).
+int fg_jit_bind_tables(hipModule_t mod, const std::vector<double> &tab, double **d_tab, hipStream_t stream) {
+    *d_tab = nullptr;
+    if (tab.empty()) return FG_OK;
+    if (hipMalloc((void **)d_tab, tab.size() * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return FG_E_HIP; }
+    if (hipMemcpyAsync(*d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return FG_E_HIP;
+    hipDeviceptr_t gp = nullptr; size_t gb = 0;
+    if (hipModuleGetGlobal(&gp, &gb, mod, "fg_jit_ctab_ptr") != hipSuccess || gb != sizeof(double *)) { (void)hipGetLastError(); return FG_E_HIP; }
+    if (hipMemcpyHtoD(gp, d_tab, sizeof(double *)) != hipSuccess) return FG_E_HIP;
+    return FG_OK;
+}
+#endif

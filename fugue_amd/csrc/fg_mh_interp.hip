@@ -135,11 +135,13 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 4000000 && lds <= 64 * 1024) {
             std::vector<long long> cost((size_t)e->prog->n_ins);
             for (int k = 0; k < e->prog->n_ins; ++k) cost[(size_t)k] = mhi_ins_cost(e->prog->ins_fast[(size_t)k]);
-            const std::string src = fg_jit_mh_source(e->prog, cost, occ);
+            std::vector<double> ctab;
+            const std::string src = fg_jit_mh_source(e->prog, cost, occ, &ctab);
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mh_mod, code.data()) == hipSuccess &&
-                hipModuleGetFunction(&e->jit_mh_fn[0], e->jit_mh_mod, occ == 4 ? "k_mh_jit_steps_occ4" : "k_mh_jit_steps_occ2") == hipSuccess) {
+                hipModuleGetFunction(&e->jit_mh_fn[0], e->jit_mh_mod, occ == 4 ? "k_mh_jit_steps_occ4" : "k_mh_jit_steps_occ2") == hipSuccess &&
+                fg_jit_bind_tables(e->jit_mh_mod, ctab, &e->d_jit_mh_tab, e->stream) == FG_OK) {
                 e->jit_mh_state = 1; e->jit_mh_W = W; e->jit_mh_lds = lds; e->jit_mh_direct = direct;
             } else { (void)hipGetLastError(); if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: MH kernel not compiled at run time (%s)\n", e->jit_log.c_str()); }
         }

@@ -22,9 +22,10 @@
 
 // the run-time code generator (fg_jit.cpp, host-only build: FG_JIT_NO_HIP) over a finalized program: both translation units
 static size_t jit_sources(const fg_program *p) {
-    const std::string a = fg_jit_hmc_source(p);
-    const std::string b = fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4);
-    return a.size() + b.size();
+    std::vector<double> ta, tb;
+    const std::string a = fg_jit_hmc_source(p, &ta);
+    const std::string b = fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, &tb);
+    return a.size() + b.size() + ta.size() + tb.size();
 }
 
 static int run_dsl(const char *path) {
