@@ -248,7 +248,7 @@ static void fuse_dots(std::vector<FgIns> &out, size_t start, std::vector<double>
         if (k0 == FG_OPND_IMM && k1 == FG_OPND_SLOT_F) { slot = FG_OPND_IDX(I.opnd[1]); c = I.imm[0]; return true; }
         return false;
     };
-    std::vector<FgIns> res(out.begin(), out.begin() + (long)start);
+    std::vector<FgIns> res;                                            // the statement's instructions only (a copy of the whole prefix per statement made compilation quadratic)
     for (size_t i = start; i < out.size();) {
         uint32_t slot; double c;
         size_t j = i;
@@ -263,7 +263,8 @@ static void fuse_dots(std::vector<FgIns> &out, size_t start, std::vector<double>
         res.push_back(D);
         i = j;
     }
-    out.swap(res);
+    out.resize(start);
+    out.insert(out.end(), res.begin(), res.end());
 }
 
 void fg_program::compile_stmt(const FgStmt &s, std::vector<FgIns> &out, int &temp_max) {
