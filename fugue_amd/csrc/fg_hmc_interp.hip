@@ -342,7 +342,7 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         if (const char *sp = std::getenv("FG_JIT")) if (std::atoi(sp) == 0) return FG_E_UNSUPPORTED;
         for (int j = 0; j < e->S; ++j) if (e->prog->site_slot[j] >= e->S) return FG_E_UNSUPPORTED;
         for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
-        if (e->prog->sub.size() + e->prog->ins_fast.size() > 4000000) return FG_E_UNSUPPORTED;
+        if (e->prog->sub.size() + e->prog->ins_fast.size() > 64000000) return FG_E_UNSUPPORTED;
         std::vector<double> ctab;
         const std::string src = fg_jit_hmc_source(e->prog, &ctab);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds

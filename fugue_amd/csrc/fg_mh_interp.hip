@@ -132,7 +132,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         else while (2 * W <= 8 && 2 * W * resident <= 16) W *= 2;
         int occ = resident * W > 8 ? 4 : 2;
         if (const char *fo = std::getenv("FG_MH_INTERP_OCC")) occ = std::atoi(fo) <= 2 ? 2 : 4;
-        if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 4000000 && lds <= 64 * 1024) {
+        if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 64000000 && lds <= 64 * 1024) {
             std::vector<long long> cost((size_t)e->prog->n_ins);
             for (int k = 0; k < e->prog->n_ins; ++k) cost[(size_t)k] = mhi_ins_cost(e->prog->ins_fast[(size_t)k]);
             std::vector<double> ctab;
