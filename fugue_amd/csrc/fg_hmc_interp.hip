@@ -383,7 +383,9 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         }
         int forced = e->mw_override;
         if (const char *sp = std::getenv("FG_HMC_INTERP_WAVES")) forced = std::atoi(sp);
-        const int wcap = std::min(FG_MWI_MAX, n_tasks);
+        int jocc = 4;
+        if (const char *oc = std::getenv("FG_HMC_JIT_OCC")) { const int o = std::atoi(oc); if (o >= 2 && o <= 4) jocc = o; }
+        const int wcap = std::min(std::min(FG_MWI_MAX, 4 * jocc), n_tasks);
         int W = 1;
         const long long n_cu = std::max(1, e->n_simd / 4);
         if (forced > 0) W = std::max(1, std::min(forced, wcap));

@@ -10,9 +10,12 @@
 // sequential parts on wave 0 -- so its results are bit-identical to k_hmc_interp_mw_steps and k_hmc_steps
 // (tests/test_gpu_jit.py).  LDS: S site rows + d momentum rows + 2 d evaluation rows + 2 + W exchange rows.
 #define FG_JIT_WMAX 16
+#ifndef FG_JIT_OCC          /* waves per SIMD the register budget allows: 4 = 128 VGPRs (fg_jit.cpp may define 2 or 3 for register-hungry programs) */
+#define FG_JIT_OCC 4
+#endif
 struct FgJitSeg { int off[FG_JIT_WMAX + 1]; const int *order; };   // wave w owns tasks order[off[w] .. off[w + 1]): 2 k + sign
 
-extern "C" __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(FG_WAVE * FG_JIT_WMAX)
+extern "C" __global__ __attribute__((amdgpu_waves_per_eu(FG_JIT_OCC, FG_JIT_OCC))) __launch_bounds__(FG_WAVE * 4 * FG_JIT_OCC)
 void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int iter0, int n_steps, int n_warmup, int welford_on, double *draws,
                      int first_sample_t, double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
@@ -159,7 +162,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
 // (fg_engine.hip), one leapfrog step per trial, the two gradients of a trial split over the waves like a transition's.  Every wave
 // carries the per-lane search state (it is a function of the trial's log-ratio, which wave 0 publishes), so the loop condition is
 // the same on all of them.
-extern "C" __global__ __attribute__((amdgpu_waves_per_eu(4, 4))) __launch_bounds__(FG_WAVE * FG_JIT_WMAX)
+extern "C" __global__ __attribute__((amdgpu_waves_per_eu(FG_JIT_OCC, FG_JIT_OCC))) __launch_bounds__(FG_WAVE * 4 * FG_JIT_OCC)
 void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, uint32_t instance, int injected, double *eps_out) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;

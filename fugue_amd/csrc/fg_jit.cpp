@@ -434,6 +434,7 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
     }
     std::string src = PROLOGUE;
     if (std::getenv("FG_JIT_INLINE")) src += "#define FG_JIT_CALL __forceinline__\n";       // experiments: densities and transcendentals inlined into the statements
+    if (const char *oc = std::getenv("FG_HMC_JIT_OCC")) { const int o = std::atoi(oc); if (o >= 2 && o <= 4) src += "#define FG_JIT_OCC " + std::to_string(o) + "\n"; }   // experiments: register budget
     src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
     src += HELPERS;
     for (const std::string &t : tables) src += t + "\n";
@@ -666,6 +667,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     const int rc = fg_jit_compile(src, code, log);
     if (log_out && log_cap > 0) std::snprintf(log_out, (size_t)log_cap, "%s", log.c_str());
     if (code_bytes) *code_bytes = (long long)code.size();
+    if (const char *out = std::getenv("FG_DEBUG_JIT_OUT")) if (rc == FG_OK) if (FILE *f = std::fopen(out, "wb")) { std::fwrite(code.data(), 1, code.size(), f); std::fclose(f); }   // for llvm-objdump / readelf
     return rc;
 }
 
