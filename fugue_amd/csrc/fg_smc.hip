@@ -448,7 +448,11 @@ __device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double
         if (ess_c[c0 + node] < target) { hi = mid; node = 2 * node + 1; } else { lo = mid; node = 2 * node + 2; }
         ++depth;
     }
+    // a pass that leaves the bracket where it found it has reached the fixed point of the bisection (lo and hi are adjacent doubles or
+    // equal: every later midpoint, hence every later decision, repeats) -- the remaining iterations of smc.rs:612-619 change nothing
+    const bool fixed = depth > 0 && lo == B.lo && hi == B.hi;
     B.lo = lo; B.hi = hi; B.iters += depth;
+    if (fixed) B.iters = 64;
     if (B.iters >= 64) { B.bnew = fmin(fmax(hi, beta + 1e-9), 1.0); B.done = 1; }   // smc.rs:620-621
     return B;
 }
