@@ -54,3 +54,11 @@ struct FgMhDev {
     const double *step_tab; uint32_t step_n;             // 1 / n^0.7 for n < step_n (DiminishingAdaptation's step, mcmc_utils.rs:118)
 };
 
+// the tile's site values <-> its LDS slot rows (slot row r of lane l: slots[r * tw]; `slots` already points at the lane)
+__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
+    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    slots[(P.n_slots - 1) * tw] = 0.0;                   // the always-zero slot (constant operands of fast opcodes)
+}
+__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
+    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[P.site_slot[j] * tw]);
+}

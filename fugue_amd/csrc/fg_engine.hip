@@ -808,7 +808,8 @@ void fg_engine_free(fg_engine *e) {
     if (e->smc_arena) hipFree(e->smc_arena);
     if (e->jit_mod) (void)hipModuleUnload(e->jit_mod);
     if (e->jit_mh_mod) (void)hipModuleUnload(e->jit_mh_mod);
-    void *ptrs[] = { e->d_jit_tab, e->d_jit_mh_tab, e->d_mhi_acc, e->d_mhi_site_ins, e->d_mwi_order, e->d_mwi_prof, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    if (e->jit_mhmw_mod) (void)hipModuleUnload(e->jit_mhmw_mod);
+    void *ptrs[] = { e->d_jit_tab, e->d_jit_mh_tab, e->d_jit_mhmw_tab, e->d_mhi_acc, e->d_mhi_site_ins, e->d_mwi_order, e->d_mwi_prof, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);
@@ -1405,7 +1406,7 @@ int fg_mh_step(fg_engine *e, int n_steps, const int32_t *h_rec_sites, int n_rec,
     }
     if (n_steps > 0) {                                                  // multi-wave tiles when every statement has a score-stream record
         const int rc = fg_mh_mw_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);
-        if (rc == FG_OK) { e->mh_iter += n_steps; e->last_mh_kernel = "k_mh_mw_steps"; return FG_OK; }
+        if (rc == FG_OK) { e->mh_iter += n_steps; return FG_OK; }
         if (rc != FG_E_UNSUPPORTED) return rc;
         const int rc2 = fg_mh_interp_launch(e, iter, n_steps, (n_rec > 0) ? (long long *)d_draws : (long long *)nullptr, first_sample_t);   // interpreter programs: statements split over waves
         if (rc2 == FG_OK) { e->mh_iter += n_steps; return FG_OK; }

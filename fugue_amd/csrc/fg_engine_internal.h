@@ -21,15 +21,6 @@
 // ======================================================================================
 // kernels
 // ======================================================================================
-__device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgChainCtx &X, long long c, double *slots, int tw) {
-    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
-    slots[(P.n_slots - 1) * tw] = 0.0;                   // the always-zero slot (constant operands of fast opcodes)
-}
-__device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
-    for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[P.site_slot[j] * tw]);
-}
-
-
 static __global__ void k_fill(double *p, long long n, double v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -92,6 +83,7 @@ struct fg_engine {
     int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; bool mhi_setup_done = false; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
     int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)
     hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr; std::string jit_log; bool jit_lds_attr = false; double *d_jit_tab = nullptr, *d_jit_mh_tab = nullptr;   // the modules' constant tables (fg_jit_bind_tables)
+    int jit_mhmw_state = 0; hipModule_t jit_mhmw_mod = nullptr; hipFunction_t jit_mhmw_fn = nullptr; double *d_jit_mhmw_tab = nullptr;   // ... the multi-wave stream MH kernel with phase B generated (fg_mh.hip)
     int jit_mh_state = 0, jit_mh_W = 1, jit_mh_direct = 0; size_t jit_mh_lds = 0; hipModule_t jit_mh_mod = nullptr; hipFunction_t jit_mh_fn[2] = {nullptr, nullptr};   // ... and its MH kernel (128- and 256-VGPR builds)
     std::string last_mh_kernel;  // kernel the last fg_mh_step launch ran (fg_mh_last_kernel)
     int mw_override = 0;       // FG_HMC_WAVES env: force waves per tile of the multi-wave HMC kernel (tests)
@@ -165,6 +157,7 @@ int fg_internal_mh_set_overrides(fg_engine *e, const fg_site_proposal *overrides
 }
 
 // fg_mh_interp.hip: multi-wave single-site MH for interpreter programs (FG_E_UNSUPPORTED: not applicable)
+long long fg_mhi_ins_cost(const FgIns &in);   // relative cost of an instruction (statement splits)
 int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t);
 
 // fg_mh.hip: multi-wave single-site MH for programs with a score stream (FG_E_UNSUPPORTED: not applicable)

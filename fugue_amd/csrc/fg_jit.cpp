@@ -81,6 +81,8 @@ struct Gen {
     // meanwhile); everything that is not a plate runs on wave 0 alone.  The accumulators are wave 0's.
     bool coop = false;
     bool ring_term = false;                      // the statement being emitted writes its term to ring row (buf * CH + rr)
+    const std::vector<int> *rows = nullptr;      // TM mode: term row of statement k when it is not k itself (the multi-wave stream kernel's rows: log_prior
+                                                 // terms first, then log_likelihood terms)
 
     std::string lit(double v) {
         if (!cvec) return ::lit(v);
@@ -110,8 +112,9 @@ struct Gen {
     void add(const std::string &s) { body += "    " + s + "\n"; }
     std::string term_row() {                     // the LDS row of the statement being emitted (TM mode); a rolled run emits ONE statement for R rows
         if (ring_term) return "ring[(buf * FG_JIT_CH + rr) * FG_WAVE]";
-        if (rolled_term) return "terms[(" + std::to_string(term) + " + r) * FG_WAVE]";
-        return "terms[" + std::to_string(term++) + " * FG_WAVE]";
+        if (rolled_term) return "terms[(" + std::to_string(rows ? (*rows)[(size_t)term] : term) + " + r) * FG_WAVE]";
+        const int k = term++;
+        return "terms[" + std::to_string(rows ? (*rows)[(size_t)k] : k) + " * FG_WAVE]";
     }
     static bool ends_statement(const FgIns &I) {
         const uint32_t code = FG_INS_OPCODE(I.op);
@@ -154,6 +157,11 @@ struct Gen {
                 for (size_t q = st[i].b; q < st[i].e; ++q) ins(v[q]);
                 if (coop) add("}");
                 i += 1; continue;
+            }
+            if (term >= 0 && rows) {                                          // a rolled run writes rows ROW0 + r: they must be consecutive
+                bool consecutive = true;
+                for (size_t q = 1; q < R; ++q) consecutive = consecutive && (*rows)[(size_t)term + q] == (*rows)[(size_t)term] + (int)q;
+                if (!consecutive) { for (size_t s2 = i; s2 < j; ++s2) for (size_t q = st[s2].b; q < st[s2].e; ++q) ins(v[q]); i = j; continue; }
             }
             const bool share = coop && R >= 16;                               // a plate long enough to share between the waves
             // one statement's code with its constants as c[0 .. K); every statement's constants into the table, in the same order
@@ -512,6 +520,72 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
     return src;
 }
 
+// The generated translation unit of the multi-wave MH kernel of a score-stream program (fg_mh_mw_body.h: pipelined random numbers, control
+// wave, in-order sums, the operand-pattern runs of plain Normal records -- all of it the hand-written kernel's) with the GENERAL
+// records of phase B (generated[k] != 0: statement k's log-density term into its LDS row) as FG_JIT_NSEG generated statement
+// segments instead of fg_score_one over the record stream.
+std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out) {
+    constexpr int NSEG = 16;
+    std::map<std::string, std::string> lp_fns;
+    FgJitTabs ctabs;
+    std::vector<std::string> tables;
+    std::vector<int> stmt_end;
+    for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) stmt_end.push_back(k + 1);
+    const int n_stmt = (int)stmt_end.size();
+    if (n_stmt < 1 || stmt_end.back() != p->n_ins || n_stmt != p->n_sstream || (int)generated.size() != n_stmt) return "";     // one record per statement, in program order
+    std::vector<int> rows((size_t)n_stmt);
+    for (int k = 0; k < n_stmt; ++k) rows[(size_t)k] = (int)p->sstream[(size_t)k].coord;
+    std::vector<long long> cum((size_t)n_stmt + 1, 0);
+    for (int k = 0, i = 0; k < n_stmt; ++k) {             // work before statement k (the generated statements only)
+        long long cs = 0; for (; i < stmt_end[(size_t)k]; ++i) cs += ins_cost[(size_t)i];
+        cum[(size_t)k + 1] = cum[(size_t)k] + (generated[(size_t)k] ? cs : 0);
+    }
+    if (cum[(size_t)n_stmt] == 0) return "";
+    auto ins_at = [&](int k) { return (size_t)(k > 0 ? stmt_end[(size_t)k - 1] : 0); };
+    std::string fns;
+    int s_at = 0;
+    for (int sg = 0; sg < NSEG; ++sg) {
+        int s_to = n_stmt;
+        if (sg + 1 < NSEG) { const long long target = cum[(size_t)n_stmt] * (sg + 1) / NSEG; s_to = s_at; while (s_to < n_stmt && cum[(size_t)s_to] < target) ++s_to; }
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.rows = &rows; g.ctabs = &ctabs;
+        for (int k = s_at; k < s_to;) {                   // maximal runs of generated statements (plates roll within a run)
+            if (!generated[(size_t)k]) { ++k; continue; }
+            int k2 = k; while (k2 < s_to && generated[(size_t)k2]) ++k2;
+            g.term = k;
+            g.emit(p->ins_fast, ins_at(k), ins_at(k2));
+            k = k2;
+        }
+        if (!g.ok) return "";
+        fns += "static __device__ __noinline__ void fg_jit_mhb_" + std::to_string(sg) + "(const double *slots, double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+               "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
+        s_at = s_to;
+    }
+    fns += "static __device__ __forceinline__ void fg_jit_mhb(int sg, const double *slots, double *terms) {\n    switch (sg) {\n";
+    for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_mhb_" + std::to_string(sg) + "(slots, terms); break;\n";
+    fns += "    default: break;\n    }\n}\n";
+    std::string src = PROLOGUE;
+    src += FG_JIT_EMBED_API;
+    src += FG_JIT_EMBED_HEAD;
+    src += FG_JIT_EMBED_INTERP;                  // fg_interp.h (fg_gradstream.h builds on it)
+    src += FG_JIT_EMBED_GRADSTREAM;              // fg_gradstream.h: fg_score_one for the control wave's undecided-kind probes, the in-order sums
+    src += HELPERS;
+    for (const std::string &t : tables) src += t + "\n";
+    for (const auto &kv : lp_fns) src += kv.second;
+    src += fns;
+    bool all = true;
+    for (char gch : generated) all = all && gch != 0;
+    if (all) src += "#define FG_MHMW_ALL 1\n";
+    src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
+           "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, slots, terms); } while (0)\n";
+    src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
+    src += "extern \"C\" __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_jit_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps,\n"
+           "        int n_warmup, long long *draws, int first_sample_t, int exp_mask, int pool_n) {\n"
+           "    fg_mh_mw_body<" + std::to_string(rk) + ", " + (split ? "true" : "false") + ">(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);\n}\n";
+    if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
+    if (ctab_out) *ctab_out = ctabs.data;
+    return src;
+}
+
 // ---- the compiler -----------------------------------------------------------------------------------------------------------
 // Two ways to the same code object.  In-process: hiprtc, bound with dlopen beside the HIP runtime in use.  Out-of-process: `hipcc --genco`
 // of the system ROCm as a child process with a clean environment.  The second exists because a host process may run on a HIP runtime
@@ -659,6 +733,17 @@ int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string
 extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long long src_cap, char *log_out, long long log_cap, long long *code_bytes) {
     if (!p) return FG_E_BAD_ARG;
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
+    if (std::getenv("FG_DEBUG_JIT_MHMW")) {                                // the multi-wave stream MH unit
+        const std::string s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr);
+        if (src_out && src_cap > 0) std::snprintf(src_out, (size_t)src_cap, "%s", s2.c_str());
+        if (code_bytes) *code_bytes = 0;
+        if (s2.empty()) return FG_E_UNSUPPORTED;
+        std::vector<char> code2; std::string log2;
+        const int rc2 = fg_jit_compile(s2, code2, log2);
+        if (log_out && log_cap > 0) std::snprintf(log_out, (size_t)log_cap, "%s", log2.c_str());
+        if (code_bytes) *code_bytes = (long long)code2.size();
+        return rc2;
+    }
     const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;

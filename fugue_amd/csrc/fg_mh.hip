@@ -24,377 +24,14 @@
 #include "fg_engine_internal.h"
 #include "fg_gradstream.h"
 #include "fg_cold.h"
+#include "fg_jit.h"
 
-#define FG_MH_WMAX 16
+#include "fg_mh_mw_body.h"
 
-// FG_MH_PROF (experiment builds, tools/prof_mh_phases.py): cycles tile 0's waves spend in each part of a step
-#ifdef FG_MH_PROF
-__device__ unsigned long long fg_mh_prof[FG_MH_WMAX][8];
-#define FG_PROF_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); prof_[i] += now_ - tprev_; tprev_ = now_; }
-#else
-#define FG_PROF_T(i)
-#endif
-
-// records [r0, r1) of the score stream at the current tile state -> term rows (row = the record's `coord` field).  Records
-// are fetched two ahead into three rotating 16-SGPR buffers (the loop is unrolled by three so that no buffer is ever
-// copied), operands one ahead; s_waitcnt by hand (SMEM returns out of order).
-#ifdef FG_EXP_MH_NOFETCH      /* timing experiments only (tools/exp_mh_terms.sh): results are wrong */
-#define FG_MH_FETCH(RC) RC = fg_fetch_grec(g, r0 + ((k + 2) & 1));
-#else
-#define FG_MH_FETCH(RC) RC = fg_fetch_grec(g, k + 2);
-#endif
-// PAT = operand pattern of a run of plain Normal records with sigma = 2^k (the host sorts them together): 1 x and mu are sites,
-// 2 x is a constant (an observation), 3 mu is a constant; 0 = any record (fg_score_one).  A pattern run reads only the
-// operands that are sites and forms -0.5 z z - ln sigma as one fma with an exact product (the rounding of the reference's two
-// operations, fg_hmc_sep.hip).  It leaves out the "z != z -> -inf" select of the scoring kernels: a NaN term (only inf - inf
-// operands produce one) makes log_alpha NaN, a -inf term makes it -inf, and both reject (mh.rs:733: `log_alpha >= 0 || u <
-// exp(log_alpha)` is false either way) -- the term rows are rewritten by the next step and never stored.  The same holds
-// for z z in [2^1024, 2^1025), where the fused form is -inf and the reference's finite but below -2^1023.
-#ifdef FG_EXP_MH_NOLDS
-#define FG_MH_OPND(RB, XB, MB) XB = xa; MB = ma;
-#else
-#define FG_MH_OPND(RB, XB, MB) if (PAT != 2) XB = slots[RB[0] * tw]; if (PAT != 3) MB = slots[RB[1] * tw];
-#endif
-#define FG_MH_TSTAGE(RA, XA, MA, RB, XB, MB, RC)                                                  \
-    __builtin_amdgcn_s_waitcnt(0xc07f);                                                           \
-    FG_MH_FETCH(RC)                                                                               \
-    FG_MH_OPND(RB, XB, MB)                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if (PAT == 0) { FgAcc3 dummy = {0.0, 0.0, 0.0}; terms[RA[3] * tw] = fg_score_one<RK>(RA, XA, MA, pool, slots, tw, dummy, lane_pool); } \
-    else {                                                                                        \
-        const double x_ = PAT == 2 ? fg_dbl(RA[4], RA[5]) : XA, m_ = PAT == 3 ? fg_dbl(RA[6], RA[7]) : MA; \
-        const double z_ = (x_ - m_) * fg_dbl(RA[10], RA[11]);                                     \
-        terms[RA[3] * tw] = __builtin_fma(-0.5, z_ * z_, -fg_dbl(RA[12], RA[13])) - 0.5 * FG_LN_2PI; \
-    }                                                                                             \
-    if (++k >= r1) break;
-template <int RK, int PAT = 0>
-__device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, const double *pool, const double *lane_pool, const double *slots, int tw, double *terms) {
-    if (r0 >= r1) return;
-    fg_u32x16 ra = fg_fetch_grec(g, r0), rb = fg_fetch_grec(g, r0 + 1), rc;
-    double xa = 0.0, ma = 0.0, xb = 0.0, mb = 0.0, xc = 0.0, mc = 0.0;
-    if (PAT != 2) xa = slots[ra[0] * tw];
-    if (PAT != 3) ma = slots[ra[1] * tw];
-    int k = r0;
-    for (;;) {
-        FG_MH_TSTAGE(ra, xa, ma, rb, xb, mb, rc)
-        FG_MH_TSTAGE(rb, xb, mb, rc, xc, mc, ra)
-        FG_MH_TSTAGE(rc, xc, mc, ra, xa, ma, rb)
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-}
-
-// Phase B works on a KIND-SORTED copy of the score stream: every record writes its own term row and the in-order sums are
-// the control wave's, so the order in which the terms are evaluated is free.  Sorted by kind, four records of one kind are
-// evaluated together in straight-line code -- their LDS round trips (operands; for an option select the option entry, then
-// the slot it names; for a Categorical table the entry) overlap instead of following each other record by record, which is
-// what a step of a mixture model waited for (C5: +15 %).
-//   class 0  Normal(x; options[z], sigma = 2^k)     class 1  Categorical site with a constant table
-//   classes 2, 3, 4  plain Normals with sigma = 2^k by operand pattern (site / site, constant x, constant mu) and
-//   class 5  everything else: the pipelined one-at-a-time loop of fg_mh_terms (plain Normals measured faster there than four
-//            at a time: the loop fetches records two ahead, a group of four waits for its own)
-#define FG_MH_NCLS 6
-struct FgMhSeg { int r[FG_MH_NCLS][FG_MH_WMAX + 1]; };   // records [r[c][w], r[c][w + 1]) of the sorted stream are wave w's share of class c
-
-// Four records of class 0 (CLS = 0) or class 1 at the tile's state -> their term rows.  `tab`: the constant pool -- the LDS copy
-// when the kernel staged it (the call sites pass the shared-memory pointer itself, so the lookups are ds_reads), else global.
-//   class 0: x is the observation (the record's immediate), mu = the site named by option z of a list of sites; an index
-//            outside the list makes mu NaN (fg_nsel_mu_lane) and the term NaN where the scoring kernels write -inf: both
-//            reject (see FG_MH_TSTAGE) and the rows are rewritten by the next step;
-//   class 1: ln p[z] from the table's precomputed logarithms, -inf outside it (distribution.rs:785-791).
-template <int CLS>
-__device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend, const double *tab, const double *slots, int tw, double *terms) {
-    fg_u32x16 r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = fg_fetch_grec(g, k + i < kend ? k + i : kend - 1);   // a short group repeats its last record (same term, same row)
-    __builtin_amdgcn_sched_barrier(0);                         // the four scalar fetches are in flight together
-    double zs[4], lp[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) zs[i] = slots[r[i][CLS == 0 ? 1 : 0] * tw];                 // the index site
-    __builtin_amdgcn_sched_barrier(0);                         // ... and so are the operand reads
-    bool ok[4];
-    if (CLS == 0) {
-        uint32_t sl[4]; double v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned long long zi = (unsigned long long)fg_as_i64(zs[i]);
-            ok[i] = zi < (unsigned long long)r[i][7];                                        // 0 <= z < K
-            sl[i] = ((const uint32_t *)(tab + r[i][6]))[4 * (ok[i] ? (uint32_t)zi : 0u)];   // option entry {u32 slot, u32 is_const = 0, f64 unused}
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = slots[sl[i] * tw];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const double m = ok[i] ? v[i] : NAN;
-            const double z = (fg_dbl(r[i][4], r[i][5]) - m) * fg_dbl(r[i][10], r[i][11]);
-            lp[i] = __builtin_fma(-0.5, z * z, -fg_dbl(r[i][12], r[i][13])) - 0.5 * FG_LN_2PI;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned long long zi = (unsigned long long)fg_as_i64(zs[i]);
-            const uint32_t base = r[i][6], K = r[i][7];
-            ok[i] = zi < (unsigned long long)K;
-            lp[i] = tab[base + K + (ok[i] ? (uint32_t)zi : 0u)];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lp[i] = ok[i] ? lp[i] : FG_NEG_INF;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) terms[r[i][3] * tw] = lp[i];
-}
-
-template <int RK, bool SPLIT /* the two in-order sums on two waves */>
-__global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt /* the kind-sorted score stream */, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
-                                                                           long long *draws, int first_sample_t, int exp_mask /* bits 1, 2, 4, 8: timing experiments only (FG_MH_EXP; results are wrong); 32: no wave priorities (A/B); 64: phase-B priority */,
-                                                                           int pool_n /* > 0: the constant pool (pool_n doubles) is staged into LDS behind the exchange rows */) {
-    extern __shared__ double lds[];
-    constexpr int tw = FG_WAVE;
-    const int lane = threadIdx.x & (FG_WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = (int)(blockDim.x >> 6);
-    const long long chain = (long long)blockIdx.x * tw + lane;
-    const bool live = chain < X.C;
-    const long long c = live ? chain : X.C - 1;
-    const int n_s = P.n_sstream, n_pri = P.n_prior_terms, n_lik = n_s - n_pri;
-    double *slots = lds + lane;
-    double *terms = lds + (long long)P.n_slots * tw + lane;
-    // exchange rows, double-buffered by step parity (8 rows each; row 16: the log_likelihood sum on its way to the control wave):
-    // 0 target site, 1 gaussian_z, 2 u(block 1), 3 u(block 2),
-    // 4 {LDS slot, value type} of the target, 5 Categorical targets: {pool base, K} of the constant table, 6 their proposed
-    // index, 7 its prior log-probability
-    double *xch = terms + (long long)n_s * tw;
-    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
-    const bool b_prio = wv != 0 && (exp_mask & 64) != 0;
-    const int rng_wave = W - 1;
-    const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
-
-    // small constant pools (Categorical tables, option lists) are read per lane: from the LDS copy a lookup costs an LDS round
-    // trip instead of a vector-memory one
-    double *pool_l = lds + (long long)(P.n_slots + n_s + 17) * tw;
-    auto pool_rd = [&](int idx) __attribute__((always_inline)) { return pool_n > 0 ? pool_l[idx] : P.pool[idx]; };
-
-    // Everything of step `it` that does not depend on the chain's state -> buffer (it & 1).
-    //   part 0: gen_range target (mh.rs:716) with its site-table entries, the uniform of block 1 and -- for a Categorical
-    //           target -- the index resampled from the constant prior table with its prior log-probability (mh.rs:516-530);
-    //   part 1: gaussian_z (mh.rs:128-132) from block 1 and the accept uniform of block 2.
-    // With W >= 3 the two parts run on two waves (block 1 is then generated twice: the parts stay independent).
-    auto publish_rng = [&](int it, int part) __attribute__((always_inline)) {
-        double *b = xch + (long long)(8 * (it & 1)) * tw;
-        FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
-        unsigned long long ra, rb;
-        if (part == 0) {
-            rng.c1 = 0; fg_rng_block(rng, ra, rb);
-            const int tg = (int)fg_pick(ra, (uint32_t)P.S);
-            const int ts = P.site_slot[tg], tvv = P.site_vtype[tg];               // per-lane gathers of small tables
-            const int cb = P.site_cat[2 * tg], cK = P.site_cat[2 * tg + 1];
-            rng.c1 = 1; fg_rng_block(rng, ra, rb);
-            const double u1 = fg_u01_of(ra);
-            b[0] = fg_as_double((long long)tg);
-            b[2 * tw] = u1;
-            b[4 * tw] = fg_as_double((long long)(uint32_t)ts | ((long long)tvv << 32));
-            b[5 * tw] = fg_as_double((long long)(uint32_t)cb | ((long long)cK << 32));
-            if (tvv == 3 && cK > 0) {                                  // first index whose cumulative probability reaches u, clamped (distribution.rs:771-784)
-                double cum = 0.0; int idx = cK;
-                for (int i0 = 0; i0 < cK; i0 += 4) {                  // four table entries in flight
-                    double pv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pv[q] = (i0 + q < cK) ? pool_rd(cb + i0 + q) : 0.0;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (i0 + q < cK) { cum += pv[q]; if (idx == cK && !(cum < u1)) idx = i0 + q; }
-                }
-                const int prop = idx < cK - 1 ? idx : cK - 1;
-                b[6 * tw] = fg_as_double((long long)prop);
-                b[7 * tw] = pool_rd(cb + cK + prop);                  // the table's precomputed ln p (-inf for p <= 0)
-            }
-        } else {
-            rng.c1 = 1; fg_rng_block(rng, ra, rb);
-            b[tw] = fg_cold_gaussian_z(ra, rb);
-            rng.c1 = 2; fg_rng_block(rng, ra, rb);
-            b[3 * tw] = fg_u01_of(ra);
-        }
-    };
-
-    // ---- control-wave state
-    double lw = 0.0, old_cell = 0.0, lqf = 0.0, lqr = 0.0, scale = 1.0, u_acc = 0.0;
-    int tslot = 0, kind0 = 0, kind_new = 0;
-    long long g = 0;
-    unsigned long long nacc = 0;
-
-    if (wv == 0) {
-        fg_load_values(P, X, c, slots, tw);
-        lw = M.lw[c];
-        // the control wave's instruction stream is the path of its tile: it is served before the term and random-number waves
-        // of the tiles it shares a SIMD with (exp_mask bit 32 switches this off: A/B)
-        if (!(exp_mask & 32)) __builtin_amdgcn_s_setprio(2);
-    }
-    for (int k = (int)threadIdx.x; k < pool_n; k += (int)blockDim.x) pool_l[k] = P.pool[k];
-    if (pool_n > 0) __syncthreads();                               // the random-number waves read the staged tables below
-    if (wv == rng_wave) { publish_rng(iter0, 0); if (n_steps > 1) publish_rng(iter0 + 1, 0); }
-    if (wv == rng_wave1) { publish_rng(iter0, 1); if (n_steps > 1) publish_rng(iter0 + 1, 1); }
-    // this wave's share of every record class, read once (indexing the kernel argument by the wave number inside the step loop
-    // is a scalar-memory round trip per class per step)
-    // -- for the instantiations with lookup classes, whose phase B is a chain of round trips; the fast-Normal one measured faster
-    // re-reading its three bounds than keeping them (it is short of scalar registers)
-    int sa_[FG_MH_NCLS], sb_[FG_MH_NCLS];
-#pragma unroll
-    for (int q = 0; q < FG_MH_NCLS; ++q) { sa_[q] = RK == 0 ? 0 : seg.r[q][wv]; sb_[q] = RK == 0 ? 0 : seg.r[q][wv + 1]; }
-#define sa(q) (RK == 0 ? seg.r[q][wv] : sa_[q])
-#define sb(q) (RK == 0 ? seg.r[q][wv + 1] : sb_[q])
-    __syncthreads();
-#ifdef FG_MH_PROF
-    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_readcyclecounter();
-#endif
-    for (int t = 0; t <= n_steps; ++t) {
-        const int iter = iter0 + t;
-        // ---- phase A
-        // the next proposal's inputs first: its adaptation state comes from HBM / L2 while step t - 1 is being finished
-        const double *b = xch + (long long)(8 * (iter & 1)) * tw;
-        int n_target = 0, n_tslot = 0; uint32_t n_tv = 0u; long long n_g = 0;
-        double n_scale = 1.0; int n_kind = 0;
-        const bool do_prop = t < n_steps && !(exp_mask & 4);
-#define FG_MH_NEXT_INPUTS                                                                                                   \
-        if (do_prop) {                                                                                                      \
-            n_target = (int)fg_as_i64(b[0]);                                                                                \
-            const long long st = fg_as_i64(b[4 * tw]);                                                                      \
-            n_tslot = (int)(uint32_t)st; n_tv = (uint32_t)(st >> 32);                                                       \
-            n_g = (long long)n_target * X.C + c;                                                                            \
-            const fg_u32x4 a0 = *(const fg_u32x4 *)(M.ad + n_g);           /* {scale, kind}: get_scale  mcmc_utils.rs:70-77 */ \
-            n_scale = fg_dbl(a0[0], a0[1]);                                                                                 \
-            n_kind = (int)a0[2];                                                                                            \
-        }
-        // log_prior and log_likelihood of step t - 1's proposal: the terms in program order.  SPLIT (long programs): one chain per
-        // wave -- a wave alone on its tile's path issues an instruction every 6 to 9 cycles
-        // (profiles/round1_f64_issue_microbench.txt), so the two independent sums run side by side on two waves and meet at a barrier
-        double pri = 0.0, lik = 0.0;
-        if (SPLIT) {
-            if (wv == 0) { FG_MH_NEXT_INPUTS }
-            if (t > 0 && !(exp_mask & 2)) {
-                if (wv == 0) pri = fg_inorder_sum1(terms, n_pri, tw);
-                else if (wv == 1) xch[16 * tw] = fg_inorder_sum1(terms + (long long)n_pri * tw, n_lik, tw);
-                // LDS only crosses this barrier: wait for the LDS counter and leave the control wave's adaptation-state gather (64
-                // lines from L2, issued above) in flight -- __syncthreads() would drain it here
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_s_barrier();
-                if (wv == 0) lik = xch[16 * tw];
-            }
-        }
-        if (wv == 0) {
-            if (!SPLIT) {                                                  // short programs: both chains on the control wave, no third barrier
-                FG_MH_NEXT_INPUTS
-                if (t > 0 && !(exp_mask & 2)) fg_inorder_sums2(terms, n_pri, terms + (long long)n_pri * tw, n_lik, tw, pri, lik);
-            }
-#undef FG_MH_NEXT_INPUTS
-            if (t > 0 && !(exp_mask & 2)) {                                // finish step t - 1
-                const int itp = iter - 1;
-                const bool adapt = itp < n_warmup;
-                FG_PROF_T(0)
-                const double prop_lw = pri + lik + 0.0;                    // total_log_weight (no factor statement has a record)
-                const double log_alpha = prop_lw - lw + (lqr - lqf);       // + dim_term == 0 (fixed structure)  mh.rs:731-732
-                const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
-                double sc = scale;
-                if (adapt) {                                               // DiminishingAdaptation::update  mcmc_utils.rs:88-150
-                    const fg_u32x4 a1 = *(const fg_u32x4 *)((const char *)(M.ad + g) + 16);   // {log_scale, total, accepted}
-                    const uint32_t tot = a1[2] + 1u;
-                    const uint32_t acn = a1[3] + (accept ? 1u : 0u);
-                    double ls = fg_dbl(a1[0], a1[1]);
-                    if (tot >= 10u) { const FgD2 r = fg_cold_mh_adapt(ls, acn, tot, M.step_tab, M.step_n); sc = r.a; ls = r.b; }
-                    if (live) {
-                        const unsigned long long lb = (unsigned long long)__double_as_longlong(ls);
-                        const fg_u32x4 w1 = { (uint32_t)lb, (uint32_t)(lb >> 32), tot, acn };
-                        *(fg_u32x4 *)((char *)(M.ad + g) + 16) = w1;
-                        M.ad[g].scale = sc;
-                    }
-                }
-                if (live && kind_new != kind0) M.ad[g].kind = kind_new;
-                if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
-                else slots[tslot * tw] = old_cell;
-                if ((!adapt || M.rec_all) && draws && live) {              // recorded cells of the CURRENT state (mh.rs:1010)
-                    long long *row = draws + (long long)(t - 1 - first_sample_t) * M.n_rec * X.C + c;
-                    for (int r = 0; r < M.n_rec; ++r) row[(long long)r * X.C] = fg_as_i64(slots[M.rec[r] * tw]);
-                }
-                // the state fetched above is stale where the next proposal hits the site just updated
-                if (do_prop && n_g == g) { n_scale = sc; n_kind = kind_new; }
-            }
-            FG_PROF_T(1)
-            if (do_prop) {                                                 // proposal of step t (mh.rs:183-294, 516-530, 557-567)
-                FgMhCtx mh;
-                mh.z = b[tw];
-                const double u1 = b[2 * tw], u2 = b[3 * tw];
-                g = n_g; tslot = n_tslot;
-                mh.target = tslot; mh.scale = n_scale; mh.kind = n_kind;
-                kind0 = n_kind;
-                mh.next_block = 2;
-                mh.lqf = 0.0; mh.lqr = 0.0;
-                mh.ov_kind = M.ov_kind; mh.ov_lo = M.ov_lo; mh.ov_hi = M.ov_hi;
-                mh.old_cell = slots[tslot * tw];
-                const uint32_t tv = n_tv;
-                int kind_eff = FG_PROP_AUTO;
-                if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
-                // f64_kind (mh.rs:339-358): an undecided site is LogSpace iff its current value is positive and its prior density
-                // at -1.0 is -inf.  Lanes hold different sites: one pass per distinct undecided site in the wave (transient -- a
-                // kind is decided once per (site, chain)).
-                const bool undecided = tv == 0u && kind_eff == FG_PROP_AUTO;
-                unsigned long long todo = __ballot(undecided);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int tl = __builtin_amdgcn_readlane(n_target, leader);
-                    const unsigned long long same = __ballot(undecided && n_target == tl);
-                    const fg_u32x16 r = fg_fetch_grec(P.sstream, P.site_rec[tl]);
-                    FgAcc3 dummy = {0.0, 0.0, 0.0};
-                    const double probe = fg_score_one<RK>(r, -1.0, slots[r[1] * tw], P.pool, slots, tw, dummy);
-                    if (undecided && n_target == tl) { kind_eff = (mh.old_cell > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN; mh.kind = kind_eff; }
-                    todo &= ~same;
-                }
-                if (tv == 3u) {                               // usize target: the index resampled from the constant prior table (mh.rs:516-530)
-                    const long long ct = fg_as_i64(b[5 * tw]);
-                    const int cat_base = (int)(uint32_t)ct, cat_K = (int)(ct >> 32);
-                    const long long prop = fg_as_i64(b[6 * tw]);
-                    const long long cur = fg_as_i64(mh.old_cell);
-                    mh.lqf += b[7 * tw];                                   // prior log-probabilities of the proposed and the current index
-                    mh.lqr += (cur < 0 || cur >= (long long)cat_K) ? FG_NEG_INF : pool_rd(cat_base + cat_K + (int)cur);
-                    mh.next_block = 2;
-                    slots[tslot * tw] = fg_as_double(prop);
-                } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
-                old_cell = mh.old_cell; lqf = mh.lqf; lqr = mh.lqr; scale = mh.scale; kind_new = mh.kind;
-                u_acc = mh.next_block == 1 ? u1 : u2;                      // the accept uniform's block (mh.rs:733)
-            }
-        } else if (t > 0 && t + 1 < n_steps && !(exp_mask & 8)) {          // buffer (iter + 1) & 1 was last read in phase A of step t - 1
-            if (wv == rng_wave) publish_rng(iter + 1, 0);
-            if (wv == rng_wave1) publish_rng(iter + 1, 1);
-        }
-        if (t == n_steps) break;
-        FG_PROF_T(2)
-        __syncthreads();                                                   // the proposal is in the tile; random numbers of step t + 1 published
-        FG_PROF_T(3)
-        // ---- phase B: every wave scores its share of the statements (on the step's path: ahead of other tiles' random-number waves)
-        if (b_prio) __builtin_amdgcn_s_setprio(1);
-        if (!(exp_mask & 1)) {
-            if (RK >= 2) {
-                if (pool_n > 0) {
-                    for (int k = sa(0); k < sb(0); k += 4) fg_mh_group4<0>(srt, k, sb(0), pool_l, slots, tw, terms);
-                    for (int k = sa(1); k < sb(1); k += 4) fg_mh_group4<1>(srt, k, sb(1), pool_l, slots, tw, terms);
-                } else {
-                    for (int k = sa(0); k < sb(0); k += 4) fg_mh_group4<0>(srt, k, sb(0), P.pool, slots, tw, terms);
-                    for (int k = sa(1); k < sb(1); k += 4) fg_mh_group4<1>(srt, k, sb(1), P.pool, slots, tw, terms);
-                }
-            }
-            fg_mh_terms<RK, 1>(srt, sa(2), sb(2), P.pool, nullptr, slots, tw, terms);
-            fg_mh_terms<RK, 2>(srt, sa(3), sb(3), P.pool, nullptr, slots, tw, terms);
-            fg_mh_terms<RK, 3>(srt, sa(4), sb(4), P.pool, nullptr, slots, tw, terms);
-            if (RK != 0 && pool_n > 0) fg_mh_terms<RK>(srt, sa(5), sb(5), P.pool, pool_l, slots, tw, terms);
-            else fg_mh_terms<RK>(srt, sa(5), sb(5), P.pool, nullptr, slots, tw, terms);
-        }
-        FG_PROF_T(4)
-        if (b_prio) __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-        FG_PROF_T(5)
-    }
-#ifdef FG_MH_PROF
-    if (blockIdx.x == 0 && lane == 0) for (int q = 0; q < 8; ++q) fg_mh_prof[wv][q] = prof_[q];
-#endif
-    if (wv == 0 && live) { M.lw[c] = lw; M.n_acc[c] += nacc; }
-#undef sa
-#undef sb
+template <int RK, bool SPLIT>
+__global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
+                                                                           long long *draws, int first_sample_t, int exp_mask, int pool_n) {
+    fg_mh_mw_body<RK, SPLIT>(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);
 }
 
 int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
@@ -466,6 +103,40 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
     const int split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
+    // the program compiled at run time (fg_jit.cpp): the same kernel with the general records (class 5: fg_score_one over the record)
+    // as sixteen generated statement segments; where they are the minority the operand-pattern classes stay the hand-written
+    // runs, which are shorter than what the generator writes for them (reference_model(20), all pattern records: 2.08e10
+    // hand-written, 1.57e10 generated; C5, 8 general records of 136: 4.33e9 with the runs, 3.89e9 all generated)
+    if (e->jit_mhmw_state == 0) {
+        e->jit_mhmw_state = -1;
+        const char *sp = std::getenv("FG_JIT");
+        if ((!sp || std::atoi(sp) != 0) && !std::getenv("FG_MH_EXP") && p->ins_fast.size() <= 200000) {
+            std::vector<long long> cost((size_t)p->n_ins);
+            for (int k = 0; k < p->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(p->ins_fast[(size_t)k]);
+            std::vector<char> generated((size_t)n_s);
+            int n_gen = 0;
+            for (int k = 0; k < n_s; ++k) n_gen += (generated[(size_t)k] = cls_of(p->sstream[k]) == 5 ? 1 : 0);
+            // mostly general records: the few pattern records too (their runs' set-up costs more than the generated statements:
+            // linreg, 2 pattern records of 22: 2.49e10 all generated, 2.08e10 with the two runs, 1.66e10 hand-written)
+            if (2 * n_gen >= n_s) std::fill(generated.begin(), generated.end(), (char)1);
+            std::vector<double> ctab;
+            const std::string src = n_gen > 0 ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab) : std::string();
+            std::vector<char> code;
+            if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
+                hipModuleLoadData(&e->jit_mhmw_mod, code.data()) == hipSuccess &&
+                hipModuleGetFunction(&e->jit_mhmw_fn, e->jit_mhmw_mod, "k_mh_mw_jit_steps") == hipSuccess &&
+                hipFuncSetAttribute((const void *)e->jit_mhmw_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                fg_jit_bind_tables(e->jit_mhmw_mod, ctab, &e->d_jit_mhmw_tab, e->stream) == FG_OK) e->jit_mhmw_state = 1;
+            else { (void)hipGetLastError(); if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: multi-wave MH kernel not compiled at run time (%s)\n", e->jit_log.c_str()); }
+        }
+    }
+    if (e->jit_mhmw_state == 1) {
+        int n_warmup = e->mh_warmup;
+        void *args[] = { &e->P, &e->X, &e->M, &e->d_mh_srt, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t, &exp_mask, &pool_n };
+        HIPCHK(hipModuleLaunchKernel(e->jit_mhmw_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
+        e->last_mh_kernel = "k_mh_mw_jit_steps W=" + std::to_string(W) + " (statements compiled at run time)";
+        return FG_OK;
+    }
     static bool attr_set_dev[64][8];
     const int variant = 2 * (rk == 0 ? 0 : (rk == 2 ? 1 : 2)) + split_sums;
     const void *fns[6] = { (const void *)k_mh_mw_steps<0, false>, (const void *)k_mh_mw_steps<0, true>, (const void *)k_mh_mw_steps<2, false>,
@@ -484,6 +155,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     }
 #undef FG_MH_LAUNCH
     HIPCHK(hipGetLastError());
+    e->last_mh_kernel = "k_mh_mw_steps W=" + std::to_string(W);
     return FG_OK;
 }
 

@@ -27,7 +27,7 @@ void k_mh_interp_mw_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMh
 FG_MHI_KERNEL(2)
 FG_MHI_KERNEL(4)
 
-static long long mhi_ins_cost(const FgIns &in) {       // the weights of fg_hmc_interp.hip's split
+long long fg_mhi_ins_cost(const FgIns &in) {       // the weights of fg_hmc_interp.hip's split
     const uint32_t code = FG_INS_OPCODE(in.op);
     if (code == FG_OP_NORMAL_FAST) return 3;
     if (code < 17u) return (in.op & FG_F_HOISTED) ? 10 : 16;
@@ -77,7 +77,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         while (W > 1 && lds_for(W) > 160 * 1024) --W;
         if (W < 2) W = 0;                                    // more statements than LDS has term rows: only the compiled kernel's direct mode below can take it
         std::vector<long long> cum(n_stmt + 1, 0);           // work before statement k
-        for (int k = 0, i = 0; k < n_stmt; ++k) { long long cs = 0; for (; i < stmt_end[k]; ++i) cs += mhi_ins_cost(ins[i]); cum[k + 1] = cum[k] + cs; }
+        for (int k = 0, i = 0; k < n_stmt; ++k) { long long cs = 0; for (; i < stmt_end[k]; ++i) cs += fg_mhi_ins_cost(ins[i]); cum[k + 1] = cum[k] + cs; }
         e->mhi_ins_off.assign(FG_MHI_MAX + 1, n_ins); e->mhi_stmt_off.assign(FG_MHI_MAX + 1, n_stmt);
         e->mhi_ins_off[0] = 0; e->mhi_stmt_off[0] = 0;
         for (int w = 1, k = 0; w < W; ++w) {                 // contiguous runs of statements, cut nearest to w / W of the work
@@ -134,7 +134,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         if (const char *fo = std::getenv("FG_MH_INTERP_OCC")) occ = std::atoi(fo) <= 2 ? 2 : 4;
         if ((!sp || std::atoi(sp) != 0) && e->prog->ins_fast.size() <= 64000000 && lds <= 64 * 1024) {
             std::vector<long long> cost((size_t)e->prog->n_ins);
-            for (int k = 0; k < e->prog->n_ins; ++k) cost[(size_t)k] = mhi_ins_cost(e->prog->ins_fast[(size_t)k]);
+            for (int k = 0; k < e->prog->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(e->prog->ins_fast[(size_t)k]);
             std::vector<double> ctab;
             const std::string src = fg_jit_mh_source(e->prog, cost, occ, &ctab);
             std::vector<char> code;

@@ -133,6 +133,7 @@ def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypat
     C, nw, ns = 150, 120, 40
     rec = list(range(cp.S))
     out = []
+    monkeypatch.setenv("FG_JIT", "0")                                      # the hand-written phase B (the generated one: the next test)
     # (multi-wave kernel?, waves per tile, the two in-order sums on two waves? -- the engine picks that for programs of >= 64 statements)
     for mw, W, split in ((0, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (1, 2, 1), (1, 4, 1), (1, 16, 1)):
         monkeypatch.setenv("FG_MH_MW", str(mw))
@@ -145,6 +146,46 @@ def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypat
         eng.device_free(d)
         out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
         eng.close()
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["hier_scale", "linreg", "ridge7", "hier_mixed", "refmodel20", "mixture", "readme"])
+def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeypatch):
+    """The same kernel with the general records of its phase B (those fg_score_one evaluates; the operand-pattern runs of plain
+    Normal records stay hand-written) generated from the program and compiled at run time (fg_jit_mhmw_source; sixteen statement
+    segments dealt to the waves): the one-wave kernel's draws, state, scales, log-weights and accept counts, for every W.
+    Programs of pattern records only keep the hand-written kernel."""
+    if name == "hier_mixed":                            # pattern records (sigma = 1, 2) and general ones (sigma a site, sigma = 0.7) in one program
+        prog = M.Program()
+        tau = prog.sample(M.addr("tau"), M.Gamma(2.0, 1.5))
+        for i in range(6):
+            m = prog.sample(M.addr("m", i), M.Normal(0.0, 2.0 if i % 2 else 0.7))
+            prog.observe(M.addr("y", i), M.Normal(m, 1.0 if i < 3 else tau), 0.3 * i - 1.0)
+    else:
+        prog = ZOO[name]() if name in ZOO else W.reference_model(20)
+    cp = E.compile_model(prog)
+    C, nw, ns = 150, 120, 40
+    rec = list(range(cp.S))
+    out, kernels = [], []
+    for jit, mw, Wv, split in ((0, 0, 1, 0), (1, 1, 2, 0), (1, 1, 4, 1), (1, 1, 8, 0), (1, 1, 16, 1), (1, 1, 0, -1)):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        monkeypatch.setenv("FG_MH_MW", str(mw))
+        if Wv: monkeypatch.setenv("FG_HMC_WAVES", str(Wv))
+        else: monkeypatch.delenv("FG_HMC_WAVES", raising=False)
+        if split >= 0: monkeypatch.setenv("FG_MH_SPLIT", str(split))
+        else: monkeypatch.delenv("FG_MH_SPLIT", raising=False)
+        eng = E.Engine(cp, C, seed=13, chain_offset=3)
+        d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
+        st = eng.mh_run(ns, nw, None, rec, d)
+        draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
+        eng.device_free(d)
+        kernels.append(eng.mh_last_kernel())
+        out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
+        eng.close()
+    want = "k_mh_mw_steps" if name in ("refmodel20", "readme") else "k_mh_mw_jit_steps"
+    assert all(k.startswith(want) for k in kernels[1:]), kernels
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)

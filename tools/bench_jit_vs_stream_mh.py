@@ -1,4 +1,5 @@
-"""adaptive_mcmc_chain: the hand-written multi-wave stream kernel against the same program compiled at run time (FG_JIT=2)."""
+"""adaptive_mcmc_chain: the hand-written multi-wave stream kernel (FG_JIT=0) against the same kernel with its statements compiled
+at run time (default) and the statement-segment kernel compiled at run time (FG_JIT=2)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,13 +10,13 @@ for name, prog, sizes in [("refmodel20", W.reference_model(20), (65536, 8192)), 
     cp = E.compile_model(prog)
     for C in sizes:
         res = {}
-        for jit in (1, 2):
+        for jit in (0, 1, 2):
             os.environ["FG_JIT"] = str(jit)
             eng = E.Engine(cp, C, seed=1)
             eng.mh_init(200)
             eng.mh_step(200); eng.synchronize()
             t0 = time.perf_counter(); eng.mh_step(400); eng.synchronize(); dt = time.perf_counter() - t0
             res[jit] = (eng.get_values(), eng.mh_scales())
-            print(f"{name:12s} C={C:6d} {eng.mh_last_kernel():44s} {C * 400 / dt:.3e} chain-steps/s (sampling)", flush=True)
+            print(f"{name:12s} C={C:6d} {eng.mh_last_kernel()[:44]:44s} {C * 400 / dt:.3e} chain-steps/s (sampling)", flush=True)
             eng.close()
-        print("   bit-identical:", all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res[1], res[2])))
+        print("   bit-identical:", all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res[0], res[1])) and all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res[0], res[2])))
