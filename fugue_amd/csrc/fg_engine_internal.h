@@ -80,9 +80,10 @@ struct fg_engine {
     std::string last_hmc_kernel;   // kernel (and waves per tile) the last fg_hmc_step launch ran (fg_hmc_last_kernel)
     bool interp_mw_disabled = false;   // FG_HMC_INTERP_MW=0: keep interpreter programs on the one-wave-per-tile HMC kernel (A/B tests)
     int *d_mwi_order = nullptr; long long *d_mwi_prof = nullptr; std::vector<int> mwi_off; std::vector<long long> mwi_cost; int mwi_W = 0, mwi_sparse = -1, mwi_calibrated = 0;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
-    int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; bool mhi_setup_done = false; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
+    int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; bool mhi_setup_done = false; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr; std::vector<int> mhi_stmt_end; std::vector<unsigned char> mhi_acc_host;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
     int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)
     hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr; std::string jit_log; bool jit_lds_attr = false; double *d_jit_tab = nullptr, *d_jit_mh_tab = nullptr;   // the modules' constant tables (fg_jit_bind_tables)
+    int jit_mhns_state = 0, jit_mhns_split = 0; hipModule_t jit_mhns_mod = nullptr; hipFunction_t jit_mhns_fn = nullptr; double *d_jit_mhns_tab = nullptr;   // ... the same kernel for a program without a score stream
     int jit_mhmw_state = 0; hipModule_t jit_mhmw_mod = nullptr; hipFunction_t jit_mhmw_fn = nullptr; double *d_jit_mhmw_tab = nullptr;   // ... the multi-wave stream MH kernel with phase B generated (fg_mh.hip)
     int jit_mh_state = 0, jit_mh_W = 1, jit_mh_direct = 0; size_t jit_mh_lds = 0; hipModule_t jit_mh_mod = nullptr; hipFunction_t jit_mh_fn[2] = {nullptr, nullptr};   // ... and its MH kernel (128- and 256-VGPR builds)
     std::string last_mh_kernel;  // kernel the last fg_mh_step launch ran (fg_mh_last_kernel)
@@ -162,5 +163,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
 
 // fg_mh.hip: multi-wave single-site MH for programs with a score stream (FG_E_UNSUPPORTED: not applicable)
 int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t);
+int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t, const std::vector<int> &stmt_end,
+                             const std::vector<unsigned char> &acc, const int *d_site_ins);
 
 extern "C" int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj);

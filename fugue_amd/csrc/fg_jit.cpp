@@ -524,7 +524,8 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
 // wave, in-order sums, the operand-pattern runs of plain Normal records -- all of it the hand-written kernel's) with the GENERAL
 // records of phase B (generated[k] != 0: statement k's log-density term into its LDS row) as FG_JIT_NSEG generated statement
 // segments instead of fg_score_one over the record stream.
-std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out) {
+std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out,
+                               const std::vector<int> *rows_in, int n_pri, int n_fac) {
     constexpr int NSEG = 16;
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
@@ -532,9 +533,10 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     std::vector<int> stmt_end;
     for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) stmt_end.push_back(k + 1);
     const int n_stmt = (int)stmt_end.size();
-    if (n_stmt < 1 || stmt_end.back() != p->n_ins || n_stmt != p->n_sstream || (int)generated.size() != n_stmt) return "";     // one record per statement, in program order
+    if (n_stmt < 1 || stmt_end.back() != p->n_ins || (int)generated.size() != n_stmt) return "";
+    if (rows_in ? (int)rows_in->size() != n_stmt : n_stmt != p->n_sstream) return "";         // one record per statement, in program order
     std::vector<int> rows((size_t)n_stmt);
-    for (int k = 0; k < n_stmt; ++k) rows[(size_t)k] = (int)p->sstream[(size_t)k].coord;
+    for (int k = 0; k < n_stmt; ++k) rows[(size_t)k] = rows_in ? (*rows_in)[(size_t)k] : (int)p->sstream[(size_t)k].coord;
     std::vector<long long> cum((size_t)n_stmt + 1, 0);
     for (int k = 0, i = 0; k < n_stmt; ++k) {             // work before statement k (the generated statements only)
         long long cs = 0; for (; i < stmt_end[(size_t)k]; ++i) cs += ins_cost[(size_t)i];
@@ -575,6 +577,13 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     bool all = true;
     for (char gch : generated) all = all && gch != 0;
     if (all) src += "#define FG_MHMW_ALL 1\n";
+    if (rows_in) {
+        // a program without a score stream: the statement count and the log_prior rows are the unit's own; a proposal that needs the
+        // model comes from the target's OWN statement of the generic program, interpreted (fg_mh_mw_body.h: the kernel's `srt` argument
+        // is then the [S][2] table of first instruction and count)
+        if (!all) return "";
+        src += "#define FG_MHMW_NS " + std::to_string(n_stmt) + "\n#define FG_MHMW_NPRI " + std::to_string(n_pri) + "\n#define FG_MHMW_NFAC " + std::to_string(n_fac) + "\n";
+    }
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
            "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, slots, terms); } while (0)\n";
     src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
@@ -734,7 +743,18 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     if (!p) return FG_E_BAD_ARG;
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
     if (std::getenv("FG_DEBUG_JIT_MHMW")) {                                // the multi-wave stream MH unit
-        const std::string s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr);
+        std::string s2;
+        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0);
+        else {                                                             // a program without a score stream: rows in accumulator order (fg_mh_mw_nostream_launch)
+            std::vector<int> rows; int n_pri = 0, n_lik = 0, n_fac = 0;
+            for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) {
+                const uint32_t code = FG_INS_OPCODE(p->ins_fast[(size_t)k].op);
+                const int a = code == FG_OP_FACTOR ? 2 : ((p->ins_fast[(size_t)k].op & FG_F_OBSERVE) != 0 || code == FG_OP_CONSTLIK) ? 1 : 0;
+                rows.push_back(a); (a == 0 ? n_pri : a == 1 ? n_lik : n_fac) += 1;
+            }
+            for (int k = 0, a = 0, b = n_pri, c = n_pri + n_lik; k < (int)rows.size(); ++k) rows[(size_t)k] = rows[(size_t)k] == 0 ? a++ : rows[(size_t)k] == 1 ? b++ : c++;
+            s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>(rows.size(), 1), 3, rows.size() >= 64, nullptr, &rows, n_pri, n_fac);
+        }
         if (src_out && src_cap > 0) std::snprintf(src_out, (size_t)src_cap, "%s", s2.c_str());
         if (code_bytes) *code_bytes = 0;
         if (s2.empty()) return FG_E_UNSUPPORTED;

@@ -34,27 +34,92 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
     fg_mh_mw_body<RK, SPLIT>(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);
 }
 
-int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
-    if (e->gt) return FG_E_UNSUPPORTED;                       // tiles in global memory: the one-wave-per-tile kernels (fg_engine.hip)
-    if (!e->P.sstream || e->S < 1 || n_steps < 1 || e->mh_mw_disabled) return FG_E_UNSUPPORTED;
+// Launch shape of the multi-wave kernel for a program of n_s statements: LDS bytes, waves per tile, the experiment / priority mask,
+// whether the two in-order sums run on two waves.
+struct FgMhMwShape { size_t lds; int W, exp_mask, split_sums, pool_n; unsigned tiles; };
+static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape &sh) {
     const fg_program *p = e->prog;
-    // every site must take a model-independent proposal: Categorical sites need a constant table, no PriorResample override
-    if (e->mh_has_prior_resample) return FG_E_UNSUPPORTED;
-    for (int j = 0; j < e->S; j++) if (p->site_vtype[j] == FG_USIZE && p->site_cat[2 * j + 1] <= 0) return FG_E_UNSUPPORTED;
-    const int n_s = e->P.n_sstream;
-    size_t lds = (size_t)(e->n_slots + n_s + 17) * FG_WAVE * sizeof(double);   // site values, term rows, 2 x 8 exchange rows + the log_likelihood sum
-    if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
-    int pool_n = 0;                                                          // stage the constant pool into LDS when it is small and the tile leaves room
-    if (e->P.sstream_kinds != 0 && p->pool.size() * 8 <= 24 * 1024 && lds + p->pool.size() * 8 <= 160 * 1024 &&
-        (160 * 1024) / lds == (160 * 1024) / (lds + p->pool.size() * 8)) { pool_n = (int)p->pool.size(); lds += p->pool.size() * 8; }
-    const unsigned tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
+    sh.lds = (size_t)(e->n_slots + n_s + 17) * FG_WAVE * sizeof(double);    // site values, term rows, 2 x 8 exchange rows + the log_likelihood sum
+    if (sh.lds > 160 * 1024) return FG_E_UNSUPPORTED;
+    sh.pool_n = 0;                                                          // stage the constant pool into LDS when it is small and the tile leaves room
+    if (stage_pool && p->pool.size() * 8 <= 24 * 1024 && sh.lds + p->pool.size() * 8 <= 160 * 1024 &&
+        (160 * 1024) / sh.lds == (160 * 1024) / (sh.lds + p->pool.size() * 8)) { sh.pool_n = (int)p->pool.size(); sh.lds += p->pool.size() * 8; }
+    sh.tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
+    const long long n_cu = std::max(1, e->n_simd / 4);
+    const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)sh.lds, ((long long)sh.tiles + n_cu - 1) / n_cu));
     int W = e->mw_override > 0 ? e->mw_override : 2;
-    if (e->mw_override <= 0) {
-        const long long n_cu = std::max(1, e->n_simd / 4);
-        const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
-        while (W < FG_MH_WMAX && resident * W < 16 && n_s >= 4 * W) W *= 2;
+    if (e->mw_override <= 0) while (W < FG_MH_WMAX && resident * W < 16 && n_s >= 4 * W) W *= 2;
+    sh.W = std::max(W, 2);                                                  // control wave + random-number wave
+    sh.exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
+    if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) sh.exp_mask |= 32;
+    else if (resident >= 2) sh.exp_mask |= 64;   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
+    // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
+    // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
+    sh.split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
+    return FG_OK;
+}
+static bool mh_mw_sites_ok(const fg_engine *e) {     // every site must take a model-independent proposal: Categorical sites need a constant table, no PriorResample override
+    if (e->gt || e->S < 1 || e->mh_mw_disabled || e->mh_has_prior_resample) return false;     // (tiles in global memory: the one-wave-per-tile kernels, fg_engine.hip)
+    for (int j = 0; j < e->S; j++) if (e->prog->site_vtype[j] == FG_USIZE && e->prog->site_cat[2 * j + 1] <= 0) return false;
+    return true;
+}
+
+// Programs WITHOUT a score stream (expression parameters, ...) on the same kernel: every statement generated (fg_jit_mhmw_source),
+// rows in accumulator order (log_prior terms, log_likelihood terms, then the terms of `factor` statements), proposals that need the model (undecided kinds, PriorResample, computed Categorical tables) through the interpreter on
+// the target's own statement (`site_ins`, device: [S][2] first instruction and count in the generic program).  Called by
+// fg_mh_interp_launch with its statement table.
+int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t, const std::vector<int> &stmt_end,
+                             const std::vector<unsigned char> &acc, const int *d_site_ins) {
+    if (e->jit_mhns_state < 0 || e->gt || e->S < 1 || e->mh_mw_disabled || n_steps < 1 || e->tw != FG_WAVE) return FG_E_UNSUPPORTED;
+    const fg_program *p = e->prog;
+    const int n_s = (int)stmt_end.size();
+    FgMhMwShape sh;
+    if (mh_mw_shape(e, n_s, false, sh) != FG_OK) return FG_E_UNSUPPORTED;
+    if (e->jit_mhns_state == 0) {
+        e->jit_mhns_state = -1;
+        const char *sp = std::getenv("FG_JIT");
+        if ((sp && std::atoi(sp) == 0) || std::getenv("FG_MH_EXP") || p->ins_fast.size() > 200000 || acc.size() != (size_t)n_s) return FG_E_UNSUPPORTED;
+        int n_acc[3] = {0, 0, 0};
+        for (int k = 0; k < n_s; ++k) { if (acc[(size_t)k] > 2) return FG_E_UNSUPPORTED; n_acc[acc[(size_t)k]] += 1; }
+        const int n_pri = n_acc[0], n_fac = n_acc[2];
+        std::vector<int> rows((size_t)n_s);
+        for (int k = 0, a = 0, b = n_pri, c = n_pri + n_acc[1]; k < n_s; ++k) rows[(size_t)k] = acc[(size_t)k] == 0 ? a++ : acc[(size_t)k] == 1 ? b++ : c++;
+        std::vector<long long> cost((size_t)p->n_ins);
+        for (int k = 0; k < p->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(p->ins_fast[(size_t)k]);
+        std::vector<double> ctab;
+        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac);
+        std::vector<char> code;
+        if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
+            hipModuleLoadData(&e->jit_mhns_mod, code.data()) == hipSuccess &&
+            hipModuleGetFunction(&e->jit_mhns_fn, e->jit_mhns_mod, "k_mh_mw_jit_steps") == hipSuccess &&
+            hipFuncSetAttribute((const void *)e->jit_mhns_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+            fg_jit_bind_tables(e->jit_mhns_mod, ctab, &e->d_jit_mhns_tab, e->stream) == FG_OK) { e->jit_mhns_state = 1; e->jit_mhns_split = sh.split_sums; }
+        else {
+            (void)hipGetLastError();
+            if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: multi-wave MH kernel not compiled at run time (%s)\n", e->jit_log.c_str());
+            return FG_E_UNSUPPORTED;
+        }
     }
-    if (W < 2) W = 2;                                                       // control wave + random-number wave
+    FgMhSeg seg;
+    std::memset(&seg, 0, sizeof(seg));
+    int n_warmup = e->mh_warmup;
+    const FgGradRec *site_ins_as_srt = (const FgGradRec *)d_site_ins;        // the unit reads its `srt` argument as the site_ins table (FG_MHMW_PROBE)
+    void *args[] = { &e->P, &e->X, &e->M, &site_ins_as_srt, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t, &sh.exp_mask, &sh.pool_n };
+    HIPCHK(hipModuleLaunchKernel(e->jit_mhns_fn, sh.tiles, 1, 1, FG_WAVE * sh.W, 1, 1, (unsigned)sh.lds, e->stream, args, nullptr));
+    e->last_mh_kernel = "k_mh_mw_jit_steps W=" + std::to_string(sh.W) + " (a program without a record stream; statements compiled at run time)";
+    return FG_OK;
+}
+
+int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
+    if (!e->P.sstream || n_steps < 1 || !mh_mw_sites_ok(e)) return FG_E_UNSUPPORTED;
+    const fg_program *p = e->prog;
+    const int n_s = e->P.n_sstream;
+    FgMhMwShape sh;
+    if (mh_mw_shape(e, n_s, e->P.sstream_kinds != 0, sh) != FG_OK) return FG_E_UNSUPPORTED;
+    const size_t lds = sh.lds;
+    const int W = sh.W, split_sums = sh.split_sums;
+    int pool_n = sh.pool_n, exp_mask = sh.exp_mask;
+    const unsigned tiles = sh.tiles;
     // the kind-sorted copy of the score stream (once per engine); within a class the records keep their program order
     const uint32_t zero_slot = (uint32_t)(e->n_slots - 1);
     auto cls_of = [zero_slot, p](const FgGradRec &r) {
@@ -93,15 +158,6 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         for (int w = 0; w <= FG_MH_WMAX; ++w) { seg.r[c][w] = at; if (w < W) at += cnt[w]; }
         shift += n % W;
     }
-    int exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
-    if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) exp_mask |= 32;
-    else {   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
-        const long long n_cu = std::max(1, e->n_simd / 4);
-        if (std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu) >= 2) exp_mask |= 64;
-    }
-    // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
-    // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
-    const int split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
     // the program compiled at run time (fg_jit.cpp): the same kernel with the general records (class 5: fg_score_one over the record)
     // as sixteen generated statement segments; where they are the minority the operand-pattern classes stay the hand-written

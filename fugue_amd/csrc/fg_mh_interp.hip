@@ -101,6 +101,7 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
         }
         for (int j = 0; j < e->S; ++j) if (site_ins[2 * j] < 0) { fg_set_error("fg_mh_interp: a site without a sample statement"); return FG_E_STATE; }
         if (dev_upload(&e->d_mhi_site_ins, site_ins)) return FG_E_HIP;
+        e->mhi_stmt_end = stmt_end; e->mhi_acc_host = acc;
         e->mhi_W = W; e->mhi_n_stmt = n_stmt; e->mhi_lds = lds_for(std::max(W, 1)); e->mhi_setup_done = true;
         {   // more than eight waves on a CU need the 128-VGPR build
             const long long n_cu = std::max(1, e->n_simd / 4), tiles = (e->C + FG_WAVE - 1) / FG_WAVE, per_cu = (tiles + n_cu - 1) / n_cu;
@@ -108,6 +109,12 @@ int fg_mh_interp_launch(fg_engine *e, int iter0, int n_steps, long long *draws, 
             e->mhi_occ = resident * W > 8 ? 4 : 2;
             if (const char *sp = std::getenv("FG_MH_INTERP_OCC")) e->mhi_occ = std::atoi(sp) <= 2 ? 2 : 4;
         }
+    }
+    // first choice: the pipelined multi-wave kernel (fg_mh.hip) around this program's generated statements (FG_JIT=2 keeps the
+    // statement-segment kernel below, for comparison)
+    if (!e->P.sstream && !force_jit && !(std::getenv("FG_MH_NOSTREAM_MW") && std::atoi(std::getenv("FG_MH_NOSTREAM_MW")) == 0)) {
+        const int rc = fg_mh_mw_nostream_launch(e, iter0, n_steps, draws, first_sample_t, e->mhi_stmt_end, e->mhi_acc_host, e->d_mhi_site_ins);
+        if (rc != FG_E_UNSUPPORTED) return rc;
     }
     FgMhi seg;
     for (int w = 0; w <= FG_MHI_MAX; ++w) { seg.ins_off[w] = e->mhi_ins_off[w]; seg.stmt_off[w] = e->mhi_stmt_off[w]; }

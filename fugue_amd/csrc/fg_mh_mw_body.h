@@ -119,6 +119,35 @@ __device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend
     for (int i = 0; i < 4; ++i) terms[r[i][3] * tw] = lp[i];
 }
 
+#ifdef FG_MHMW_NS
+// Programs without a score stream (a unit compiled at run time; `srt` is then the [S][2] table of each site's own statement in the
+// generic program: first instruction, count).  The lanes whose proposal needs the model get it from that statement, interpreted in the
+// propose-and-score mode (SingleSiteProposalHandler, mh.rs:298-570) ahead of the scoring run: the statement's parameters read only
+// other sites, which hold the chain's current values, so the proposed value, log q(x'|x), log q(x|x'), the decided kind and the accept
+// uniform's block are those of a whole propose-and-score run (fg_mh_interp_body.h does the same).  One pass per distinct such target
+// in the wave; the other lanes see no target there.
+struct FgMhmwPre { double lqf, lqr; int kind, next_block; };
+static __device__ __noinline__ FgMhmwPre fg_mhmw_model_proposals(const FgIns *ins, const int *site_ins, const double *pool, double *slots, bool live, bool walk, int target,
+                                                                 FgMhCtx pre, unsigned long long seed, uint32_t gchain, uint32_t iter) {
+    FgStream rng = fg_stream(seed, gchain, iter, FG_RNG_MH);
+    unsigned long long ra, rb;
+    fg_rng_block(rng, ra, rb);
+    pre.rng = rng;                                            // at block 1
+    if (walk) pre.target = -1;
+    unsigned long long todo = __ballot(!walk);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int tl = __builtin_amdgcn_readlane(target, leader);
+        const unsigned long long same = __ballot(!walk && target == tl);
+        FgAcc3 A = {0.0, 0.0, 0.0};
+        fg_exec<FG_MODE_MH, false>(ins + site_ins[2 * tl], site_ins[2 * tl + 1], pool, slots, FG_WAVE, A, nullptr, nullptr, 0, live, &pre);
+        todo &= ~same;
+    }
+    FgMhmwPre r = { pre.lqf, pre.lqr, pre.kind, pre.next_block };
+    return r;
+}
+#endif
+
 template <int RK, bool SPLIT /* the two in-order sums on two waves */>
 __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgChainCtx &X, const FgMhDev &M, const FgGradRec *srt /* the kind-sorted score stream */, const FgMhSeg &seg, int iter0, int n_steps, int n_warmup,
                                               long long *draws, int first_sample_t, int exp_mask /* bits 1, 2, 4, 8: timing experiments only (FG_MH_EXP; results are wrong); 32: no wave priorities (A/B); 64: phase-B priority */,
@@ -131,7 +160,11 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
     const long long chain = (long long)blockIdx.x * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
+#ifdef FG_MHMW_NS          /* a compiled unit of a program without a score stream: its statements, log_prior rows first */
+    constexpr int n_s = FG_MHMW_NS, n_pri = FG_MHMW_NPRI, n_fac = FG_MHMW_NFAC /* `factor` statements: the last rows */, n_lik = n_s - n_pri - n_fac;
+#else
     const int n_s = P.n_sstream, n_pri = P.n_prior_terms, n_lik = n_s - n_pri;
+#endif
     double *slots = lds + lane;
     double *terms = lds + (long long)P.n_slots * tw + lane;
     // exchange rows, double-buffered by step parity (8 rows each; row 16: the log_likelihood sum on its way to the control wave):
@@ -264,7 +297,13 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                 const int itp = iter - 1;
                 const bool adapt = itp < n_warmup;
                 FG_PROF_T(0)
+#ifdef FG_MHMW_NS
+                double fac = 0.0;
+                if (n_fac > 0) fac = fg_inorder_sum1(terms + (long long)(n_pri + n_lik) * tw, n_fac, tw);
+                const double prop_lw = pri + lik + fac;                    // total_log_weight  trace.rs:168-177
+#else
                 const double prop_lw = pri + lik + 0.0;                    // total_log_weight (no factor statement has a record)
+#endif
                 const double log_alpha = prop_lw - lw + (lqr - lqf);       // + dim_term == 0 (fixed structure)  mh.rs:731-732
                 const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
                 double sc = scale;
@@ -306,6 +345,16 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                 const uint32_t tv = n_tv;
                 int kind_eff = FG_PROP_AUTO;
                 if (tv == 0u) { kind_eff = mh.ov_kind ? mh.ov_kind[tslot] : FG_PROP_AUTO; if (kind_eff == FG_PROP_AUTO) kind_eff = mh.kind; }
+#ifdef FG_MHMW_NS            /* a program without a score stream: a lane whose proposal needs the model (an undecided kind, PriorResample, a Categorical site
+                                with a computed table) gets it from its target's OWN statement, interpreted (fg_mhmw_model_proposals) */
+                const int cat_K0 = (int)(fg_as_i64(b[5 * tw]) >> 32);
+                const bool walk = tv == 0u ? (kind_eff == FG_PROP_GAUSSIAN || kind_eff == FG_PROP_LOGSPACE || kind_eff == FG_PROP_REFLECT)
+                                           : (tv == 1u || tv == 2u || tv == 4u || (tv == 3u && cat_K0 > 0));
+                const bool mixed = !__all(walk);
+                FgMhmwPre mp = {0.0, 0.0, 0, 2};
+                if (mixed) mp = fg_mhmw_model_proposals(P.ins, (const int *)srt, P.pool, slots, live, walk, n_target, mh, X.seed, gchain, (uint32_t)iter);
+                if (walk) {
+#else
                 // f64_kind (mh.rs:339-358): an undecided site is LogSpace iff its current value is positive and its prior density
                 // at -1.0 is -inf.  Lanes hold different sites: one pass per distinct undecided site in the wave (transient -- a
                 // kind is decided once per (site, chain)).
@@ -321,6 +370,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                     if (undecided && n_target == tl) { kind_eff = (mh.old_cell > 0.0 && !fg_finite(probe)) ? FG_PROP_LOGSPACE : FG_PROP_GAUSSIAN; mh.kind = kind_eff; }
                     todo &= ~same;
                 }
+#endif
                 if (tv == 3u) {                               // usize target: the index resampled from the constant prior table (mh.rs:516-530)
                     const long long ct = fg_as_i64(b[5 * tw]);
                     const int cat_base = (int)(uint32_t)ct, cat_K = (int)(ct >> 32);
@@ -331,8 +381,15 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                     mh.next_block = 2;
                     slots[tslot * tw] = fg_as_double(prop);
                 } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+#ifdef FG_MHMW_NS
+                }
+                if (!walk) { mh.lqf = mp.lqf; mh.lqr = mp.lqr; mh.kind = mp.kind; mh.next_block = mp.next_block; }
+#endif
                 old_cell = mh.old_cell; lqf = mh.lqf; lqr = mh.lqr; scale = mh.scale; kind_new = mh.kind;
                 u_acc = mh.next_block == 1 ? u1 : u2;                      // the accept uniform's block (mh.rs:733)
+#ifdef FG_MHMW_NS            /* a sampler-based proposal drew more than one block */
+                if (mixed && mh.next_block > 2) u_acc = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)mh.next_block, (uint32_t)iter, FG_RNG_MH).a;
+#endif
             }
         } else if (t > 0 && t + 1 < n_steps && !(exp_mask & 8)) {          // buffer (iter + 1) & 1 was last read in phase A of step t - 1
             if (wv == rng_wave) publish_rng(iter + 1, 0);

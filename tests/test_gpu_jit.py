@@ -89,6 +89,7 @@ def test_jit_mh_is_bit_identical_to_the_interpreter(name, with_overrides, monkey
         ov[f64[0]] = (E.PROP_PRIOR_RESAMPLE, 0.0, 0.0)
         ov[f64[1]] = (E.PROP_GAUSSIAN, 0.0, 0.0)
     out, kernels = [], []
+    monkeypatch.setenv("FG_MH_NOSTREAM_MW", "0")                           # the statement-segment kernel itself (the pipelined kernel: the next test)
     for jit, mw, W, occ in ((0, 0, 0, 0), (1, 1, 0, 0), (1, 1, 1, 2), (1, 1, 2, 4), (1, 1, 4, 2), (1, 1, 8, 4)):
         monkeypatch.setenv("FG_JIT", str(jit))
         monkeypatch.setenv("FG_HMC_INTERP_MW", str(mw))
@@ -107,6 +108,43 @@ def test_jit_mh_is_bit_identical_to_the_interpreter(name, with_overrides, monkey
         for a, b in zip(out[0], o):
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
+@pytest.mark.parametrize("name,with_overrides", [("alldists", False), ("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("logistic", False), ("coin", False)])
+def test_jit_mh_pipelined_kernel_for_programs_without_a_stream(name, with_overrides, monkeypatch):
+    """Programs without a score stream on the pipelined multi-wave MH kernel (fg_mh_mw_body.h: random numbers of step t + 1 drawn
+    while step t is scored, control wave, in-order sums) with every statement generated and the undecided-kind probe interpreted from
+    the proposals that need the model (undecided kinds, PriorResample overrides, computed Categorical tables) interpreted from the
+    target's own statement: the one-wave interpreter kernel's draws, state, scales, log-weights and accept counts for every W."""
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 150, 100, 40
+    rec = list(range(cp.S))
+    ov = None
+    if with_overrides:
+        ov = [None] * cp.S
+        f64 = [j for j in range(cp.S) if cp.site_vtypes[j] == 0]
+        ov[f64[0]] = (E.PROP_PRIOR_RESAMPLE, 0.0, 0.0)
+        ov[f64[1]] = (E.PROP_GAUSSIAN, 0.0, 0.0)
+    out, kernels = [], []
+    for jit, Wv, split in ((0, 0, -1), (1, 0, -1), (1, 2, 0), (1, 4, 1), (1, 8, 0), (1, 16, 1)):
+        monkeypatch.setenv("FG_JIT", str(jit))
+        monkeypatch.setenv("FG_HMC_INTERP_MW", str(jit))
+        if Wv: monkeypatch.setenv("FG_HMC_WAVES", str(Wv))
+        else: monkeypatch.delenv("FG_HMC_WAVES", raising=False)
+        if split >= 0: monkeypatch.setenv("FG_MH_SPLIT", str(split))
+        else: monkeypatch.delenv("FG_MH_SPLIT", raising=False)
+        eng = E.Engine(cp, C, seed=17, chain_offset=4)
+        d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
+        st = eng.mh_run(ns, nw, ov, rec, d)
+        kernels.append(eng.mh_last_kernel())
+        draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
+        eng.device_free(d)
+        out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
+        eng.close()
+    assert kernels[0] == "k_mh_steps W=1" and all(k.startswith("k_mh_mw_jit_steps W=") for k in kernels[1:]), kernels
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 
 def test_jit_rolls_plates_and_scores_long_programs_directly(monkeypatch):
     """A plate of observations (statements that differ only in their constants) becomes one loop over a constant table in the
@@ -116,6 +154,7 @@ def test_jit_rolls_plates_and_scores_long_programs_directly(monkeypatch):
     cp = E.compile_model(W.logistic_regression(*W.classification_data(300)[:2]))
     C = 130
     out = []
+    monkeypatch.setenv("FG_MH_NOSTREAM_MW", "0")                           # (the pipelined kernel has term rows for this program: the segment kernel's direct mode is what is tested)
     for jit in (0, 1):
         monkeypatch.setenv("FG_JIT", str(jit))
         eng = E.Engine(cp, C, seed=5)
@@ -155,7 +194,7 @@ def test_jit_matches_the_interpreter_on_random_expression_programs(seed, monkeyp
         eng.mh_step(40)
         out.append((v, lj, eps, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), kh, eng.mh_last_kernel()))
         eng.close()
-    assert out[1][6].startswith("k_hmc_jit_steps") and out[1][7].startswith("k_mh_jit_steps"), out[1][6:]
+    assert out[1][6].startswith("k_hmc_jit_steps") and out[1][7].startswith(("k_mh_jit_steps", "k_mh_mw_jit_steps")), out[1][6:]
     for a, b in zip(out[0][:6], out[1][:6]):
         assert np.array_equal(a, b, equal_nan=True)
 
@@ -174,7 +213,7 @@ def test_a_failed_compilation_falls_back_to_the_interpreter_kernels(monkeypatch,
         eng.mh_init(10); eng.mh_step(20)
         out.append((v, eng.get_values(), eng.mh_scales(), kh, eng.mh_last_kernel()))
         eng.close()
-    assert out[0][3].startswith("k_hmc_jit_steps") and out[0][4].startswith("k_mh_jit_steps"), out[0][3:]
+    assert out[0][3].startswith("k_hmc_jit_steps") and out[0][4].startswith(("k_mh_jit_steps", "k_mh_mw_jit_steps")), out[0][3:]
     assert out[1][3].startswith("k_hmc_interp_mw_steps") and out[1][4].startswith("k_mh_interp_mw_steps"), out[1][3:]
     for a, b in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, b, equal_nan=True)
@@ -244,7 +283,7 @@ for jit in ("0", "1"):
     eng.mh_init(10); eng.mh_step(20); eng.synchronize()
     out.append((kh, eng.mh_last_kernel(), v, eng.get_values().tobytes()))
     eng.close()
-assert out[1][0].startswith("k_hmc_jit_steps") and out[1][1].startswith("k_mh_jit_steps"), out[1][:2]
+assert out[1][0].startswith("k_hmc_jit_steps") and out[1][1].startswith(("k_mh_jit_steps", "k_mh_mw_jit_steps")), out[1][:2]
 assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
 print("ok")
 """)
@@ -260,6 +299,7 @@ def test_jit_mh_segments_with_rolled_plates(monkeypatch):
     from fugue_amd import workloads as W
     cp = E.compile_model(W.logistic_regression(*W.classification_data(60)[:2]))
     out = []
+    monkeypatch.setenv("FG_MH_NOSTREAM_MW", "0")
     for jit, W_ in ((0, 0), (1, 1), (1, 2), (1, 8)):
         monkeypatch.setenv("FG_JIT", str(jit))
         if W_: monkeypatch.setenv("FG_MH_INTERP_WAVES", str(W_))
