@@ -690,6 +690,7 @@ def leg_mh(X):
     if scratch is not None:
         scratch.close()
     acc = eng.mh_stats().accept_rate
+    mh_kernel = eng.mh_last_kernel()
     eng.close()
     dt = float(np.median(dts))
     S, O = cp.S, cp.O
@@ -701,7 +702,7 @@ def leg_mh(X):
             "config": {"workload": f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91: S=20, O=19), {C} chains/GPU, "
                                    f"{nw} adapting + {ns} sampling steps, all timed", "steps_per_launch": n_launch},
             "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
-                         "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
+                         "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src, "kernel": mh_kernel, "avg_launch_ms": launch_ms,
                          "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3),
                          "note": "(S + O) log-pdfs x 8 flops per chain step / HIP-event time",
                          "hbm_nominal": {"achieved": C * n_launch * bytes_per_step / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -726,6 +727,7 @@ def leg_c5(X):
         dts.append(clock.region(lambda: ev.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), 200, 100))))
         events.extend(ev)
     launch_ms, n_launch = full_launch_ms(events)
+    mh_kernel = eng.mh_last_kernel()
     eng.close()
     dt = float(np.median(dts))
     tflops = C * n_launch * (cp.S + cp.O) * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
@@ -734,7 +736,7 @@ def leg_c5(X):
             "timed_regions": {"repeats": len(dts), "steps_each": 200, "value": spread([world * C * 200 / t for t in dts])},
             "config": {"workload": f"C5: 4-component mixture, S={cp.S} (4 f64 + 64 usize), O={cp.O}, {C} chains/GPU, 200 sampling steps after 200 adapting"},
             "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
-                         "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src, "kernel": "k_mh_mw_steps", "avg_launch_ms": launch_ms,
+                         "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src, "kernel": mh_kernel, "avg_launch_ms": launch_ms,
                          "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3),
                          "note": "(S + O) log-pdfs x 8 flops per chain step / HIP-event time; Categorical table lookups counted as log-pdfs",
                          "hbm_nominal": {"achieved": C * n_launch * (8 * cp.S + 40) / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}}

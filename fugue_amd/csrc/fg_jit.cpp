@@ -762,6 +762,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
         const int rc2 = fg_jit_compile(s2, code2, log2);
         if (log_out && log_cap > 0) std::snprintf(log_out, (size_t)log_cap, "%s", log2.c_str());
         if (code_bytes) *code_bytes = (long long)code2.size();
+        if (const char *out = std::getenv("FG_DEBUG_JIT_OUT")) if (rc2 == FG_OK) if (FILE *f = std::fopen(out, "wb")) { std::fwrite(code2.data(), 1, code2.size(), f); std::fclose(f); }
         return rc2;
     }
     const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr);

@@ -14,7 +14,11 @@ CONFIGS = {
     "hmc|c3|65536|fd_sparse|L16": ("k_hmc_lin_steps", 1, 2, "transition"),
     "hmc|c3|8192|fd_sparse|L16": ("k_hmc_lin_steps", 1, 3, "transition"),
     "mh|refmodel20|65536": ("k_mh_mw_steps", 100, 6, "chain step of every chain"),
-    "mh|c5|262144": ("k_mh_mw_steps", 100, 2, "chain step of every chain"),
+    "mh|c5|262144": ("k_mh_mw", 100, 2, "chain step of every chain"),       # k_mh_mw_jit_steps since the general records are compiled at run time
+    # the pipelined multi-wave MH kernel around statements compiled at run time (k_mh_mw_jit_steps): general stream records, no stream at all
+    "mh|zoo:hier_scale|65536": ("_steps", 100, 2, "chain step of every chain"),
+    "mh|zoo:alldists|65536": ("_steps", 100, 2, "chain step of every chain"),
+    "mh|zoo:logistic100|65536": ("_steps", 100, 2, "chain step of every chain"),
     "smc|c4|1048576": ("", 1, 0, "run"),
     # programs without a record stream: compiled at run time (k_hmc_jit_steps); with FG_JIT=0 in the environment the interpreter kernel
     "hmc|zoo:alldists|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
@@ -50,6 +54,16 @@ def main(key):
             eng.hmc_step(5)
         eng.synchronize()
         print(key, eng.hmc_last_kernel())
+    elif parts[0] == "mh" and parts[1].startswith("zoo:"):
+        from tests.models import ZOO
+        C = int(parts[2])
+        cp = E.compile_model(W.logistic_regression(*W.classification_data(100)[:2]) if parts[1] == "zoo:logistic100" else ZOO[parts[1][4:]]())
+        eng = E.Engine(cp, C, seed=2)
+        eng.mh_init(200)
+        for _ in range(4):                           # 2 adapting, then the 2 sampling launches that are kept
+            eng.mh_step(100)
+        eng.synchronize()
+        print(key, eng.mh_last_kernel())
     elif parts[0] == "hmc" and parts[1] == "c3":
         C = int(parts[2])
         X, y, _ = W.ridge_data(1024, 32)
