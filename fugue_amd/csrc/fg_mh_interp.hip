@@ -27,14 +27,21 @@ void k_mh_interp_mw_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMh
 FG_MHI_KERNEL(2)
 FG_MHI_KERNEL(4)
 
-long long fg_mhi_ins_cost(const FgIns &in) {       // the weights of fg_hmc_interp.hip's split
+long long fg_mhi_ins_cost(const FgIns &in) {         // relative cost of an instruction, in units of about ten VALU instructions
     const uint32_t code = FG_INS_OPCODE(in.op);
     if (code == FG_OP_NORMAL_FAST) return 3;
-    if (code < 17u) return (in.op & FG_F_HOISTED) ? 10 : 16;
+    if (code < 17u) {
+        // by distribution: the size of the compiled log-density (the code objects of `alldists`; the lgamma-based ones at 0.6 of
+        // their static size -- one branch of lgamma runs), general / hoisted parameters
+        static const int general[17] = { 24, 25, 120, 10, 25, 60, 3, 12, 12, 64, 14, 21, 13, 62, 130, 2, 40 };
+        static const int hoisted[17] = { 3, 25, 110, 5, 16, 11, 1, 2, 12, 12, 2, 12, 13, 56, 16, 2, 33 };
+        if ((in.op & FG_F_XHOIST) && (in.op & FG_F_HOISTED)) return 13;
+        return (in.op & FG_F_HOISTED) ? hoisted[code] : general[code];
+    }
     switch (code) {
     case FG_OP_EXP: case FG_OP_LN: case FG_OP_SIN: case FG_OP_COS: case FG_OP_TANH: return 6;
-    case FG_OP_POW: case FG_OP_RPOW: return 14;
-    case FG_OP_DIV: case FG_OP_RDIV: case FG_OP_SQRT: return 3;
+    case FG_OP_POW: case FG_OP_RPOW: return 26;
+    case FG_OP_DIV: case FG_OP_RDIV: case FG_OP_SQRT: return 4;
     case FG_OP_DOT: return 1 + (long long)in.opnd[1] / 2;
     default: return 1;
     }
