@@ -230,6 +230,23 @@ __device__ __forceinline__ void fg_inorder_run2(const double *p, int rem, int tw
         for (int q = 0; q < CH; ++q) { const double v = (q < rem) ? x[q] : 0.0; a += v; b += v; }
     }
 }
+// ... to ONE running sum (the rows ahead of the first moved term: the two log-joints are still the same number there)
+template <int CH>
+__device__ __forceinline__ void fg_inorder_run1(const double *p, int rem, int tw, double &a) {
+    double x[CH];
+    for (; rem >= CH; rem -= CH, p += (long long)CH * tw) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) x[q] = p[q * tw];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) a += x[q];
+    }
+    if (rem > 0) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) x[q] = p[q * tw];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) a += (q < rem) ? x[q] : 0.0;
+    }
+}
 // one chain of the above (a kernel whose waves take one sum each)
 template <int CH = 8>
 __device__ __forceinline__ double fg_inorder_sum1(const double *A, int na, int tw) {

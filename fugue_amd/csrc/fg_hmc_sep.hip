@@ -275,6 +275,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                     if (nobs >= 3) FG_SEP_TERM_TO(3, T)
                 }
                 __syncthreads();                                     // every statement's term at q is in T
+                int ppos = 0, lpos = n_pri;                          // the wave's running prefixes of log_prior / log_likelihood rows at this q
+                double PS = 0.0, LS = 0.0;
                 for (int i = k0; i < k1; ++i) {                      // two full in-order scoring sums per own coordinate, own terms substituted
                     const FgSepCoord cd = P.sep_coord[i];
                     const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
@@ -283,19 +285,31 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                     FG_SEP_LOAD(0) FG_SEP_LOAD(1) FG_SEP_LOAD(2) FG_SEP_LOAD(3)
                     const double q = qrow[i * tw];
                     const double qp = q + h, qm = q - h;             // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
-                    double Pp = 0.0, Pm = 0.0, Lp = 0.0, Lm = 0.0;
+                    double Pp, Pm, Lp, Lm;
                     {                                                // log_prior: the coordinate's own sample statement is its only prior term
-                        // the rows between the own ones: eight at compile-time offsets per chunk (ds_read2st64_b64, no address arithmetic or
-                        // loop control per row; fg_inorder_run2)
+                        // Ahead of the own row the two sums are the same number, and the same for every coordinate: the wave keeps
+                        // that prefix (rows [0, ppos) added in order from 0.0) and extends it from one own coordinate to the next
+                        // instead of adding it twice per coordinate (+4 %; dealing the coordinates so that every wave has the same
+                        // number of additions changed nothing: the phase is not bound by them).  Behind the own row, eight rows at
+                        // compile-time offsets per chunk (ds_read2st64_b64, no address arithmetic or loop control per row; fg_inorder_run2).
                         FG_SEPD_OWN(0, tp0, tm0)
                         const int r0 = (int)a0[1];
-                        fg_inorder_run2<8>(T, r0, tw, Pp, Pm);
-                        Pp += tp0; Pm += tm0;
+                        if (r0 < ppos) { ppos = 0; PS = 0.0; }
+                        fg_inorder_run1<8>(T + (long long)ppos * tw, r0 - ppos, tw, PS);
+                        ppos = r0;
+                        Pp = PS + tp0; Pm = PS + tm0;
                         fg_inorder_run2<8>(T + (long long)(r0 + 1) * tw, n_pri - r0 - 1, tw, Pp, Pm);
                     }
                     {                                                // log_likelihood: its observe statements, in program (= row) order
                         int k = n_pri;
-                        if (nobs >= 1) { FG_SEPD_OWN(1, tp1, tm1) const int r1 = (int)a1[1]; fg_inorder_run2<8>(T + (long long)k * tw, r1 - k, tw, Lp, Lm); Lp += tp1; Lm += tm1; k = r1 + 1; }
+                        if (nobs >= 1) {                             // the same prefix, of the rows ahead of the first own observation
+                            FG_SEPD_OWN(1, tp1, tm1)
+                            const int r1 = (int)a1[1];
+                            if (r1 < lpos) { lpos = n_pri; LS = 0.0; }
+                            fg_inorder_run1<8>(T + (long long)lpos * tw, r1 - lpos, tw, LS);
+                            lpos = r1;
+                            Lp = LS + tp1; Lm = LS + tm1; k = r1 + 1;
+                        } else { Lp = 0.0; Lm = 0.0; }
                         if (nobs >= 2) { FG_SEPD_OWN(2, tp2, tm2) const int r2 = (int)a2[1]; fg_inorder_run2<8>(T + (long long)k * tw, r2 - k, tw, Lp, Lm); Lp += tp2; Lm += tm2; k = r2 + 1; }
                         if (nobs >= 3) { FG_SEPD_OWN(3, tp3, tm3) const int r3 = (int)a3[1]; fg_inorder_run2<8>(T + (long long)k * tw, r3 - k, tw, Lp, Lm); Lp += tp3; Lm += tm3; k = r3 + 1; }
                         fg_inorder_run2<8>(T + (long long)k * tw, n_s - k, tw, Lp, Lm);
