@@ -9,7 +9,7 @@
 #include <cstdio>
 template <int MODE> __global__ void k(double *out, long long *t, int n) {
     double a = out[threadIdx.x], b = 1.0000001, c = 1e-9, a2 = a + 1.0, a3 = a + 2.0, a4 = a + 3.0;
-    int sacc = 0, x = threadIdx.x, y = 1;
+    int sacc = 0, x = threadIdx.x, y = 1, z1 = threadIdx.x + 3, z2 = threadIdx.x + 5;
     long long c0 = clock64(), w0 = wall_clock64();
     for (int i = 0; i < n; i++) {
         if (MODE == 0) {
@@ -36,13 +36,23 @@ template <int MODE> __global__ void k(double *out, long long *t, int n) {
         } else if (MODE == 7) {
 #pragma unroll
             for (int j = 0; j < 8; j++) { a = __builtin_fma(a, b, c); asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(y)); }
+        } else if (MODE == 9) {                       // the two multiplies of a Philox round
+#pragma unroll
+            for (int j = 0; j < 8; j++) { asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(y)); asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(y) : "v"(x)); }
+        } else if (MODE == 10) {                      // independent: 16 v_mul_hi_u32 on four registers
+#pragma unroll
+            for (int j = 0; j < 4; j++) { asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(sacc)); asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(y) : "v"(sacc));
+                                          asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(z1) : "v"(sacc)); asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(z2) : "v"(sacc)); }
+        } else if (MODE == 11) {                      // 8 v_mul_hi_u32 + 8 v_add_f64 (do they share a pipe?)
+#pragma unroll
+            for (int j = 0; j < 8; j++) { asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(y)); a = a + c; }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++) { asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(y) : "v"(x), "v"(y)); asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x) : "v"(y), "v"(x)); }
         }
     }
     long long c1 = clock64(), w1 = wall_clock64();
-    out[threadIdx.x + blockIdx.x * blockDim.x] = a + a2 + a3 + a4 + sacc + x + y;
+    out[threadIdx.x + blockIdx.x * blockDim.x] = a + a2 + a3 + a4 + sacc + x + y + z1 + z2;
     if (threadIdx.x == 0 && blockIdx.x == 0) { t[0] = c1 - c0; t[1] = w1 - w0; }
 }
 template <int MODE> void run(const char *name, int waves, double *d, long long *t) {
@@ -56,7 +66,7 @@ template <int MODE> void run(const char *name, int waves, double *d, long long *
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(h, t, 16, hipMemcpyDeviceToHost);
     const double mhz = (double)h[0] / ((double)h[1] / 100.0);
-    printf("waves/SIMD=%d %-28s %5.1f cycles/instr/wave  clock %.0f MHz  kernel %.3f ms: one instr per %.1f cycles per SIMD (at the measured clock)\n", waves, name,
+    printf("waves/SIMD=%d %-44s %5.1f cycles/instr/wave  clock %.0f MHz  kernel %.3f ms: one instr per %.1f cycles per SIMD (at the measured clock)\n", waves, name,
            (double)h[0] / n / 16.0, mhz, ms, (ms * 1e-3 * mhz * 1e6) / (16.0 * n * waves));
 }
 int main() {
@@ -70,6 +80,9 @@ int main() {
         run<5>("16 v_mov_b32", waves, d, t);
         run<6>("16 v_add_u32", waves, d, t);
         run<7>("8 v_fma_f64 + 8 v_add_u32", waves, d, t);
+        run<9>("8 x (v_mul_hi_u32, v_mul_lo_u32) dependent", waves, d, t);
+        run<10>("16 v_mul_hi_u32 on 4 registers", waves, d, t);
+        run<11>("8 v_mul_hi_u32 + 8 v_add_f64", waves, d, t);
     }
     return 0;
 }
