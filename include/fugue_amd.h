@@ -220,9 +220,11 @@ int64_t fg_hmc_iterations(const fg_engine *e);
  * observation-major gradient), "k_hmc_stream_steps W=4" (gradient / score streams), "k_hmc_steps W=1" (interpreter);
  * "" before the first launch.  The pointer is valid until the engine's next launch. */
 const char *fg_hmc_last_kernel(const fg_engine *e);
-/* The same for fg_mh_step / fg_mh_run: "k_mh_mw_steps W=4" (score-stream programs), "k_mh_jit_steps W=4 (compiled at run time)",
- * "k_mh_interp_mw_steps W=2", "k_mh_steps W=1".  Programs without a record stream (a parameter that is an expression) are compiled at
- * run time by hiprtc when it is present (FG_JIT=0 keeps them on the interpreter kernels): "k_hmc_jit_steps ..." / "k_mh_jit_steps ...". */
+/* The same for fg_mh_step / fg_mh_run: "k_mh_mw_steps W=4" (score-stream programs of plain Normal records), "k_mh_mw_jit_steps W=4 ..."
+ * (the same pipelined kernel around statements compiled at run time: score-stream programs with general records, programs without a
+ * record stream), "k_mh_jit_steps W=4 (compiled at run time)" (programs whose term rows do not fit LDS), "k_mh_interp_mw_steps W=2",
+ * "k_mh_steps W=1".  Compilation at run time uses hiprtc or hipcc when present (FG_JIT=0 keeps every program on the hand-written and
+ * interpreter kernels). */
 const char *fg_mh_last_kernel(const fg_engine *e);
 /* HmcSession::step_recorded (hmc.rs:811-817) for every chain: ONE transition, and for the n_recorded chains h_chain_ids
  * the leapfrog trajectory with the Hamiltonian at each integration point (LeapfrogPoint, hmc.rs:338-343):
