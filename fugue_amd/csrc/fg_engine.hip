@@ -810,7 +810,7 @@ void fg_engine_free(fg_engine *e) {
     if (e->jit_mh_mod) (void)hipModuleUnload(e->jit_mh_mod);
     if (e->jit_mhmw_mod) (void)hipModuleUnload(e->jit_mhmw_mod);
     if (e->jit_mhns_mod) (void)hipModuleUnload(e->jit_mhns_mod);
-    void *ptrs[] = { e->d_jit_tab, e->d_jit_mh_tab, e->d_jit_mhmw_tab, e->d_jit_mhns_tab, e->d_mhi_acc, e->d_mhi_site_ins, e->d_mwi_order, e->d_mwi_prof, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
+    void *ptrs[] = { e->d_mh_catu_c, e->d_mh_catu, e->d_jit_tab, e->d_jit_mh_tab, e->d_jit_mhmw_tab, e->d_jit_mhns_tab, e->d_mhi_acc, e->d_mhi_site_ins, e->d_mwi_order, e->d_mwi_prof, e->d_gtile, e->d_lin_tab, e->d_lin_meta, e->d_mh_srt, e->d_sep, e->d_sep_coord, e->d_sep_free, e->d_site_rec, e->d_sobs, e->d_ins, e->d_ins_fast, e->d_coord, e->d_gstream, e->d_sstream, e->d_sub, e->d_sub_off, e->d_f64_slot, e->d_site_slot, e->d_vtype, e->d_site_cat, e->d_pool, e->d_values, e->d_acc, e->d_logp,
                      e->d_tmp, e->d_itmp };
     for (void *q : ptrs) if (q) hipFree(q);
     if (e->stream && e->own_stream) hipStreamDestroy(e->stream);

@@ -526,7 +526,7 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
 // records of phase B (generated[k] != 0: statement k's log-density term into its LDS row) as FG_JIT_NSEG generated statement
 // segments instead of fg_score_one over the record stream.
 std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out,
-                               const std::vector<int> *rows_in, int n_pri, int n_fac) {
+                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream) {
     constexpr int NSEG = 16;
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
@@ -602,7 +602,7 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     bool all = true;
     for (char gch : generated) all = all && gch != 0;
     if (all) src += "#define FG_MHMW_ALL 1\n";
-    if (rows_in) {
+    if (no_stream) {
         // a program without a score stream: the statement count and the log_prior rows are the unit's own; a proposal that needs the
         // model comes from the target's OWN statement of the generic program, interpreted (fg_mh_mw_body.h: the kernel's `srt` argument
         // is then the [S][2] table of first instruction and count)
@@ -769,7 +769,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
     if (std::getenv("FG_DEBUG_JIT_MHMW")) {                                // the multi-wave stream MH unit
         std::string s2;
-        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0);
+        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false);
         else {                                                             // a program without a score stream: rows in accumulator order (fg_mh_mw_nostream_launch)
             std::vector<int> rows; int n_pri = 0, n_lik = 0, n_fac = 0;
             for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) {
@@ -778,7 +778,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
                 rows.push_back(a); (a == 0 ? n_pri : a == 1 ? n_lik : n_fac) += 1;
             }
             for (int k = 0, a = 0, b = n_pri, c = n_pri + n_lik; k < (int)rows.size(); ++k) rows[(size_t)k] = rows[(size_t)k] == 0 ? a++ : rows[(size_t)k] == 1 ? b++ : c++;
-            s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>(rows.size(), 1), 3, rows.size() >= 64, nullptr, &rows, n_pri, n_fac);
+            s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>(rows.size(), 1), 3, rows.size() >= 64, nullptr, &rows, n_pri, n_fac, true);
         }
         if (src_out && src_cap > 0) std::snprintf(src_out, (size_t)src_cap, "%s", s2.c_str());
         if (code_bytes) *code_bytes = 0;

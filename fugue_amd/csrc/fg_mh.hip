@@ -87,7 +87,7 @@ int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *dr
         std::vector<long long> cost((size_t)p->n_ins);
         for (int k = 0; k < p->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(p->ins_fast[(size_t)k]);
         std::vector<double> ctab;
-        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac);
+        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac, true);
         std::vector<char> code;
         if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
             hipModuleLoadData(&e->jit_mhns_mod, code.data()) == hipSuccess &&
@@ -113,9 +113,38 @@ int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *dr
 int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int first_sample_t) {
     if (!e->P.sstream || n_steps < 1 || !mh_mw_sites_ok(e)) return FG_E_UNSUPPORTED;
     const fg_program *p = e->prog;
-    const int n_s = e->P.n_sstream;
+    const int n_s = e->P.n_sstream, n_pri = e->P.n_prior_terms;
+    // Categorical sites with a uniform constant table whose terms are the last rows of log_prior: no rows (FgMhSeg)
+    if (e->mh_ncu < 0) {
+        e->mh_ncu = 0;
+        std::vector<int> ks;
+        for (int k = 0; k < n_s; ++k) if (p->sstream[k].flags & FG_G_CATC) ks.push_back(k);
+        int n_tab_sites = 0;
+        for (int j = 0; j < e->S; ++j) n_tab_sites += (p->site_vtype[j] == FG_USIZE && p->site_cat[2 * j + 1] > 0) ? 1 : 0;
+        const int n_c = (int)ks.size();
+        bool ok = n_c >= 4 && n_c == n_tab_sites && n_c <= n_pri && !(std::getenv("FG_MH_CATU") && std::atoi(std::getenv("FG_MH_CATU")) == 0);
+        std::vector<double> cs; std::vector<FgMhCatU> info;
+        for (int q = 0; q < n_c && ok; ++q) {
+            const FgGradRec &r = p->sstream[ks[(size_t)q]];
+            uint32_t w[2]; std::memcpy(w, &r.mimm, 8);                       // {pool base, K}: p[0 .. K), then ln p[0 .. K)
+            ok = (int)r.coord == n_pri - n_c + q && w[1] >= 1;               // the last rows of log_prior, in program order
+            for (uint32_t i = 1; i < w[1] && ok; ++i) ok = fg_as_i64(p->pool[w[0] + w[1] + i]) == fg_as_i64(p->pool[w[0] + w[1]]) && p->pool[w[0] + i] > 0.0;
+            if (ok) ok = p->pool[w[0]] > 0.0;
+            if (ok) { cs.push_back(p->pool[w[0] + w[1]]); FgMhCatU cu; cu.slot = (int)r.xi; cu.K = (int)w[1]; info.push_back(cu); }
+        }
+        if (ok) {
+            e->mh_catu_same = 1; e->mh_catu_c0 = cs[0];
+            for (double v : cs) if (fg_as_i64(v) != fg_as_i64(cs[0])) e->mh_catu_same = 0;
+            while (cs.size() % 8 || cs.size() < (size_t)n_c + 16) cs.push_back(0.0);      // read eight at a time, eight ahead
+            FgMhCatU *d_info = nullptr;
+            if (dev_upload(&e->d_mh_catu_c, cs) || dev_upload(&d_info, info)) return FG_E_HIP;
+            e->d_mh_catu = d_info;
+            e->mh_ncu = n_c;
+        }
+    }
+    const int n_cu = e->mh_ncu, n_rows = n_s - n_cu;                       // term rows of the tile
     FgMhMwShape sh;
-    if (mh_mw_shape(e, n_s, e->P.sstream_kinds != 0, sh) != FG_OK) return FG_E_UNSUPPORTED;
+    if (mh_mw_shape(e, n_rows, e->P.sstream_kinds != 0, sh) != FG_OK) return FG_E_UNSUPPORTED;
     const size_t lds = sh.lds;
     const int W = sh.W, split_sums = sh.split_sums;
     int pool_n = sh.pool_n, exp_mask = sh.exp_mask;
@@ -141,7 +170,10 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         std::vector<FgGradRec> srt;
         e->mh_cls_off[0] = 0;
         for (int c = 0; c < FG_MH_NCLS; ++c) {
-            for (int k = 0; k < n_s; ++k) if (cls_of(p->sstream[k]) == c) srt.push_back(p->sstream[k]);
+            for (int k = 0; k < n_s; ++k) if (cls_of(p->sstream[k]) == c && !(n_cu > 0 && c == 1)) {
+                srt.push_back(p->sstream[k]);
+                if (n_cu > 0 && (int)srt.back().coord >= n_pri) srt.back().coord -= (uint32_t)n_cu;      // log_likelihood rows follow the shortened log_prior
+            }
             e->mh_cls_off[c + 1] = (int)srt.size();
         }
         for (int q = 0; q < 4; ++q) srt.push_back(p->sstream[(size_t)n_s + (size_t)(q & 1)]);    // readable records past the end (fetched ahead, never evaluated)
@@ -158,6 +190,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         for (int w = 0; w <= FG_MH_WMAX; ++w) { seg.r[c][w] = at; if (w < W) at += cnt[w]; }
         shift += n % W;
     }
+    seg.n_cu = n_cu; seg.catu_c = e->d_mh_catu_c; seg.catu = (const FgMhCatU *)e->d_mh_catu; seg.catu_same = e->mh_catu_same; seg.catu_c0 = e->mh_catu_c0;
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
     // the program compiled at run time (fg_jit.cpp): the same kernel with the general records (class 5: fg_score_one over the record)
     // as sixteen generated statement segments; where they are the minority the operand-pattern classes stay the hand-written
@@ -171,12 +204,17 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             for (int k = 0; k < p->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(p->ins_fast[(size_t)k]);
             std::vector<char> generated((size_t)n_s);
             int n_gen = 0;
-            for (int k = 0; k < n_s; ++k) n_gen += (generated[(size_t)k] = cls_of(p->sstream[k]) == 5 ? 1 : 0);
+            std::vector<int> rows((size_t)n_s);
+            for (int k = 0; k < n_s; ++k) {
+                n_gen += (generated[(size_t)k] = cls_of(p->sstream[k]) == 5 ? 1 : 0);
+                rows[(size_t)k] = (int)p->sstream[k].coord - ((n_cu > 0 && (int)p->sstream[k].coord >= n_pri) ? n_cu : 0);
+            }
             // mostly general records: the few pattern records too (their runs' set-up costs more than the generated statements:
             // linreg, 2 pattern records of 22: 2.49e10 all generated, 2.08e10 with the two runs, 1.66e10 hand-written)
-            if (2 * n_gen >= n_s) std::fill(generated.begin(), generated.end(), (char)1);
+            if (2 * n_gen >= n_s) for (int k = 0; k < n_s; ++k) generated[(size_t)k] = (n_cu > 0 && (p->sstream[k].flags & FG_G_CATC)) ? 0 : 1;   // (row-less terms have no statement to run)
             std::vector<double> ctab;
-            const std::string src = n_gen > 0 ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab) : std::string();
+            // (a handful of general records among many pattern records: the runs alone -- C5 with two tiles on a CU: 7.0e9 against 6.7e9)
+            const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false) : std::string();
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mhmw_mod, code.data()) == hipSuccess &&

@@ -69,7 +69,20 @@ __device__ __forceinline__ void fg_mh_terms(const FgGradRec *g, int r0, int r1, 
 //   class 5  everything else: the pipelined one-at-a-time loop of fg_mh_terms (plain Normals measured faster there than four
 //            at a time: the loop fetches records two ahead, a group of four waits for its own)
 #define FG_MH_NCLS 6
-struct FgMhSeg { int r[FG_MH_NCLS][FG_MH_WMAX + 1]; };   // records [r[c][w], r[c][w + 1]) of the sorted stream are wave w's share of class c
+// Categorical sites whose constant table is uniform (a mixture's assignments with equal weights): ln p[z] is the same number c for
+// every index in range, so such a site's log_prior term needs neither a row nor a lookup.  When these terms are the LAST n_cu rows
+// of log_prior, the kernel keeps no rows for them (the mixture of BASELINE's C5: 64 of 222 rows -- and with them the second tile a
+// CU's LDS did not have room for) and the control wave adds the constants c[0 .. n_cu) after the rows, in the same order.  A site
+// whose index is out of range (only ever an injected value: proposals come from the table) makes its term -inf: the control wave
+// counts such sites per chain and, while any chain of the tile has one, forms the tail from the cells themselves.
+struct FgMhCatU { int slot, K; };
+struct FgMhSeg {
+    int r[FG_MH_NCLS][FG_MH_WMAX + 1];   // records [r[c][w], r[c][w + 1]) of the sorted stream are wave w's share of class c
+    int n_cu;                            // uniform-table Categorical terms at the end of log_prior that have no row (0: none)
+    int catu_same; double catu_c0;       // every constant is catu_c0 (the sites share one table)
+    const double *catu_c;                // [n_cu, padded with 0.0 to a multiple of 8 plus 8] their constants
+    const FgMhCatU *catu;                // [n_cu] their sites' cells and table sizes
+};
 
 // Four records of class 0 (CLS = 0) or class 1 at the tile's state -> their term rows.  `tab`: the constant pool -- the LDS copy
 // when the kernel staged it (the call sites pass the shared-memory pointer itself, so the lookups are ds_reads), else global.
@@ -161,9 +174,10 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
 #ifdef FG_MHMW_NS          /* a compiled unit of a program without a score stream: its statements, log_prior rows first */
-    constexpr int n_s = FG_MHMW_NS, n_pri = FG_MHMW_NPRI, n_fac = FG_MHMW_NFAC /* `factor` statements: the last rows */, n_lik = n_s - n_pri - n_fac;
+    constexpr int n_s = FG_MHMW_NS, n_pri = FG_MHMW_NPRI, n_fac = FG_MHMW_NFAC /* `factor` statements: the last rows */, n_lik = n_s - n_pri - n_fac, n_cu = 0;
 #else
-    const int n_s = P.n_sstream, n_pri = P.n_prior_terms, n_lik = n_s - n_pri;
+    const int n_cu = seg.n_cu;                                      // (terms without a row: FgMhSeg)
+    const int n_s = P.n_sstream - n_cu, n_pri = P.n_prior_terms - n_cu, n_lik = n_s - n_pri;
 #endif
     double *slots = lds + lane;
     double *terms = lds + (long long)P.n_slots * tw + lane;
@@ -228,10 +242,17 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
     int tslot = 0, kind0 = 0, kind_new = 0;
     long long g = 0;
     unsigned long long nacc = 0;
+    int nbad = 0;                                                  // this chain's row-less Categorical sites whose index is out of range
+    bool cur_bad = false;                                          // ... and whether the current proposal replaces one
 
     if (wv == 0) {
         fg_load_values(P, X, c, slots, tw);
         lw = M.lw[c];
+        for (int j = 0; j < n_cu; ++j) {
+            const FgMhCatU cu = seg.catu[j];
+            const long long zi = fg_as_i64(slots[cu.slot * tw]);
+            nbad += (zi < 0 || zi >= (long long)cu.K) ? 1 : 0;
+        }
         // the control wave's instruction stream is the path of its tile: it is served before the term and random-number waves
         // of the tiles it shares a SIMD with (exp_mask bit 32 switches this off: A/B)
         if (!(exp_mask & 32)) __builtin_amdgcn_s_setprio(2);
@@ -271,6 +292,29 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
             n_scale = fg_dbl(a0[0], a0[1]);                                                                                 \
             n_kind = (int)a0[2];                                                                                            \
         }
+        // the row-less tail of log_prior (FgMhSeg): the constants, eight per scalar load; from the cells while a chain holds a bad index
+#define FG_MH_CATU_TAIL                                                                                                     \
+        if (n_cu > 0) {                                                                                                     \
+            if (__builtin_expect(__any(nbad != 0), 0)) {                                                                    \
+                for (int j = 0; j < n_cu; ++j) {                                                                            \
+                    const FgMhCatU cu = seg.catu[j];                                                                        \
+                    const long long zi = fg_as_i64(slots[cu.slot * tw]);                                                    \
+                    pri += (zi < 0 || zi >= (long long)cu.K) ? FG_NEG_INF : fg_uniform(seg.catu_c[j]);                      \
+                }                                                                                                           \
+            } else if (seg.catu_same) {                             /* one constant for all of them (equal tables): no loads */    \
+                const double c0_ = fg_uniform(seg.catu_c0);                                                                 \
+                int j = 0;                                                                                                  \
+                for (; j + 8 <= n_cu; j += 8) { _Pragma("unroll") for (int q = 0; q < 8; ++q) pri += c0_; }                  \
+                for (; j < n_cu; ++j) pri += c0_;                                                                           \
+            } else {                                                /* eight per scalar load, the next eight on their way */  \
+                fg_u32x16 cb_ = fg_fetch_grec((const FgGradRec *)seg.catu_c, 0);                                            \
+                for (int j = 0; j < n_cu; j += 8) {                                                                         \
+                    const fg_u32x16 cn_ = fg_fetch_grec((const FgGradRec *)seg.catu_c, (j >> 3) + 1);                       \
+                    _Pragma("unroll") for (int q = 0; q < 8; ++q) if (j + q < n_cu) pri += fg_dbl(cb_[2 * q], cb_[2 * q + 1]); \
+                    cb_ = cn_;                                                                                              \
+                }                                                                                                           \
+            }                                                                                                               \
+        }
         // log_prior and log_likelihood of step t - 1's proposal: the terms in program order.  SPLIT (long programs): one chain per
         // wave -- a wave alone on its tile's path issues an instruction every 6 to 9 cycles
         // (profiles/round1_f64_issue_microbench.txt), so the two independent sums run side by side on two waves and meet at a barrier
@@ -278,7 +322,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
         if (SPLIT) {
             if (wv == 0) { FG_MH_NEXT_INPUTS }
             if (t > 0 && !(exp_mask & 2)) {
-                if (wv == 0) pri = fg_inorder_sum1(terms, n_pri, tw);
+                if (wv == 0) { pri = fg_inorder_sum1(terms, n_pri, tw); FG_MH_CATU_TAIL }
                 else if (wv == 1) xch[16 * tw] = fg_inorder_sum1(terms + (long long)n_pri * tw, n_lik, tw);
                 // LDS only crosses this barrier: wait for the LDS counter and leave the control wave's adaptation-state gather (64
                 // lines from L2, issued above) in flight -- __syncthreads() would drain it here
@@ -290,9 +334,10 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
         if (wv == 0) {
             if (!SPLIT) {                                                  // short programs: both chains on the control wave, no third barrier
                 FG_MH_NEXT_INPUTS
-                if (t > 0 && !(exp_mask & 2)) fg_inorder_sums2(terms, n_pri, terms + (long long)n_pri * tw, n_lik, tw, pri, lik);
+                if (t > 0 && !(exp_mask & 2)) { fg_inorder_sums2(terms, n_pri, terms + (long long)n_pri * tw, n_lik, tw, pri, lik); FG_MH_CATU_TAIL }
             }
 #undef FG_MH_NEXT_INPUTS
+#undef FG_MH_CATU_TAIL
             if (t > 0 && !(exp_mask & 2)) {                                // finish step t - 1
                 const int itp = iter - 1;
                 const bool adapt = itp < n_warmup;
@@ -321,7 +366,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                     }
                 }
                 if (live && kind_new != kind0) M.ad[g].kind = kind_new;
-                if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); }
+                if (accept) { lw = prop_lw; nacc += 1ull; if (live) X.values[g] = fg_as_i64(slots[tslot * tw]); if (cur_bad) nbad -= 1; }
                 else slots[tslot * tw] = old_cell;
                 if ((!adapt || M.rec_all) && draws && live) {              // recorded cells of the CURRENT state (mh.rs:1010)
                     long long *row = draws + (long long)(t - 1 - first_sample_t) * M.n_rec * X.C + c;
@@ -381,6 +426,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                     mh.next_block = 2;
                     slots[tslot * tw] = fg_as_double(prop);
                 } else fg_mh_walk_proposal(mh, tv, kind_eff, tslot, slots, tw);
+                if (n_cu > 0) { const long long cur = fg_as_i64(mh.old_cell); const int cK = (int)(fg_as_i64(b[5 * tw]) >> 32); cur_bad = tv == 3u && cK > 0 && (cur < 0 || cur >= (long long)cK); }
 #ifdef FG_MHMW_NS
                 }
                 if (!walk) { mh.lqf = mp.lqf; mh.lqr = mp.lqr; mh.kind = mp.kind; mh.next_block = mp.next_block; }

@@ -191,6 +191,47 @@ def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeyp
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
+@pytest.mark.parametrize("K,n", [(4, 10), (3, 21)])
+def test_mh_mixture_without_rows_for_uniform_categorical_priors(K, n, monkeypatch):
+    """The mixture pattern (examples/mixture_models.rs:77-112 with fixed equal weights): every assignment's log_prior term is the
+    same constant ln(1/K), so the multi-wave kernel keeps no rows for them and the control wave adds the constants after the rows of
+    log_prior, in order (FgMhSeg).  Against the one-wave kernel and against the kernel WITH those rows (FG_MH_CATU=0), also with
+    indices injected out of range (their terms are -inf)."""
+    data, _ = W.mixture_data(n)
+    cp = E.compile_model(W.mixture(data, K=K))
+    C, nw, ns = 200, 150, 60
+    rec = list(range(cp.S))
+    zs = [j for j in range(cp.S) if cp.site_vtypes[j] == 3]
+    out = []
+    for inject in (False, True):
+        res = []
+        for mw, catu, jit, Wv in ((0, 1, 0, 1), (1, 0, 0, 4), (1, 1, 0, 2), (1, 1, 0, 8), (1, 1, 1, 0), (1, 1, 1, 16)):
+            monkeypatch.setenv("FG_MH_MW", str(mw)); monkeypatch.setenv("FG_MH_CATU", str(catu)); monkeypatch.setenv("FG_JIT", str(jit))
+            if Wv: monkeypatch.setenv("FG_HMC_WAVES", str(Wv))
+            else: monkeypatch.delenv("FG_HMC_WAVES", raising=False)
+            eng = E.Engine(cp, C, seed=21, chain_offset=2)
+            eng.mh_init(nw)                                         # draws the start from the prior (mh.rs:950-957)
+            if inject:
+                v = eng.get_values()
+                v[zs[0], ::3] = K + 2; v[zs[1], 1::4] = -1; v[zs[-1], ::5] = K      # out of range in some chains, two sites at once in a few
+                eng.set_values(v)                                   # (re-scores the cached log-weight: -inf in those chains)
+                assert np.isneginf(eng.mh_log_weight()[::3]).all()
+            eng.mh_step(nw)
+            d = eng.device_alloc(ns * cp.S * C * 8)
+            eng.mh_step(ns, rec, d)
+            draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
+            eng.device_free(d)
+            res.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), eng.mh_stats().accept_rate))
+            eng.close()
+        for o in res[1:]:
+            for a, b in zip(res[0], o):
+                assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+        out.append(res[0])
+    assert not np.array_equal(out[0][0], out[1][0])                # the injected indices changed the chains
+    # ... and such a chain stays where it is, as in the reference: log q(x|x') of the move back is -inf too, so log_alpha is NaN (mh.rs:731-733)
+    assert np.isneginf(out[1][3][::3]).all() and np.isfinite(out[0][3]).all()
+
+
 @pytest.mark.parametrize("name,with_overrides", [("alldists", False), ("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("coin", False), ("logistic", False)])
 def test_mh_interp_multiwave_is_bit_identical(name, with_overrides, monkeypatch):
     """Programs without a score stream split a step's scoring run between W waves (k_mh_interp_mw_steps, fg_mh_interp.hip: each
