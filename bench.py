@@ -643,7 +643,14 @@ def leg_dense(X):
     n_stmt, d = 2 * N_SITES, cp.d
     evals_sem = (2 * d * (L + 1)) * n_stmt + n_stmt
     evals_exec = (L + 1) * (n_stmt + 2 * 2 * d) + n_stmt
-    adds = (L + 1) * 2 * d * n_stmt                                           # the in-order additions of the 2 d scoring runs per gradient
+    # the in-order additions the kernel performs per gradient: both whole-run sums of a coordinate are the same number ahead of its
+    # own row (that prefix is added once per wave and extended from one own coordinate to the next), two chains behind it
+    import re as _re
+    Wd = int((_re.search(r"W=(\d+)", kernel) or [0, 16])[1])
+    n_w = max(1, d // max(1, Wd))
+    prefix = n_w * Wd * (Wd - 1) // 2 + Wd * (n_w - 1)
+    adds = (L + 1) * 2 * (d * (d - 1) + 2 * d + prefix)                       # x 2: log_prior and log_likelihood (one statement of each per coordinate)
+    adds_sem = (L + 1) * 2 * d * n_stmt                                       # ... of the 2 d whole scoring runs as the reference performs them
     sem = C * n_launch * evals_sem * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
     exe = C * n_launch * (evals_exec * FLOPS_PER_NORMAL_LOGPDF + adds) / (launch_ms * 1e-3) / 1e12
     ent, src = pmc_entry(f"hmc|normal32|{C}|fd_dense|L{L}")
@@ -654,8 +661,10 @@ def leg_dense(X):
                          "kernel": kernel, "avg_launch_ms": launch_ms, "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src,
                          "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3), "executed_source": src,
                          "dense_semantics_tflops": sem,
-                         "note": "achieved = what the dense kernel computes: every statement's density once per gradient + the moved ones at +-h (x 8 flops) + ALL the "
-                                 "in-order additions of the 2 d whole scoring runs (1 flop each); dense_semantics_tflops = SURVEY 8d's 2 d (S+O) log-pdfs x 8 flops per "
+                         "in_order_additions_per_gradient": {"performed": adds // (L + 1), "of_the_2d_whole_runs": adds_sem // (L + 1)},
+                         "note": "achieved = what the dense kernel computes: every statement's density once per gradient + the moved ones at +-h (x 8 flops) + the "
+                                 "in-order additions it performs (1 flop each: the part of the two whole-run sums ahead of a coordinate's own row is one number, "
+                                 "added once per wave; the same bits as 2 d whole scoring runs); dense_semantics_tflops = SURVEY 8d's 2 d (S+O) log-pdfs x 8 flops per "
                                  "gradient at this rate (re-evaluating densities that did not move), which exceeds the peak and is NOT executed"}}
 
 

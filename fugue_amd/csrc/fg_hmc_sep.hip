@@ -199,11 +199,17 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     // d = 32, so one tile's in-order sums / accept step overlap the other tile's trajectories.
     const int srows = P.n_sep_free > 0 ? P.n_slots : 0;
     double *slots = lds + lane;
-    double *kin0 = lds + (long long)srows * tw + lane;
-    double *kin1 = kin0 + (long long)d * tw;
-    double *terms = kin1 + (long long)d * tw;
-    double *xch = terms + (long long)(DENSE ? 2 * n_s : n_s) * tw;   // rows: 0 step size, 1 accepted, 2 divergence bits
-    double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only: positions and momenta between gradients
+    // DENSE: (site values) | score terms | exchange | positions | momenta -- q and p live in LDS rows between gradients, and at the
+    // end of a trajectory the same rows take the two kinetic-energy terms of each coordinate (p0's is formed again from its random
+    // number then: one Box-Muller pair per two coordinates and transition against d rows per tile).  4 d + 2 n_s + 3 rows with
+    // separate kinetic rows and double-buffered terms left ONE tile on a CU at d = 32; 2 d + n_s + 3 = 131 rows leave two, and one
+    // tile's barriers overlap the other's arithmetic (tools/exp_dense_residency.py: d = 19 / 20 either side of that boundary ran
+    // 4.3e9 / 2.2e9 leapfrog-steps/s).
+    double *terms = lds + (long long)(srows + (DENSE ? 0 : 2 * d)) * tw + lane;
+    double *xch = terms + (long long)n_s * tw;                      // rows: 0 step size, 1 accepted, 2 divergence bits
+    double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only
+    double *kin0 = DENSE ? qrow : lds + (long long)srows * tw + lane;
+    double *kin1 = DENSE ? prow : kin0 + (long long)d * tw;
     const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
     const bool prio_turns = seg.c[FG_SEP_WMAX] < 0;               // host flag (the last boundary is otherwise d)
     const double *mi = MASS ? H.m_inv + c : nullptr;
@@ -222,7 +228,6 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             const fg_u32x16 r = fg_fetch_grec(P.sstream, (int)f.sidx);
             FgAcc3 dummy = {0.0, 0.0, 0.0};
             terms[f.trow * tw] = fg_score_one<0>(r, slots[r[0] * tw], slots[r[1] * tw], P.pool, slots, tw, dummy);
-            if (DENSE) terms[((long long)n_s + f.trow) * tw] = terms[f.trow * tw];
         }
         if (iter0 < n_warmup) e_cur = eps;
         else {                                                 // frozen_or_current: hmc.rs:789-798
@@ -254,14 +259,12 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                 if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
                 else z = zb;
                 const double p = MASS ? z * ms[(long long)i * X.C] : z;
-                const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
-                kin0[i * tw] = MASS ? p * p * mii : p * p;
                 prow[i * tw] = p;
                 qrow[i * tw] = fg_as_double(X.values[(long long)P.f64_site[i] * X.C + c]);
             }
-            int tb = 0;
             for (int gs = 0; gs <= L; ++gs) {                        // leapfrog, hmc.rs:353-407
-                double *T = terms + (long long)tb * n_s * tw;
+                double *T = terms;
+                if (gs > 0) __syncthreads();                         // the previous gradient's sums have read T
                 for (int i = k0; i < k1; ++i) {                      // the own statements at the current q
                     const FgSepCoord cd = P.sep_coord[i];
                     const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
@@ -325,13 +328,17 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                     prow[i * tw] = p;
                     if (gs < L) qrow[i * tw] = q + (MASS ? e * mii : e) * p;   // hmc.rs:391-393
                 }
-                tb ^= 1;                                                // the next gradient's terms go to the other buffer
             }
-            termsE = terms + (long long)(tb ^ 1) * n_s * tw;             // the terms of the last gradient are the endpoint's
-            for (int i = k0; i < k1; ++i) {
+            termsE = terms;                                              // the terms of the last gradient are the endpoint's
+            for (int i = k0; i < k1; ++i) {                              // the proposal row; then the kinetic terms of p0 and p in the rows of q and p
+                double z;
+                if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
+                else z = zb;
+                const double p0 = MASS ? z * ms[(long long)i * X.C] : z;
                 const double mii = MASS ? mi[(long long)i * X.C] : 1.0;
                 const double p = prow[i * tw];
-                if (live) H.p0_scratch[(long long)i * X.C + c] = qrow[i * tw];   // the proposal row
+                if (live) H.p0_scratch[(long long)i * X.C + c] = qrow[i * tw];
+                kin0[i * tw] = MASS ? p0 * p0 * mii : p0 * p0;
                 kin1[i * tw] = MASS ? p * p * mii : p * p;
             }
         } else
@@ -502,7 +509,7 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const int tw = half ? FG_WAVE / 2 : FG_WAVE;
     const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
     const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
-                        (dense ? (size_t)e->P.n_sstream + 2 * (size_t)e->d : 0);     // dense: second term buffer, q and p rows
+                        (dense ? 8 : 0);     // (dense: the kinetic terms end the tile -- the in-order sums read whole chunks of eight rows)
     const size_t lds = rows * tw * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
