@@ -268,10 +268,10 @@ struct Gen {
             char sig[96];
             std::snprintf(sig, sizeof sig, "fg_jit_lp_%u_%d%d%d%d", code, (int)hoisted, (int)pow2, (int)sh, (int)xh);
             if (!lp_fns->count(sig)) {
-                char def[640];
+                char def[768];
                 std::snprintf(def, sizeof def,
                               "static __device__ FG_JIT_CALL double %s(double xf, long long xi, double p0, double p1, double p2, double h0, double h1, double h2, double h3, double h4) {\n"
-                              "    const double hh[5] = { h0, h1, h2, h3, h4 };\n    return fg_logpdf(%uu, %s, %s, xf, xi, p0, p1, p2, hh, %s, %s);\n}\n",
+                              "    const double hh[5] = { h0, h1, h2, h3, h4 };\n    return fg_logpdf(%uu, %s, %s, FG_JIT_OPQ(xf), xi, FG_JIT_OPQ(p0), FG_JIT_OPQ(p1), FG_JIT_OPQ(p2), hh, %s, %s);\n}\n",
                               sig, code, hoisted ? "true" : "false", pow2 ? "true" : "false", sh ? "true" : "false", xh ? "true" : "false");
                 (*lp_fns)[sig] = def;
             }
@@ -396,15 +396,24 @@ typedef unsigned long size_t;
 
 const char *HELPERS = R"FGJ(
 // the transcendental opcodes behind calls, as in fg_interp.h (same ocml functions: same bits)
-#ifndef FG_JIT_CALL
+// FG_JIT_INLINED (experiment, see fg_jit_inlined): densities and transcendentals are inlined into the statements that use them (no call,
+// no arguments moved into the callee's registers).  An inlined libm call must still see RUN-TIME arguments: with a literal
+// the compiler would evaluate log(0.7) itself, or turn pow(x, 2.0) into x * x -- other bits than ocml's code gives the interpreter.
+// fg_jit_opq hands its argument through an empty (not volatile: it may move and merge) asm statement: the value is in a register and opaque to constant propagation.
+#ifdef FG_JIT_INLINED
+#define FG_JIT_CALL __forceinline__
+static __device__ __forceinline__ double fg_jit_opq(double x) { asm("" : "+v"(x)); return x; }
+#define FG_JIT_OPQ(x) fg_jit_opq(x)
+#else
 #define FG_JIT_CALL __noinline__
+#define FG_JIT_OPQ(x) (x)
 #endif
-static __device__ FG_JIT_CALL double fg_jit_exp(double x) { return exp(x); }
-static __device__ FG_JIT_CALL double fg_jit_log(double x) { return log(x); }
-static __device__ FG_JIT_CALL double fg_jit_sin(double x) { return sin(x); }
-static __device__ FG_JIT_CALL double fg_jit_cos(double x) { return cos(x); }
-static __device__ FG_JIT_CALL double fg_jit_tanh(double x) { return tanh(x); }
-static __device__ FG_JIT_CALL double fg_jit_pow(double x, double y) { return pow(x, y); }
+static __device__ FG_JIT_CALL double fg_jit_exp(double x) { return exp(FG_JIT_OPQ(x)); }
+static __device__ FG_JIT_CALL double fg_jit_log(double x) { return log(FG_JIT_OPQ(x)); }
+static __device__ FG_JIT_CALL double fg_jit_sin(double x) { return sin(FG_JIT_OPQ(x)); }
+static __device__ FG_JIT_CALL double fg_jit_cos(double x) { return cos(FG_JIT_OPQ(x)); }
+static __device__ FG_JIT_CALL double fg_jit_tanh(double x) { return tanh(FG_JIT_OPQ(x)); }
+static __device__ FG_JIT_CALL double fg_jit_pow(double x, double y) { return pow(FG_JIT_OPQ(x), FG_JIT_OPQ(y)); }
 // the module's constant tables (FgJitTabs): one device buffer, its address stored here by the engine after hipModuleLoadData
 #define FG_JIT_AS4 __attribute__((address_space(4)))
 __device__ const double *fg_jit_ctab_ptr = nullptr;
@@ -414,6 +423,12 @@ static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vty
 )FGJ";
 
 }  // namespace
+
+// densities and transcendentals inlined into the statements (HELPERS: FG_JIT_INLINED)?  An experiment (FG_JIT_INLINE=1), not the default:
+// with arguments the compiler can see through, inlining gained 2 ... 20 % -- by evaluating lgamma(2.0) or log(0.5) at compile time with
+// the host's libm, i.e. possibly other bits than the interpreter's; with the arguments made opaque (as here) the same work is done at run
+// time in many copies and the kernels are slower than with calls (hier_scale HMC 3.5e9 -> 2.1e9, MH 7.7e9 -> 6.0e9).
+static bool fg_jit_inlined() { const char *v = std::getenv("FG_JIT_INLINE"); return v && std::atoi(v) != 0; }
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
 std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out) {
@@ -442,7 +457,7 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
                "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
     std::string src = PROLOGUE;
-    if (std::getenv("FG_JIT_INLINE")) src += "#define FG_JIT_CALL __forceinline__\n";       // experiments: densities and transcendentals inlined into the statements
+    if (fg_jit_inlined()) src += "#define FG_JIT_INLINED 1\n";
     if (const char *oc = std::getenv("FG_HMC_JIT_OCC")) { const int o = std::atoi(oc); if (o >= 2 && o <= 4) src += "#define FG_JIT_OCC " + std::to_string(o) + "\n"; }   // experiments: register budget
     src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
     src += HELPERS;
@@ -497,6 +512,7 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_seg_" + std::to_string(sg) + "(slots, terms); break;\n";
     fns += "    default: break;\n    }\n}\n";
     std::string src = PROLOGUE;
+    if (fg_jit_inlined()) src += "#define FG_JIT_INLINED 1\n";
     src += FG_JIT_EMBED_API;                     // include/fugue_amd.h (proposal kinds, error codes)
     src += FG_JIT_EMBED_HEAD;                    // fg_ir.h, fg_math.h, fg_cold.h, fg_dev_types.h
     src += FG_JIT_EMBED_INTERP;                  // fg_interp.h: the propose-and-score mode for model-dependent proposals
@@ -591,6 +607,7 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_mhb_" + std::to_string(sg) + "(slots, terms); break;\n";
     fns += "    default: break;\n    }\n}\n";
     std::string src = PROLOGUE;
+    if (fg_jit_inlined()) src += "#define FG_JIT_INLINED 1\n";
     src += FG_JIT_EMBED_API;
     src += FG_JIT_EMBED_HEAD;
     src += FG_JIT_EMBED_INTERP;                  // fg_interp.h (fg_gradstream.h builds on it)
