@@ -29,6 +29,9 @@ __device__ unsigned long long fg_hmc_prof[FG_SEP_WMAX][8];
 #define FG_PROF_T(i)
 #endif
 struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
+#ifndef FG_SEP_STAGGER
+#define FG_SEP_STAGGER 2          /* x 4 096 cycles: the late start of a CU's second tile (k_hmc_sep_steps) */
+#endif
 
 // a coordinate's records: by scalar loads from a wave-uniform pointer (SGPRs), or -- half tiles, where the two lane halves of a
 // wave run different coordinates -- by per-lane loads (VGPRs)
@@ -174,18 +177,21 @@ __device__ __noinline__ FgD3 fg_sep_trajectory_checked(RB rb, double q, double p
 // MODE: 0 = dependency-aware finite difference (FG_GRAD_FD_SPARSE), 1 = DENSE, 2 = analytic (FG_GRAD_ANALYTIC)
 // HALF (MODE 0, programs whose coordinates all have the same record shape with power-of-two sigmas): a tile is 32 chains, the
 // lower lane half of a wave runs coordinate i of a Box-Muller pair and the upper half coordinate i + 1 of the SAME chains -- half
-// the work per wave and twice the tiles when 64-chain tiles would leave CUs without one (8 192 chains on 256 CUs).  Per
+// the work per wave and twice the tiles when 64-chain tiles would leave CUs without one (8 192 chains on 256 CUs).  HALF = 2:
+// quarter tiles of 16 chains, four coordinates per wave in its four lane groups -- when even half tiles leave a CU with ONE tile, whose
+// waves all wait while wave 0 adds and decides (tools/prof_hmc_phases.py at 8 192 chains: 8 200 of a transition's 22 400 ticks); two
+// quarter tiles per CU take turns.  Per
 // (chain, coordinate) the arithmetic is unchanged; wave 0's in-order sums run in both halves on the same rows.
-template <bool MASS, int MODE, bool HALF = false>
+template <bool MASS, int MODE, int HALF = 0 /* 1: half tiles, 2: quarter tiles */>
 __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgSegSep seg, int iter0, int n_steps,
                                                                              int n_warmup, int welford_on, double *draws, int first_sample_t,
                                                                              double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
-    constexpr int tw = HALF ? FG_WAVE / 2 : FG_WAVE;
+    constexpr int tw = FG_WAVE >> HALF;
     constexpr bool DENSE = MODE == 1, AN = MODE == 2;
     static_assert(!HALF || MODE == 0, "half tiles: sparse finite difference only");
     const int lane = threadIdx.x & (tw - 1);                       // chain of the tile
-    const int half = HALF ? (int)((threadIdx.x >> 5) & 1u) : 0;
+    const int half = HALF == 1 ? (int)((threadIdx.x >> 5) & 1u) : (HALF == 2 ? (int)((threadIdx.x >> 4) & 3u) : 0);   // which of the wave's 2 / 4 coordinates this lane runs
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long chain = (long long)blockIdx.x * tw + lane;
     const bool live = chain < X.C;                                 // stores of the lane's own coordinate
@@ -211,7 +217,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     double *kin0 = DENSE ? qrow : lds + (long long)srows * tw + lane;
     double *kin1 = DENSE ? prow : kin0 + (long long)d * tw;
     const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
-    const bool prio_turns = seg.c[FG_SEP_WMAX] < 0;               // host flag (the last boundary is otherwise d)
+    const bool prio_turns = seg.c[FG_SEP_WMAX] == -1;             // host flags (the last boundary is otherwise d)
+    const int stagger = seg.c[FG_SEP_WMAX] <= -2 ? -seg.c[FG_SEP_WMAX] - 1 : 0;   // 1: the second half of the grid starts late, 2: the odd tiles
     const double *mi = MASS ? H.m_inv + c : nullptr;
     const double *ms = MASS ? H.mass_sqrt + c : nullptr;
     const double h = fg_uniform(H.h), two_h = fg_uniform(2.0 * H.h), rcp_2h = fg_uniform(1.0 / (2.0 * H.h));
@@ -243,6 +250,13 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
 #ifdef FG_HMC_PROF
     unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_readcyclecounter();
 #endif
+    // Two tiles that start together on a CU stay in step -- both in their trajectories (the SIMDs full), then both waiting for their
+    // wave 0 (the SIMDs empty).  The odd tiles start a wave-0 phase late: one tile's sums and accept step then fall into the other's
+    // trajectories for the whole launch (the lag neither grows nor shrinks: each is ahead of the other for as long as it is behind).
+    // Measured: +5 % for two half tiles on a CU (16 384 chains), nothing for two quarter tiles, -5 % for 64-chain tiles (which come
+    // in several rounds and fall out of step by themselves): the host asks for it in the first case only.
+    if (stagger && (stagger == 1 ? blockIdx.x >= (gridDim.x + 1) / 2 : (blockIdx.x & 1u) != 0u))
+        for (int q = 0; q < FG_SEP_STAGGER; ++q) __builtin_amdgcn_s_sleep(64);            // 64 x 64 cycles each
     for (int t = 0; t < n_steps; ++t) {
         const int iter = iter0 + t;
         const bool warming = iter < n_warmup;
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                 kin1[i * tw] = MASS ? p * p * mii : p * p;
             }
         } else
-        for (int i = k0; i < k1; i += HALF ? 2 : 1) {
+        for (int i = k0; i < k1; i += 1 << HALF) {
             // The SIMD's arbiter serves its oldest wave first: of the two waves a tile has on a SIMD the younger one (waves 4..7 of
             // 8) took 30 % longer over the same work and the tile waited for it at the barrier (tools/prof_hmc_phases.py).  The two
             // take turns at the higher priority, one coordinate each: +4 % (either wave always ahead, or turns per transition: -3 %).
@@ -350,7 +364,10 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             const bool on = !HALF || i + half < d;                   // odd d: the upper half idles on the last pair
             const int ci = HALF ? (on ? i + half : i) : i;           // the lane's coordinate
             double z;
-            if (HALF) {
+            if (HALF == 2) {                                         // quarter tiles: every lane group forms its own coordinate's pair (the pair's two groups: twice)
+                const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(ci >> 1), (uint32_t)iter, FG_RNG_HMC);
+                z = (ci & 1) ? zz.b : zz.a;
+            } else if (HALF) {
                 // Both lane halves carry the same chains, so generating a pair in both would double the Philox + Box-Muller work per
                 // chain.  Instead a wave takes its pairs two at a time: the lower half generates this pair, the upper half the wave's
                 // NEXT pair, and each hands the other the component it needs (one cross-half exchange per pair).  An idle upper half
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         const bool acc = xch[tw] != 0.0;
         unsigned long long wn = 0;
         if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
-        for (int i0 = k0; i0 < k1; i0 += HALF ? 2 : 1) {          // commit or roll back the own f64 sites
+        for (int i0 = k0; i0 < k1; i0 += 1 << HALF) {             // commit or roll back the own f64 sites
             const bool on = !HALF || i0 + half < d;
             const int i = HALF ? (on ? i0 + half : i0) : i0;
             const long long g = (long long)P.f64_site[i] * X.C + c;
@@ -498,15 +515,18 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const long long tiles64 = (e->C + FG_WAVE - 1) / FG_WAVE;
     // half tiles (32 chains per workgroup, the two coordinates of a Box-Muller pair in the two lane halves): when 64-chain tiles
     // would leave half of the CUs without one, for programs whose coordinates all have one record shape with power-of-two sigmas
-    bool half = false;
+    int half = 0;                                            // 1: half tiles, 2: quarter tiles (16 chains, four coordinates per wave)
     if (!dense && !analytic && e->d >= 2) {
         const std::vector<FgSepCoord> &cd = e->prog->sep_coord;
         bool uniform = true;
         for (const FgSepCoord &q : cd) uniform = uniform && q.n == cd[0].n && (q.n & 256);
-        half = uniform && 2 * tiles64 <= n_cu;
-        if (const char *hv = std::getenv("FG_HMC_SEP_HALF")) half = uniform && std::atoi(hv) != 0;
+        // half tiles up to two of them per CU (16 384 chains: 1.57e10 with 64-chain tiles, 1.67e10, 1.75e10 with the late start below);
+        // quarter tiles where even half tiles leave CUs without one (4 096 chains: 6.7e9 -> 9.2e9; at 8 192 the two are level)
+        if (uniform && tiles64 <= n_cu) half = (4 * tiles64 < 2 * n_cu && e->d >= 8) ? 2 : 1;
+        if (const char *hv = std::getenv("FG_HMC_SEP_HALF")) half = uniform ? std::max(0, std::min(2, std::atoi(hv))) : 0;
+        if (half == 2 && e->d < 4) half = 1;
     }
-    const int tw = half ? FG_WAVE / 2 : FG_WAVE;
+    const int tw = FG_WAVE >> half;
     const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
     const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
                         (dense ? 8 : 0);     // (dense: the kinetic terms end the tile -- the in-order sums read whole chunks of eight rows)
@@ -515,22 +535,26 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
     // chain counts) leave CUs with one tile -- the waves then come from sharing the tile.  Every wave owns >= 2 coordinates
     // (a half tile: >= 1 pair, both coordinates at once).
-    const int pairs = (e->d + 1) / 2;
+    const int unit = half == 2 ? 4 : 2;                      // coordinates a wave takes at a time
+    const int pairs = (e->d + unit - 1) / unit;
     int W = e->mw_override > 0 ? e->mw_override : 1;
     if (e->mw_override <= 0) {
         const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)lds, ((long long)tiles + n_cu - 1) / n_cu));
         while (W < FG_SEP_WMAX && resident * W < 16 && (half ? pairs >= 2 * W : e->d >= 4 * W)) W *= 2;     // (a half tile with a pair per wave beats two pairs per wave sharing their random numbers: 1.31e10 against 1.25e10 at 8 192 chains)
     }
-    while (W > 1 && 2 * (W - 1) >= e->d + 1) W /= 2;             // no empty waves
+    while (W > 1 && unit * (W - 1) >= e->d + 1) W /= 2;          // no empty waves
     FgSegSep seg;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
-    for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, 2 * (int)((long long)pairs * w / W));
+    for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, unit * (int)((long long)pairs * w / W));
     if (W == 8 && !half && !(std::getenv("FG_HMC_PRIO") && std::atoi(std::getenv("FG_HMC_PRIO")) == 0)) seg.c[FG_SEP_WMAX] = -1;   // priority turns: two waves of a tile per SIMD
-    static bool attr_set_dev[64][8];
-    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = half ? 6 + mass : 2 * mode + mass;
-    const void *fns[8] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
+    if (half == 1 && (long long)tiles > n_cu && (long long)tiles <= 2 * n_cu) seg.c[FG_SEP_WMAX] = -3;                                  // two half tiles on a CU: the odd ones start late (+5 %; 64-chain tiles lose 5 % to it)
+    if (const char *sg = std::getenv("FG_HMC_STAGGER")) { const int v = std::atoi(sg); seg.c[FG_SEP_WMAX] = (v == 1 || v == 2) ? -1 - v : (seg.c[FG_SEP_WMAX] <= -2 ? e->d : seg.c[FG_SEP_WMAX]); }   // experiments
+    static bool attr_set_dev[64][10];
+    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = half ? 4 + 2 * half + mass : 2 * mode + mass;
+    const void *fns[10] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
                            (const void *)k_hmc_sep_steps<true, 1>, (const void *)k_hmc_sep_steps<false, 2>, (const void *)k_hmc_sep_steps<true, 2>,
-                           (const void *)k_hmc_sep_steps<false, 0, true>, (const void *)k_hmc_sep_steps<true, 0, true> };
+                           (const void *)k_hmc_sep_steps<false, 0, 1>, (const void *)k_hmc_sep_steps<true, 0, 1>,
+                           (const void *)k_hmc_sep_steps<false, 0, 2>, (const void *)k_hmc_sep_steps<true, 0, 2> };
     bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
         const hipError_t he = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -542,11 +566,12 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     switch (variant) {
         case 0: FG_SEP_LAUNCH(false, 0); break; case 1: FG_SEP_LAUNCH(true, 0); break; case 2: FG_SEP_LAUNCH(false, 1); break;
         case 3: FG_SEP_LAUNCH(true, 1); break;  case 4: FG_SEP_LAUNCH(false, 2); break; case 5: FG_SEP_LAUNCH(true, 2); break;
-        case 6: FG_SEP_LAUNCH(false, 0, true); break; default: FG_SEP_LAUNCH(true, 0, true); break;
+        case 6: FG_SEP_LAUNCH(false, 0, 1); break; case 7: FG_SEP_LAUNCH(true, 0, 1); break;
+        case 8: FG_SEP_LAUNCH(false, 0, 2); break; default: FG_SEP_LAUNCH(true, 0, 2); break;
     }
 #undef FG_SEP_LAUNCH
     HIPCHK(hipGetLastError());
-    e->last_hmc_kernel = std::string(dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : (half ? "k_hmc_sep_steps (half tiles) W=" : "k_hmc_sep_steps W="))) + std::to_string(W);
+    e->last_hmc_kernel = std::string(dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : (half == 2 ? "k_hmc_sep_steps (quarter tiles) W=" : (half ? "k_hmc_sep_steps (half tiles) W=" : "k_hmc_sep_steps W=")))) + std::to_string(W);
     return FG_OK;
 }
 

@@ -401,7 +401,7 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     # coordinates share one record shape with power-of-two sigmas -- elsewhere the switch is ignored and the run repeats the full tile
     layouts = [(0, 1, 0), (1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0)]
     if mode == E.GRAD_FD_SPARSE and name in ("normal32", "indep_uniform5"):
-        layouts += [(1, 1, 1), (1, 2, 1), (1, 4, 1), (1, 16, 1)]
+        layouts += [(1, 1, 1), (1, 2, 1), (1, 4, 1), (1, 16, 1), (1, 1, 2), (1, 2, 2), (1, 8, 2)]      # 2: quarter tiles (16 chains, four coordinates per wave)
     for sep, W, half in layouts:
         monkeypatch.setenv("FG_HMC_SEP", str(sep))
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
@@ -412,7 +412,8 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
         draws = eng.download(d, (ns, cp.d, C))
         eng.device_free(d)
         pos, info = eng.hmc_step_info(3)
-        assert ("half tiles" in eng.hmc_last_kernel()) == bool(half) and ("k_hmc_sep_steps" in eng.hmc_last_kernel()) == bool(sep)
+        assert ("half tiles" in eng.hmc_last_kernel()) == (half == 1) and ("quarter tiles" in eng.hmc_last_kernel()) == (half == 2)
+        assert ("k_hmc_sep_steps" in eng.hmc_last_kernel()) == bool(sep)
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
                     eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
         eng.close()
