@@ -52,7 +52,8 @@ static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape
     sh.W = std::max(W, 2);                                                  // control wave + random-number wave
     sh.exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
     if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) sh.exp_mask |= 32;
-    else if (resident >= 2) sh.exp_mask |= 64;   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
+    else if (resident >= 2) sh.exp_mask |= 64;
+    if (resident >= 3 && !(std::getenv("FG_MH_STAGGER") && std::atoi(std::getenv("FG_MH_STAGGER")) == 0)) sh.exp_mask |= 128;   // bit 128: the tiles of a CU start a quarter of a step apart (reference_model(20), four tiles per CU: +4.7 %; two tiles: nothing)   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
     // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
     // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
     sh.split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);

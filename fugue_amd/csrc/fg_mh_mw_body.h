@@ -163,7 +163,7 @@ static __device__ __noinline__ FgMhmwPre fg_mhmw_model_proposals(const FgIns *in
 
 template <int RK, bool SPLIT /* the two in-order sums on two waves */>
 __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgChainCtx &X, const FgMhDev &M, const FgGradRec *srt /* the kind-sorted score stream */, const FgMhSeg &seg, int iter0, int n_steps, int n_warmup,
-                                              long long *draws, int first_sample_t, int exp_mask /* bits 1, 2, 4, 8: timing experiments only (FG_MH_EXP; results are wrong); 32: no wave priorities (A/B); 64: phase-B priority */,
+                                              long long *draws, int first_sample_t, int exp_mask /* bits 1, 2, 4, 8: timing experiments only (FG_MH_EXP; results are wrong); 32: no wave priorities (A/B); 64: phase-B priority; 128 / 256: staggered start */,
                                               int pool_n /* > 0: the constant pool (pool_n doubles) is staged into LDS behind the exchange rows */) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE;
@@ -274,6 +274,11 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
 #ifdef FG_MH_PROF
     unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_readcyclecounter();
 #endif
+    if (exp_mask & 384) {                                          // tiles that start together on a CU run their control-wave phases at the same time: started a part of a step apart
+                                                                   // (bit 128: by tile number, the host's choice with >= 3 tiles per CU; 256: by quarter of the grid) they fill each other's gaps
+        const unsigned ph = (exp_mask & 128) ? (blockIdx.x & 3u) : ((blockIdx.x * 4u / gridDim.x) & 3u);
+        for (unsigned q = 0; q < ph; ++q) __builtin_amdgcn_s_sleep(27);
+    }
     for (int t = 0; t <= n_steps; ++t) {
         const int iter = iter0 + t;
         // ---- phase A
