@@ -20,7 +20,7 @@ for seed in range(first, first + count):
         out.append((v, lj, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), kh, eng.mh_last_kernel()))
         eng.close()
     same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(out[0][:5], out[1][:5]))
-    compiled = out[1][5].startswith("k_hmc_jit") and out[1][6].startswith("k_mh_jit")
+    compiled = out[1][5].startswith("k_hmc_jit") and out[1][6].startswith(("k_mh_jit", "k_mh_mw_jit"))
     if not same or not compiled:
         bad += 1
         print("seed", seed, "MISMATCH" if not same else "not compiled", out[1][5], out[1][6], flush=True)
