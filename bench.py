@@ -22,16 +22,18 @@ region, inside the library (fg_diag_rhat_ess: O(d) doubles per rank).
 `--gpus N` without a torchrun environment starts the N ranks itself (a `python -m torch.distributed.run` child, before
 anything here touches HIP) and relays rank 0's line.
 
-One JSON line on stdout (rank 0):
+One JSON line on stdout (rank 0), at most ~5 KB -- the driver's record keeps the contract keys, `roofline`, `cpu_baseline` and a tail:
   roofline      the dominant kernel (as reported by the engine: fg_hmc_last_kernel): algorithmic log-pdf evaluations x 8 flops /
-                HIP-event time against the f64 vector peak; `executed` and `traffic` from the committed rocprofv3 --pmc passes
-                of the same configuration (profiles/round3_pmc.json; `*_source` says which entry, or why there is none).
+                HIP-event time against the f64 vector peak; executed flops / VALU issue / `traffic` from the committed rocprofv3 --pmc
+                passes of the same configuration (profiles/roundN_pmc.json, newest first; `executed_source` says which entry).
   cpu_baseline  the CPU oracle (C restatement of the reference algorithm, dense FD) on this box's host cores, bounded sample.
-  hmc_fd_dense  the reference's arithmetic verbatim on the GPU: value, roofline, and the like-for-like ratio to cpu_baseline.
-  c3            BASELINE configs[2]: ridge regression, 32 coefficients x 1 024 observations (coordinates interact) at 65 536 and
-                8 192 chains per GPU, each with roofline; its own cpu_baseline.
-  mh, c5, smc   the MCMC / SMC halves of the metric, each with roofline (+ cpu_baseline).
-  validity      a fixed 200 + 200 run of the headline model at 65 536 chains: |pooled mean - closed form| <= 1e-3, split R-hat.
+  check, validity   statistics of the timed draws; a fixed 200 + 200 run of the headline model at 65 536 chains:
+                |pooled mean - closed form| <= 1e-3, split R-hat.
+  legs          LAST in the line: value / roofline.frac / kernel / cpu baseline of every other half of BASELINE's metric --
+                mh (+ mh_8192), c5 (+ c5_32768), smc, c3_65536, c3_8192, hmc_fd_dense (the reference's arithmetic verbatim; the only
+                GPU figure the CPU baseline may be divided into), hmc_8192.
+The verbose document (every leg's notes, spreads, sub-objects) goes to --full-out (default gpurun_out/bench_full.json) and, with
+--full, to stdout instead of the compact line; the committed copy is profiles/roundN_bench_full.json.
 """
 from __future__ import annotations
 
@@ -76,6 +78,9 @@ def parse(argv=None):
                     "engine starts (the GPU's clocks settle over the first tens of ms of f64 load); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline leg only (no MH / SMC / C3 / C5 / dense / validity legs)")
+    ap.add_argument("--full", action="store_true", help="print the verbose document (every leg's notes, spreads and sub-objects) instead of the compact line")
+    ap.add_argument("--full-out", default=os.environ.get("FG_BENCH_FULL_OUT", os.path.join("gpurun_out", "bench_full.json")),
+                    help="where the verbose document is written beside the compact line ('' = nowhere)")
     ap.add_argument("--cpu-chains", type=int, default=4096)
     ap.add_argument("--cpu-transitions", type=int, default=64)
     return ap.parse_args(argv)
@@ -206,22 +211,25 @@ def cpu_baseline_smc(n=1 << 20):
 
 
 # ------------------------------------------------------------------------------------------ profile lookups
-PMC_FILE = "round3_pmc.json"
+PMC_FILES = ("round4_pmc.json", "round3_pmc.json")       # the newest committed set that holds the entry is used
 
 
 def pmc_entry(key):
     """The committed rocprofv3 --pmc entry of one configuration (profiles/round3_pmc.json, written by tools/prof_round3_collect.py):
     per-transition (or per-step / per-run) counter values of the dominant kernel and FETCH_SIZE / WRITE_SIZE bytes.  Returns
     (entry or None, source string)."""
-    path = os.path.join(ROOT, "profiles", PMC_FILE)
-    try:
-        doc = json.load(open(path))
-    except Exception as ex:                                                    # noqa: BLE001
-        return None, f"no profiles/{PMC_FILE} ({type(ex).__name__})"
-    ent = doc.get("entries", {}).get(key)
-    if ent is None:
-        return None, f"profiles/{PMC_FILE} has no entry `{key}` (this run is not a profiled configuration)"
-    return ent, f"profiles/{PMC_FILE}[{key}]"
+    why = []
+    for name in PMC_FILES:
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception as ex:                                                # noqa: BLE001
+            why.append(f"no profiles/{name} ({type(ex).__name__})")
+            continue
+        ent = doc.get("entries", {}).get(key)
+        if ent is not None:
+            return ent, f"profiles/{name}[{key}]"
+        why.append(f"profiles/{name} has no entry `{key}`")
+    return None, "; ".join(why) + " (this run is not a profiled configuration)"
 
 
 def executed_from_pmc(ent, units, seconds):
@@ -532,7 +540,7 @@ def run_rank(args):
         # a thread of this process may still be inside RCCL: no further leg, no further collective
         out["check"]["note"] += "; the cross-rank exchange FAILED -- remaining legs skipped"
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(args, out)
         return EXIT_DIAGNOSTICS_FAILED
     if not args.no_extras:
         out["mh"] = leg_mh(X)
@@ -544,6 +552,9 @@ def run_rank(args):
         out["c5"] = leg_c5(X)
         progress(rank, "c5 leg done")
         if rank == 0:
+            if args.scaling == "weak" and C != 8192:
+                out["hmc_8192"] = leg_hmc_small(X, 8192)
+                progress(rank, "hmc at 8192 chains done")
             out["hmc_fd_dense"] = leg_dense(X)
             progress(rank, "dense leg done")
             out["extras"] = extras(X)
@@ -563,11 +574,126 @@ def run_rank(args):
                 out["smc"]["cpu_baseline"] = cpu_baseline_smc()
             if "c3" in out:
                 out["c3"]["cpu_baseline"] = cpu_baseline_c3(host_cores())
-        print(json.dumps(out), flush=True)
+        emit(args, out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+# ------------------------------------------------------------------------------------------ the line
+def _sig(x, n=4):
+    return float(f"{x:.{n}g}") if isinstance(x, float) and np.isfinite(x) else x
+
+
+def _leg(d, extra=()):
+    """One leg of the verbose document -> value, roofline fraction, kernel, CPU baseline."""
+    if not d:
+        return None
+    rf, cb = d.get("roofline", {}), d.get("cpu_baseline") or {}
+    o = {"value": _sig(d.get("value")), "unit": d.get("unit"), "frac": _sig(rf.get("frac"), 3), "bound": rf.get("bound"), "kernel": rf.get("kernel")}
+    if "frac_kind" in rf:
+        o["frac_kind"] = rf["frac_kind"].split(" -- ")[0][:60]
+    if "reference_implied" in rf:
+        o["reference_implied_frac"] = _sig(rf["reference_implied"]["frac"], 3)
+    if rf.get("counter_traffic_frac") is not None:
+        o["counter_traffic_frac"] = _sig(rf["counter_traffic_frac"], 3)
+    ex = rf.get("executed") or {}
+    if ex:
+        o["executed_f64_tflops"] = _sig(ex.get("f64_tflops"), 3)
+        o["valu_issue"] = _sig(ex.get("valu_issue_share_of_simd_cycles_at_2.1GHz"), 3)
+        o["f64_share_of_valu"] = _sig(ex.get("f64_share_of_valu"), 3)
+    if cb:
+        o["cpu"] = {"value": _sig(cb.get("value")), "cores": cb.get("cores"), "kind": cb.get("kind")}
+        if cb.get("value") and d.get("value"):
+            o["vs_cpu"] = _sig(d["value"] / cb["value"], 3)
+    for k in extra:
+        if k in d:
+            o[k] = _sig(d[k]) if isinstance(d[k], float) else d[k]
+    return o
+
+
+def compact(full):
+    """The ONE line the driver records: the contract keys, `roofline` and `cpu_baseline` of the headline kernel, then -- LAST, so that a
+    tail of the line still holds them -- `legs`: value / roofline fraction / kernel / CPU baseline of every other half of BASELINE's
+    metric (mh, c5, smc, c3 at both chain counts, the reference-verbatim dense HMC).  Notes, spreads and sub-objects live in the verbose
+    document (`--full`, written to --full-out; the committed copy is profiles/roundN_bench_full.json)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full[k] for k in keep if k in full}
+    cfg = full["config"]
+    line["config"] = {"workload": cfg["workload"], "chains_per_gpu": cfg.get("chains_per_gpu"), "chains_total": cfg.get("chains_total"), "n_leapfrog": cfg.get("n_leapfrog"),
+                      "grad": cfg["grad"] + (" (engine default: the reference's central difference over the statements that read the coordinate; "
+                                             "reference-verbatim dense FD = legs.hmc_fd_dense)" if cfg["grad"] == "fd_sparse" else ""),
+                      "transitions_per_launch": cfg.get("transitions_per_launch"), "sharding": cfg.get("sharding")}
+    rf = full["roofline"]
+    ex = rf.get("executed") or {}
+    line["roofline"] = {"bound": rf["bound"], "achieved": _sig(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"], "frac": _sig(rf["frac"], 3),
+                        "traffic": rf.get("traffic"), "kernel": rf["kernel"], "avg_launch_ms": _sig(rf["avg_launch_ms"]),
+                        "logpdf_evals_per_transition": rf["logpdf_evals_per_transition"], "flops_per_logpdf": rf["flops_per_logpdf"],
+                        "executed_f64_tflops": _sig(ex.get("f64_tflops"), 3), "valu_issue": _sig(ex.get("valu_issue_share_of_simd_cycles_at_2.1GHz"), 3),
+                        "executed_source": rf.get("executed_source")}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
+        if "like_for_like" in cb:
+            line["cpu_baseline"]["like_for_like_ratio_gpu_fd_dense"] = _sig(cb["like_for_like"]["ratio"], 3)
+    line["timed_regions_value"] = [_sig(v) for v in full["timed_regions"]["value"]["all"]]
+    ck = full["check"]
+    line["check"] = {k: _sig(ck[k], 3) if isinstance(ck[k], float) else ck[k] for k in ("posterior_mean_max_abs_err", "accept_rate", "n_divergent", "split_rhat_max", "chains_in_rhat",
+                                                                                       "diagnostics_path", "diagnostics_exchange_bytes_per_rank") if k in ck}
+    line["check"]["diagnostics_path"] = str(line["check"].get("diagnostics_path", ""))[:200]
+    if "validity" in full:
+        v = full["validity"]
+        line["validity"] = {"posterior_mean_max_abs_err": _sig(v["posterior_mean_max_abs_err"], 3), "target_1e-3": v["target_1e-3"], "split_rhat_max": _sig(v["split_rhat_max"], 5),
+                            "n_divergent": v["n_divergent"], "run": v["run"]}
+    if "full_document" in full:
+        line["full_document"] = full["full_document"]
+    legs = {}
+    if "mh" in full:
+        legs["mh"] = _leg(full["mh"], ("accept_rate",))
+        legs["mh"]["workload"] = "adaptive_mcmc_chain reference_model(20), 200 adapting + 400 sampling steps, all timed"
+        pr = full["mh"].get("per_gpu_kernel_rate") or {}
+        if pr:
+            legs["mh"]["adapting"], legs["mh"]["sampling"] = _sig(pr["adapting"], 3), _sig(pr["sampling"], 3)
+        for k in ("chains_8192",):
+            if k in full["mh"]:
+                legs["mh_8192"] = _leg(full["mh"][k])
+    if "c5" in full:
+        legs["c5"] = _leg(full["c5"])
+        legs["c5"]["workload"] = "C5 mixture S=68 O=64, 262144 chains (weak) / sharded (strong), sampling"
+        if "chains_32768" in full["c5"]:
+            legs["c5_32768"] = _leg(full["c5"]["chains_32768"])
+    if "smc" in full:
+        legs["smc"] = _leg(full["smc"], ("seconds_per_run", "tempering_steps", "log_evidence"))
+        legs["smc"]["adaptation"] = "gpu batched / cpu sequential (reference order)"
+    if "c3" in full:
+        for tag in ("chains_65536", "chains_8192"):
+            if tag in full["c3"]:
+                e = dict(full["c3"][tag]); e["unit"] = full["c3"]["unit"]
+                if tag == "chains_65536" and "cpu_baseline" in full["c3"]:
+                    e["cpu_baseline"] = full["c3"]["cpu_baseline"]
+                legs["c3_" + tag[7:]] = _leg(e)
+    if "hmc_fd_dense" in full:
+        legs["hmc_fd_dense"] = _leg(full["hmc_fd_dense"])
+        legs["hmc_fd_dense"]["workload"] = "headline model, grad_log_joint verbatim (the reference's arithmetic)"
+    if "hmc_8192" in full:
+        legs["hmc_8192"] = _leg(full["hmc_8192"])
+    if legs:
+        line["legs"] = legs
+    return line
+
+
+def emit(args, full):
+    """Rank 0: the verbose document to --full-out (best effort), the compact line (or, with --full, the document) to stdout."""
+    if args.full_out:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.full_out)), exist_ok=True)
+            with open(args.full_out, "w") as f:
+                json.dump(full, f)
+            full["full_document"] = args.full_out
+        except OSError as ex:
+            full["full_document"] = f"not written ({ex})"
+    print(json.dumps(full if args.full else compact(full), separators=(",", ":")), flush=True)
 
 
 def timed_hmc(X, cp, C, cfg, n_warm, n_timed, per_launch, repeats, seed=1, with_draws=False, local=False):
@@ -621,14 +747,51 @@ def leg_c3(X):
         val = world * C * nt * L / dt
         ent, src = pmc_entry(f"hmc|c3|{C}|fd_sparse|L{L}")
         tfl = C * n_launch * flops_step * L / (launch_ms * 1e-3) / 1e12
+        # what k_hmc_lin_steps EXECUTES per (chain, observation, gradient): every wave forms the D products and the D prefix additions,
+        # carries the two suffix chains of its M = D / W coordinates (2 (D - p) additions at position p) and two densities per
+        # coordinate (8 operations each); half tiles put the two signs into the two lane halves (both halves form products and
+        # prefixes).  One flop per add / mul (unfused: the reference's rounding).  DESIGN 3.9; tools/isa_loops.py counts the same loop.
+        import re as _re
+        Wl = int((_re.search(r"W=(\d+)", kernel) or [0, max(1, d // 4)])[1])
+        Ml = max(1, d // max(1, Wl))
+        half = "half" in kernel
+        per_obs = (Wl * (4 * d + 16 * Ml) + d * (d + 1)) if half else (Wl * (2 * d + 16 * Ml) + d * (d + 1))
+        exec_grad = cp.O * per_obs + 2 * d * FLOPS_PER_NORMAL_LOGPDF          # + each coordinate's prior record at q_j +- h
+        exe = C * n_launch * exec_grad * (L + 1) / (launch_ms * 1e-3) / 1e12 if "k_hmc_lin" in kernel else None
+        pm = executed_from_pmc(ent, n_launch, launch_ms * 1e-3)
+        frac_exec = (exe if exe is not None else (pm or {}).get("f64_tflops", tfl)) / F64_VALU_PEAK_TFLOPS
         out[tag] = {"value": val, "chains_per_gpu": C, "seconds_per_transition": dt / nt, "timed_regions": {"repeats": len(dts), "steps_each": nt, "value": spread([world * C * nt * L / t for t in dts])},
                     "accept_rate": st.accept_rate,
-                    "roofline": {"bound": "valu_f64", "achieved": tfl, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F64_VALU_PEAK_TFLOPS,
+                    "roofline": {"bound": "valu_f64", "achieved": frac_exec * F64_VALU_PEAK_TFLOPS, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac_exec,
+                                 "frac_kind": "executed f64 add / mul (1 flop each) of the launch / HIP-event time",
+                                 "reference_implied": {"achieved": tfl, "frac": tfl / F64_VALU_PEAK_TFLOPS,
+                                                       "note": "SURVEY 8d's dense-semantics flops (the reference's 2 d whole-model runs per gradient) at this rate: "
+                                                               "NOT executed -- the kernel shares products and prefix sums between coordinates"},
                                  "kernel": kernel, "avg_launch_ms": launch_ms, "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src,
-                                 "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3), "executed_source": src,
-                                 "note": "achieved = SURVEY 8d's dense-semantics flops of the transitions of a launch / HIP-event time (the work the reference's "
-                                         "arithmetic implies); executed = the f64 instructions the kernel issues (PMC), 1 flop per add / mul"}}
+                                 "executed": pm, "executed_source": src,
+                                 "note": "achieved / frac = the f64 operations the kernel executes (counted from its loop structure: per observation every wave forms D "
+                                         "products + D prefix additions + the suffix chains and densities of its own coordinates) over HIP-event time; unfused "
+                                         "add / mul tops out at half of the FMA peak; `executed` = the same from the committed PMC entry when this configuration has one"}}
     return out
+
+
+def leg_hmc_small(X, C):
+    """The headline model at the chain count a GPU holds when BASELINE's 65 536-chain job is sharded 8 x (strong scaling): the latency
+    regime (half tiles).  Rank 0 alone; same config as the headline."""
+    E, W = X.E, X.W
+    cp = E.compile_model(W.normal_sites(N_SITES))
+    L, d, nt = 16, cp.d, 200
+    dts, launch_ms, n_launch, kernel, st = timed_hmc(X, cp, C, E.hmc_config(n_leapfrog=L), 100, nt, 25, 3, local=True)
+    dt = float(np.median(dts))
+    evals = (2 * d * (L + 1)) * 2 + 2 * N_SITES
+    tfl = C * n_launch * evals * FLOPS_PER_NORMAL_LOGPDF / (launch_ms * 1e-3) / 1e12
+    ent, src = pmc_entry(f"hmc|normal32|{C}|fd_sparse|L{L}")
+    return {"metric": "hmc_leapfrog_steps_per_sec", "value": C * nt * L / dt, "unit": "leapfrog-steps/s", "n_gpus": 1,
+            "timed_regions": {"repeats": len(dts), "steps_each": nt, "value": spread([C * nt * L / t for t in dts])},
+            "config": {"workload": f"C2-normal32, {C} chains, L=16, fd_sparse, 100 adaptive warmup transitions untimed"},
+            "roofline": {"bound": "valu_f64", "achieved": tfl, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F64_VALU_PEAK_TFLOPS,
+                         "kernel": kernel, "avg_launch_ms": launch_ms, "traffic": traffic_from_pmc(ent, n_launch), "traffic_source": src,
+                         "executed": executed_from_pmc(ent, n_launch, launch_ms * 1e-3), "executed_source": src}}
 
 
 def leg_dense(X):
@@ -671,9 +834,18 @@ def leg_dense(X):
 def leg_mh(X):
     """The MCMC half of BASELINE's metric: adaptive_mcmc_chain on the reference's own bench model
     (benches/f_perf.rs:78-109: reference_model(20), 20 sample + 19 observe sites) at 65 536 chains per GPU; chain steps are
-    counted over warmup + sampling: 200 adapting + 400 sampling steps, all timed."""
-    args, E, W, torch, clock, stream, world, rank, dev = X.args, X.E, X.W, X.torch, X.clock, X.stream, X.world, X.rank, X.dev
+    counted over warmup + sampling: 200 adapting + 400 sampling steps, all timed.  `chains_8192`: the same at the
+    8 192 chains a GPU holds when a 65 536-chain job is sharded 8 x (the latency regime)."""
+    args, world = X.args, X.world
     C = shard(args.chains, world, args.scaling)
+    out = _mh_refmodel(X, C, args.spinup)
+    if args.scaling == "weak" and C != 8192:
+        out["chains_8192"] = _mh_refmodel(X, 8192, 0.0)
+    return out
+
+
+def _mh_refmodel(X, C, spinup):
+    E, W, torch, clock, stream, world, rank, dev = X.E, X.W, X.torch, X.clock, X.stream, X.world, X.rank, X.dev
     cp = E.compile_model(W.reference_model(20))
     eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=dev)
     eng.set_stream(stream.cuda_stream)
@@ -681,20 +853,23 @@ def leg_mh(X):
     eng.mh_init(nw)
     eng.mh_step(per)                                       # untimed: first-launch effects
     scratch = None
-    if args.spinup > 0:                                    # clock spin-up on a scratch engine, as in the HMC leg
+    if spinup > 0:                                         # clock spin-up on a scratch engine, as in the HMC leg
         scratch = E.Engine(cp, C, seed=987654321, chain_offset=rank * C, device=dev)
         scratch.set_stream(stream.cuda_stream)
         scratch.mh_init(0)
         t_sp = time.perf_counter()
-        while time.perf_counter() - t_sp < args.spinup:
+        while time.perf_counter() - t_sp < spinup:
             scratch.mh_step(4 * per)
             torch.cuda.synchronize()
-    dts, events = [], []
+    dts, events, phase = [], [], {"adapting": [], "sampling": []}
     for _ in range(3):
         eng.mh_init(nw)
         ev = []
         dts.append(clock.region(lambda: ev.extend(stepped(torch, stream, lambda n, done: eng.mh_step(n), nw + ns, per))))
         events.extend(ev)
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+        phase["adapting"].append(C * nw / (sum(ms[: nw // per]) * 1e-3))
+        phase["sampling"].append(C * ns / (sum(ms[nw // per:]) * 1e-3))
     launch_ms, n_launch = full_launch_ms(events)
     if scratch is not None:
         scratch.close()
@@ -708,6 +883,8 @@ def leg_mh(X):
     ent, src = pmc_entry(f"mh|refmodel20|{C}")
     return {"metric": "mh_chain_steps_per_sec", "value": world * C * (nw + ns) / dt, "unit": "chain-steps/s", "n_gpus": world,
             "accept_rate": acc, "timed_regions": {"repeats": len(dts), "steps_each": nw + ns, "value": spread([world * C * (nw + ns) / t for t in dts])},
+            "per_gpu_kernel_rate": {"adapting": float(np.median(phase["adapting"])), "sampling": float(np.median(phase["sampling"])),
+                                    "note": "chain-steps/s of this rank's launches by HIP events, the two phases apart"},
             "config": {"workload": f"adaptive_mcmc_chain, reference_model(20) (benches/f_perf.rs:78-91: S=20, O=19), {C} chains/GPU, "
                                    f"{nw} adapting + {ns} sampling steps, all timed", "steps_per_launch": n_launch},
             "roofline": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
@@ -721,9 +898,18 @@ def leg_mh(X):
 
 def leg_c5(X):
     """BASELINE configs[4]: 4-component Gaussian mixture (4 f64 + 64 usize sites, 64 observations), adaptive_mcmc_chain at
-    262 144 chains (per GPU in the weak mode; in total, sharded, in the strong mode = BASELINE's 8 x 32 768)."""
-    args, E, W, torch, clock, stream, world, rank, dev = X.args, X.E, X.W, X.torch, X.clock, X.stream, X.world, X.rank, X.dev
+    262 144 chains (per GPU in the weak mode; in total, sharded, in the strong mode = BASELINE's 8 x 32 768).  `chains_32768`:
+    BASELINE's per-GPU share, measured on this GPU."""
+    args, world = X.args, X.world
     C = 262144 if args.scaling == "weak" else shard(262144, world, "strong")
+    out = _mh_c5(X, C)
+    if args.scaling == "weak":
+        out["chains_32768"] = _mh_c5(X, 32768)
+    return out
+
+
+def _mh_c5(X, C):
+    E, W, torch, clock, stream, world, rank, dev = X.E, X.W, X.torch, X.clock, X.stream, X.world, X.rank, X.dev
     data, _ = W.mixture_data(64)
     cp = E.compile_model(W.mixture(data))
     eng = E.Engine(cp, C, seed=1, chain_offset=rank * C, device=dev)
@@ -788,7 +974,10 @@ def leg_smc(X):
                        "adaptation": "batched: the shared DiminishingAdaptation is updated once per rejuvenation sweep from per-site counts (DESIGN deviation ii); the "
                                      "CPU baseline beside it runs the reference's sequential form (one update per particle)",
                        "sharding": "replicas only" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic_from_pmc(ent, 1), "traffic_source": src,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "frac_kind": "ALGORITHMIC bytes (SURVEY 8d) / host wall time of the run -- not counter traffic",
+                         "counter_traffic_frac": (traffic_from_pmc(ent, 1) / dt / 1e9 / HBM_PEAK_GBS) if traffic_from_pmc(ent, 1) else None,
+                         "traffic": traffic_from_pmc(ent, 1), "traffic_source": src,
                          "kernel": "whole fg_smc_run (next_beta bisection + reweight + scan + resample + gather + rejuvenation)",
                          "bytes_per_particle_per_tempering_step": per_particle_step,
                          "note": "SURVEY 8d algorithmic bytes x particles x tempering steps / wall time of the whole run (host-timed, launch gaps "

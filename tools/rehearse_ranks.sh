@@ -26,8 +26,10 @@ j = json.loads(open("gpurun_out/rehearse_all.out").read().strip().splitlines()[-
 assert j["n_gpus"] == 2 and j["check"]["chains_in_rhat"] == 2 * 16384, j["check"]
 assert 0 < j["check"]["diagnostics_exchange_bytes_per_rank"] < 1 << 20, j["check"]          # O(d) doubles, not O(chains)
 print("pass 1 ok:", j["check"]["diagnostics_path"], "| exchanged", j["check"]["diagnostics_exchange_bytes_per_rank"], "B per rank")
-for leg in ("mh", "smc", "c3", "c5", "hmc_fd_dense", "validity"):
-    assert leg in j, leg
+assert "validity" in j
+for leg in ("mh", "smc", "c3_65536", "c3_8192", "c5", "hmc_fd_dense"):
+    assert leg in j["legs"] and j["legs"][leg]["value"] > 0, leg
+assert len(open("gpurun_out/rehearse_all.out").read().strip().splitlines()[-1]) <= 6144, "the line must fit the driver's tail"
 import os
 j = json.loads(open("gpurun_out/rehearse_rccl.out").read().strip().splitlines()[-1])
 p = j["check"]["diagnostics_path"]
@@ -37,6 +39,15 @@ else:                                                  # this RCCL build hung in
     assert p.startswith("failed") and j["check"]["chains_in_rhat"] == 16384, j["check"]
 print("pass 2 ok:", p[:140])
 j = json.loads(open("gpurun_out/rehearse_hang.out").read().strip().splitlines()[-1])
-assert j["check"]["diagnostics_path"].startswith("failed") and j["check"]["chains_in_rhat"] == 16384 and "mh" not in j, j["check"]
+assert j["check"]["diagnostics_path"].startswith("failed") and j["check"]["chains_in_rhat"] == 16384 and "legs" not in j, j["check"]
 print("pass 3 ok:", j["check"]["diagnostics_path"][:90])
+PY
+# pass 4: strong scaling -- the job is 65 536 chains IN TOTAL (BASELINE configs 3 and 5 sharded): every leg's whole-job rate, two ranks
+timeout -k 10 300 python bench.py --gpus 2 --scaling strong --steps 100 --warmup 50 --no-cpu-baseline > gpurun_out/rehearse_strong.out 2> gpurun_out/rehearse_strong.err || { echo "pass 4 FAILED"; tail -5 gpurun_out/rehearse_strong.err; exit 1; }
+python - <<'PY'
+import json
+j = json.loads(open("gpurun_out/rehearse_strong.out").read().strip().splitlines()[-1])
+assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["chains_per_gpu"] == 32768 and j["config"]["chains_total"] == 65536, j["config"]
+print("pass 4 ok (strong, 2 ranks on ONE device: rates are not measurements): headline %.3g" % j["value"],
+      " ".join("%s %.3g" % (k, v["value"]) for k, v in j["legs"].items()))
 PY
