@@ -34,6 +34,35 @@ def test_rust_binding_declares_every_entry_point():
     assert bound == set(E.ABI_SYMBOLS), bound ^ set(E.ABI_SYMBOLS)
 
 
+def test_rust_binding_and_ctypes_state_the_headers_abi():
+    """Argument counts, pointer-ness / const-ness, integer widths and `#[repr(C)]` field order of rust/fugue-gpu/src/ffi.rs, and the
+    ctypes declarations the tests call through, against include/fugue_amd.h -- parsed, not compiled (tests/abi_check.py)."""
+    from tests import abi_check as A
+    header = open(os.path.join(ROOT, "include", "fugue_amd.h")).read()
+    ffi = open(os.path.join(ROOT, "rust", "fugue-gpu", "src", "ffi.rs")).read()
+    parsed = A.parse_header(header)
+    assert set(parsed["fns"]) == set(E.ABI_SYMBOLS) and len(parsed["structs"]) >= 7 and len(parsed["callbacks"]) == 2
+    assert A.compare_header_rust(header, ffi) == []
+    assert A.compare_header_ctypes(header, E.lib()) == []
+    # the check has teeth: a swapped field, a dropped argument, a narrowed integer, a lost `const` and a swapped pair of arguments fail
+    mutations = [
+        ("pub n_leapfrog: i32, pub target_accept: f64,", "pub target_accept: f64, pub n_leapfrog: i32,", "struct fg_hmc_config"),
+        ("pub fn fg_program_data(p: *mut fg_program, name: *const c_char, v: *const f64, n: i64) -> c_int;",
+         "pub fn fg_program_data(p: *mut fg_program, name: *const c_char, v: *const f64) -> c_int;", "fg_program_data: 3 arguments"),
+        ("v: *const f64, n: i64) -> c_int;", "v: *const f64, n: i32) -> c_int;", "fg_program_data: argument 3"),
+        ("pub fn fg_program_n_sites(p: *const fg_program)", "pub fn fg_program_n_sites(p: *mut fg_program)", "fg_program_n_sites: argument 0"),
+        ("pub log_evidence: f64, pub n_steps: i32, pub n_model_runs: i64", "pub log_evidence: f64, pub n_steps: i64, pub n_model_runs: i64", "struct fg_smc_result"),
+        ("lo: i64, hi: i64) -> c_int;", "lo: i64, hi: u64) -> c_int;", "fg_program_sample_discrete_uniform: argument 3"),
+    ]
+    for old, new, expect in mutations:
+        assert old in ffi, old
+        bad = A.compare_header_rust(header, ffi.replace(old, new, 1))
+        assert bad and any(expect in b for b in bad), (expect, bad)
+    bad = A.compare_header_rust(header.replace("int fg_program_factor(fg_program *p, const fg_tok *toks, int n);",
+                                               "int fg_program_factor(fg_program *p, int n, const fg_tok *toks);"), ffi)
+    assert any("fg_program_factor" in b for b in bad)
+
+
 @pytest.mark.parametrize("name", list(ZOO))
 def test_site_order_is_lexicographic_and_matches_oracle(oracle, name):
     prog = ZOO[name]()

@@ -10,6 +10,8 @@ if which == "ref":
     cp, C = E.compile_model(W.reference_model(20)), 65536
 else:
     cp, C = E.compile_model(W.mixture(W.mixture_data(64)[0])), 262144
+if len(sys.argv) > 2:
+    C = int(sys.argv[2])
 eng = E.Engine(cp, C, seed=1)
 n = 200
 for label, nw in (("adapting", 100000), ("sampling", 0)):
@@ -18,7 +20,7 @@ for label, nw in (("adapting", 100000), ("sampling", 0)):
     out = (ctypes.c_ulonglong * (16 * 8))()
     assert E.lib().fg_debug_mh_prof(out) == 0
     a = np.array(out, dtype=np.float64).reshape(16, 8) / n
-    print(which, label, "cycles per step (s_memtime ticks), waves 0..15:")
+    print(which, C, "chains", eng.mh_last_kernel(), label, "cycles per step (s_memtime ticks), waves 0..15:")
     for w in range(16):
         if a[w].sum() > 0:
             print("  wave %2d: " % w + " ".join("%7.0f" % x for x in a[w, :6]) + "   total %7.0f" % a[w, :6].sum())
