@@ -57,5 +57,7 @@ static __device__ __noinline__ FgD2 fg_cold_mh_adapt(double log_scale, uint32_t 
     FgD2 r; r.a = sc; r.b = ls;
     return r;
 }
+// ln of the 53-bit uniform of a Philox word (the accept test of the multi-wave MH kernels compares it with log_alpha); NaN for u = 0
+static __device__ __noinline__ double fg_cold_lnu(unsigned long long r) { const double u = fg_u01_of(r); return u > 0.0 ? fg_fast_log(u) : NAN; }
 // gaussian_z (mh.rs:128-132) from one Philox block
 static __device__ __noinline__ double fg_cold_gaussian_z(unsigned long long a, unsigned long long b) { return fg_gaussian_z_of(a, b); }

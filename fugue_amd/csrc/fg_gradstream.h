@@ -273,6 +273,55 @@ __device__ __forceinline__ double fg_inorder_sum1(const double *A, int na, int t
     return a;
 }
 
+// The same sums for a wave whose instruction count IS its tile's path (the decider of fg_mh_mw2_body.h): a tail of rem < 8 rows is
+// rem loads and rem additions behind two scalar jumps -- the rows go to the END of the register chunk and both unrolled sequences are
+// entered (8 - rem) places in -- instead of 8 loads, 8 additions and 16 selects of "+ 0.0" (a lone wave pays ~8 cycles per
+// instruction whatever it is).  Split in two calls so that the caller can issue other LDS reads between the chunks and the tails.
+struct FgSums2 { double a, b; const double *pa, *pb; int ra, rb; };
+__device__ __forceinline__ FgSums2 fg_inorder_sums2_chunks(const double *A, int na, const double *B, int nb, int tw) {
+    FgSums2 s; s.a = 0.0; s.b = 0.0; s.pa = A; s.pb = B;
+    const int n = na < nb ? na : nb;
+    int k = 0;
+    for (; k + 8 <= n; k += 8, s.pa += 8LL * tw, s.pb += 8LL * tw) {         // both chains, 8 rows of each in flight
+        double x[8], u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x[q] = s.pa[q * tw]; u[q] = s.pb[q * tw]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s.a += x[q]; s.b += u[q]; }
+    }
+    s.ra = na - k; s.rb = nb - k;
+    for (; s.ra >= 8; s.ra -= 8, s.pa += 8LL * tw) { double x[8]; _Pragma("unroll") for (int q = 0; q < 8; ++q) x[q] = s.pa[q * tw]; _Pragma("unroll") for (int q = 0; q < 8; ++q) s.a += x[q]; }
+    for (; s.rb >= 8; s.rb -= 8, s.pb += 8LL * tw) { double x[8]; _Pragma("unroll") for (int q = 0; q < 8; ++q) x[q] = s.pb[q * tw]; _Pragma("unroll") for (int q = 0; q < 8; ++q) s.b += x[q]; }
+    return s;
+}
+#define FG_TAIL_LOAD(X, P, R)                                                                                  \
+    switch (R) { case 7: X[1] = P[1 * tw]; [[fallthrough]]; case 6: X[2] = P[2 * tw]; [[fallthrough]]; case 5: X[3] = P[3 * tw]; [[fallthrough]]; \
+                 case 4: X[4] = P[4 * tw]; [[fallthrough]]; case 3: X[5] = P[5 * tw]; [[fallthrough]]; case 2: X[6] = P[6 * tw]; [[fallthrough]]; \
+                 case 1: X[7] = P[7 * tw]; [[fallthrough]]; default: break; }
+#define FG_TAIL_ADD(X, ACC, R)                                                                                 \
+    switch (R) { case 7: ACC += X[1]; [[fallthrough]]; case 6: ACC += X[2]; [[fallthrough]]; case 5: ACC += X[3]; [[fallthrough]]; \
+                 case 4: ACC += X[4]; [[fallthrough]]; case 3: ACC += X[5]; [[fallthrough]]; case 2: ACC += X[6]; [[fallthrough]]; \
+                 case 1: ACC += X[7]; [[fallthrough]]; default: break; }
+__device__ __forceinline__ void fg_inorder_sums2_tails(FgSums2 &s, int tw) {
+    double x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double *qa = s.pa - (long long)(8 - s.ra) * tw, *qb = s.pb - (long long)(8 - s.rb) * tw;   // row k of a tail -> register 8 - rem + k
+    FG_TAIL_LOAD(x, qa, s.ra)
+    FG_TAIL_LOAD(u, qb, s.rb)
+    FG_TAIL_ADD(x, s.a, s.ra)
+    FG_TAIL_ADD(u, s.b, s.rb)
+}
+__device__ __forceinline__ double fg_inorder_sum1_exact(const double *A, int na, int tw) {
+    double a = fg_inorder_sum1(A, na & ~7, tw);
+    const int rem = na & 7;
+    double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double *qa = A + (long long)(na & ~7) * tw - (long long)(8 - rem) * tw;
+    FG_TAIL_LOAD(x, qa, rem)
+    FG_TAIL_ADD(x, a, rem)
+    return a;
+}
+#undef FG_TAIL_LOAD
+#undef FG_TAIL_ADD
+
 struct FgGradAcc { double sp, sm, prip, prim; bool bad; };
 struct FgGradK { double h, hk, two_h, rcp_2h; bool two_kicks; };   // wave-uniform constants of one gradient
 

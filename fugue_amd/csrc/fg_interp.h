@@ -168,6 +168,43 @@ __device__ __forceinline__ void fg_mh_walk_proposal(FgMhCtx &mh, uint32_t vtype,
     }
 }
 
+// The same proposals as a pure function of the target's current cell (the speculative proposer of the pipelined multi-wave MH
+// kernel, fg_mh_mw2_body.h, forms a step's proposal for BOTH outcomes of the step before it): the operations of
+// fg_mh_walk_proposal, in its order.  lqf / lqr start from 0.0 like a fresh FgMhCtx; nb = the block of the accept uniform.
+struct FgMhCand { double prop, lqf, lqr; int nb; };
+__device__ __forceinline__ FgMhCand fg_mh_walk_pure(uint32_t vtype, int kind, double curd, double scale, double z, double lo, double hi) {
+    FgMhCand c; c.lqf = 0.0; c.lqr = 0.0; c.nb = 2;
+    const long long curi = fg_as_i64(curd);
+    if (vtype == 0u) {
+        double prop = curd, f = 0.0, r = 0.0;
+        if (kind == FG_PROP_GAUSSIAN) prop = curd + scale * z;                                // mh.rs:183-187
+        else if (kind == FG_PROP_LOGSPACE) {                                                  // mh.rs:201-224
+            if (curd <= 0.0) { prop = FG_MIN_POSITIVE; c.nb = 1; }
+            else { const double pr = exp(log(curd) + scale * z);
+                   prop = fg_finite(pr) ? fmax(pr, FG_MIN_POSITIVE) : FG_F64_MAX; }
+            f = fg_logspace_lq(curd, prop, scale); r = fg_logspace_lq(prop, curd, scale);
+        } else {                                                                              // Reflect: mh.rs:237-257
+            double pr = curd + scale * z;
+            if (hi - lo <= 0.0) prop = curd;
+            else { for (int it = 0; it < 100000 && (pr < lo || pr > hi); ++it) {
+                       if (pr < lo) pr = 2.0 * lo - pr;
+                       if (pr > hi) pr = 2.0 * hi - pr; }
+                   prop = pr < lo ? lo : (pr > hi ? hi : pr); }
+        }
+        c.lqf += f; c.lqr += r;
+        c.prop = prop;
+    } else if (vtype == 1u) {                // FlipProposal: mh.rs:263-269 (draws nothing)
+        c.prop = fg_as_double(curi ? 0LL : 1LL);
+        c.nb = 1;
+    } else if (vtype == 2u) {                // DiscreteWalkProposal: mh.rs:285-294
+        const long long k = curi + fg_f2i_sat(round(scale * z));
+        c.prop = fg_as_double(k >= 0 ? k : -k - 1);
+    } else {                                 // i64 walk: mh.rs:557-567
+        c.prop = fg_as_double(curi + fg_f2i_sat(round(scale * z)));
+    }
+    return c;
+}
+
 // Executes instructions [0, n) of `prog` for this lane.  `slots` = &lds_tile[lane]; `tw` = tile width
 // (lanes of the wave that own a chain = blockDim.x): slot k of this lane is slots[k * tw].
 // `prog` must have two readable instructions past `n` (the host pads the arrays).

@@ -542,7 +542,7 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
 // records of phase B (generated[k] != 0: statement k's log-density term into its LDS row) as FG_JIT_NSEG generated statement
 // segments instead of fg_score_one over the record stream.
 std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out,
-                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream) {
+                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream, bool pipe) {
     constexpr int NSEG = 16;
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
@@ -629,9 +629,11 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
            "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, slots, terms); } while (0)\n";
     src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
+    const bool pipe2 = pipe && !no_stream;       // the step loop with the serial recipe split over waves (stream programs)
+    if (pipe2) src += FG_JIT_EMBED_MHMW2_BODY;   // fg_mh_mw2_body.h
     src += "extern \"C\" __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_jit_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps,\n"
            "        int n_warmup, long long *draws, int first_sample_t, int exp_mask, int pool_n) {\n"
-           "    fg_mh_mw_body<" + std::to_string(rk) + ", " + (split ? "true" : "false") + ">(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);\n}\n";
+           "    " + std::string(pipe2 ? "fg_mh_mw2_body<" : "fg_mh_mw_body<") + std::to_string(rk) + ", " + (split ? "true" : "false") + ">(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);\n}\n";
     if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
     if (ctab_out) *ctab_out = ctabs.data;
     return src;
@@ -786,7 +788,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
     if (std::getenv("FG_DEBUG_JIT_MHMW")) {                                // the multi-wave stream MH unit
         std::string s2;
-        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false);
+        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false, std::getenv("FG_MH_PIPE") && std::atoi(std::getenv("FG_MH_PIPE")) == 1);
         else {                                                             // a program without a score stream: rows in accumulator order (fg_mh_mw_nostream_launch)
             std::vector<int> rows; int n_pri = 0, n_lik = 0, n_fac = 0;
             for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) {

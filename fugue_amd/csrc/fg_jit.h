@@ -9,7 +9,7 @@ struct fg_program;
 std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out);       // "" = not covered by the generator
 std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost, int occ, std::vector<double> *ctab_out);   // ins_cost[k]: relative cost of instruction k of ins_fast; occ: 2 / 4 waves per SIMD (256 / 128 VGPRs)
 std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split,
-                               std::vector<double> *ctab_out, const std::vector<int> *rows_in = nullptr, int n_pri = -1, int n_fac = 0, bool no_stream = false);   // the multi-wave stream MH kernel, the general records of phase B generated
+                               std::vector<double> *ctab_out, const std::vector<int> *rows_in = nullptr, int n_pri = -1, int n_fac = 0, bool no_stream = false, bool pipe = false);   // the multi-wave stream MH kernel, the general records of phase B generated; pipe: around fg_mh_mw2_body.h's step loop
                                // (rows_in: a program without a score stream -- statement k's term row: log_prior rows [0, n_pri) first, the n_fac `factor` rows last)
 int fg_jit_compile(const std::string &src, std::vector<char> &code, std::string &log);  // FG_OK / FG_E_UNSUPPORTED (no hiprtc) / FG_E_HIP
 int fg_jit_get_code(const std::string &src, std::vector<char> &code, std::string &log);   // fg_jit_compile behind a per-process and an on-disk cache

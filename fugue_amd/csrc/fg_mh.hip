@@ -27,6 +27,15 @@
 #include "fg_jit.h"
 
 #include "fg_mh_mw_body.h"
+#include "fg_mh_mw2_body.h"
+
+// the same step with its serial recipe split over waves (round 4, fg_mh_mw2_body.h: decider / speculative proposer); FG_MH_PIPE=0 keeps
+// the one-control-wave loop above (A/B, identity tests)
+template <int RK, bool SPLIT>
+__global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw2_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
+                                                                            long long *draws, int first_sample_t, int exp_mask, int pool_n) {
+    fg_mh_mw2_body<RK, SPLIT>(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);
+}
 
 template <int RK, bool SPLIT>
 __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps, int n_warmup,
@@ -36,10 +45,23 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
 
 // Launch shape of the multi-wave kernel for a program of n_s statements: LDS bytes, waves per tile, the experiment / priority mask,
 // whether the two in-order sums run on two waves.
-struct FgMhMwShape { size_t lds; int W, exp_mask, split_sums, pool_n; unsigned tiles; };
-static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape &sh) {
+struct FgMhMwShape { size_t lds; int W, exp_mask, split_sums, pool_n, pipe; unsigned tiles; };
+static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape &sh, bool pipe_ok = false) {
     const fg_program *p = e->prog;
-    sh.lds = (size_t)(e->n_slots + n_s + 17) * FG_WAVE * sizeof(double);    // site values, term rows, 2 x 8 exchange rows + the log_likelihood sum
+    // the pipelined step loop (fg_mh_mw2_body.h): stream programs
+    // -- opt-in (FG_MH_PIPE=1): identical results, but measured 5-20 % slower than the one-control-wave loop at every chain count
+    // (profiles/round4_mh_pipeline_experiment.txt): what it takes off the decider's path comes back as the proposer's phase B
+    sh.pipe = (pipe_ok && std::getenv("FG_MH_PIPE") && std::atoi(std::getenv("FG_MH_PIPE")) == 1 && !std::getenv("FG_MH_EXP")) ? 1 : 0;
+    sh.split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
+    int pipe_bits = 0, xrows = 17;                                          // one-control-wave loop: 2 x 8 exchange rows + the log_likelihood sum
+    bool all_f64 = true;
+    for (int j = 0; j < e->S; ++j) { if (p->site_vtype[j] == FG_USIZE) pipe_bits |= 512; if (p->site_vtype[j] == FG_BOOL) pipe_bits |= 1024; all_f64 = all_f64 && p->site_vtype[j] == FG_F64; }
+    if (sh.pipe) {
+        if (all_f64 && !e->M.ov_kind) pipe_bits |= 2048;                    // every proposal is a walk on an f64 site with the support-based kind: the proposer's short path
+        const int nr = 3 + ((pipe_bits & 512) ? 1 : 0) + ((pipe_bits & 1024) ? 1 : 0);
+        xrows = 2 * nr + 9 + (sh.split_sums ? 2 : 0);                       // fg_mh_mw2_body.h: two random-number buffers, 8 candidate rows, the decision, (sum + tag)
+    } else if (pipe_ok && !(pipe_bits & (512 | 1024))) pipe_bits |= 4096;   // a stream program without Categorical / bool sites: nobody reads block 1's uniform (fg_mh_mw_body.h)
+    sh.lds = (size_t)(e->n_slots + n_s + xrows) * FG_WAVE * sizeof(double); // site values, term rows, exchange rows
     if (sh.lds > 160 * 1024) return FG_E_UNSUPPORTED;
     sh.pool_n = 0;                                                          // stage the constant pool into LDS when it is small and the tile leaves room
     if (stage_pool && p->pool.size() * 8 <= 24 * 1024 && sh.lds + p->pool.size() * 8 <= 160 * 1024 &&
@@ -50,13 +72,12 @@ static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape
     int W = e->mw_override > 0 ? e->mw_override : 2;
     if (e->mw_override <= 0) while (W < FG_MH_WMAX && resident * W < 16 && n_s >= 4 * W) W *= 2;
     sh.W = std::max(W, 2);                                                  // control wave + random-number wave
-    sh.exp_mask = std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0;
+    sh.exp_mask = (std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0) | pipe_bits;
     if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) sh.exp_mask |= 32;
     else if (resident >= 2) sh.exp_mask |= 64;
     if (resident >= 3 && !(std::getenv("FG_MH_STAGGER") && std::atoi(std::getenv("FG_MH_STAGGER")) == 0)) sh.exp_mask |= 128;   // bit 128: the tiles of a CU start a quarter of a step apart (reference_model(20), four tiles per CU: +4.7 %; two tiles: nothing)   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
     // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
-    // the second wave returns (reference_model(20), 4 tiles per CU: -3 %)
-    sh.split_sums = std::getenv("FG_MH_SPLIT") ? (std::atoi(std::getenv("FG_MH_SPLIT")) != 0 ? 1 : 0) : (n_s >= 64 ? 1 : 0);
+    // the second wave returns (reference_model(20), 4 tiles per CU: -3 %) -- split_sums, above
     return FG_OK;
 }
 static bool mh_mw_sites_ok(const fg_engine *e) {     // every site must take a model-independent proposal: Categorical sites need a constant table, no PriorResample override
@@ -145,7 +166,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     }
     const int n_cu = e->mh_ncu, n_rows = n_s - n_cu;                       // term rows of the tile
     FgMhMwShape sh;
-    if (mh_mw_shape(e, n_rows, e->P.sstream_kinds != 0, sh) != FG_OK) return FG_E_UNSUPPORTED;
+    if (mh_mw_shape(e, n_rows, e->P.sstream_kinds != 0, sh, true) != FG_OK) return FG_E_UNSUPPORTED;
     const size_t lds = sh.lds;
     const int W = sh.W, split_sums = sh.split_sums;
     int pool_n = sh.pool_n, exp_mask = sh.exp_mask;
@@ -183,13 +204,28 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     FgMhSeg seg;
     // in phase B all waves share the records of every class evenly; the remainders of successive classes go to different waves
     int shift = 0;
+    // the pipelined loop's proposer spends phase B on the adaptation state and the next step's candidates: no records where the tile has
+    // waves to spare, half a share otherwise
+    const int w_pro = (sh.pipe && W >= 3) ? ((split_sums && W > 2) ? 2 : 1) : -1;
     for (int c = 0; c < FG_MH_NCLS; ++c) {
         const int a = e->mh_cls_off[c], n = e->mh_cls_off[c + 1] - a;
         int cnt[FG_MH_WMAX] = {0};
-        for (int w = 0; w < W; ++w) cnt[(w + shift) % W] = (int)((long long)n * (w + 1) / W - (long long)n * w / W);
+        if (w_pro < 0) {
+            for (int w = 0; w < W; ++w) cnt[(w + shift) % W] = (int)((long long)n * (w + 1) / W - (long long)n * w / W);
+            shift += n % W;
+        } else {                                                            // 2 (W - 1) half shares for the others, one (W < 8) or none for the proposer
+            const int units = 2 * (W - 1) + (W < 8 ? 1 : 0);
+            int at_u = 0, given = 0;
+            for (int q = 0; q < W; ++q) {
+                const int w = (q + shift) % W;
+                const int u = w == w_pro ? (W < 8 ? 1 : 0) : 2;
+                const int upto = (int)((long long)n * (at_u + u) / units);
+                cnt[w] = upto - given; given = upto; at_u += u;
+            }
+            shift += n % W;
+        }
         int at = a;
         for (int w = 0; w <= FG_MH_WMAX; ++w) { seg.r[c][w] = at; if (w < W) at += cnt[w]; }
-        shift += n % W;
     }
     seg.n_cu = n_cu; seg.catu_c = e->d_mh_catu_c; seg.catu = (const FgMhCatU *)e->d_mh_catu; seg.catu_same = e->mh_catu_same; seg.catu_c0 = e->mh_catu_c0;
     const int rk = e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3);       // record kinds the instantiation understands (fg_score_one)
@@ -215,7 +251,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             if (2 * n_gen >= n_s) for (int k = 0; k < n_s; ++k) generated[(size_t)k] = (n_cu > 0 && (p->sstream[k].flags & FG_G_CATC)) ? 0 : 1;   // (row-less terms have no statement to run)
             std::vector<double> ctab;
             // (a handful of general records among many pattern records: the runs alone -- C5 with two tiles on a CU: 7.0e9 against 6.7e9)
-            const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false) : std::string();
+            const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false, sh.pipe != 0) : std::string();
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mhmw_mod, code.data()) == hipSuccess &&
@@ -229,28 +265,32 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         int n_warmup = e->mh_warmup;
         void *args[] = { &e->P, &e->X, &e->M, &e->d_mh_srt, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t, &exp_mask, &pool_n };
         HIPCHK(hipModuleLaunchKernel(e->jit_mhmw_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
-        e->last_mh_kernel = "k_mh_mw_jit_steps W=" + std::to_string(W) + " (statements compiled at run time)";
+        e->last_mh_kernel = std::string(sh.pipe ? "k_mh_mw2_jit_steps W=" : "k_mh_mw_jit_steps W=") + std::to_string(W) + " (statements compiled at run time)";
         return FG_OK;
     }
-    static bool attr_set_dev[64][8];
-    const int variant = 2 * (rk == 0 ? 0 : (rk == 2 ? 1 : 2)) + split_sums;
-    const void *fns[6] = { (const void *)k_mh_mw_steps<0, false>, (const void *)k_mh_mw_steps<0, true>, (const void *)k_mh_mw_steps<2, false>,
-                           (const void *)k_mh_mw_steps<2, true>, (const void *)k_mh_mw_steps<3, false>, (const void *)k_mh_mw_steps<3, true> };
+    static bool attr_set_dev[64][16];
+    const int variant = 2 * (rk == 0 ? 0 : (rk == 2 ? 1 : 2)) + split_sums + (sh.pipe ? 6 : 0);
+    const void *fns[12] = { (const void *)k_mh_mw_steps<0, false>, (const void *)k_mh_mw_steps<0, true>, (const void *)k_mh_mw_steps<2, false>,
+                            (const void *)k_mh_mw_steps<2, true>, (const void *)k_mh_mw_steps<3, false>, (const void *)k_mh_mw_steps<3, true>,
+                            (const void *)k_mh_mw2_steps<0, false>, (const void *)k_mh_mw2_steps<0, true>, (const void *)k_mh_mw2_steps<2, false>,
+                            (const void *)k_mh_mw2_steps<2, true>, (const void *)k_mh_mw2_steps<3, false>, (const void *)k_mh_mw2_steps<3, true> };
     bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
         const hipError_t he = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-#define FG_MH_LAUNCH(R, SP) hipLaunchKernelGGL((k_mh_mw_steps<R, SP>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, \
-                                               e->mh_warmup, draws, first_sample_t, exp_mask, pool_n)
+#define FG_MH_LAUNCH(K, R, SP) hipLaunchKernelGGL((K<R, SP>), dim3(tiles), dim3(FG_WAVE * W), lds, e->stream, e->P, e->X, e->M, e->d_mh_srt, seg, iter0, n_steps, \
+                                                  e->mh_warmup, draws, first_sample_t, exp_mask, pool_n)
     switch (variant) {
-        case 0: FG_MH_LAUNCH(0, false); break; case 1: FG_MH_LAUNCH(0, true); break; case 2: FG_MH_LAUNCH(2, false); break;
-        case 3: FG_MH_LAUNCH(2, true); break;  case 4: FG_MH_LAUNCH(3, false); break; default: FG_MH_LAUNCH(3, true); break;
+        case 0: FG_MH_LAUNCH(k_mh_mw_steps, 0, false); break; case 1: FG_MH_LAUNCH(k_mh_mw_steps, 0, true); break; case 2: FG_MH_LAUNCH(k_mh_mw_steps, 2, false); break;
+        case 3: FG_MH_LAUNCH(k_mh_mw_steps, 2, true); break;  case 4: FG_MH_LAUNCH(k_mh_mw_steps, 3, false); break; case 5: FG_MH_LAUNCH(k_mh_mw_steps, 3, true); break;
+        case 6: FG_MH_LAUNCH(k_mh_mw2_steps, 0, false); break; case 7: FG_MH_LAUNCH(k_mh_mw2_steps, 0, true); break; case 8: FG_MH_LAUNCH(k_mh_mw2_steps, 2, false); break;
+        case 9: FG_MH_LAUNCH(k_mh_mw2_steps, 2, true); break;  case 10: FG_MH_LAUNCH(k_mh_mw2_steps, 3, false); break; default: FG_MH_LAUNCH(k_mh_mw2_steps, 3, true); break;
     }
 #undef FG_MH_LAUNCH
     HIPCHK(hipGetLastError());
-    e->last_mh_kernel = "k_mh_mw_steps W=" + std::to_string(W);
+    e->last_mh_kernel = std::string(sh.pipe ? "k_mh_mw2_steps W=" : "k_mh_mw_steps W=") + std::to_string(W);
     return FG_OK;
 }
 

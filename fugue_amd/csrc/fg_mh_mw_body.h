@@ -190,6 +190,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
     const bool b_prio = wv != 0 && (exp_mask & 64) != 0;
     const int rng_wave = W - 1;
     const int rng_wave1 = W >= 3 ? W - 2 : W - 1;                  // the wave of part 1
+    const bool skip_u1 = (exp_mask & 4096) != 0;
 
     // small constant pools (Categorical tables, option lists) are read per lane: from the LDS copy a lookup costs an LDS round
     // trip instead of a vector-memory one
@@ -199,8 +200,15 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
     // Everything of step `it` that does not depend on the chain's state -> buffer (it & 1).
     //   part 0: gen_range target (mh.rs:716) with its site-table entries, the uniform of block 1 and -- for a Categorical
     //           target -- the index resampled from the constant prior table with its prior log-probability (mh.rs:516-530);
-    //   part 1: gaussian_z (mh.rs:128-132) from block 1 and the accept uniform of block 2.
-    // With W >= 3 the two parts run on two waves (block 1 is then generated twice: the parts stay independent).
+    //   part 1: gaussian_z (mh.rs:128-132) from block 1 and ln u of the accept uniform of block 2.
+    // With W >= 3 the two parts run on two waves (block 1 is then generated twice: the parts stay independent) -- unless nobody
+    // needs block 1's uniform itself (exp_mask bit 4096, the host's: a stream program without Categorical or bool sites draws it only
+    // for the accept test of a log-space walk at a non-positive value, which then regenerates it).
+    // The accept test `log_alpha >= 0 || u < exp(log_alpha)` (mh.rs:733) is decided from ln u where that decides it: ln u < log_alpha - m
+    // accepts and ln u > log_alpha + m rejects for m = 1e-9 (1 + |log_alpha|), three orders above the error of the two transcendentals
+    // (exp underflows only where ln u > log_alpha + m anyway: u >= 2^-53); inside the margin (probability ~1e-9 per lane and step), for
+    // u = 0, a NaN and when the accept uniform is another block's, the control wave evaluates the reference's own expression.  The
+    // decisions are the reference's -- and exp leaves the control wave's path.
     auto publish_rng = [&](int it, int part) __attribute__((always_inline)) {
         double *b = xch + (long long)(8 * (it & 1)) * tw;
         FgStream rng; rng.k0 = sk0; rng.k1 = sk1; rng.c0 = gchain; rng.c2 = (uint32_t)it; rng.c3 = FG_RNG_MH;
@@ -210,10 +218,9 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
             const int tg = (int)fg_pick(ra, (uint32_t)P.S);
             const int ts = P.site_slot[tg], tvv = P.site_vtype[tg];               // per-lane gathers of small tables
             const int cb = P.site_cat[2 * tg], cK = P.site_cat[2 * tg + 1];
-            rng.c1 = 1; fg_rng_block(rng, ra, rb);
-            const double u1 = fg_u01_of(ra);
+            double u1 = 0.0;
+            if (!skip_u1) { rng.c1 = 1; fg_rng_block(rng, ra, rb); u1 = fg_u01_of(ra); b[2 * tw] = u1; }
             b[0] = fg_as_double((long long)tg);
-            b[2 * tw] = u1;
             b[4 * tw] = fg_as_double((long long)(uint32_t)ts | ((long long)tvv << 32));
             b[5 * tw] = fg_as_double((long long)(uint32_t)cb | ((long long)cK << 32));
             if (tvv == 3 && cK > 0) {                                  // first index whose cumulative probability reaches u, clamped (distribution.rs:771-784)
@@ -233,13 +240,13 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
             rng.c1 = 1; fg_rng_block(rng, ra, rb);
             b[tw] = fg_cold_gaussian_z(ra, rb);
             rng.c1 = 2; fg_rng_block(rng, ra, rb);
-            b[3 * tw] = fg_u01_of(ra);
+            b[3 * tw] = fg_cold_lnu(ra);                              // ln u of block 2 (NaN for u = 0), off the control wave's path
         }
     };
 
     // ---- control-wave state
-    double lw = 0.0, old_cell = 0.0, lqf = 0.0, lqr = 0.0, scale = 1.0, u_acc = 0.0;
-    int tslot = 0, kind0 = 0, kind_new = 0;
+    double lw = 0.0, old_cell = 0.0, lqf = 0.0, lqr = 0.0, scale = 1.0, u_acc = 0.0 /* the accept uniform, or NaN: regenerate it */, lnu_acc = 0.0 /* its ln, or NaN */;
+    int tslot = 0, kind0 = 0, kind_new = 0, nb_acc = 2;
     long long g = 0;
     unsigned long long nacc = 0;
     int nbad = 0;                                                  // this chain's row-less Categorical sites whose index is out of range
@@ -355,7 +362,17 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                 const double prop_lw = pri + lik + 0.0;                    // total_log_weight (no factor statement has a record)
 #endif
                 const double log_alpha = prop_lw - lw + (lqr - lqf);       // + dim_term == 0 (fixed structure)  mh.rs:731-732
-                const bool accept = (log_alpha >= 0.0) || (u_acc < fg_cold_exp(log_alpha));    // mh.rs:733
+                // mh.rs:733  log_alpha >= 0 || u < exp(log_alpha), from ln u outside the margin (above)
+                const double mrg = 1e-9 * (1.0 + fabs(log_alpha));
+                const bool sure_acc = log_alpha >= 0.0 || lnu_acc < log_alpha - mrg;
+                const bool sure_rej = lnu_acc > log_alpha + mrg;
+                bool accept = sure_acc;
+                if (__builtin_expect(__any(!sure_acc && !sure_rej), 0)) {
+                    double u_ = u_acc;
+                    if (__any(!sure_acc && !sure_rej && u_ != u_)) { const double ur = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)nb_acc, (uint32_t)itp, FG_RNG_MH).a; if (u_ != u_) u_ = ur; }
+                    const bool exact = (log_alpha >= 0.0) || (u_ < fg_cold_exp(log_alpha));
+                    if (!sure_acc && !sure_rej) accept = exact;
+                }
                 double sc = scale;
                 if (adapt) {                                               // DiminishingAdaptation::update  mcmc_utils.rs:88-150
                     const fg_u32x4 a1 = *(const fg_u32x4 *)((const char *)(M.ad + g) + 16);   // {log_scale, total, accepted}
@@ -384,7 +401,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
             if (do_prop) {                                                 // proposal of step t (mh.rs:183-294, 516-530, 557-567)
                 FgMhCtx mh;
                 mh.z = b[tw];
-                const double u1 = b[2 * tw], u2 = b[3 * tw];
+                const double lnu2 = b[3 * tw];
                 g = n_g; tslot = n_tslot;
                 mh.target = tslot; mh.scale = n_scale; mh.kind = n_kind;
                 kind0 = n_kind;
@@ -437,10 +454,10 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                 if (!walk) { mh.lqf = mp.lqf; mh.lqr = mp.lqr; mh.kind = mp.kind; mh.next_block = mp.next_block; }
 #endif
                 old_cell = mh.old_cell; lqf = mh.lqf; lqr = mh.lqr; scale = mh.scale; kind_new = mh.kind;
-                u_acc = mh.next_block == 1 ? u1 : u2;                      // the accept uniform's block (mh.rs:733)
-#ifdef FG_MHMW_NS            /* a sampler-based proposal drew more than one block */
-                if (mixed && mh.next_block > 2) u_acc = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)mh.next_block, (uint32_t)iter, FG_RNG_MH).a;
-#endif
+                nb_acc = mh.next_block;                                    // the accept uniform's block (mh.rs:733)
+                lnu_acc = nb_acc == 2 ? lnu2 : NAN;
+                u_acc = NAN;
+                if (!skip_u1 && __any(nb_acc == 1)) { const double u1 = b[2 * tw]; if (nb_acc == 1) u_acc = u1; }
             }
         } else if (t > 0 && t + 1 < n_steps && !(exp_mask & 8)) {          // buffer (iter + 1) & 1 was last read in phase A of step t - 1
             if (wv == rng_wave) publish_rng(iter + 1, 0);

@@ -135,20 +135,28 @@ def test_mh_multiwave_kernel_is_identical_to_the_one_wave_kernel(name, monkeypat
     out = []
     monkeypatch.setenv("FG_JIT", "0")                                      # the hand-written phase B (the generated one: the next test)
     # (multi-wave kernel?, waves per tile, the two in-order sums on two waves? -- the engine picks that for programs of >= 64 statements)
-    for mw, W, split in ((0, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (1, 2, 1), (1, 4, 1), (1, 16, 1)):
+    # pipe: the one-control-wave loop (the default) or the step's serial recipe split over waves (FG_MH_PIPE=1, fg_mh_mw2_body.h:
+    # decider / speculative proposer -- kept as an opt-in: identical results, measured slower)
+    kernels = []
+    for mw, W, split, pipe in ((0, 1, 0, 1), (1, 2, 0, 1), (1, 4, 0, 1), (1, 8, 0, 1), (1, 16, 0, 1), (1, 2, 1, 1), (1, 3, 1, 1), (1, 4, 1, 1), (1, 16, 1, 1),
+                               (1, 2, 0, 0), (1, 4, 0, 0), (1, 16, 0, 0), (1, 4, 1, 0), (1, 16, 1, 0)):
         monkeypatch.setenv("FG_MH_MW", str(mw))
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
         monkeypatch.setenv("FG_MH_SPLIT", str(split))
+        monkeypatch.setenv("FG_MH_PIPE", str(pipe))
         eng = E.Engine(cp, C, seed=13, chain_offset=3)
         d = eng.device_alloc(max(1, ns * cp.S * C) * 8)
         st = eng.mh_run(ns, nw, None, rec, d)
         draws = eng.download(d, (ns, cp.S, C), dtype=np.int64)
         eng.device_free(d)
+        kernels.append(eng.mh_last_kernel())
         out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
         eng.close()
-    for o in out[1:]:
+    if name != "coin":                                                     # (an expression parameter: no score stream, the interpreter kernels)
+        assert kernels[1].startswith("k_mh_mw2_steps") and kernels[-1].startswith("k_mh_mw_steps"), kernels
+    for k, o in zip(kernels[1:], out[1:]):
         for a, b in zip(out[0], o):
-            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True), k
 
 
 @pytest.mark.parametrize("name", ["hier_scale", "linreg", "ridge7", "hier_mixed", "refmodel20", "mixture", "readme"])
@@ -169,9 +177,10 @@ def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeyp
     C, nw, ns = 150, 120, 40
     rec = list(range(cp.S))
     out, kernels = [], []
-    for jit, mw, Wv, split in ((0, 0, 1, 0), (1, 1, 2, 0), (1, 1, 4, 1), (1, 1, 8, 0), (1, 1, 16, 1), (1, 1, 0, -1)):
+    for jit, mw, Wv, split, pipe in ((0, 0, 1, 0, 1), (1, 1, 2, 0, 1), (1, 1, 4, 1, 1), (1, 1, 8, 0, 1), (1, 1, 16, 1, 1), (1, 1, 0, -1, 1), (1, 1, 4, 0, 0), (1, 1, 16, 1, 0)):
         monkeypatch.setenv("FG_JIT", str(jit))
         monkeypatch.setenv("FG_MH_MW", str(mw))
+        monkeypatch.setenv("FG_MH_PIPE", str(pipe))
         if Wv: monkeypatch.setenv("FG_HMC_WAVES", str(Wv))
         else: monkeypatch.delenv("FG_HMC_WAVES", raising=False)
         if split >= 0: monkeypatch.setenv("FG_MH_SPLIT", str(split))
@@ -184,8 +193,8 @@ def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeyp
         kernels.append(eng.mh_last_kernel())
         out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
         eng.close()
-    want = "k_mh_mw_steps" if name in ("refmodel20", "readme") else "k_mh_mw_jit_steps"
-    assert all(k.startswith(want) for k in kernels[1:]), kernels
+    want = ("k_mh_mw2_steps", "k_mh_mw_steps") if name in ("refmodel20", "readme") else ("k_mh_mw2_jit_steps", "k_mh_mw_jit_steps")
+    assert all(k.startswith(want[0]) for k in kernels[1:6]) and all(k.startswith(want[1]) for k in kernels[6:]), kernels
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
