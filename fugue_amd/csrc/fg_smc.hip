@@ -758,19 +758,24 @@ struct FgSmcDev {
 // SCORE: 0 = score stream of fast Normals, 3 = + linear predictors / option selects / Categorical tables, 2 = + general
 // distribution records, -1 = the interpreter (programs without a score stream).  The stream variants carry no interpreter
 // code and run 4 tiles per 256-thread block.
-template <int SCORE>
-__global__ __launch_bounds__(FG_SMC_WPB(SCORE) * FG_WAVE, SCORE == 2 ? 1 : (SCORE < 0 ? FG_MIN_WAVES : 4)) void k_smc_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st,
+// GT: a program whose tile exceeds a CU's LDS (or has more sites than the block histogram) -- one wave per block, the tile in the
+// engine's global scratch (fg_engine.hip), the block's counts added straight into its row of M.blk.  adaptive_smc has
+// no size limit in the reference (smc.rs:455-581, 631-713).
+template <int SCORE, bool GT = false>
+__global__ __launch_bounds__(GT ? FG_WAVE : FG_SMC_WPB(SCORE) * FG_WAVE, (GT || SCORE == 2) ? 1 : (SCORE < 0 ? FG_MIN_WAVES : 4)) void k_smc_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st,
                                                                                                               uint32_t move_id) {
-    extern __shared__ double lds[];
-    __shared__ unsigned int hist[2][FG_SMC_HIST];                   // the block's proposal / accept counts per site
+    extern __shared__ double lds_[];
+    __shared__ unsigned int hist[2][GT ? 1 : FG_SMC_HIST];          // the block's proposal / accept counts per site
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
-    for (int j = (int)threadIdx.x; j < 2 * FG_SMC_HIST; j += (int)blockDim.x) (&hist[0][0])[j] = 0u;
+    unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
+    if (GT) { for (int j = lane; j < 2 * M.S; j += FG_WAVE) row[j] = 0u; __threadfence_block(); }
+    else { for (int j = (int)threadIdx.x; j < 2 * FG_SMC_HIST; j += (int)blockDim.x) (&hist[0][0])[j] = 0u; }
     __syncthreads();
     const long long chain = ((long long)blockIdx.x * (blockDim.x >> 6) + wv) * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
-    double *slots = lds + (long long)wv * P.n_slots * tw + lane;          // one tile per wave
+    double *slots = (GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_ + (long long)wv * P.n_slots * tw) + lane;   // one tile per wave
     fg_load_values(P, X, c, slots, tw);
     const double beta = st->beta;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
@@ -808,14 +813,14 @@ __global__ __launch_bounds__(FG_SMC_WPB(SCORE) * FG_WAVE, SCORE == 2 ? 1 : (SCOR
         const int s_lead = __builtin_amdgcn_readlane(site, leader);
         const unsigned long long same = __ballot(live && site == s_lead);
         if (lane == leader) {
-            atomicAdd(&hist[0][s_lead], (unsigned int)__popcll(same));
             const unsigned int na = (unsigned int)__popcll(same & acc_mask);
-            if (na) atomicAdd(&hist[1][s_lead], na);
+            if (GT) { atomicAdd(&row[s_lead], (unsigned int)__popcll(same)); if (na) atomicAdd(&row[M.S + s_lead], na); }
+            else { atomicAdd(&hist[0][s_lead], (unsigned int)__popcll(same)); if (na) atomicAdd(&hist[1][s_lead], na); }
         }
         todo &= ~same;
     }
+    if (GT) return;
     __syncthreads();
-    unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
     for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
 }
 // The reference's OWN rejuvenation order (fg_smc_config.sequential_adaptation; smc.rs:482,544-553,698-713): particle-major, and ONE
@@ -824,12 +829,12 @@ __global__ __launch_bounds__(FG_SMC_WPB(SCORE) * FG_WAVE, SCORE == 2 ? 1 : (SCOR
 // stores): the moves, their random numbers and the update are k_smc_rejuv's / DiminishingAdaptation::update (mcmc_utils.rs:88-150)
 // one at a time.  Orders of magnitude slower than the batched sweeps (a few us per move): the mode exists so that parity with
 // the reference's semantics can be CHECKED (tests/test_gpu_smc.py against the oracle's unbatched form), not to be fast.
-template <int SCORE>
+template <int SCORE, bool GT = false>
 __global__ __launch_bounds__(FG_WAVE) void k_smc_rejuv_seq(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st, uint32_t move0, int n_moves) {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_[];
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x;
-    double *slots = lds + lane;
+    double *slots = (GT ? X.gtile : lds_) + lane;
     const double beta = st->beta;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32);
     for (long long c = 0; c < X.C; ++c) {
@@ -1101,6 +1106,16 @@ int set_device_or_fail(int device) {
 
 }  // namespace
 
+// the engine's global tile scratch [tiles][rows][64] (fg_engine.hip allocates it for programs beyond one CU's LDS; an engine that only
+// meets the limit in rejuvenation -- more sites than the block histogram -- gets it here, once)
+static int smc_global_tile(fg_engine *e) {
+    if (e->d_gtile) return FG_OK;
+    e->X.gtile_rows = e->n_slots + e->d + 2 + FG_MW_MAX;
+    if (int rc = dev_alloc(&e->d_gtile, (size_t)((e->C + e->tw - 1) / e->tw) * e->X.gtile_rows * e->tw)) return rc;
+    e->X.gtile = e->d_gtile;
+    return FG_OK;
+}
+
 extern "C" {
 
 void fg_smc_config_default(fg_smc_config *c) {      // SMCConfig::default, smc.rs:181-189
@@ -1222,22 +1237,27 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
                 hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, -std::log((double)N));
                 if (e->d > 0) {
                     const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
-                    const int wpb = FG_SMC_WPB(score);                                  // tiles (waves) per block
-                    const size_t lds_r = e->lds_score * wpb;
-                    if (lds_r > 150 * 1024 || S > FG_SMC_HIST) { fg_set_error("SMC rejuvenation: tile does not fit LDS"); cleanup(); SC.free_all(); return FG_E_LIMIT; }
+                    // tiles (waves) per block: as many as the kernel is built for and 150 KB of LDS hold; a tile beyond one CU's LDS (or more
+                    // sites than the block histogram has) lives in the engine's global scratch, one wave per block
+                    const bool big = e->lds_score > 150 * 1024 || S > FG_SMC_HIST;
+                    if (big) SMC_TRY(smc_global_tile(e));
+                    const int wpb = big ? 1 : (int)std::max<size_t>(1, std::min<size_t>((size_t)FG_SMC_WPB(score), (150 * 1024) / std::max<size_t>(1, e->lds_score)));
+                    const size_t lds_r = big ? 0 : e->lds_score * wpb;
                     const unsigned nblk = (unsigned)((N + (long long)e->tw * wpb - 1) / ((long long)e->tw * wpb));
                     if (cfg->sequential_adaptation) {               // the reference's order: one wave, particle by particle (k_smc_rejuv_seq)
                         const uint32_t mv0 = (uint32_t)((steps - 1) * cfg->rejuvenation_steps);
-#define SMC_SEQ(SC_) do { SMC_TRY(set_lds(k_smc_rejuv_seq<SC_>, std::max<size_t>(e->lds_score, 64 * 1024 + 1))); \
-                          hipLaunchKernelGGL(k_smc_rejuv_seq<SC_>, dim3(1), dim3(FG_WAVE), e->lds_score, s, e->P, e->X, M, (const FgSmcScalars *)st, mv0, cfg->rejuvenation_steps); } while (0)
+#define SMC_SEQ(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv_seq<SC_, true>), dim3(1), dim3(FG_WAVE), 0, s, e->P, e->X, M, (const FgSmcScalars *)st, mv0, cfg->rejuvenation_steps); \
+                          else { SMC_TRY(set_lds(k_smc_rejuv_seq<SC_>, std::max<size_t>(e->lds_score, 64 * 1024 + 1))); \
+                                 hipLaunchKernelGGL(k_smc_rejuv_seq<SC_>, dim3(1), dim3(FG_WAVE), e->lds_score, s, e->P, e->X, M, (const FgSmcScalars *)st, mv0, cfg->rejuvenation_steps); } } while (0)
                         if (score == 0) SMC_SEQ(0); else if (score == 3) SMC_SEQ(3); else if (score == 2) SMC_SEQ(2); else SMC_SEQ(-1);
 #undef SMC_SEQ
                         n_runs += 2 * N * cfg->rejuvenation_steps;
                     } else
                     for (int r = 0; r < cfg->rejuvenation_steps; ++r) {
                         const uint32_t mv = (uint32_t)((steps - 1) * cfg->rejuvenation_steps + r);
-#define SMC_REJUV(SC_) do { SMC_TRY(set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))); \
-                            hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); } while (0)
+#define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); \
+                            else { SMC_TRY(set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))); \
+                                   hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); } } while (0)
                         if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2); else SMC_REJUV(-1);
 #undef SMC_REJUV
                         hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, M, S, (int)nblk);
@@ -1384,14 +1404,16 @@ int fg_smc_rejuvenate(fg_engine *e, double beta, int steps, uint32_t first_move_
     HIPCHK(hipMemsetAsync(W.base + W.o_ls, 0, W.o_st - W.o_ls, s));            // log_scale, acc, tot = 0; scale = 1
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((Sn + TB - 1) / TB)), dim3(TB), 0, s, W.M.scale, (long long)Sn, 1.0);
     const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
-    const int wpb = FG_SMC_WPB(score);
-    const size_t lds_r = e->lds_score * wpb;
-    if (lds_r > 150 * 1024 || S > FG_SMC_HIST) { fg_set_error("SMC rejuvenation: tile does not fit LDS"); return FG_E_LIMIT; }
+    const bool big = e->lds_score > 150 * 1024 || S > FG_SMC_HIST;            // (as in fg_smc_run)
+    if (big) { if (int rc_ = smc_global_tile(e)) return rc_; }
+    const int wpb = big ? 1 : (int)std::max<size_t>(1, std::min<size_t>((size_t)FG_SMC_WPB(score), (150 * 1024) / std::max<size_t>(1, e->lds_score)));
+    const size_t lds_r = big ? 0 : e->lds_score * wpb;
     const unsigned nblk = (unsigned)((N + (long long)e->tw * wpb - 1) / ((long long)e->tw * wpb));
     for (int r = 0; r < steps; ++r) {
         const uint32_t mv = first_move_id + (uint32_t)r;
-#define SMC_REJUV(SC_) do { if (int rc_ = set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))) return rc_; \
-                            hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); } while (0)
+#define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); \
+                            else { if (int rc_ = set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))) return rc_; \
+                                   hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); } } while (0)
         if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2); else SMC_REJUV(-1);
 #undef SMC_REJUV
         hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, W.M, S, (int)nblk);

@@ -51,10 +51,13 @@ __device__ __forceinline__ bool fg_rec_gradient(const FgProgramDev &P, double *s
 // Replays the next transition's leapfrog trajectory of the chains ids[0..K): point 0 = (q0, p0), then one point per
 // completed step; traj [K][L+1][d], ham [K][L+1] = -log pi(q) + kinetic energy (hmc.rs:371-381), n_points [K] (a trajectory
 // that leaves the support stops at its last finite point, hmc.rs:384-398).  Nothing of the engine's state is written.
-template <bool AN>
+// gt: a program whose tile (sites + momentum + gradient rows) exceeds a CU's LDS records from a scratch in global memory
+// ([blocks][n_slots + 2 d][64]): step_recorded has no size limit in the reference (hmc.rs:811-817).
+template <bool AN, bool GT = false>
 __global__ __launch_bounds__(FG_WAVE, FG_MIN_WAVES) void k_hmc_record(FgProgramDev P, FgChainCtx X, FgHmcDev H, const long long *ids, int K, int iter, int n_warmup,
-                                                                      double *traj, double *ham, int *n_points) {
-    extern __shared__ double lds[];
+                                                                      double *traj, double *ham, int *n_points, double *gt) {
+    extern __shared__ double lds_[];
+    double *lds = GT ? gt + (size_t)blockIdx.x * (P.n_slots + 2 * P.d) * FG_WAVE : lds_;
     constexpr int tw = FG_WAVE;
     const int l = blockIdx.x * tw + threadIdx.x;
     const bool live = l < K;
@@ -111,20 +114,25 @@ int fg_hmc_step_recorded(fg_engine *e, int n_recorded, const int64_t *h_chain_id
     // the mass-matrix reset runs between transitions: a recorded transition never straddles it
     if (n_recorded > 0) {
         const int L = e->H.L, d = e->d;
-        long long *d_ids = nullptr; double *d_traj = nullptr, *d_ham = nullptr; int *d_np = nullptr;
+        long long *d_ids = nullptr; double *d_traj = nullptr, *d_ham = nullptr, *d_gt = nullptr; int *d_np = nullptr;
         const size_t nt = (size_t)n_recorded * (L + 1) * d, nh = (size_t)n_recorded * (L + 1);
         if (dev_alloc(&d_ids, (size_t)n_recorded) || dev_alloc(&d_traj, nt) || dev_alloc(&d_ham, nh) || dev_alloc(&d_np, (size_t)n_recorded)) return FG_E_HIP;
         hipError_t he = hipMemcpyAsync(d_ids, h_chain_ids, (size_t)n_recorded * 8, hipMemcpyHostToDevice, e->stream);
         const unsigned nb = (unsigned)((n_recorded + FG_WAVE - 1) / FG_WAVE);
         if (he == hipSuccess) {
             const size_t lds = (size_t)(e->n_slots + 2 * e->d) * FG_WAVE * sizeof(double);
-            if (lds > 160 * 1024) { (void)hipFree(d_ids); (void)hipFree(d_traj); (void)hipFree(d_ham); (void)hipFree(d_np); fg_set_error("fg_hmc_step_recorded: tile does not fit LDS"); return FG_E_LIMIT; }
-            if (e->cfg.grad_mode == FG_GRAD_ANALYTIC) {
+            if (lds > 160 * 1024) {                                        // the tile in global memory (zeroed: the always-zero slot is written by fg_load_values anyway)
+                if (dev_alloc(&d_gt, (size_t)nb * (e->n_slots + 2 * e->d) * FG_WAVE)) he = hipErrorOutOfMemory;
+                if (he == hipSuccess) {
+                    if (e->cfg.grad_mode == FG_GRAD_ANALYTIC) hipLaunchKernelGGL((k_hmc_record<true, true>), dim3(nb), dim3(FG_WAVE), 0, e->stream, e->P, e->X, e->H, (const long long *)d_ids, n_recorded, e->iter, e->n_warmup, d_traj, d_ham, d_np, d_gt);
+                    else hipLaunchKernelGGL((k_hmc_record<false, true>), dim3(nb), dim3(FG_WAVE), 0, e->stream, e->P, e->X, e->H, (const long long *)d_ids, n_recorded, e->iter, e->n_warmup, d_traj, d_ham, d_np, d_gt);
+                }
+            } else if (e->cfg.grad_mode == FG_GRAD_ANALYTIC) {
                 he = hipFuncSetAttribute((const void *)k_hmc_record<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (he == hipSuccess) hipLaunchKernelGGL(k_hmc_record<true>, dim3(nb), dim3(FG_WAVE), lds, e->stream, e->P, e->X, e->H, (const long long *)d_ids, n_recorded, e->iter, e->n_warmup, d_traj, d_ham, d_np);
+                if (he == hipSuccess) hipLaunchKernelGGL(k_hmc_record<true>, dim3(nb), dim3(FG_WAVE), lds, e->stream, e->P, e->X, e->H, (const long long *)d_ids, n_recorded, e->iter, e->n_warmup, d_traj, d_ham, d_np, (double *)nullptr);
             } else {
                 he = hipFuncSetAttribute((const void *)k_hmc_record<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (he == hipSuccess) hipLaunchKernelGGL(k_hmc_record<false>, dim3(nb), dim3(FG_WAVE), lds, e->stream, e->P, e->X, e->H, (const long long *)d_ids, n_recorded, e->iter, e->n_warmup, d_traj, d_ham, d_np);
+                if (he == hipSuccess) hipLaunchKernelGGL(k_hmc_record<false>, dim3(nb), dim3(FG_WAVE), lds, e->stream, e->P, e->X, e->H, (const long long *)d_ids, n_recorded, e->iter, e->n_warmup, d_traj, d_ham, d_np, (double *)nullptr);
             }
         }
         if (he == hipSuccess) he = hipGetLastError();
@@ -132,7 +140,7 @@ int fg_hmc_step_recorded(fg_engine *e, int n_recorded, const int64_t *h_chain_id
         if (he == hipSuccess) he = hipMemcpyAsync(h_ham, d_ham, nh * 8, hipMemcpyDeviceToHost, e->stream);
         if (he == hipSuccess) he = hipMemcpyAsync(h_n_points, d_np, (size_t)n_recorded * 4, hipMemcpyDeviceToHost, e->stream);
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-        (void)hipFree(d_ids); (void)hipFree(d_traj); (void)hipFree(d_ham); (void)hipFree(d_np);
+        (void)hipFree(d_ids); (void)hipFree(d_traj); (void)hipFree(d_ham); (void)hipFree(d_np); if (d_gt) (void)hipFree(d_gt);
         if (he != hipSuccess) { fg_set_error(hipGetErrorString(he)); return FG_E_HIP; }
     }
     return fg_internal_hmc_step(e, 1, nullptr, nullptr, d_info);       // the transition itself: the ordinary path, same random numbers

@@ -207,7 +207,7 @@ def test_models_larger_than_one_lds_tile(oracle):
     """hmc_chain has no size limit in the reference (hmc.rs:238-260).  A program whose 64-chain tile exceeds the 160 KB of a CU
     keeps its tile in a global scratch and runs on the one-wave-per-tile kernels: 400 independent sites (tile 419 KB) and a
     200-coefficient regression (215 KB) run the log-joint, HMC transitions under injected momentum / uniform against the oracle,
-    a short adaptive hmc_run and single-site MH."""
+    a short adaptive hmc_run, single-site MH, a recorded trajectory (step_recorded) and adaptive_smc with rejuvenation."""
     rng = np.random.default_rng(2)
     X, y, _ = W.ridge_data(30, 200)
     for name, prog in (("normal_sites(400)", W.normal_sites(400)), ("ridge 200 x 30", W.ridge_regression(X, y))):
@@ -241,6 +241,45 @@ def test_models_larger_than_one_lds_tile(oracle):
         st = eng.mh_run(40, 40, None, [0, cp.S - 1], buf := eng.device_alloc(40 * 2 * C * 8))
         assert 0.05 < st.accept_rate < 0.95, name
         eng.device_free(buf)
+        eng.close()
+        # step_recorded (hmc.rs:811-817) from a tile in global memory: RNG-neutral, and every point the oracle's leapfrog
+        rec, plain = E.Engine(cp, C, seed=3), E.Engine(cp, C, seed=3)
+        cfg = E.hmc_config(n_leapfrog=3, init_step_size=0.01)
+        rec.hmc_init(cfg, 0); plain.hmc_init(cfg, 0)
+        ids = [0, 63, 64, 95]
+        before = rec.get_values()
+        traj, ham, npts = rec.hmc_step_recorded(ids, 3)
+        plain.hmc_step(1)
+        assert np.array_equal(rec.get_values(), plain.get_values()), name
+        for k, c in enumerate(ids):
+            q0 = np.ascontiguousarray(before[om.f64_sites, c]).view(np.float64)
+            assert np.array_equal(traj[k, 0], q0) and npts[k] == 4 and np.isfinite(ham[k]).all(), name
+            p0k, _ = oracle.hmc_momentum(3, c, 0, cp.d)
+            qo, po, dv = om.leapfrog(before[:, c], q0.copy(), p0k.copy(), 0.01, 3)
+            assert not dv and np.allclose(traj[k, 3], qo, rtol=1e-6, atol=1e-6), name
+        rec.close(); plain.close()
+        # adaptive_smc has no size limit either (smc.rs:455-581, 631-713): the beta ladder, the evidence and the particles of a run with
+        # rejuvenation against the oracle (batched adaptation on both sides), tile and block histogram in global memory
+        n = 512
+        eng = E.Engine(cp, n, seed=11)
+        got = eng.smc_run(rejuvenation_steps=2, ess_threshold=0.5, resampling_method=E.RESAMPLE_SYSTEMATIC)
+        exp = om.smc_run(n, 11, method=E.RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=2, batched=1)
+        assert len(got["betas"]) == len(exp["betas"]) > 3, (name, len(got["betas"]), len(exp["betas"]))
+        np.testing.assert_allclose(got["betas"], exp["betas"], rtol=1e-9, err_msg=name)
+        assert got["log_evidence"] == pytest.approx(exp["log_evidence"], rel=1e-9), name
+        g, o = got["values"].view(np.float64), exp["values"].view(np.float64)
+        bad = (~np.isclose(g, o, rtol=1e-8, atol=1e-11)).any(axis=0)
+        assert bad.sum() <= 4, (name, int(bad.sum()))                 # a knife-edge accept / resample boundary
+        assert got["n_model_runs"] == exp["n_model_evals"], name
+        eng.close()
+        # ... and in the reference's own sequential order (one wave walks the particles, its tile in global memory): a small population
+        n = 64
+        eng = E.Engine(cp, n, seed=12)
+        got = eng.smc_run(rejuvenation_steps=1, ess_threshold=0.5, resampling_method=E.RESAMPLE_SYSTEMATIC, sequential_adaptation=True)
+        exp = om.smc_run(n, 12, method=E.RESAMPLE_SYSTEMATIC, ess_threshold=0.5, rejuvenation_steps=1, batched=0)
+        assert len(exp["betas"]) > 2, name
+        np.testing.assert_allclose(got["betas"], exp["betas"], rtol=1e-9, err_msg=name)
+        assert got["log_evidence"] == pytest.approx(exp["log_evidence"], rel=1e-9), name
         eng.close()
 
 
