@@ -947,7 +947,7 @@ static bool hmc_jit_preferred(const fg_engine *e) {
     if (!e->P.gstream) return true;
     if (e->gt || e->tw != FG_WAVE) return false;
     if (e->P.sep && !e->sep_disabled && e->d >= 1) return false;                                     // fg_hmc_sep_launch takes it
-    if (e->P.lin_tab && !e->lin_disabled && (e->d == 8 || e->d == 16 || e->d == 32)) return false;   // fg_hmc_lin_launch takes it
+    if (e->P.lin_tab && !e->lin_disabled && e->d >= 2 && e->d <= 64) return false;   // fg_hmc_lin_launch takes it
     const bool forced = std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2;
     int rkj = 0;
     const std::vector<FgGradRec> &gsj = e->prog->gstream;

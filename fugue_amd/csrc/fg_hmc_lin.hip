@@ -88,52 +88,69 @@ __device__ __forceinline__ void fg_lin_prior_pair(const fg_u32x16 &r, double qv,
 // record(s) and the N observe statements, then the half-kick(s) on p_k.  Returns "some own force component was non-finite".
 template <int D, int W, int WV, bool P2>
 __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const int *meta_v, const FgGradRec *gs_v, const fg_lds_double *slots,
-                                         fg_lds_double *pl, double h_v, double hk, int two_kicks_v) {
-    constexpr int M = D / W, HB = D / 2, ROWB = FG_LIN_ROW_DOUBLES(D) * 8, tw = FG_WAVE;
+                                         fg_lds_double *pl, double h_v, double hk, int two_kicks_v, int d_v) {
+    // a row's coefficients arrive in NC chunks of CS (two SGPR buffers, the next chunk requested while the current one is used);
+    // QL (D = 64): q stays in LDS and is read a chunk at a time -- 64 coordinates in registers would be the whole budget
+    constexpr int M = D / W, CS = D >= 32 ? 16 : D / 2, NC = D / CS, ROWB = FG_LIN_ROW_DOUBLES(D) * 8, tw = FG_WAVE;
+    constexpr bool QL = D > 32;
     constexpr int PLAST = fg_lin_pos(W, WV, M - 1);
+    static_assert(NC % 2 == 0, "the next row's first chunk lands in buffer 0");
     const FG_AS4 char *row = fg_uniform_ptr(tab_v);
     const FG_AS4 int *meta = (const FG_AS4 int *)fg_uniform_ptr(meta_v);
-    const int N = __builtin_amdgcn_readfirstlane(n_obs_v);
+    const int N = __builtin_amdgcn_readfirstlane(n_obs_v), d_real = __builtin_amdgcn_readfirstlane(d_v);
     const bool two_kicks = __builtin_amdgcn_readfirstlane(two_kicks_v) != 0;
     const double h = fg_uniform(h_v), two_h = fg_uniform(2.0 * h_v), rcp_2h = fg_uniform(1.0 / (2.0 * h_v));
-    double q[D];
+    double q[QL ? CS : D];
+    if (!QL) {
 #pragma unroll
-    for (int t = 0; t < D; ++t) q[t] = slots[meta[t] * tw];
+        for (int t = 0; t < D; ++t) q[t] = slots[meta[t] * tw];
+    }
+    double qown[M];                                               // the own coordinates' values (QL: q itself is not resident)
+#pragma unroll
+    for (int a = 0; a < M; ++a) qown[a] = slots[meta[fg_lin_pos(W, WV, a)] * tw];
     double sp[M], sm[M];
 #pragma unroll
     for (int a = 0; a < M; ++a) { sp[a] = 0.0; sm[a] = 0.0; }
-    FgLinHalf<HB> ca, cb;
+    FgLinHalf<CS> cf[2];
     fg_u32x4 ha = *(const FG_AS4 fg_u32x4 *)row;                  // c0
-    ca.load(row + 16);
+    cf[0].load(row + 16);
     for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // this row's first half (requested half a row ago)
-        cb.load(row + 16 + 8 * HB);
-        const fg_u32x8 hb = *(const FG_AS4 fg_u32x8_r *)(row + 16 + 16 * HB);          // y, 1 / sigma, ln sigma, sigma
-        const fg_u32x4 hf = *(const FG_AS4 fg_u32x4 *)(row + 16 + 16 * HB + 32);     // flags
-        __builtin_amdgcn_sched_barrier(0);
-        double S = fg_dbl(ha[0], ha[1]);
+        double S = 0.0;
         double mp[M], mm[M];
+        fg_u32x8 hb; fg_u32x4 hf;
 #define FG_LIN_TERM(t, CF)                                                                          \
         {                                                                                           \
             const double c_ = (CF);                                                                 \
-            const double P_ = q[t] * c_;                                                            \
+            const double qt_ = q[QL ? (t) % CS : (t)];                                              \
+            const double P_ = qt_ * c_;                                                             \
             _Pragma("unroll") for (int a = 0; a < M; ++a) {                                         \
                 if (fg_lin_pos(W, WV, a) < (t)) { mp[a] = mp[a] + P_; mm[a] = mm[a] + P_; }         \
                 if (fg_lin_pos(W, WV, a) == (t)) {                                                  \
-                    const double qp_ = q[t] + h, qm_ = q[t] - h;          /* the perturbed coordinate holds orig +- h (hmc.rs:317-319) */ \
+                    const double qp_ = qt_ + h, qm_ = qt_ - h;            /* the perturbed coordinate holds orig +- h (hmc.rs:317-319) */ \
                     mp[a] = S + qp_ * c_; mm[a] = S + qm_ * c_;                                     \
                 }                                                                                   \
             }                                                                                       \
             if ((t) < PLAST) S = S + P_;                                                            \
         }
 #pragma unroll
-        for (int t = 0; t < HB; ++t) FG_LIN_TERM(t, ca.get(t))
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // the second half and the statement's constants
-        ha = *(const FG_AS4 fg_u32x4 *)(row + ROWB);              // the next row's first half (one zero row follows the table)
-        ca.load(row + ROWB + 16);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < NC; ++c) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // this chunk (requested a chunk ago)
+            if (c == 0) S = fg_dbl(ha[0], ha[1]);
+            if (c + 1 < NC) cf[(c + 1) & 1].load(row + 16 + 8 * CS * (c + 1));
+            else { ha = *(const FG_AS4 fg_u32x4 *)(row + ROWB); cf[0].load(row + ROWB + 16); }     // the next row's first chunk (one zero row follows the table)
+            if (c == 0) {
+                hb = *(const FG_AS4 fg_u32x8_r *)(row + 16 + 8 * D);                               // y, 1 / sigma, ln sigma, sigma
+                hf = *(const FG_AS4 fg_u32x4 *)(row + 16 + 8 * D + 32);                            // flags
+            }
+            if (QL) {
+                const fg_u32x16 mc = *(const FG_AS4 fg_u32x16 *)((const FG_AS4 char *)meta + 64 * c);   // the coordinates at this chunk's term positions
 #pragma unroll
-        for (int t = HB; t < D; ++t) FG_LIN_TERM(t, cb.get(t - HB))
+                for (int j = 0; j < CS; ++j) q[j] = slots[mc[j] * tw];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CS; ++j) FG_LIN_TERM(c * CS + j, cf[c & 1].get(j))
+        }
 #undef FG_LIN_TERM
         const double y = fg_dbl(hb[0], hb[1]), inv = fg_dbl(hb[2], hb[3]), lns = fg_dbl(hb[4], hb[5]);
         const uint32_t fl = hf[0];
@@ -160,12 +177,13 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
 #pragma unroll
     for (int a = 0; a < M; ++a) {
         const int pos = fg_lin_pos(W, WV, a);
+        if (pos >= d_real) continue;                                         // a padded term position (d < D): no coordinate
         const int k = meta[pos], r0 = meta[D + 2 * k], nr = meta[D + 2 * k + 1];
         double prip = 0.0, prim = 0.0;
         for (int j = 0; j < nr; ++j) {
             const fg_u32x16 r = *(const FG_AS4 fg_u32x16 *)(gs + 64 * (long long)(r0 + j));
             double lpp, lpm;
-            fg_lin_prior_pair(r, q[pos], h, lpp, lpm);
+            fg_lin_prior_pair(r, qown[a], h, lpp, lpm);
             prip += lpp; prim += lpm;
         }
         const double tp = prip + sp[a], tm = prim + sm[a];                   // total_log_weight (log_factors = +0.0 adds nothing)
@@ -189,12 +207,12 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
 // CUs idle (8 192 chains = 128 tiles on 256 CUs: BASELINE's 8-GPU sharding of C3).
 template <int D, int W, int WV, bool P2>
 __device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, const int *meta_v, const FgGradRec *gs_v, const fg_lds_double *slots,
-                                              fg_lds_double *pl, double h_v, double hk, int two_kicks_v) {
+                                              fg_lds_double *pl, double h_v, double hk, int two_kicks_v, int d_v) {
     constexpr int M = D / W, HB = D / 2, ROWB = FG_LIN_ROW_DOUBLES(D) * 8, tw = FG_WAVE / 2;
     constexpr int PLAST = fg_lin_pos(W, WV, M - 1);
     const FG_AS4 char *row = fg_uniform_ptr(tab_v);
     const FG_AS4 int *meta = (const FG_AS4 int *)fg_uniform_ptr(meta_v);
-    const int N = __builtin_amdgcn_readfirstlane(n_obs_v);
+    const int N = __builtin_amdgcn_readfirstlane(n_obs_v), d_real = __builtin_amdgcn_readfirstlane(d_v);
     const bool two_kicks = __builtin_amdgcn_readfirstlane(two_kicks_v) != 0;
     const double h = fg_uniform(h_v), two_h = fg_uniform(2.0 * h_v), rcp_2h = fg_uniform(1.0 / (2.0 * h_v));
     const bool upper = (threadIdx.x & 32u) != 0u;
@@ -255,6 +273,7 @@ __device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, 
 #pragma unroll
     for (int a = 0; a < M; ++a) {
         const int pos = fg_lin_pos(W, WV, a);
+        if (pos >= d_real) continue;                                         // a padded term position (d < D): no coordinate
         const int k = meta[pos], r0 = meta[D + 2 * k], nr = meta[D + 2 * k + 1];
         double pri = 0.0;
         for (int j = 0; j < nr; ++j) {
@@ -280,15 +299,17 @@ __device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, 
 template <int D, int W, bool P2, bool HALF, int WV>
 struct FgLinDispatch {
     static __device__ __forceinline__ bool run(int wv, const double *tab, int n_obs, const int *meta, const FgGradRec *gs, const fg_lds_double *slots,
-                                               fg_lds_double *pl, double h, double hk, int two_kicks) {
-        if (wv == WV) return HALF ? fg_lin_grad_half<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks)
-                                  : fg_lin_grad<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
-        return FgLinDispatch<D, W, P2, HALF, WV + 1>::run(wv, tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks);
+                                               fg_lds_double *pl, double h, double hk, int two_kicks, int d) {
+        if (wv == WV) {
+            if constexpr (HALF) return fg_lin_grad_half<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
+            else return fg_lin_grad<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
+        }
+        return FgLinDispatch<D, W, P2, HALF, WV + 1>::run(wv, tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
     }
 };
 template <int D, int W, bool P2, bool HALF>
 struct FgLinDispatch<D, W, P2, HALF, W> {
-    static __device__ __forceinline__ bool run(int, const double *, int, const int *, const FgGradRec *, const fg_lds_double *, fg_lds_double *, double, double, int) { return false; }
+    static __device__ __forceinline__ bool run(int, const double *, int, const int *, const FgGradRec *, const fg_lds_double *, fg_lds_double *, double, double, int, int) { return false; }
 };
 
 // HALF: 32 chains per workgroup (fg_lin_grad_half); everything outside the gradient runs in both lane halves on the same chain
@@ -307,14 +328,15 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
     const long long c = chain < X.C ? chain : X.C - 1;
     double *slots = lds + lane;
     double *pl = lds + (long long)P.n_slots * tw + lane;
-    double *xch = lds + (long long)(P.n_slots + D) * tw + lane;      // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    const int d = P.d;                                              // the coordinates (D = d padded to the next built size: 8 / 16 / 32 term positions)
+    double *xch = lds + (long long)(P.n_slots + d) * tw + lane;      // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
     const int L = H.L;
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     int own[M];                                                   // the own coordinates (wave-uniform)
 #pragma unroll
-    for (int a = 0; a < M; ++a) own[a] = P.lin_meta[fg_lin_pos(W, wv, a)];
+    for (int a = 0; a < M; ++a) own[a] = fg_lin_pos(W, wv, a) < d ? P.lin_meta[fg_lin_pos(W, wv, a)] : -1;      // (-1: a padded position)
     // wave 0 owns the per-chain sampler state
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
@@ -328,12 +350,12 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
         const bool warming = iter < n_warmup;
         double h0 = 0.0, u = 0.0;
         // p0 ~ N(0, M) (hmc.rs:436-441): Box-Muller pair j of the chain's (iteration) Philox stream is block j
-        constexpr int n_pairs = (D + 1) >> 1;
+        const int n_pairs = (d + 1) >> 1;
         for (int j = HALF ? 2 * wv + half : wv; j < n_pairs; j += HALF ? 2 * W : W) {
             const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)j, (uint32_t)iter, FG_RNG_HMC);
             const int i = 2 * j;
             pl[i * tw] = zz.a * (ms ? ms[(long long)i * X.C] : 1.0);
-            if (i + 1 < D) pl[(i + 1) * tw] = zz.b * (ms ? ms[(long long)(i + 1) * X.C] : 1.0);
+            if (i + 1 < d) pl[(i + 1) * tw] = zz.b * (ms ? ms[(long long)(i + 1) * X.C] : 1.0);
         }
         if (wv == 0) {
             double e;
@@ -354,12 +376,13 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
         bool bad = false;
         for (int gs = 0; gs <= L; ++gs) {                       // leapfrog, hmc.rs:353-407
             bad = FgLinDispatch<D, W, P2, HALF, 0>::run(wv, P.lin_tab, P.lin_n, P.lin_meta, P.gstream, (const fg_lds_double *)slots, (fg_lds_double *)pl, H.h, hk,
-                                                  (gs > 0 && gs < L) ? 1 : 0) || bad;
+                                                  (gs > 0 && gs < L) ? 1 : 0, d) || bad;
             __syncthreads();                                     // every p kicked, every read of q done
             if (gs < L) {
 #pragma unroll
                 for (int a = 0; a < M; ++a) {
                     const int k = own[a];
+                    if (k < 0) continue;
                     if (mi) slots[k * tw] += e * mi[(long long)k * X.C] * pl[k * tw];
                     else slots[k * tw] += e * pl[k * tw];        // eps * 1.0 * p == eps * p
                 }
@@ -401,11 +424,12 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
 #pragma unroll
         for (int a = 0; a < M; ++a) {                             // commit or roll back this wave's f64 sites
             const int i = own[a];
+            if (i < 0) continue;
             const long long g = (long long)P.f64_site[i] * X.C + c;
             if (acc) { if (live) X.values[g] = fg_as_i64(slots[i * tw]); }
             else slots[i * tw] = fg_as_double(X.values[g]);
             const double x = slots[i * tw];
-            if (live && pos_all) pos_all[((long long)t * D + i) * X.C + c] = x;
+            if (live && pos_all) pos_all[((long long)t * d + i) * X.C + c] = x;
             if (warming) {
                 if (welford_on) {                                 // Welford::push: hmc.rs:202-211
                     const long long gi = (long long)i * X.C + c;
@@ -416,7 +440,7 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
                     const double delta2 = x - mean;
                     if (live) { H.w_mean[gi] = mean; H.w_m2[gi] += delta * delta2; }
                 }
-            } else if (draws && live) draws[((long long)(t - first_sample_t) * D + i) * X.C + c] = x;   // hmc.rs:577-582
+            } else if (draws && live) draws[((long long)(t - first_sample_t) * d + i) * X.C + c] = x;   // hmc.rs:577-582
         }
         if (warming && welford_on) {
             __syncthreads();                                      // all waves hold the old count
@@ -435,13 +459,14 @@ void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_
 int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *draws, int first_sample_t, double *pos_all, double *info) {
     if (e->gt) return FG_E_UNSUPPORTED;                       // tiles in global memory: the one-wave-per-tile kernels (fg_engine.hip)
     if (!e->P.lin_tab || e->cfg.grad_mode != FG_GRAD_FD_SPARSE || e->lin_disabled || e->tw != FG_WAVE) return FG_E_UNSUPPORTED;
-    const int D = e->d;
-    if (D != 8 && D != 16 && D != 32) return FG_E_UNSUPPORTED;
+    if (e->d < 2 || e->d > 64) return FG_E_UNSUPPORTED;      // (the table exists for d <= 64: fg_program.cpp)
+    const int D = e->d <= 8 ? 8 : (e->d <= 16 ? 16 : (e->d <= 32 ? 32 : 64));     // term positions of the build that takes it (padded with +0.0 terms)
     const long long n_cu = std::max(1, e->n_simd / 4);
     const long long tiles64 = (e->C + FG_WAVE - 1) / FG_WAVE;
     // half tiles (32 chains per workgroup) when 64-chain tiles would leave half of the CUs without one
     bool half = 2 * tiles64 <= n_cu;
     if (const char *hv = std::getenv("FG_HMC_LIN_HALF")) half = std::atoi(hv) != 0;
+    if (D == 64) half = false;                               // (64 positions: 16 waves of four, q read from LDS; full tiles only)
     const int tw = half ? FG_WAVE / 2 : FG_WAVE;
     const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
     const size_t lds = (size_t)(e->n_slots + e->d + 2 + FG_LIN_WMAX) * tw * sizeof(double);
@@ -451,13 +476,13 @@ int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     // slower at every chain count, also where they double the waves per SIMD (8 192 chains: 5.9e6 against 7.0e6 leapfrog-steps/s);
     // FG_HMC_WAVES = D / 2 keeps that layout reachable for the bit-identity tests.
     int W = D / 4;
-    if (e->mw_override == D / 4 || e->mw_override == D / 2) W = e->mw_override;
-    const int variant = 2 * ((D == 32 ? 0 : (D == 16 ? 4 : 8)) + (W == D / 2 ? 2 : 0) + (e->P.lin_p2 ? 1 : 0)) + (half ? 1 : 0);
-    static bool attr_set_dev[64][24];
+    if (D < 64 && (e->mw_override == D / 4 || e->mw_override == D / 2)) W = e->mw_override;
+    const int variant = D == 64 ? 24 + (e->P.lin_p2 ? 1 : 0) : 2 * ((D == 32 ? 0 : (D == 16 ? 4 : 8)) + (W == D / 2 ? 2 : 0) + (e->P.lin_p2 ? 1 : 0)) + (half ? 1 : 0);
+    static bool attr_set_dev[64][26];
 #define FG_LIN_KERNELS2(X, H, O) X(0 + O, 32, 8, false, H) X(2 + O, 32, 8, true, H) X(4 + O, 32, 16, false, H) X(6 + O, 32, 16, true, H) X(8 + O, 16, 4, false, H) \
                                  X(10 + O, 16, 4, true, H) X(12 + O, 16, 8, false, H) X(14 + O, 16, 8, true, H) X(16 + O, 8, 2, false, H) X(18 + O, 8, 2, true, H) \
                                  X(20 + O, 8, 4, false, H) X(22 + O, 8, 4, true, H)
-#define FG_LIN_KERNELS(X) FG_LIN_KERNELS2(X, false, 0) FG_LIN_KERNELS2(X, true, 1)
+#define FG_LIN_KERNELS(X) FG_LIN_KERNELS2(X, false, 0) FG_LIN_KERNELS2(X, true, 1) X(24, 64, 16, false, false) X(25, 64, 16, true, false)
     const void *fn = nullptr;
 #define FG_LIN_FN(V, DD, WW, PP, HH) if (variant == V) fn = (const void *)k_hmc_lin_steps<DD, WW, PP, HH>;
     FG_LIN_KERNELS(FG_LIN_FN)

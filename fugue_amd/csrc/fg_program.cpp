@@ -749,8 +749,12 @@ int fg_program::finalize() {
                 else if (coord_at[t] != slot) ok = false;
                 if (slot < 0 || slot >= d) ok = false;
             }
-        if (ok && !stm.empty()) {
-            const int rowd = FG_LIN_ROW_DOUBLES(d);
+        if (ok && !stm.empty() && d <= 64) {
+            // the kernel is built for 8, 16, 32 and 64 term positions: any other d <= 64 is padded with terms that read the always-zero slot
+            // with coefficient +0.0 -- behind the last real term every sum only gains "+ (+0.0)", which changes no bit of a sum that is
+            // not -0.0 and no log-density at all (the predictor enters through (y - mu)^2)
+            const int dp = d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 32 ? 32 : 64));
+            const int rowd = FG_LIN_ROW_DOUBLES(dp);
             lin_n = (int)stm.size(); lin_p2 = 1;
             lin_tab.assign(((size_t)lin_n + 1) * rowd, 0.0);
             for (int s = 0; s < lin_n; s++) {
@@ -758,14 +762,16 @@ int fg_program::finalize() {
                 double *row = &lin_tab[(size_t)s * rowd];
                 row[0] = r.mimm;
                 for (int t = 0; t < d; t++) row[2 + t] = pool[r.maskx + 2 * (size_t)t + 1];
-                double *tail = row + 2 + d;
+                double *tail = row + 2 + dp;
                 tail[0] = r.ximm + 0.0;                              // (x + hx) with hx = 0: what fg_grec_math forms for a constant x
                 tail[1] = r.inv; tail[2] = r.lns; tail[3] = r.sigma;
                 tail[4] = fg_as_double((long long)(r.flags & (FG_G_POW2 | FG_G_DIV)));
                 if (!(r.flags & FG_G_POW2)) lin_p2 = 0;
             }
             lin_meta.assign(coord_at.begin(), coord_at.end());
+            for (int t = d; t < dp; t++) lin_meta.push_back(n_slots - 1);            // padded term positions read the always-zero slot
             for (int k = 0; k < d; k++) { lin_meta.push_back(cstart[k]); lin_meta.push_back(npri[k]); }
+            lin_meta.push_back(0); lin_meta.push_back(0);                            // (readable past the end)
         }
     }
     if (pool.empty()) pool.push_back(0.0);

@@ -47,7 +47,7 @@ struct fg_program {
     // dense regressions (fg_hmc_lin.hip): every coordinate's force terms are its own prior record(s) plus the SAME lin_n linear-predictor
     // observe statements, each reading all d coordinates once in one common term order
     std::vector<double> lin_tab;      // [lin_n + 1] rows of FgLinRow doubles (fg_ir.h); empty when the program is not of that shape
-    std::vector<int> lin_meta;        // [d] coordinate at term position t, then [d][2] {first prior record in gstream, count}
+    std::vector<int> lin_meta;        // [dp] coordinate at term position t (dp = d padded to 8 / 16 / 32: the always-zero slot beyond d), then [d][2] {first prior record in gstream, count}
     int lin_n = 0, lin_p2 = 0;        // observations; every observe sigma is a power of two
     std::vector<double> pool;
     int n_slots = 0, n_ins = 0;

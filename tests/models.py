@@ -121,6 +121,11 @@ ZOO["hier_scale"] = hier_scale
 ZOO["ridge8"] = lambda: W.ridge_regression(*W.ridge_data(20, 8)[:2])
 ZOO["ridge16"] = lambda: W.ridge_regression(*W.ridge_data(12, 16)[:2], sigma=0.8)
 ZOO["ridge32"] = lambda: W.ridge_regression(*W.ridge_data(16, 32)[:2])
+ZOO["ridge24"] = lambda: W.ridge_regression(*W.ridge_data(20, 24)[:2], sigma=0.8)    # dense regressions between the built sizes: padded term positions
+ZOO["ridge12"] = lambda: W.ridge_regression(*W.ridge_data(14, 12)[:2])
+ZOO["ridge5"] = lambda: W.ridge_regression(*W.ridge_data(9, 5)[:2])
+ZOO["ridge64"] = lambda: W.ridge_regression(*W.ridge_data(12, 64)[:2])               # 64 term positions: sixteen waves, q read from LDS
+ZOO["ridge40"] = lambda: W.ridge_regression(*W.ridge_data(10, 40)[:2], sigma=0.8)
 
 
 def linreg_forms() -> M.Program:

@@ -423,19 +423,25 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
 
 
-@pytest.mark.parametrize("name,adapt_mass", [("ridge8", False), ("ridge8", True), ("ridge16", False), ("ridge16", True), ("ridge32", False), ("ridge32", True)])
+@pytest.mark.parametrize("name,adapt_mass", [("ridge8", False), ("ridge8", True), ("ridge16", False), ("ridge16", True), ("ridge32", False), ("ridge32", True),
+                                             ("ridge24", True), ("ridge12", False), ("ridge7", True), ("ridge5", False), ("ridge64", True), ("ridge40", False)])
 def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
     """Dense regressions take the observation-major gradient (k_hmc_lin_steps: a wave owns D / W term positions, forms every
     observation's products and prefix sums once and carries the suffix sums of its own coordinates side by side).  Per
     (coordinate, observation, sign) the additions and multiplications are the gradient stream's in the same order, so draws,
     step sizes, mass matrix, log-joint, statistics and per-transition info agree BIT FOR BIT with k_hmc_stream_steps -- for
-    both waves-per-tile layouts, on full (64-chain) and half (32-chain) tiles."""
+    both waves-per-tile layouts, on full (64-chain) and half (32-chain) tiles.  The kernel is built for 8, 16 and 32 term positions:
+    any other coefficient count up to 32 runs padded with terms that read the always-zero slot (24, 12, 7, 5 coefficients here); 33 .. 64
+    coefficients take the 64-position build (64, 40 here)."""
     monkeypatch.setenv("FG_JIT", "0")          # the hand-written kernels themselves; the compiled form is compared with them in tests/test_gpu_jit.py
     cp = E.compile_model(ZOO[name]())
     assert E.lib().fg_program_stream_records(cp.h, 4) > 0
     C, nw, ns = 150, 40, 25
     out = []
-    for lin, W_, half in ((0, 1, 0), (1, cp.d // 4, 0), (1, cp.d // 2, 0), (1, cp.d // 4, 1), (1, cp.d // 2, 1)):
+    dp = 8 if cp.d <= 8 else (16 if cp.d <= 16 else (32 if cp.d <= 32 else 64))
+    layouts = ((0, 1, 0), (1, dp // 4, 0), (1, dp // 2, 0), (1, dp // 4, 1), (1, dp // 2, 1))
+    if dp == 64: layouts = ((0, 1, 0), (1, 16, 0))          # 33 .. 64 coefficients: sixteen waves of four positions, q read from LDS a chunk at a time; full tiles
+    for lin, W_, half in layouts:
         monkeypatch.setenv("FG_HMC_LIN", str(lin))
         monkeypatch.setenv("FG_HMC_WAVES", str(W_))
         monkeypatch.setenv("FG_HMC_LIN_HALF", str(half))      # half tiles: 32 chains per workgroup, the two signs of the finite difference in the two lane halves
@@ -445,6 +451,7 @@ def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
         draws = eng.download(d, (ns, cp.d, C))
         eng.device_free(d)
         pos, info = eng.hmc_step_info(3)
+        assert ("k_hmc_lin_steps" in eng.hmc_last_kernel()) == bool(lin), eng.hmc_last_kernel()
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
                     eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
         eng.close()
