@@ -62,3 +62,25 @@ __device__ __forceinline__ void fg_load_values(const FgProgramDev &P, const FgCh
 __device__ __forceinline__ void fg_store_values(const FgProgramDev &P, const FgChainCtx &X, long long c, const double *slots, int tw) {
     for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[P.site_slot[j] * tw]);
 }
+
+// ---- adaptive_smc (fg_smc.hip; the rejuvenation kernel of a model compiled at run time, fg_hmc_jit_body.h)
+struct FgSmcScalars {      // device-resident scalars of one SMC run
+    double beta, bnew, lo, hi, mid, one, target_ess;
+    double log_evidence, log_norm, lse1, lse2, ess;
+    int done, force_one;
+    // lookahead bisection (k_smc_ess_pass): candidates of the current pass, bisection steps taken, arrival ticket
+    double cand[8];
+    int n_cand, iters, first;
+    unsigned int ticket;
+    double dbeta;          // bnew - beta of the reweight in flight (k_smc_finish phase 3 advances beta itself; k_smc_apply uses this)
+};
+// rejuvenation: tempered_single_site_mh (smc.rs:631-688), one move per particle
+struct FgSmcDev {
+    double *ll, *lprior;              // [N]
+    double *scale, *log_scale;        // [S] shared DiminishingAdaptation (smc.rs:482)
+    long long *acc, *tot;             // [S]
+    unsigned int *sw_n, *sw_a;        // [S] per-sweep proposal / accept counts
+    unsigned int *blk;                // [n_blocks][2][S] per-block proposal / accept counts of the sweep in flight
+    int S;
+};
+#define FG_SMC_HIST 320               /* sites of a program (LDS bounds a tile to 320 cells) */

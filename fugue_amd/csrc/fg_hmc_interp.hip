@@ -334,9 +334,9 @@ int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double 
 // ---- the same kernel around a model compiled at run time (fg_jit.cpp, fg_hmc_jit_body.h) --------------------------------------
 struct FgJitSeg { int off[FG_MWI_MAX + 1]; const int *order; };
 
-// the program's compiled HMC module (once per engine) and the task split of its kernels; FG_E_UNSUPPORTED when there is none
-static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
-    if (e->jit_state < 0 || e->gt || e->tw != FG_WAVE || e->d < 1 || e->cfg.grad_mode == FG_GRAD_FD_DENSE) return FG_E_UNSUPPORTED;
+// the program's compiled module (once per engine): HMC transitions, the step-size search, adaptive_smc's rejuvenation move
+static int jit_hmc_module(fg_engine *e) {
+    if (e->jit_state < 0 || e->gt || e->tw != FG_WAVE || e->d < 1) return FG_E_UNSUPPORTED;
     if (e->jit_state == 0) {
         e->jit_state = -1;
         if (const char *sp = std::getenv("FG_JIT")) if (std::atoi(sp) == 0) return FG_E_UNSUPPORTED;
@@ -354,12 +354,41 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         }
         if (hipModuleLoadData(&e->jit_mod, code.data()) != hipSuccess || hipModuleGetFunction(&e->jit_fn, e->jit_mod, "k_hmc_jit_steps") != hipSuccess ||
             hipModuleGetFunction(&e->jit_fn_eps, e->jit_mod, "k_hmc_jit_find_eps") != hipSuccess ||
+            hipModuleGetFunction(&e->jit_fn_rejuv, e->jit_mod, "k_smc_jit_rejuv") != hipSuccess ||
             fg_jit_bind_tables(e->jit_mod, ctab, &e->d_jit_tab, e->stream) != FG_OK) {
             e->jit_log = "hipModuleLoadData / hipModuleGetFunction / table upload failed"; (void)hipGetLastError();
             return FG_E_UNSUPPORTED;
         }
         e->jit_state = 1;
     }
+    return FG_OK;
+}
+
+// adaptive_smc's rejuvenation move of a program without a score stream through the compiled model (k_smc_jit_rejuv, fg_hmc_jit_body.h);
+// FG_E_UNSUPPORTED: the interpreter kernel k_smc_rejuv<-1> takes it.  n_blk_out: blocks launched (rows of M.blk that k_smc_adapt adds).
+int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars *st, uint32_t move_id, unsigned *n_blk_out) {
+    if (e->S > FG_SMC_HIST) return FG_E_UNSUPPORTED;
+    if (int rc = jit_hmc_module(e)) return rc;
+    const size_t tile = (size_t)e->S * FG_WAVE * sizeof(double);
+    if (tile > 150 * 1024) return FG_E_UNSUPPORTED;
+    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, (150 * 1024) / tile));           // tiles (waves) per block
+    const size_t lds = tile * wpb;
+    if (lds > 64 * 1024 && !e->jit_rejuv_attr) {
+        if (hipFuncSetAttribute((const void *)e->jit_fn_rejuv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); return FG_E_UNSUPPORTED; }
+        e->jit_rejuv_attr = true;
+    }
+    const unsigned nblk = (unsigned)((e->C + (long long)FG_WAVE * wpb - 1) / ((long long)FG_WAVE * wpb));
+    FgSmcDev Mv = M;
+    void *args[] = { &e->P, &e->X, &Mv, &st, &move_id };
+    HIPCHK(hipModuleLaunchKernel(e->jit_fn_rejuv, nblk, 1, 1, FG_WAVE * wpb, 1, 1, (unsigned)lds, e->stream, args, nullptr));
+    if (n_blk_out) *n_blk_out = nblk;
+    return FG_OK;
+}
+
+// ... and the task split of its HMC kernels; FG_E_UNSUPPORTED when there is none
+static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
+    if (e->cfg.grad_mode == FG_GRAD_FD_DENSE) return FG_E_UNSUPPORTED;
+    if (int rc = jit_hmc_module(e)) return rc;
     const int n_tasks = 2 * e->d;
     {   // LDS: S site rows + d momentum rows + 2 d evaluation rows + exchange rows; beyond 64 KB the module's functions need the attribute
         const size_t lds_max = (size_t)((long long)e->S + 3LL * e->d + 2 + FG_MWI_MAX) * FG_WAVE * sizeof(double);

@@ -259,3 +259,64 @@ void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, 
     }
     if (wv == 0 && live) eps_out[c] = fmin(fmax(eps, 1e-6), 1e3);
 }
+
+
+// ---- adaptive_smc's rejuvenation move (tempered_single_site_mh, smc.rs:631-688) around the same compiled model: k_smc_rejuv<-1>
+// (fg_smc.hip) with the two scoring runs of a move as fg_jit_score instead of the interpreter -- the same operations in the same order,
+// so the same particles, decisions and counts (tests/test_gpu_jit.py).  One tile (S site rows) per wave, `blockDim.x / 64` tiles per block.
+extern "C" __global__ __launch_bounds__(FG_WAVE * 16)
+void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st, uint32_t move_id) {
+    extern __shared__ double lds[];
+    __shared__ unsigned int hist[2][FG_SMC_HIST];                   // the block's proposal / accept counts per site
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
+    for (int j = (int)threadIdx.x; j < 2 * FG_SMC_HIST; j += (int)blockDim.x) (&hist[0][0])[j] = 0u;
+    __syncthreads();
+    const long long chain = ((long long)blockIdx.x * (blockDim.x >> 6) + wv) * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + (long long)wv * P.S * tw + lane;                // one tile per wave: the site rows (expression temporaries are registers here)
+    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    const double beta = st->beta;
+    const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
+    FgStream rng = fg_stream(X.seed, gchain, move_id, FG_RNG_SMC_REJUV);
+    unsigned long long ra, rb;
+    fg_rng_block(rng, ra, rb);
+    const int k = (int)fg_pick(ra, (uint32_t)P.d);            // f64_sites[rng.gen_range(0..len)]  smc.rs:650
+    const int site = P.f64_site[k];                           // sorted site index (adaptation / values row)
+    const double scale = M.scale[site];                       // get_scale  smc.rs:651
+    const double z = fg_cold_normal_pair(sk0, sk1, gchain, 1u, move_id, FG_RNG_SMC_REJUV).a;      // Normal(0,1).sample  smc.rs:655 (block 1)
+    const double cur = slots[k * tw];                         // LDS slot of coordinate k is k
+    const double prop = cur + scale * z;
+    double pri[2], lik[2];
+    for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed: two model runs  smc.rs:662-675
+        slots[k * tw] = pass ? prop : cur;
+        double pr, lk, fc;
+        fg_jit_score(slots, pr, lk, fc);
+        pri[pass] = pr; lik[pass] = lk + fc;
+    }
+    const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
+    const double u = fg_cold_u01_pair(sk0, sk1, gchain, 2u, move_id, FG_RNG_SMC_REJUV).a;     // block 2
+    const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));                  // smc.rs:680
+    if (live) {
+        if (accept) X.values[(long long)site * X.C + c] = fg_as_i64(prop);
+        M.lprior[c] = accept ? pri[1] : pri[0];               // the freshly scored trace is returned either way
+        M.ll[c] = accept ? lik[1] : lik[0];
+    }
+    unsigned long long todo = __ballot(live);
+    const unsigned long long acc_mask = __ballot(live && accept);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int s_lead = __builtin_amdgcn_readlane(site, leader);
+        const unsigned long long same = __ballot(live && site == s_lead);
+        if (lane == leader) {
+            atomicAdd(&hist[0][s_lead], (unsigned int)__popcll(same));
+            const unsigned int na = (unsigned int)__popcll(same & acc_mask);
+            if (na) atomicAdd(&hist[1][s_lead], na);
+        }
+        todo &= ~same;
+    }
+    __syncthreads();
+    unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
+    for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
+}

@@ -26,16 +26,7 @@
 #define SCAN_ITEMS 8
 #define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
 
-struct FgSmcScalars {      // device-resident scalars of one SMC run
-    double beta, bnew, lo, hi, mid, one, target_ess;
-    double log_evidence, log_norm, lse1, lse2, ess;
-    int done, force_one;
-    // lookahead bisection (k_smc_ess_pass): candidates of the current pass, bisection steps taken, arrival ticket
-    double cand[8];
-    int n_cand, iters, first;
-    unsigned int ticket;
-    double dbeta;          // bnew - beta of the reweight in flight (k_smc_finish phase 3 advances beta itself; k_smc_apply uses this)
-};
+// (FgSmcScalars, FgSmcDev: fg_dev_types.h -- the rejuvenation kernel compiled at run time takes them too)
 // few, large blocks: a pass is dominated by what follows the sums -- one ticket atomic per block, the last block's sweep over the
 // blocks' partials -- not by the two exps per particle (512 x 256: 1.13 ms per run, 128 x 512: 1.00 ms, 2048 x 256: 2.3 ms)
 #ifndef ESS_BLOCKS
@@ -745,15 +736,6 @@ __global__ void k_smc_gather(const long long *src, long long *dst, const double 
 // ---------------------------------------------------------------------------------------
 // rejuvenation: tempered_single_site_mh (smc.rs:631-688), one move per particle
 // ---------------------------------------------------------------------------------------
-struct FgSmcDev {
-    double *ll, *lprior;              // [N]
-    double *scale, *log_scale;        // [S] shared DiminishingAdaptation (smc.rs:482)
-    long long *acc, *tot;             // [S]
-    unsigned int *sw_n, *sw_a;        // [S] per-sweep proposal / accept counts
-    unsigned int *blk;                // [n_blocks][2][S] per-block proposal / accept counts of the sweep in flight
-    int S;
-};
-#define FG_SMC_HIST 320               /* sites of a program (LDS bounds a tile to 320 cells) */
 #define FG_SMC_WPB(SCORE) ((SCORE) < 0 ? 1 : ((SCORE) == 2 ? 4 : 16))   /* tiles (waves) per block of k_smc_rejuv<SCORE> */
 // SCORE: 0 = score stream of fast Normals, 3 = + linear predictors / option selects / Categorical tables, 2 = + general
 // distribution records, -1 = the interpreter (programs without a score stream).  The stream variants carry no interpreter
@@ -1258,9 +1240,11 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
 #define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); \
                             else { SMC_TRY(set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))); \
                                    hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); } } while (0)
-                        if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2); else SMC_REJUV(-1);
+                        unsigned nb_adapt = nblk;
+                        if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2);
+                        else if (big || fg_smc_jit_rejuv_launch(e, M, (const FgSmcScalars *)st, mv, &nb_adapt) != FG_OK) SMC_REJUV(-1);   // the compiled model where there is one
 #undef SMC_REJUV
-                        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, M, S, (int)nblk);
+                        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, M, S, (int)nb_adapt);
                         n_runs += 2 * N;
                     }
                 }
@@ -1414,9 +1398,11 @@ int fg_smc_rejuvenate(fg_engine *e, double beta, int steps, uint32_t first_move_
 #define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); \
                             else { if (int rc_ = set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))) return rc_; \
                                    hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); } } while (0)
-        if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2); else SMC_REJUV(-1);
+        unsigned nb_adapt = nblk;
+        if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2);
+        else if (big || fg_smc_jit_rejuv_launch(e, W.M, (const FgSmcScalars *)W.st, mv, &nb_adapt) != FG_OK) SMC_REJUV(-1);
 #undef SMC_REJUV
-        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, W.M, S, (int)nblk);
+        hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, W.M, S, (int)nb_adapt);
     }
     HIPCHK(hipGetLastError());
     if (h_accept_rate) {

@@ -147,6 +147,23 @@ def test_jit_mh_pipelined_kernel_for_programs_without_a_stream(name, with_overri
 
 
 
+@pytest.mark.parametrize("name", ["alldists", "poisson_glm", "hier_logsigma", "logistic"])
+def test_jit_smc_rejuvenation_is_identical_to_the_interpreter(name, monkeypatch):
+    """adaptive_smc on a program without a score stream: the rejuvenation move's two scoring runs through the model compiled at run time
+    (k_smc_jit_rejuv) against the interpreter kernel (k_smc_rejuv<-1>) -- the same ladder, evidence, particles and weights, bit for bit."""
+    cp = E.compile_model(ZOO[name]())
+    out = []
+    for jit in ("0", "1"):
+        monkeypatch.setenv("FG_JIT", jit)
+        eng = E.Engine(cp, 3000, seed=17)
+        r = eng.smc_run(rejuvenation_steps=2, ess_threshold=0.5)
+        out.append((r["betas"], r["log_evidence"], r["values"], r["weights"], r["n_model_runs"]))
+        eng.close()
+    assert len(out[0][0]) >= 2
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 def test_jit_rolls_plates_and_scores_long_programs_directly(monkeypatch):
     """A plate of observations (statements that differ only in their constants) becomes one loop over a constant table in the
     generated code; a program with more statements than LDS has term rows runs MH with the in-order accumulators on one wave
