@@ -28,7 +28,7 @@ __device__ unsigned long long fg_hmc_prof[FG_SEP_WMAX][8];
 #else
 #define FG_PROF_T(i)
 #endif
-struct FgSegSep { int c[FG_SEP_WMAX + 1]; };
+struct FgSegSep { int c[FG_SEP_WMAX + 1]; int sum4; };   // sum4: the four in-order sums of a transition's end on four waves (tiles that are alone on their CU)
 #ifndef FG_SEP_STAGGER
 #define FG_SEP_STAGGER 2          /* x 4 096 cycles: the late start of a CU's second tile (k_hmc_sep_steps) */
 #endif
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     // tile's barriers overlap the other's arithmetic (tools/exp_dense_residency.py: d = 19 / 20 either side of that boundary ran
     // 4.3e9 / 2.2e9 leapfrog-steps/s).
     double *terms = lds + (long long)(srows + (DENSE ? 0 : 2 * d)) * tw + lane;
-    double *xch = terms + (long long)n_s * tw;                      // rows: 0 step size, 1 accepted, 2 divergence bits
+    double *xch = terms + (long long)n_s * tw;                      // rows: 0 step size, 1 accepted, 2 divergence bits, (sparse) 3 .. 6 three of the sums and the accept uniform
     double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only
     double *kin0 = DENSE ? qrow : lds + (long long)srows * tw + lane;
     double *kin1 = DENSE ? prow : kin0 + (long long)d * tw;
@@ -257,6 +257,13 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     // in several rounds and fall out of step by themselves): the host asks for it in the first case only.
     if (stagger && (stagger == 1 ? blockIdx.x >= (gridDim.x + 1) / 2 : (blockIdx.x & 1u) != 0u))
         for (int q = 0; q < FG_SEP_STAGGER; ++q) __builtin_amdgcn_s_sleep(64);            // 64 x 64 cycles each
+    // The momentum of a transition needs nothing of the transition before it: while wave 0 adds, decides and adapts, the other waves
+    // draw the Box-Muller pair their NEXT transition starts with (Philox is counter based: the same numbers).  A tile that is alone on
+    // its CU otherwise leaves that phase's SIMD cycles empty (8 192 chains: a quarter of a trajectory's instructions are this pair).
+    FgD2 zpre = {0.0, 0.0};
+    bool have_pre = false;
+    const uint32_t first_block = DENSE ? 0u : (HALF == 2 ? (uint32_t)(((k0 + half < d) ? k0 + half : k0) >> 1)
+                                                         : (uint32_t)(k0 >> 1) + ((HALF == 1 && half && k0 + 2 < k1) ? 1u : 0u));
     for (int t = 0; t < n_steps; ++t) {
         const int iter = iter0 + t;
         const bool warming = iter < n_warmup;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             const int ci = HALF ? (on ? i + half : i) : i;           // the lane's coordinate
             double z;
             if (HALF == 2) {                                         // quarter tiles: every lane group forms its own coordinate's pair (the pair's two groups: twice)
-                const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(ci >> 1), (uint32_t)iter, FG_RNG_HMC);
+                const FgD2 zz = (HALF != 0 && i == k0 && have_pre) ? zpre : fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(ci >> 1), (uint32_t)iter, FG_RNG_HMC);
                 z = (ci & 1) ? zz.b : zz.a;
             } else if (HALF) {
                 // Both lane halves carry the same chains, so generating a pair in both would double the Philox + Box-Muller work per
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                 // (odd d, last pair) repeats the lower half's coordinate: the same values to the same cells.
                 if (!(((i - k0) >> 1) & 1)) {
                     zh_next = i + 2 < k1;
-                    zzh = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1) + ((half && zh_next) ? 1u : 0u), (uint32_t)iter, FG_RNG_HMC);
+                    zzh = (HALF != 0 && i == k0 && have_pre) ? zpre : fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1) + ((half && zh_next) ? 1u : 0u), (uint32_t)iter, FG_RNG_HMC);
                     const double ob = __shfl_xor(zzh.b, 32, 64);       // this pair's second component, from the lower half
                     z = half ? (on ? (zh_next ? ob : zzh.b) : zzh.a) : zzh.a;
                 } else {
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                     z = half ? (on ? zzh.b : zzh.a) : oa;
                 }
             }
-            else if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
+            else if (!(i & 1)) { const FgD2 zz = (HALF != 0 && i == k0 && have_pre) ? zpre : fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
             else z = zb;
             double p = MASS ? z * ms[(long long)ci * X.C] : z;
             const double mii = MASS ? mi[(long long)ci * X.C] : 1.0;
@@ -423,12 +430,33 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         FG_PROF_T(0)
         __syncthreads();                                         // every coordinate's endpoint and terms
         FG_PROF_T(1)
+        // four in-order sums (independent chains): H0's and the endpoint's kinetic energy in coordinate order, log_prior and
+        // log_likelihood in program order (score_full, hmc.rs:283-299).  A tile with a CU to itself (small chain counts: nothing else
+        // hides wave 0's serial phase) adds them on four waves, a fifth draws the accept uniform; wave 0 keeps the first sum and picks the
+        // others up behind a barrier -- the same additions in the same order either way.
+        const int W = (int)(blockDim.x >> 6);
+        const bool sum4 = HALF != 0 && seg.sum4 != 0 && W >= 4;        // (compile-time off for 64-chain tiles: their instantiation keeps its registers)
+        double s0 = 0.0;
+        if (sum4) {
+            if (wv == 0) s0 = fg_inorder_sum1(kin0, d, tw);
+            else if (wv == 1) xch[3 * tw] = fg_inorder_sum1(kin1, d, tw);
+            else if (wv == 2) xch[4 * tw] = fg_inorder_sum1(termsE, n_pri, tw);
+            else if (wv == 3) xch[5 * tw] = fg_inorder_sum1(termsE + (long long)n_pri * tw, n_s - n_pri, tw);
+            if (wv == (W > 4 ? 4 : 3)) xch[6 * tw] = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)((d + 1) >> 1), (uint32_t)iter, FG_RNG_HMC).a;
+            __syncthreads();
+        }
+        have_pre = false;
+        if (HALF != 0 && seg.sum4 != 0 && wv != 0 && t + 1 < n_steps && k0 < k1 && !(k0 & 1)) {
+            zpre = fg_cold_normal_pair(sk0, sk1, gchain, first_block, (uint32_t)(iter + 1), FG_RNG_HMC);
+            have_pre = true;
+        }
         if (wv == 0) {
-            // four in-order sums, interleaved (independent chains): H0's and the endpoint's kinetic energy in coordinate
-            // order, log_prior and log_likelihood in program order (score_full, hmc.rs:283-299)
-            double s0, s1, pri, lik;
-            fg_inorder_sums2<8>(kin0, d, kin1, d, tw, s0, s1);
-            fg_inorder_sums2<8>(termsE, n_pri, termsE + (long long)n_pri * tw, n_s - n_pri, tw, pri, lik);
+            double s1, pri, lik;
+            if (sum4) { s1 = xch[3 * tw]; pri = xch[4 * tw]; lik = xch[5 * tw]; }
+            else {
+                fg_inorder_sums2<8>(kin0, d, kin1, d, tw, s0, s1);
+                fg_inorder_sums2<8>(termsE, n_pri, termsE + (long long)n_pri * tw, n_s - n_pri, tw, pri, lik);
+            }
             const double h0 = -lj + 0.5 * s0;                        // hmc.rs:442-443
             const double lj_new = pri + lik + 0.0;                   // total_log_weight (log_factors = 0: no factor statement has a record)
             bool div = fg_as_i64(xch[2 * tw]) != 0;
@@ -437,7 +465,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
             if (!div) {
                 const double h_new = -lj_new + 0.5 * s1;
                 ap = fg_cold_accept_prob(h0, h_new);             // hmc.rs:460
-                const double u = fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)((d + 1) >> 1), (uint32_t)iter, FG_RNG_HMC).a;
+                const double u = sum4 ? xch[6 * tw] : fg_cold_u01_pair(sk0, sk1, gchain, (uint32_t)((d + 1) >> 1), (uint32_t)iter, FG_RNG_HMC).a;
                 acc = u < ap;                                    // hmc.rs:461
             }
             if (acc) lj = lj_new;
@@ -529,7 +557,7 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const int tw = FG_WAVE >> half;
     const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
     const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
-                        (dense ? 8 : 0);     // (dense: the kinetic terms end the tile -- the in-order sums read whole chunks of eight rows)
+                        (dense ? 8 : 4 + 8);     // (dense: the kinetic terms end the tile -- the in-order sums read whole chunks of eight rows; sparse: 4 exchange rows + the chunk a sum may read past them)
     const size_t lds = rows * tw * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
@@ -544,6 +572,8 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     }
     while (W > 1 && unit * (W - 1) >= e->d + 1) W /= 2;          // no empty waves
     FgSegSep seg;
+    seg.sum4 = (!dense && half != 0) ? 1 : 0;                    // a tile alone on its CU: the transition's four end sums on four waves
+    if (const char *sv = std::getenv("FG_HMC_SUM4")) seg.sum4 = std::atoi(sv) != 0 ? 1 : 0;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
     for (int w = 0; w < W; ++w) seg.c[w] = std::min(e->d, unit * (int)((long long)pairs * w / W));
     if (W == 8 && !half && !(std::getenv("FG_HMC_PRIO") && std::atoi(std::getenv("FG_HMC_PRIO")) == 0)) seg.c[FG_SEP_WMAX] = -1;   // priority turns: two waves of a tile per SIMD
