@@ -76,7 +76,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
                 const int task = seg.order[jj];
                 const int k = task >> 1;
                 const double orig = slots[k * tw];
-                ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, slots);      // hmc.rs:317-321
+                ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, FG_JIT_LDS(slots));      // hmc.rs:317-321
             }
             __syncthreads();                                  // every evaluation of this gradient done, every read of q done
             for (int k = wv; k < d; k += W) {
@@ -96,7 +96,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         double lj_new = FG_NEG_INF;
         if (wv == 0) {
             double pr = 0.0, lk = 0.0, fc = 0.0;
-            fg_jit_score(slots, pr, lk, fc);
+            fg_jit_score(FG_JIT_LDS(slots), pr, lk, fc);
             lj_new = pr + lk + fc;                            // total_log_weight (trace.rs:198-200)
         }
         xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
@@ -212,7 +212,7 @@ void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, 
                 const int task = seg.order[jj];
                 const int k = task >> 1;
                 const double orig = slots[k * tw];
-                ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, slots);
+                ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, FG_JIT_LDS(slots));
             }
             __syncthreads();
             for (int k = wv; k < d; k += W) {
@@ -229,7 +229,7 @@ void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, 
         __syncthreads();
         if (wv == 0) {
             double pr = 0.0, lk = 0.0, fc = 0.0;
-            fg_jit_score(slots, pr, lk, fc);
+            fg_jit_score(FG_JIT_LDS(slots), pr, lk, fc);
             const double lj1 = pr + lk + fc;
             bool div = !fg_finite(lj1);
             for (int w = 0; w < W; ++w) div = div || xch[(2 + w) * tw] != 0.0;
@@ -292,7 +292,7 @@ void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalar
     for (int pass = 0; pass < 2; ++pass) {                    // score current, then proposed: two model runs  smc.rs:662-675
         slots[k * tw] = pass ? prop : cur;
         double pr, lk, fc;
-        fg_jit_score(slots, pr, lk, fc);
+        fg_jit_score(FG_JIT_LDS(slots), pr, lk, fc);
         pri[pass] = pr; lik[pass] = lk + fc;
     }
     const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679

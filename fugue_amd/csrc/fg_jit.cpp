@@ -82,6 +82,7 @@ struct Gen {
     // meanwhile); everything that is not a plate runs on wave 0 alone.  The accumulators are wave 0's.
     bool coop = false;
     bool ring_term = false;                      // the statement being emitted writes its term to ring row (buf * CH + rr)
+    bool mh_terms = false;                       // the multi-wave MH kernel's phase B: a term row may hold NaN for -inf (see FG_OP_NORMAL_FAST)
     const std::vector<int> *rows = nullptr;      // TM mode: term row of statement k when it is not k itself (the multi-wave stream kernel's rows: log_prior
                                                  // terms first, then log_likelihood terms)
 
@@ -226,8 +227,19 @@ struct Gen {
             if (op & FG_F_POW2SCALE) z = "double z = dl * " + lit(I.h[4]) + ";";
             else if (op & FG_F_RCPSCALE) z = "double z = fg_div_const(dl, " + lit(I.imm[2]) + ", " + lit(I.h[4]) + ");";
             else z = "double z = dl / " + lit(I.imm[2]) + ";";
-            add("{ const double xv = " + lit(I.imm[0]) + " + " + slot(I.opnd[0]) + "; const double mv = " + lit(I.imm[1]) + " + " + slot(I.opnd[1]) +
-                "; const double dl = xv - mv; " + z + " double lp = -0.5 * z * z - " + lit(I.h[0]) + " - 0.5 * FG_LN_2PI; lp = (z != z) ? FG_NEG_INF : lp; " + accum + " }");
+            // operand = imm + slot (fg_interp.h).  Outside rolled runs (whose statements share one text): `0.0 + x` is x up to the sign of a
+            // zero, which the density cannot see -- x and mu enter through (x - mu)^2 -- so a zero immediate is not added, and a constant
+            // operand (the always-zero slot) is one literal.  mh_terms (the multi-wave MH kernel's term rows): no "NaN -> -inf" select -- a NaN
+            // term makes log_alpha NaN where -inf makes it -inf, both reject, and the rows are never stored (fg_mh_mw_body.h).
+            auto operand = [&](double imm, uint32_t sl) -> std::string {
+                if (cvec) return lit(imm) + " + " + slot(sl);
+                if ((int)sl == p.n_slots - 1) return ::lit(imm + 0.0);
+                if (imm == 0.0) return slot(sl);
+                return lit(imm) + " + " + slot(sl);
+            };
+            add("{ const double xv = " + operand(I.imm[0], I.opnd[0]) + "; const double mv = " + operand(I.imm[1], I.opnd[1]) +
+                "; const double dl = xv - mv; " + z + " double lp = -0.5 * z * z - " + lit(I.h[0]) + " - 0.5 * FG_LN_2PI; " +
+                ((mh_terms && !cvec) ? std::string() : std::string("lp = (z != z) ? FG_NEG_INF : lp; ")) + accum + " }");
             return;
         }
         if (code < 17u) {
@@ -368,6 +380,10 @@ Rtc &rtc() {
 }
 
 const char *PROLOGUE = R"FGJ(
+// the tile rows a generated function reads and writes are LDS: through a generic pointer every access of a noinline function is a FLAT
+// one (hundreds of cycles, a vmcnt wait each, no batching) -- the qualified pointer makes them ds_read / ds_write with immediate offsets
+#define FG_LDSQ __attribute__((address_space(3)))
+#define FG_JIT_LDS(p) ((FG_LDSQ double *)(p))
 #define FG_BUILD 1
 #define FG_JIT_RTC 1
 #define FG_WAVE 64
@@ -442,10 +458,10 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         g.ctabs = &ctabs;
         g.emit(p->sub, (size_t)p->coord[k].sub_off, (size_t)p->coord[k].sub_off + (size_t)p->coord[k].sub_n);
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const double *slots) {\n" + g.decls() + g.body +
+        fns += "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
                "    (void)acc;\n    return pr + lk + fc;\n}\n";
     }
-    fns += "static __device__ __forceinline__ double fg_jit_task(int k, double pert, const double *slots) {\n    switch (k) {\n";
+    fns += "static __device__ __forceinline__ double fg_jit_task(int k, double pert, const FG_LDSQ double *slots) {\n    switch (k) {\n";
     for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_sub_" + std::to_string(k) + "(pert, slots);\n";
     fns += "    default: return 0.0;\n    }\n}\n";
     {
@@ -453,7 +469,7 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         g.ctabs = &ctabs;
         g.emit(p->ins_fast, 0, (size_t)p->n_ins);
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ void fg_jit_score(const double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+        fns += "static __device__ __noinline__ void fg_jit_score(const FG_LDSQ double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
     std::string src = PROLOGUE;
@@ -496,7 +512,7 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
         g.ctabs = &ctabs;
         g.emit(p->ins_fast, (size_t)(s_at > 0 ? stmt_end[(size_t)s_at - 1] : 0), (size_t)(s_to > 0 ? stmt_end[(size_t)s_to - 1] : 0));
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ void fg_jit_seg_" + std::to_string(sg) + "(const double *slots, double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+        fns += "static __device__ __noinline__ void fg_jit_seg_" + std::to_string(sg) + "(const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
         s_at = s_to;
     }
@@ -505,10 +521,10 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
         Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.ctabs = &ctabs; g.coop = true;
         g.emit(p->ins_fast, 0, (size_t)p->n_ins);
         if (!g.ok) return "";
-        fns += "#define FG_JIT_CH 32\nstatic __device__ __noinline__ void fg_jit_score_coop(const double *slots, double *ring, int wv, int W, double &pr_out, double &lk_out, double &fc_out) {\n"
+        fns += "#define FG_JIT_CH 32\nstatic __device__ __noinline__ void fg_jit_score_coop(const FG_LDSQ double *slots, FG_LDSQ double *ring, int wv, int W, double &pr_out, double &lk_out, double &fc_out) {\n"
                "    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body + "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
-    fns += "static __device__ __forceinline__ void fg_jit_terms(int sg, const double *slots, double *terms) {\n    switch (sg) {\n";
+    fns += "static __device__ __forceinline__ void fg_jit_terms(int sg, const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    switch (sg) {\n";
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_seg_" + std::to_string(sg) + "(slots, terms); break;\n";
     fns += "    default: break;\n    }\n}\n";
     std::string src = PROLOGUE;
@@ -521,8 +537,8 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
     for (const auto &kv : lp_fns) src += kv.second;
     src += fns;
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
-           "#define FG_MHI_SCORE() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_terms(sg_, slots, terms); (void)i0; (void)i1; (void)s0; } while (0)\n"
-           "#define FG_MHI_DIRECT_SCORE() fg_jit_score_coop(slots, terms, wv, W, A.prior, A.lik, A.fac)\n"
+           "#define FG_MHI_SCORE() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_terms(sg_, FG_JIT_LDS(slots), FG_JIT_LDS(terms)); (void)i0; (void)i1; (void)s0; } while (0)\n"
+           "#define FG_MHI_DIRECT_SCORE() fg_jit_score_coop(FG_JIT_LDS(slots), FG_JIT_LDS(terms), wv, W, A.prior, A.lik, A.fac)\n"
            "#define FG_MHI_PRIV_BLOCKS(W) 1\n";
     src += FG_JIT_EMBED_MH_BODY;                 // fg_mh_interp_body.h
     src += R"FGJ(
@@ -542,8 +558,10 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
 // records of phase B (generated[k] != 0: statement k's log-density term into its LDS row) as FG_JIT_NSEG generated statement
 // segments instead of fg_score_one over the record stream.
 std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out,
-                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream, bool pipe) {
-    constexpr int NSEG = 16;
+                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream, bool pipe, int nseg, int ctl_share16, int sum_pri, int sum_lik) {
+    // statement segments: sixteen dealt to the waves (sg = wave, wave + W, ...), or -- nseg = the launch's waves per tile -- ONE per wave:
+    // a wave's statements are then one straight-line function whose LDS reads are all in flight together
+    const int NSEG = (nseg >= 2 && nseg <= 16) ? nseg : 16;
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
     std::vector<std::string> tables;
@@ -573,25 +591,31 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cum[(size_t)a + 1] - cum[(size_t)a] > cum[(size_t)b + 1] - cum[(size_t)b]; });
         // the control wave (segments 0 and 8 at W <= 8) also proposes, adds the terms and decides, and scores at the lower
         // priority: it starts with half a segment on its account (alldists, 65 536 chains: 1.29e9 without, 1.60e9 with; 1.46e9 cut contiguously)
-        long long load[NSEG] = {0};
-        load[0] = load[8] = std::min<long long>((45 + n_stmt) / 2, cum[(size_t)n_stmt] / (2 * NSEG));
+        std::vector<long long> load((size_t)NSEG, 0);
+        load[0] = std::min<long long>((45 + n_stmt) / 2, cum[(size_t)n_stmt] / (2 * NSEG));
+        if (NSEG > 8) load[8] = load[0];
         for (int k : order) {
             int best = 0;
             for (int sg = 1; sg < NSEG; ++sg) if (load[sg] < load[best]) best = sg;
             seg_of[(size_t)k] = best; load[best] += cum[(size_t)k + 1] - cum[(size_t)k];
         }
     } else {
+        // (one segment per wave: the control wave's -- segment 0 -- is `ctl_share` sixteenths of the others', it has the step's path besides)
+        const int ctl16 = (nseg >= 2 && nseg <= 16) ? ctl_share16 : 16;
+        const long long units = 16LL * (NSEG - 1) + ctl16;
         int s_at = 0;
+        long long at_u = 0;
         for (int sg = 0; sg < NSEG; ++sg) {
+            at_u += sg == 0 ? ctl16 : 16;
             int s_to = n_stmt;
-            if (sg + 1 < NSEG) { const long long target = cum[(size_t)n_stmt] * (sg + 1) / NSEG; s_to = s_at; while (s_to < n_stmt && cum[(size_t)s_to] < target) ++s_to; }
+            if (sg + 1 < NSEG) { const long long target = cum[(size_t)n_stmt] * at_u / units; s_to = s_at; while (s_to < n_stmt && cum[(size_t)s_to] < target) ++s_to; }
             for (int k = s_at; k < s_to; ++k) if (generated[(size_t)k]) seg_of[(size_t)k] = sg;
             s_at = s_to;
         }
     }
     std::string fns;
     for (int sg = 0; sg < NSEG; ++sg) {
-        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.rows = &rows; g.ctabs = &ctabs;
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.rows = &rows; g.ctabs = &ctabs; g.mh_terms = !no_stream;
         for (int k = 0; k < n_stmt;) {                    // maximal runs of consecutive statements of this segment (plates roll within a run)
             if (seg_of[(size_t)k] != sg) { ++k; continue; }
             int k2 = k; while (k2 < n_stmt && seg_of[(size_t)k2] == sg) ++k2;
@@ -600,10 +624,10 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
             k = k2;
         }
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ void fg_jit_mhb_" + std::to_string(sg) + "(const double *slots, double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+        fns += "static __device__ __noinline__ void fg_jit_mhb_" + std::to_string(sg) + "(const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
     }
-    fns += "static __device__ __forceinline__ void fg_jit_mhb(int sg, const double *slots, double *terms) {\n    switch (sg) {\n";
+    fns += "static __device__ __forceinline__ void fg_jit_mhb(int sg, const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    switch (sg) {\n";
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_mhb_" + std::to_string(sg) + "(slots, terms); break;\n";
     fns += "    default: break;\n    }\n}\n";
     std::string src = PROLOGUE;
@@ -626,8 +650,26 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
         if (!all) return "";
         src += "#define FG_MHMW_NS " + std::to_string(n_stmt) + "\n#define FG_MHMW_NPRI " + std::to_string(n_pri) + "\n#define FG_MHMW_NFAC " + std::to_string(n_fac) + "\n";
     }
+    // the control wave's in-order sums with the row counts as literals: straight-line loads and additions (every row of a chain is
+    // added in program order from 0.0 -- fg_inorder_sums2's additions -- without chunk loops, tails of selected zeros or address arithmetic)
+    if (!no_stream && sum_pri >= 0 && sum_lik >= 0 && sum_pri + sum_lik <= 160) {
+        std::string f = "static __device__ __noinline__ void fg_jit_sums2(const FG_LDSQ double *terms, double &pri_out, double &lik_out) {\n    double a = 0.0, b = 0.0;\n";
+        for (int k = 0; k < std::max(sum_pri, sum_lik); ++k) {
+            if (k < sum_pri) f += "    a += terms[" + std::to_string(k) + " * FG_WAVE];";
+            if (k < sum_lik) f += "    b += terms[" + std::to_string(sum_pri + k) + " * FG_WAVE];";
+            f += "\n";
+        }
+        f += "    pri_out = a; lik_out = b;\n}\n";
+        f += "static __device__ __noinline__ double fg_jit_sum_pri(const FG_LDSQ double *terms) {\n    double a = 0.0;\n";
+        for (int k = 0; k < sum_pri; ++k) f += "    a += terms[" + std::to_string(k) + " * FG_WAVE];\n";
+        f += "    return a;\n}\nstatic __device__ __noinline__ double fg_jit_sum_lik(const FG_LDSQ double *terms) {\n    double b = 0.0;\n";
+        for (int k = 0; k < sum_lik; ++k) f += "    b += terms[" + std::to_string(sum_pri + k) + " * FG_WAVE];\n";
+        f += "    return b;\n}\n";
+        src += f;
+        src += "#define FG_MHMW_SUMS2(PRI, LIK) fg_jit_sums2(FG_JIT_LDS(terms), PRI, LIK)\n#define FG_MHMW_SUM_PRI() fg_jit_sum_pri(FG_JIT_LDS(terms))\n#define FG_MHMW_SUM_LIK() fg_jit_sum_lik(FG_JIT_LDS(terms))\n";
+    }
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
-           "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, slots, terms); } while (0)\n";
+           "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, FG_JIT_LDS(slots), FG_JIT_LDS(terms)); } while (0)\n";
     src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
     const bool pipe2 = pipe && !no_stream;       // the step loop with the serial recipe split over waves (stream programs)
     if (pipe2) src += FG_JIT_EMBED_MHMW2_BODY;   // fg_mh_mw2_body.h
@@ -788,7 +830,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
     if (std::getenv("FG_DEBUG_JIT_MHMW")) {                                // the multi-wave stream MH unit
         std::string s2;
-        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false, std::getenv("FG_MH_PIPE") && std::atoi(std::getenv("FG_MH_PIPE")) == 1);
+        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false, std::getenv("FG_MH_PIPE") && std::atoi(std::getenv("FG_MH_PIPE")) == 1, std::getenv("FG_DEBUG_JIT_NSEG") ? std::atoi(std::getenv("FG_DEBUG_JIT_NSEG")) : 0, 16, p->n_prior_terms, p->n_sstream - p->n_prior_terms);
         else {                                                             // a program without a score stream: rows in accumulator order (fg_mh_mw_nostream_launch)
             std::vector<int> rows; int n_pri = 0, n_lik = 0, n_fac = 0;
             for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) {

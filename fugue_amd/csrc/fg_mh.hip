@@ -248,10 +248,24 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             }
             // mostly general records: the few pattern records too (their runs' set-up costs more than the generated statements:
             // linreg, 2 pattern records of 22: 2.49e10 all generated, 2.08e10 with the two runs, 1.66e10 hand-written)
+            // Programs of pattern records only (plain Normals with sigma = 2^k): round 3 kept the hand-written record runs -- the generated
+            // functions read their tile through generic pointers then (FLAT accesses) and lost.  With LDS-qualified pointers the generated
+            // statements win from ~20 statements up (reference_model(20): level at 65 536 chains, +16 % at 16 384 and 8 192; normal32 +9 % /
+            // +14 %; reference_model(50) +13 %), not on short programs (reference_model(8): -4 %) and not where phase B is table lookups
+            // (C5: -19 %): profiles/round4_mh_generated_statements.txt.  FG_MH_GEN_ALL = 0 / 1 forces either.
+            bool gen_all = n_gen == 0 && n_s >= 20 && e->mh_cls_off[2] == 0;              // (no class-0 / class-1 lookup records)
+            if (const char *gv = std::getenv("FG_MH_GEN_ALL")) gen_all = std::atoi(gv) != 0;
+            // one segment per wave of this launch shape (all of a wave's statements in one straight-line function) where every statement
+            // is generated; the control wave takes `ctl16` sixteenths of a share
+            int nseg = W, ctl16 = 16;                                                            // (reference_model(20), 65 536 chains: sampling 2.21e10 -> 2.61e10; linreg +19 %, hier_scale +9 %)
+            if (const char *nv = std::getenv("FG_MH_NSEG")) { if (std::atoi(nv) == 0) nseg = 0; }
+            if (const char *cv = std::getenv("FG_MH_CTL16")) ctl16 = std::max(0, std::min(16, std::atoi(cv)));
+            if (gen_all) n_gen = n_s;
             if (2 * n_gen >= n_s) for (int k = 0; k < n_s; ++k) generated[(size_t)k] = (n_cu > 0 && (p->sstream[k].flags & FG_G_CATC)) ? 0 : 1;   // (row-less terms have no statement to run)
             std::vector<double> ctab;
             // (a handful of general records among many pattern records: the runs alone -- C5 with two tiles on a CU: 7.0e9 against 6.7e9)
-            const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false, sh.pipe != 0) : std::string();
+            const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false, sh.pipe != 0, (2 * n_gen >= n_s) ? nseg : 0, ctl16,
+                                                                       (std::getenv("FG_MH_JIT_SUMS") && std::atoi(std::getenv("FG_MH_JIT_SUMS")) == 1) ? n_pri - n_cu : -1, n_s - n_pri) : std::string();   // (the control wave's sums as generated straight-line code: measured SLOWER than the chunked loops -- reference_model(20) 2.30e10 against 2.70e10 -- an experiment switch)
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mhmw_mod, code.data()) == hipSuccess &&

@@ -140,8 +140,10 @@ __device__ __forceinline__ void fg_mh_group4(const FgGradRec *g, int k, int kend
 // uniform's block are those of a whole propose-and-score run (fg_mh_interp_body.h does the same).  One pass per distinct such target
 // in the wave; the other lanes see no target there.
 struct FgMhmwPre { double lqf, lqr; int kind, next_block; };
-static __device__ __noinline__ FgMhmwPre fg_mhmw_model_proposals(const FgIns *ins, const int *site_ins, const double *pool, double *slots, bool live, bool walk, int target,
+static __device__ __noinline__ FgMhmwPre fg_mhmw_model_proposals(const FgIns *ins, const int *site_ins, const double *pool, double *slots_generic, bool live, bool walk, int target,
                                                                  FgMhCtx pre, unsigned long long seed, uint32_t gchain, uint32_t iter) {
+    // the tile is LDS: through the parameter's generic pointer every access of this out-of-line function would be a FLAT one
+    double *slots = (double *)(__attribute__((address_space(3))) double *)slots_generic;
     FgStream rng = fg_stream(seed, gchain, iter, FG_RNG_MH);
     unsigned long long ra, rb;
     fg_rng_block(rng, ra, rb);
@@ -334,8 +336,13 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
         if (SPLIT) {
             if (wv == 0) { FG_MH_NEXT_INPUTS }
             if (t > 0 && !(exp_mask & 2)) {
+#ifdef FG_MHMW_SUM_PRI       /* a unit compiled at run time: the sums as straight-line code (fg_jit.cpp) */
+                if (wv == 0) { pri = FG_MHMW_SUM_PRI(); FG_MH_CATU_TAIL }
+                else if (wv == 1) xch[16 * tw] = FG_MHMW_SUM_LIK();
+#else
                 if (wv == 0) { pri = fg_inorder_sum1(terms, n_pri, tw); FG_MH_CATU_TAIL }
                 else if (wv == 1) xch[16 * tw] = fg_inorder_sum1(terms + (long long)n_pri * tw, n_lik, tw);
+#endif
                 // LDS only crosses this barrier: wait for the LDS counter and leave the control wave's adaptation-state gather (64
                 // lines from L2, issued above) in flight -- __syncthreads() would drain it here
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -346,7 +353,11 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
         if (wv == 0) {
             if (!SPLIT) {                                                  // short programs: both chains on the control wave, no third barrier
                 FG_MH_NEXT_INPUTS
+#ifdef FG_MHMW_SUMS2
+                if (t > 0 && !(exp_mask & 2)) { FG_MHMW_SUMS2(pri, lik); FG_MH_CATU_TAIL }
+#else
                 if (t > 0 && !(exp_mask & 2)) { fg_inorder_sums2(terms, n_pri, terms + (long long)n_pri * tw, n_lik, tw, pri, lik); FG_MH_CATU_TAIL }
+#endif
             }
 #undef FG_MH_NEXT_INPUTS
 #undef FG_MH_CATU_TAIL
