@@ -109,7 +109,8 @@ int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *dr
         std::vector<long long> cost((size_t)p->n_ins);
         for (int k = 0; k < p->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(p->ins_fast[(size_t)k]);
         std::vector<double> ctab;
-        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac, true);
+        const int nseg_ns = (std::getenv("FG_MH_NSEG_NS") && std::atoi(std::getenv("FG_MH_NSEG_NS")) == 0) ? 0 : sh.W;       // one statement segment per wave (logistic +12 %, poisson_glm +16 %, hier_logsigma +8 %, alldists level)
+        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac, true, false, nseg_ns);
         std::vector<char> code;
         if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
             hipModuleLoadData(&e->jit_mhns_mod, code.data()) == hipSuccess &&
@@ -250,10 +251,10 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             // linreg, 2 pattern records of 22: 2.49e10 all generated, 2.08e10 with the two runs, 1.66e10 hand-written)
             // Programs of pattern records only (plain Normals with sigma = 2^k): round 3 kept the hand-written record runs -- the generated
             // functions read their tile through generic pointers then (FLAT accesses) and lost.  With LDS-qualified pointers the generated
-            // statements win from ~20 statements up (reference_model(20): level at 65 536 chains, +16 % at 16 384 and 8 192; normal32 +9 % /
-            // +14 %; reference_model(50) +13 %), not on short programs (reference_model(8): -4 %) and not where phase B is table lookups
+            // statements, one segment per wave, win (reference_model(20): sampling 2.24e10 -> 2.70e10 at 65 536 chains, 3.9e9 -> 4.6e9 at 8 192;
+            // reference_model(8) 3.0e10 -> 3.4e10 / 4.4e9 -> 5.6e9; normal32, reference_model(50) +13 %) -- not where phase B is table lookups
             // (C5: -19 %): profiles/round4_mh_generated_statements.txt.  FG_MH_GEN_ALL = 0 / 1 forces either.
-            bool gen_all = n_gen == 0 && n_s >= 20 && e->mh_cls_off[2] == 0;              // (no class-0 / class-1 lookup records)
+            bool gen_all = n_gen == 0 && n_s >= (std::getenv("FG_MH_GEN_MIN") ? std::atoi(std::getenv("FG_MH_GEN_MIN")) : 8) && e->mh_cls_off[2] == 0;              // (no class-0 / class-1 lookup records)
             if (const char *gv = std::getenv("FG_MH_GEN_ALL")) gen_all = std::atoi(gv) != 0;
             // one segment per wave of this launch shape (all of a wave's statements in one straight-line function) where every statement
             // is generated; the control wave takes `ctl16` sixteenths of a share

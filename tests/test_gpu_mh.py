@@ -193,7 +193,7 @@ def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeyp
         kernels.append(eng.mh_last_kernel())
         out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
         eng.close()
-    # (a pattern-only program of >= 20 statements has its statements generated too since round 4; a two-statement one keeps the record runs)
+    # (a pattern-only program of >= 8 statements has its statements generated too since round 4; a two-statement one keeps the record runs)
     want = ("k_mh_mw2_steps", "k_mh_mw_steps") if name == "readme" else ("k_mh_mw2_jit_steps", "k_mh_mw_jit_steps")
     assert all(k.startswith(want[0]) for k in kernels[1:6]) and all(k.startswith(want[1]) for k in kernels[6:]), kernels
     for o in out[1:]:
