@@ -266,7 +266,7 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             std::vector<double> ctab;
             // (a handful of general records among many pattern records: the runs alone -- C5 with two tiles on a CU: 7.0e9 against 6.7e9)
             const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false, sh.pipe != 0, (2 * n_gen >= n_s) ? nseg : 0, ctl16,
-                                                                       (std::getenv("FG_MH_JIT_SUMS") && std::atoi(std::getenv("FG_MH_JIT_SUMS")) == 1) ? n_pri - n_cu : -1, n_s - n_pri) : std::string();   // (the control wave's sums as generated straight-line code: measured SLOWER than the chunked loops -- reference_model(20) 2.30e10 against 2.70e10 -- an experiment switch)
+                                                                       (std::getenv("FG_MH_JIT_SUMS") && std::atoi(std::getenv("FG_MH_JIT_SUMS")) == 0) ? -1 : n_pri - n_cu, n_s - n_pri) : std::string();   // (the control wave's in-order sums as inlined straight-line code with the row counts as literals: reference_model(20) sampling 2.71e10 -> 2.89e10; behind a CALL they lost -- a call drains the adaptation-state gather that is in flight across the sums)
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mhmw_mod, code.data()) == hipSuccess &&
