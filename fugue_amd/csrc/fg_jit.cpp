@@ -512,7 +512,7 @@ std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &
         g.ctabs = &ctabs;
         g.emit(p->ins_fast, (size_t)(s_at > 0 ? stmt_end[(size_t)s_at - 1] : 0), (size_t)(s_to > 0 ? stmt_end[(size_t)s_to - 1] : 0));
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ void fg_jit_seg_" + std::to_string(sg) + "(const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+        fns += "static __device__ __noinline__ void fg_jit_seg_" + std::to_string(sg) + "(const FG_LDSQ double *__restrict__ slots, FG_LDSQ double *__restrict__ terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
         s_at = s_to;
     }
@@ -624,7 +624,7 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
             k = k2;
         }
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ void fg_jit_mhb_" + std::to_string(sg) + "(const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
+        fns += "static __device__ __noinline__ void fg_jit_mhb_" + std::to_string(sg) + "(const FG_LDSQ double *__restrict__ slots, FG_LDSQ double *__restrict__ terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
     }
     fns += "static __device__ __forceinline__ void fg_jit_mhb(int sg, const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    switch (sg) {\n";
