@@ -217,7 +217,10 @@ struct Gen {
         }
     }
 
+    std::string acc_int;                         // acc == (double) of this integer cell (set by a LOAD of an integer slot, valid for the next instruction only)
     void ins(const FgIns &I) {
+        const std::string acc_int_was = acc_int;
+        acc_int.clear();
         const uint32_t op = I.op, code = FG_INS_OPCODE(op);
         const bool observe = (op & FG_F_OBSERVE) != 0u;
         const bool ends = code == FG_OP_NORMAL_FAST || code < 17u;
@@ -294,7 +297,10 @@ struct Gen {
         const std::string x0 = opnd(I.opnd[0], I.imm[0]);
         switch (code) {
         case FG_OP_FACTOR: add((term >= 0 || ring_term) ? term_row() + " = " + x0 + ";" : "fc += " + x0 + ";"); break;
-        case FG_OP_LOAD: add("acc = " + x0 + ";"); break;
+        case FG_OP_LOAD:
+            add("acc = " + x0 + ";");
+            if (FG_OPND_KIND(I.opnd[0]) == FG_OPND_SLOT_I) { acc_int = slot(FG_OPND_IDX(I.opnd[0])); return; }     // (a GATHER that follows indexes with the integer itself)
+            break;
         case FG_OP_ADD: add("acc = acc + " + x0 + ";"); break;
         case FG_OP_SUB: add("acc = acc - " + x0 + ";"); break;
         case FG_OP_MUL: add("acc = acc * " + x0 + ";"); break;
@@ -319,6 +325,12 @@ struct Gen {
         case FG_OP_STORE: { const std::string t = slot(I.aux); if (t == "0.0" || t == "pert" || t[0] == 's') { ok = false; break; } add(t + " = acc;"); break; }
         case FG_OP_GATHER: {
             const int K = (int)I.opnd[1];
+            // the index: acc >= 0, < K and integral (fg_interp.h).  When acc is an integer site's cell converted to double (the LOAD just
+            // before), the same three tests on the integer: no conversion there and back (exact for every 64-bit value: K <= 64)
+            if (!acc_int_was.empty() && !cvec)
+                add("{ const long long ji_ = fg_as_i64(" + acc_int_was + "); const bool ok_ = (unsigned long long)ji_ < " + std::to_string(K) + "ull; const int j = ok_ ? (int)ji_ : 0; " +
+                    pick((int)I.aux, K, "j", "gv") + "acc = ok_ ? gv : NAN; }");
+            else
             add("{ const bool ok_ = (acc >= 0.0) && (acc < " + lit((double)K) + ") && (acc == floor(acc)); const int j = ok_ ? (int)acc : 0; " + pick((int)I.aux, K, "j", "gv") +
                 "acc = ok_ ? gv : NAN; }");
             break; }
