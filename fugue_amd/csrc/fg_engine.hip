@@ -979,9 +979,15 @@ int fg_hmc_init(fg_engine *e, const fg_hmc_config *cfg, int n_warmup) {
     if (!cfg || n_warmup < 0) return FG_E_BAD_ARG;
     if (int rc = hmc_lds_ok(e)) return rc;
     if (cfg->grad_mode != FG_GRAD_FD_DENSE && cfg->grad_mode != FG_GRAD_FD_SPARSE && cfg->grad_mode != FG_GRAD_ANALYTIC) { fg_set_error("unknown grad_mode"); return FG_E_BAD_ARG; }
+    // FG_GRAD_ANALYTIC: closed forms in the stream / register-resident kernels when every force term is a Normal with constant sigma;
+    // any other program through the forward-mode derivative of its sub-programs in the unit compiled at run time (fg_jit.cpp: Gen::ins_ad)
+    e->an_jit = false;
     if (cfg->grad_mode == FG_GRAD_ANALYTIC && (e->d == 0 || !e->P.gstream || fg_program_stream_records(e->prog, 2) > 1 || e->tw != FG_WAVE)) {
-        fg_set_error("FG_GRAD_ANALYTIC needs every force term to be a Normal with constant sigma whose mean is a site, a constant or a linear predictor");
-        return FG_E_UNSUPPORTED; }
+        if (e->d == 0 || e->tw != FG_WAVE || e->gt || !fg_hmc_jit_has_ad(e)) {
+            fg_set_error("FG_GRAD_ANALYTIC: no closed form for this program (force terms other than Normals with constant sigma need the run-time compiler: hiprtc / hipcc)");
+            return FG_E_UNSUPPORTED; }
+        e->an_jit = true;
+    }
     if (cfg->n_leapfrog < 1 || cfg->n_leapfrog > 100000) { fg_set_error("n_leapfrog must be in [1, 100000] (a trajectory of 0 steps never moves: hmc.rs:385)"); return FG_E_BAD_ARG; }
     if (!(cfg->finite_diff_eps > 0.0) || !std::isfinite(cfg->finite_diff_eps)) { fg_set_error("finite_diff_eps must be positive and finite"); return FG_E_BAD_ARG; }
     const bool mass = cfg->adapt_mass && n_warmup >= 4;                 // hmc.rs:704-708
@@ -1020,6 +1026,11 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
     const unsigned tiles = (unsigned)((e->C + e->tw - 1) / e->tw);
     const bool dense_stream = e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.sstream != nullptr && e->P.sstream_kinds == 0;
     const bool analytic = e->cfg.grad_mode == FG_GRAD_ANALYTIC;
+    if (analytic && e->an_jit) {                              // the analytic gradient of a program without closed-form records: the compiled unit
+        const int rc = fg_hmc_jit_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+        if (rc != FG_OK) fg_set_error("FG_GRAD_ANALYTIC: the compiled kernel is not available for this launch");
+        return rc == FG_E_UNSUPPORTED ? FG_E_STATE : rc;
+    }
     {   // independent-sites programs: whole trajectories in registers (fg_hmc_sep.hip)
         const int rc = fg_hmc_sep_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
         if (rc != FG_E_UNSUPPORTED) return rc;

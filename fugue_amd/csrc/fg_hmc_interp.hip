@@ -344,7 +344,8 @@ static int jit_hmc_module(fg_engine *e) {
         for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
         if (e->prog->sub.size() + e->prog->ins_fast.size() > 64000000) return FG_E_UNSUPPORTED;
         std::vector<double> ctab;
-        const std::string src = fg_jit_hmc_source(e->prog, &ctab);
+        bool has_ad = false;
+        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
@@ -359,10 +360,13 @@ static int jit_hmc_module(fg_engine *e) {
             e->jit_log = "hipModuleLoadData / hipModuleGetFunction / table upload failed"; (void)hipGetLastError();
             return FG_E_UNSUPPORTED;
         }
-        e->jit_state = 1;
+        e->jit_state = 1; e->jit_has_ad = has_ad;
     }
     return FG_OK;
 }
+
+// does the compiled module hold the analytic gradient of this program (FG_GRAD_ANALYTIC beyond Normal force terms)?  Compiles it if need be.
+bool fg_hmc_jit_has_ad(fg_engine *e) { return jit_hmc_module(e) == FG_OK && e->jit_has_ad; }
 
 // adaptive_smc's rejuvenation move of a program without a score stream through the compiled model (k_smc_jit_rejuv, fg_hmc_jit_body.h);
 // FG_E_UNSUPPORTED: the interpreter kernel k_smc_rejuv<-1> takes it.  n_blk_out: blocks launched (rows of M.blk that k_smc_adapt adds).

@@ -36,6 +36,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     const double h = H.h;
+    const bool analytic = H.grad_mode == 2 /* FG_GRAD_ANALYTIC */;      // (the step-size search keeps the finite difference, like the stream kernels')
     for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
@@ -75,12 +76,15 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
             for (int jj = j0; jj < j1; ++jj) {
                 const int task = seg.order[jj];
                 const int k = task >> 1;
+#ifdef FG_JIT_HAS_AD       /* FG_GRAD_ANALYTIC (opt-in): the "+" task of a coordinate forms d log pi / d q_k itself, the "-" task nothing */
+                if (analytic) { if (!(task & 1)) ev_lp[task * tw] = fg_jit_dtask(k, FG_JIT_LDS(slots)); continue; }
+#endif
                 const double orig = slots[k * tw];
                 ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, FG_JIT_LDS(slots));      // hmc.rs:317-321
             }
             __syncthreads();                                  // every evaluation of this gradient done, every read of q done
             for (int k = wv; k < d; k += W) {
-                const double g = (ev_lp[2 * k * tw] - ev_lp[(2 * k + 1) * tw]) / (2.0 * h);    // hmc.rs:322
+                const double g = analytic ? ev_lp[2 * k * tw] : (ev_lp[2 * k * tw] - ev_lp[(2 * k + 1) * tw]) / (2.0 * h);    // hmc.rs:322
                 bad = bad || !fg_finite(g);
                 double p = pl[k * tw];
                 p += hk * g;                                  // hmc.rs:389 / :400

@@ -217,8 +217,122 @@ struct Gen {
         }
     }
 
+    // ---- FG_GRAD_ANALYTIC for any program (opt-in; the reference has only the finite difference): forward-mode derivative of a
+    // coordinate's sub-program with respect to that coordinate.  Every instruction carries (value, d value / d q_k): acc / dacc, tN / dtN;
+    // the coordinate's own slot has derivative 1, every other cell and constant 0; a statement adds d lp = fg_dlogpdf(...) to dtot.
+    // Values are the interpreter's operations in its order; the derivatives are the textbook rules.
+    int ad_slot = -1;                            // >= 0: emit derivative code (ins -> ins_ad)
+    std::string dslot(uint32_t idx) {
+        if ((int)idx == p.n_slots - 1) return "0.0";
+        if ((int)idx < (int)p.site_vtype.size()) return (int)idx == ad_slot ? "1.0" : "0.0";
+        temps.insert((int)idx);
+        return "dt" + std::to_string(idx);
+    }
+    std::string dopnd(uint32_t w) { return FG_OPND_KIND(w) == FG_OPND_SLOT_F ? dslot(FG_OPND_IDX(w)) : std::string("0.0"); }
+    void ins_ad(const FgIns &I) {
+        const uint32_t op = I.op, code = FG_INS_OPCODE(op);
+        if (code == FG_OP_NORMAL_FAST) {
+            const std::string dxv = dslot(I.opnd[0]), dmv = dslot(I.opnd[1]);
+            // (the constants are named whether or not the statement moves with the coordinate: rolled statements share one text and one table layout)
+            const std::string i0 = lit(I.imm[0]), i1 = lit(I.imm[1]), sg = lit(I.imm[2]), h4 = lit(I.h[4]);
+            if (dxv == "0.0" && dmv == "0.0") return;
+            const std::string z = (op & FG_F_POW2SCALE) ? "dl * " + h4 : "dl / " + sg;
+            const std::string dz = (op & FG_F_POW2SCALE) ? "(" + dxv + " - " + dmv + ") * " + h4 : "(" + dxv + " - " + dmv + ") / " + sg;
+            add("{ const double xv = " + i0 + " + " + slot(I.opnd[0]) + "; const double mv = " + i1 + " + " + slot(I.opnd[1]) + "; const double dl = xv - mv; const double z = " + z +
+                "; dtot += -z * (" + dz + "); }");
+            return;
+        }
+        if (code < 17u) {
+            const bool invalid = (op & FG_F_INVALID) != 0u;
+            const uint32_t vtype = FG_INS_VTYPE(op), xw = I.opnd[0];
+            if (code == 3u) {                                                 // Categorical: lp = ln p[x]; a constant table has no derivative
+                const uint32_t bw = I.opnd[1]; const int K = (int)I.opnd[2];
+                if (FG_OPND_KIND(bw) == FG_OPND_POOL) return;
+                const int base = (int)FG_OPND_IDX(bw);
+                std::string xi = FG_OPND_KIND(xw) == FG_OPND_SLOT_I ? "fg_as_i64(" + slot(FG_OPND_IDX(xw)) + ")"
+                                                                      : "fg_jit_int_of(" + opnd(xw, I.imm[0]) + ", " + std::to_string(vtype) + "u)";
+                if (invalid) { add("dtot = NAN;"); return; }
+                std::string dpick = "double dpv = " + dslot((uint32_t)base) + "; ";
+                for (int q = 1; q < K; ++q) dpick += "dpv = (j == " + std::to_string(q) + ") ? " + dslot((uint32_t)(base + q)) + " : dpv; ";
+                add("{ const long long xi = " + xi + "; const bool oob = xi < 0 || xi >= " + std::to_string(K) + "LL; const int j = oob ? 0 : (int)xi; " + pick(base, K, "j", "pv") + dpick +
+                    "dtot += (oob || !(pv > 0.0)) ? NAN : dpv / pv; }");
+                return;
+            }
+            const std::string p0 = opnd(I.opnd[1], I.imm[1]), p1 = opnd(I.opnd[2], I.imm[2]), p2 = opnd(I.opnd[3], I.imm[3]);
+            (void)lit(I.h[0]); (void)lit(I.h[1]); (void)lit(I.h[2]); (void)lit(I.h[3]); (void)lit(I.h[4]);     // (the value code's table layout)
+            const std::string dx = vtype == 0u ? dopnd(xw) : std::string("0.0"), d0 = dopnd(I.opnd[1]), d1 = dopnd(I.opnd[2]), d2 = dopnd(I.opnd[3]);
+            std::string xs;
+            if (vtype == 0u) xs = "const double xf = " + opnd(xw, I.imm[0]) + "; const long long xi = 0;";
+            else if (FG_OPND_KIND(xw) == FG_OPND_SLOT_I) xs = "const double xf = 0.0; const long long xi = fg_as_i64(" + slot(FG_OPND_IDX(xw)) + ");";
+            else xs = "const double xf = 0.0; const long long xi = fg_jit_int_of(" + opnd(xw, I.imm[0]) + ", " + std::to_string(vtype) + "u);";
+            if (dx == "0.0" && d0 == "0.0" && d1 == "0.0" && d2 == "0.0") return;
+            if (invalid) { add("dtot = NAN;"); return; }
+            char sig[64];
+            std::snprintf(sig, sizeof sig, "fg_jit_dlp_%u", code);
+            if (!lp_fns->count(sig)) {
+                char def[512];
+                std::snprintf(def, sizeof def,
+                              "static __device__ FG_JIT_CALL double %s(double xf, long long xi, double p0, double p1, double p2, double dx, double d0, double d1, double d2) {\n"
+                              "    return fg_dlogpdf(%uu, xf, xi, p0, p1, p2, dx, d0, d1, d2);\n}\n", sig, code);
+                (*lp_fns)[sig] = def;
+            }
+            add("{ " + xs + " dtot += " + sig + "(xf, xi, " + p0 + ", " + p1 + ", " + p2 + ", " + dx + ", " + d0 + ", " + d1 + ", " + d2 + "); }");
+            return;
+        }
+        const std::string x0 = opnd(I.opnd[0], I.imm[0]), dx0 = dopnd(I.opnd[0]);
+        switch (code) {
+        case FG_OP_FACTOR: if (dx0 != "0.0") add("dtot += " + dx0 + ";"); break;
+        case FG_OP_LOAD: add("acc = " + x0 + "; dacc = " + dx0 + ";"); break;
+        case FG_OP_ADD: add("acc = acc + " + x0 + "; dacc = dacc + " + dx0 + ";"); break;
+        case FG_OP_SUB: add("acc = acc - " + x0 + "; dacc = dacc - " + dx0 + ";"); break;
+        case FG_OP_MUL: add("{ const double a_ = acc, b_ = " + x0 + "; acc = a_ * b_; dacc = dacc * b_ + a_ * " + dx0 + "; }"); break;
+        case FG_OP_DIV: add("{ const double b_ = " + x0 + "; acc = acc / b_; dacc = (dacc - acc * " + dx0 + ") / b_; }"); break;
+        case FG_OP_RSUB: add("acc = " + x0 + " - acc; dacc = " + dx0 + " - dacc;"); break;
+        case FG_OP_RDIV: add("{ const double a_ = acc; acc = " + x0 + " / a_; dacc = (" + dx0 + " - acc * dacc) / a_; }"); break;
+        case FG_OP_NEG: add("acc = -acc; dacc = -dacc;"); break;
+        case FG_OP_EXP: add("acc = fg_jit_exp(acc); dacc = acc * dacc;"); break;
+        case FG_OP_LN: add("dacc = dacc / acc; acc = fg_jit_log(acc);"); break;
+        case FG_OP_SQRT: add("acc = sqrt(acc); dacc = dacc / (2.0 * acc);"); break;
+        case FG_OP_ABS: add("dacc = acc < 0.0 ? -dacc : dacc; acc = fabs(acc);"); break;
+        case FG_OP_FLOOR: add("acc = floor(acc); dacc = 0.0;"); break;
+        case FG_OP_SIN: add("{ const double a_ = acc; acc = fg_jit_sin(a_); dacc = fg_jit_cos(a_) * dacc; }"); break;
+        case FG_OP_COS: add("{ const double a_ = acc; acc = fg_jit_cos(a_); dacc = -fg_jit_sin(a_) * dacc; }"); break;
+        case FG_OP_TANH: add("acc = fg_jit_tanh(acc); dacc = (1.0 - acc * acc) * dacc;"); break;
+        case FG_OP_POW:                                                   // acc ^ x0
+            if (dx0 == "0.0") add("{ const double a_ = acc, b_ = " + x0 + "; acc = fg_jit_pow(a_, b_); dacc = b_ * fg_jit_pow(a_, b_ - 1.0) * dacc; }");
+            else add("{ const double a_ = acc, b_ = " + x0 + "; acc = fg_jit_pow(a_, b_); dacc = acc * (" + dx0 + " * fg_jit_log(a_) + b_ * dacc / a_); }");
+            break;
+        case FG_OP_RPOW:                                                  // x0 ^ acc
+            add("{ const double a_ = acc, b_ = " + x0 + "; acc = fg_jit_pow(b_, a_); dacc = acc * (dacc * fg_jit_log(b_) + a_ * " + dx0 + " / b_); }");
+            break;
+        case FG_OP_MIN: add("{ const double b_ = " + x0 + "; dacc = (acc <= b_) ? dacc : " + dx0 + "; acc = fmin(acc, b_); }"); break;
+        case FG_OP_MAX: add("{ const double b_ = " + x0 + "; dacc = (acc >= b_) ? dacc : " + dx0 + "; acc = fmax(acc, b_); }"); break;
+        case FG_OP_CLAMP: add("{ const double lo_ = " + x0 + ", hi_ = " + opnd(I.opnd[1], I.imm[1]) + "; dacc = acc < lo_ ? " + dx0 + " : (acc > hi_ ? " + dopnd(I.opnd[1]) + " : dacc); acc = fg_clamp(acc, lo_, hi_); }"); break;
+        case FG_OP_MAC: add("{ const double a_ = " + x0 + ", b_ = " + opnd(I.opnd[1], I.imm[1]) + "; const double t_ = a_ * b_; acc = acc + t_; dacc = dacc + (" + dx0 + " * b_ + a_ * " + dopnd(I.opnd[1]) + "); }"); break;
+        case FG_OP_STORE: { const std::string t = slot(I.aux); if (t == "0.0" || t == "pert" || t[0] == 's') { ok = false; break; } add(t + " = acc; d" + t + " = dacc;"); break; }
+        case FG_OP_GATHER: {
+            const int K = (int)I.opnd[1];
+            std::string dpick = "double dgv = " + dslot((uint32_t)I.aux) + "; ";
+            for (int q = 1; q < K; ++q) dpick += "dgv = (j == " + std::to_string(q) + ") ? " + dslot((uint32_t)((int)I.aux + q)) + " : dgv; ";
+            add("{ const bool ok_ = (acc >= 0.0) && (acc < " + lit((double)K) + ") && (acc == floor(acc)); const int j = ok_ ? (int)acc : 0; " + pick((int)I.aux, K, "j", "gv") + dpick +
+                "acc = ok_ ? gv : NAN; dacc = ok_ ? dgv : NAN; }");
+            break; }
+        case FG_OP_CONSTLIK: (void)lit(I.imm[0]); break;
+        case FG_OP_DOT: {
+            const int n = (int)I.opnd[1];
+            for (int t = 0; t < n; ++t) {
+                long long sb; std::memcpy(&sb, &p.pool[(size_t)I.aux + 2 * t], 8);
+                const std::string cf = lit(p.pool[(size_t)I.aux + 2 * t + 1]);
+                add("acc = acc + " + slot((uint32_t)sb) + " * " + cf + "; dacc = dacc + " + dslot((uint32_t)sb) + " * " + cf + ";");
+            }
+            break; }
+        default: ok = false; break;
+        }
+    }
+
     std::string acc_int;                         // acc == (double) of this integer cell (set by a LOAD of an integer slot, valid for the next instruction only)
     void ins(const FgIns &I) {
+        if (ad_slot >= 0) { ins_ad(I); return; }
         const std::string acc_int_was = acc_int;
         acc_int.clear();
         const uint32_t op = I.op, code = FG_INS_OPCODE(op);
@@ -347,7 +461,8 @@ struct Gen {
     }
     std::string decls() const {
         std::string s = "    double acc = 0.0, pr = 0.0, lk = 0.0, fc = 0.0;\n";
-        for (int t : temps) s += "    double t" + std::to_string(t) + " = 0.0;\n";
+        if (ad_slot >= 0) s += "    double dacc = 0.0, dtot = 0.0;\n";
+        for (int t : temps) s += "    double t" + std::to_string(t) + " = 0.0;\n" + (ad_slot >= 0 ? "    double dt" + std::to_string(t) + " = 0.0;\n" : std::string());
         return s;
     }
 };
@@ -459,7 +574,7 @@ static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vty
 static bool fg_jit_inlined() { const char *v = std::getenv("FG_JIT_INLINE"); return v && std::atoi(v) != 0; }
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
-std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out) {
+std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out) {
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
     std::vector<std::string> tables;
@@ -472,6 +587,25 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         if (!g.ok) return "";
         fns += "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
                "    (void)acc;\n    return pr + lk + fc;\n}\n";
+    }
+    // FG_GRAD_ANALYTIC: d/dq_k of the same sub-program (forward mode; Gen::ins_ad).  A program the derivative emission does not cover keeps
+    // the finite difference only (the engine then refuses the analytic mode for it, as before).
+    bool has_ad = true;
+    std::string dfns;
+    for (int k = 0; k < d && has_ad; ++k) {
+        Gen g{*p}; g.ad_slot = p->coord[k].slot; g.lp_fns = &lp_fns; g.tables = &tables;
+        g.ctabs = &ctabs;
+        g.emit(p->sub, (size_t)p->coord[k].sub_off, (size_t)p->coord[k].sub_off + (size_t)p->coord[k].sub_n);
+        if (!g.ok) { has_ad = false; break; }
+        dfns += "static __device__ __noinline__ double fg_jit_dsub_" + std::to_string(k) + "(const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
+                "    (void)acc; (void)pr; (void)lk; (void)fc; (void)dacc;\n    return dtot;\n}\n";
+    }
+    if (has_ad_out) *has_ad_out = has_ad;
+    if (has_ad) {
+        fns += dfns;
+        fns += "#define FG_JIT_HAS_AD 1\nstatic __device__ __forceinline__ double fg_jit_dtask(int k, const FG_LDSQ double *slots) {\n    switch (k) {\n";
+        for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_dsub_" + std::to_string(k) + "(slots);\n";
+        fns += "    default: return 0.0;\n    }\n}\n";
     }
     fns += "static __device__ __forceinline__ double fg_jit_task(int k, double pert, const FG_LDSQ double *slots) {\n    switch (k) {\n";
     for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_sub_" + std::to_string(k) + "(pert, slots);\n";
@@ -863,7 +997,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
         if (const char *out = std::getenv("FG_DEBUG_JIT_OUT")) if (rc2 == FG_OK) if (FILE *f = std::fopen(out, "wb")) { std::fwrite(code2.data(), 1, code2.size(), f); std::fclose(f); }
         return rc2;
     }
-    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr);
+    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr, nullptr);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;
     if (src.empty()) return FG_E_UNSUPPORTED;

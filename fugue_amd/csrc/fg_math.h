@@ -239,6 +239,57 @@ FG_HD double fg_logpdf(uint32_t kind, bool hoisted, bool pow2, double xf, long l
 }
 
 // ---------------------------------------------------------------------------------------
+// FG_GRAD_ANALYTIC for every distribution (north_star: "finite-difference (and where available analytic) gradients"; opt-in, never
+// the default -- the reference has only the finite difference, hmc.rs:304-329): the directional derivative of fg_logpdf,
+//     d lp = dlp/dx dx + dlp/dp0 dp0 + dlp/dp1 dp1 + dlp/dp2 dp2,
+// in the parameterisations of distribution.rs (Gamma(shape, rate), InverseGamma(shape, scale), Weibull(shape, scale), StudentT(df, loc,
+// scale), Exponential(rate)).  NaN where the density is not finite (outside the support, invalid parameters, an endpoint with infinite
+// density): the force is then non-finite and the transition diverges, as with the finite difference of a -inf log-joint.  Discrete
+// values have no dx.  fg_digamma: recurrence up to 6, then the asymptotic series (|error| < 1e-12 for x > 0).
+// ---------------------------------------------------------------------------------------
+FG_HD double fg_digamma(double x) {
+    if (!(x > 0.0) || !fg_finite(x)) return NAN;
+    double r = 0.0;
+    while (x < 6.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    // 1/12, 1/120, 1/252, 1/240, 1/132, 691/32760, 1/12
+    const double t = f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f * (1.0 / 132.0 - f * (691.0 / 32760.0 - f / 12.0))))));
+    return r + log(x) - 0.5 / x - t;
+}
+FG_HD double fg_dlogpdf(uint32_t kind, double xf, long long xi, double p0, double p1, double p2, double dx, double dp0, double dp1, double dp2) {
+    const double hh[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    const double lp = fg_logpdf(kind, false, false, xf, xi, p0, p1, p2, hh);
+    if (!fg_finite(lp)) return NAN;
+    switch (kind) {
+    case 12: { const double z = (xf - p0) / p1; return (-z / p1) * (dx - dp0) + ((z * z - 1.0) / p1) * dp1; }                 // Normal(mu, sigma)
+    case 15: { const double w = p1 - p0; return dp0 / w - dp1 / w; }                                                          // Uniform(a, b): -ln(b - a)
+    case 11: { const double lx = log(xf), z = (lx - p0) / p1;                                                                 // LogNormal(mu, sigma)
+               return (-(1.0 + z / p1) / xf) * dx + (z / p1) * dp0 + ((z * z - 1.0) / p1) * dp1; }
+    case 7: return -p0 * dx + (1.0 / p0 - xf) * dp0;                                                                          // Exponential(rate)
+    case 0: return (xi ? 1.0 / p0 : -1.0 / (1.0 - p0)) * dp0;                                                                 // Bernoulli(p)
+    case 1: { const double ps = fg_digamma(p0 + p1);                                                                          // Beta(a, b)
+              return ((p0 - 1.0) / xf - (p1 - 1.0) / (1.0 - xf)) * dx + (log(xf) - fg_digamma(p0) + ps) * dp0 + (log(1.0 - xf) - fg_digamma(p1) + ps) * dp1; }
+    case 8: return ((p0 - 1.0) / xf - p1) * dx + (log(p1) + log(xf) - fg_digamma(p0)) * dp0 + (p0 / p1 - xf) * dp1;           // Gamma(shape, rate)
+    case 2: { const double n = (double)(unsigned long long)p0, k = (double)xi; return (k / p1 - (n - k) / (1.0 - p1)) * dp1; } // Binomial(n, p)
+    case 13: return ((double)xi / p0 - 1.0) * dp0;                                                                            // Poisson(lambda)
+    case 14: { const double z = (xf - p1) / p2, q = p0 + z * z;                                                               // StudentT(df, loc, scale)
+               const double gx = -(p0 + 1.0) * z / (p2 * q);
+               const double gdf = 0.5 * fg_digamma(0.5 * (p0 + 1.0)) - 0.5 * fg_digamma(0.5 * p0) - 0.5 / p0 - 0.5 * log1p(z * z / p0) + 0.5 * (p0 + 1.0) * z * z / (p0 * q);
+               return gx * (dx - dp1) + gdf * dp0 + (((p0 + 1.0) * z * z / q - 1.0) / p2) * dp2; }
+    case 4: { const double z = (xf - p0) / p1, q = 1.0 + z * z;                                                               // Cauchy(loc, scale)
+              return (-2.0 * z / (p1 * q)) * (dx - dp0) + ((2.0 * z * z / q - 1.0) / p1) * dp1; }
+    case 10: { const double dl = xf - p0, sg = dl > 0.0 ? 1.0 : (dl < 0.0 ? -1.0 : 0.0);                                      // Laplace(loc, scale)
+               return (-sg / p1) * (dx - dp0) + ((fabs(dl) / p1 - 1.0) / p1) * dp1; }
+    case 16: { const double r = xf / p1, lr = log(r), rk = pow(r, p0);                                                        // Weibull(shape k, scale lambda)
+               return ((p0 - 1.0) / xf - p0 * rk / xf) * dx + (1.0 / p0 + lr - rk * lr) * dp0 + (p0 * (rk - 1.0) / p1) * dp1; }
+    case 5: return ((0.5 * p0 - 1.0) / xf - 0.5) * dx + (0.5 * log(xf) - 0.5 * FG_LN_2 - 0.5 * fg_digamma(0.5 * p0)) * dp0;   // ChiSquared(k)
+    case 9: return (-(p0 + 1.0) / xf + p1 / (xf * xf)) * dx + (log(p1) - fg_digamma(p0) - log(xf)) * dp0 + (p0 / p1 - 1.0 / xf) * dp1;   // InverseGamma(shape, scale)
+    case 6: return 0.0;                                                                                                       // DiscreteUniform: constant in its support
+    default: return NAN;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Philox4x32-10 stream: key = seed, counter = (chain, block, iteration, purpose).
 // Each call to fg_rng_block yields two u64 and advances `block`.
 // ---------------------------------------------------------------------------------------

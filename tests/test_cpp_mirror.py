@@ -53,3 +53,14 @@ def test_fast_log_and_sincos_are_within_one_ulp(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fast math ok" in r.stdout
+
+
+def test_log_density_derivatives_match_difference_quotients(tmp_path):
+    """fg_dlogpdf / fg_digamma (the opt-in analytic gradients of the 17 distributions) against Richardson-extrapolated central
+    differences of fg_logpdf on ~4e4 random (family, parameters, value, direction) draws inside the supports."""
+    exe = str(tmp_path / "test_dlogpdf")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_dlogpdf.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "directional derivatives" in r.stdout

@@ -164,6 +164,30 @@ def test_jit_smc_rejuvenation_is_identical_to_the_interpreter(name, monkeypatch)
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
+@pytest.mark.parametrize("name", ["alldists", "logistic", "poisson_glm", "hier_logsigma", "hier_scale", "mixture", "coin", "rand3"])
+def test_analytic_gradients_of_any_program_match_the_finite_difference(name):
+    """FG_GRAD_ANALYTIC beyond Normal force terms (north_star: "finite-difference (and where available analytic) gradients"; opt-in):
+    the forward-mode derivative of every sub-program in the unit compiled at run time (Gen::ins_ad: the 17 distributions' partial
+    derivatives -- fg_dlogpdf, checked on the host against difference quotients in tests/cpp/test_dlogpdf.cpp -- and the chain rule
+    through the expression opcodes) against the reference's central difference: the same trajectories to the finite difference's own
+    noise.  Fixed step size, a few transitions; a chain whose accept test sits on a knife edge may part ways."""
+    cp = E.compile_model(ZOO[name]())
+    C, ns = 256, 4
+    out = {}
+    for mode in (E.GRAD_FD_SPARSE, E.GRAD_ANALYTIC):
+        eng = E.Engine(cp, C, seed=23)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=5, init_step_size=0.02), ns, 0, d)
+        out[mode] = (eng.download(d, (ns, cp.d, C)), st.accept_rate, eng.hmc_last_kernel())
+        eng.device_free(d)
+        eng.close()
+    fd, an = out[E.GRAD_FD_SPARSE], out[E.GRAD_ANALYTIC]
+    assert an[2].startswith("k_hmc_jit_steps"), an[2]
+    bad = (~np.isclose(fd[0], an[0], rtol=2e-5, atol=2e-6)).any(axis=(0, 1))
+    assert bad.sum() <= 2, (name, int(bad.sum()), np.abs(fd[0] - an[0]).max())
+    assert np.isfinite(an[0]).all() and abs(fd[1] - an[1]) < 0.02 and an[1] > 0.3
+
+
 def test_jit_rolls_plates_and_scores_long_programs_directly(monkeypatch):
     """A plate of observations (statements that differ only in their constants) becomes one loop over a constant table in the
     generated code; a program with more statements than LDS has term rows runs MH with the in-order accumulators on one wave

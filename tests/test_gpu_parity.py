@@ -512,12 +512,22 @@ def test_analytic_gradient_matches_finite_difference(oracle, name):
         _close(g_an, -x + (y - x) / 0.25, 1e-13, 1e-13)
 
 
-def test_analytic_mode_is_refused_where_unavailable():
+def test_analytic_mode_is_refused_where_unavailable(monkeypatch):
+    """Force terms other than Normals with constant sigma take their analytic gradient from the unit compiled at run time (round 4,
+    tests/test_gpu_jit.py); without the run-time compiler there is none and the mode is refused -- never a silent finite difference."""
+    monkeypatch.setenv("FG_JIT", "0")
     for name in ("hier_scale", "mixture", "alldists"):
         eng = E.Engine(E.compile_model(ZOO[name]()), 64, seed=1)
         with pytest.raises(E.EngineError) as ei:
             eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_ANALYTIC), 10)
         assert ei.value.code == E.FG_E_UNSUPPORTED
+        eng.close()
+    monkeypatch.delenv("FG_JIT")
+    eng = E.Engine(E.compile_model(ZOO["hier_scale"]()), 64, seed=1)
+    eng.hmc_init(E.hmc_config(grad_mode=E.GRAD_ANALYTIC), 10)
+    eng.hmc_step(3)
+    assert eng.hmc_last_kernel().startswith("k_hmc_jit_steps")
+    eng.close()
 
 
 def test_issue_priorities_change_no_result(monkeypatch):
