@@ -229,11 +229,12 @@ static long long mwi_ins_cost(const FgIns &in) {
     }
 }
 
-// longest-processing-time split of the 2 d tasks (task 2 k + sign costs cost[k]) over W waves; returns the makespan
-static long long mwi_split(const std::vector<long long> &cost, int W, std::vector<std::vector<int>> *bins_out) {
+// longest-processing-time split of the 2 d tasks (task 2 k + sign costs cost[k]) over W waves; returns the makespan.
+// plus_only: the "-" tasks cost nothing and are left out of the bins (FG_GRAD_ANALYTIC in the compiled kernel: one task per coordinate)
+static long long mwi_split(const std::vector<long long> &cost, int W, std::vector<std::vector<int>> *bins_out, bool plus_only = false) {
     const int n_tasks = 2 * (int)cost.size();
-    std::vector<int> by(n_tasks);
-    for (int k = 0; k < n_tasks; ++k) by[k] = k;
+    std::vector<int> by;
+    for (int k = 0; k < n_tasks; ++k) if (!plus_only || !(k & 1)) by.push_back(k);
     std::stable_sort(by.begin(), by.end(), [&](int a, int b) { return cost[a >> 1] > cost[b >> 1]; });
     std::vector<std::vector<int>> bins(W);
     std::vector<long long> load(W, 0);
@@ -269,7 +270,7 @@ int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double 
     int forced = e->mw_override;
     if (const char *sp = std::getenv("FG_HMC_INTERP_WAVES")) forced = std::atoi(sp);
     if (!e->d_mwi_order) {
-        HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)n_tasks * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)2 * n_tasks * sizeof(int)));
         HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
         HIPCHK(hipMemsetAsync(e->d_mwi_prof, 0, (size_t)n_tasks * sizeof(long long), e->stream));
     }
@@ -404,7 +405,7 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         }
     }
     if (!e->d_mwi_order) {
-        HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)n_tasks * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)2 * n_tasks * sizeof(int)));      // (the second half: the split of the analytic mode)
         HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
     }
     if (e->mwi_sparse != 2 || e->mwi_W <= 0) {             // (2: the split of the compiled kernel)
@@ -433,7 +434,16 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
             std::sort(bins[w].begin(), bins[w].end());
             order.insert(order.end(), bins[w].begin(), bins[w].end());
         }
-        HIPCHK(hipMemcpyAsync(e->d_mwi_order, order.data(), (size_t)n_tasks * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        // FG_GRAD_ANALYTIC: one derivative task per coordinate, dealt over the same W waves (the step-size search keeps the split above)
+        mwi_split(e->mwi_cost, W, &bins, true);
+        e->mwi_off_an.assign(FG_MWI_MAX + 1, n_tasks + e->d);
+        order.resize(n_tasks);
+        for (int w = 0; w < W; ++w) {
+            e->mwi_off_an[w] = (int)order.size();
+            std::sort(bins[w].begin(), bins[w].end());
+            order.insert(order.end(), bins[w].begin(), bins[w].end());
+        }
+        HIPCHK(hipMemcpyAsync(e->d_mwi_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         e->mwi_W = W; e->mwi_sparse = 2;
     }
@@ -463,6 +473,7 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     FgJitSeg seg;
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
     seg.order = e->d_mwi_order;
+    if (e->cfg.grad_mode == FG_GRAD_ANALYTIC && e->jit_has_ad) for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off_an[w];
     int n_warmup = e->n_warmup;
     void *args[] = { &e->P, &e->X, &e->H, &seg, &iter0, &n, &n_warmup, &welford_on, &draws, &first_sample_t, &pos_all, &info };
     HIPCHK(hipModuleLaunchKernel(e->jit_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds_for(W), e->stream, args, nullptr));
