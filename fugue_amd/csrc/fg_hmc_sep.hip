@@ -28,7 +28,8 @@ __device__ unsigned long long fg_hmc_prof[FG_SEP_WMAX][8];
 #else
 #define FG_PROF_T(i)
 #endif
-struct FgSegSep { int c[FG_SEP_WMAX + 1]; int sum4; };   // sum4: the four in-order sums of a transition's end on four waves (tiles that are alone on their CU)
+struct FgSegSep { int c[FG_SEP_WMAX + 1]; int sum4;       // sum4: the four in-order sums of a transition's end on four waves (tiles that are alone on their CU)
+                  int own[FG_SEP_WMAX][4], n_own[FG_SEP_WMAX]; };   // MODE 3 (dense, coordinates in registers): each wave's <= 4 coordinates (whole Box-Muller pairs), ascending
 #ifndef FG_SEP_STAGGER
 #define FG_SEP_STAGGER 2          /* x 4 096 cycles: the late start of a CU's second tile (k_hmc_sep_steps) */
 #endif
@@ -168,6 +169,126 @@ __device__ __noinline__ FgD3 fg_sep_trajectory_checked(RB rb, double q, double p
     return r;
 }
 
+// ---- MODE 3: the dense mode with a wave's coordinates in registers ------------------------------------------------------------
+// The two whole log-joints of coordinate i differ from the plain in-order sum of the rows only behind i's own row, and the rows a wave
+// adds for its <= 4 coordinates are the same rows: every row is read ONCE per wave and added to the running prefix (the sum all
+// coordinates still share) and to the two sums of every coordinate whose own row lies behind -- the additions of two full scoring
+// runs per coordinate (hmc.rs:304-329), each sum in program order, one LDS read per up to nine additions instead of one per two.
+// K: coordinates already behind their own row; PSON: the shared prefix still runs.
+template <int K, bool PSON>
+__device__ __forceinline__ void fg_dense_add_rows(const double *p, int cnt, int tw, double &PS, double (&ap)[4], double (&am)[4]) {
+#define FG_DENSE_BLOCK(R) { double y[R];                                                        \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) y[q] = p[q * tw];                         \
+        _Pragma("unroll") for (int q = 0; q < R; ++q) { if (PSON) PS += y[q];                   \
+            _Pragma("unroll") for (int jj = 0; jj < K; ++jj) { ap[jj] += y[q]; am[jj] += y[q]; } } \
+        p += (long long)R * tw; }
+    for (; cnt >= 8; cnt -= 8) FG_DENSE_BLOCK(8)
+    if (cnt & 4) FG_DENSE_BLOCK(4)
+    if (cnt & 2) FG_DENSE_BLOCK(2)
+    if (cnt & 1) FG_DENSE_BLOCK(1)
+#undef FG_DENSE_BLOCK
+}
+// one section (rows [lo, hi): log_prior or log_likelihood) for NC coordinates with own rows r[0] < r[1] < ... and own terms tp / tm
+// at q + h / q - h: ap[j] / am[j] = the section's in-order sum with row r[j] replaced
+template <int NC>
+__device__ __forceinline__ void fg_dense_section(const double *T, int tw, int lo, int hi, const int (&r)[4], const double (&tp)[4], const double (&tm)[4],
+                                                 double (&ap)[4], double (&am)[4]) {
+    double PS = 0.0;
+    int pos = lo;
+#define FG_DENSE_STEP(J) if (NC > J) {                                                          \
+        fg_dense_add_rows<J, true>(T + (long long)pos * tw, r[J] - pos, tw, PS, ap, am);       \
+        const double x = T[(long long)r[J] * tw];                                               \
+        ap[J] = PS + tp[J]; am[J] = PS + tm[J];                                                 \
+        _Pragma("unroll") for (int jj = 0; jj < J; ++jj) { ap[jj] += x; am[jj] += x; }          \
+        if (NC > J + 1) PS += x;                                                                \
+        pos = r[J] + 1; }
+    FG_DENSE_STEP(0) FG_DENSE_STEP(1) FG_DENSE_STEP(2) FG_DENSE_STEP(3)
+#undef FG_DENSE_STEP
+    fg_dense_add_rows<NC, false>(T + (long long)pos * tw, hi - pos, tw, PS, ap, am);
+}
+
+// The whole trajectory of a wave's NC coordinates (L + 1 gradients, hmc.rs:353-407) with q, p and the statements' constants in
+// registers.  Per gradient: the own statements' terms at q into this gradient's term rows (two row sets take turns: ONE barrier per
+// gradient), barrier, the sums above, kick and drift.  OBS: every coordinate has one observation.  All sigmas are powers of two
+// (host check): (x - mu) / sigma is the exact product with 1 / sigma.  Returns "a force component was non-finite".
+template <int NC, bool OBS, bool MASS>
+__device__ __forceinline__ bool fg_dense_trajectory(const FgProgramDev &P, const FgChainCtx &X, const FgHmcDev &H, const int (&own)[4], double *T0, double *T1,
+                                                    double *kin0, double *kin1, int tw, int n_pri, int n_s, int L, double e, double h, double two_h,
+                                                    double rcp_2h, uint32_t sk0, uint32_t sk1, uint32_t gchain, uint32_t iter, long long c, bool live) {
+    int ci[4] = {0, 0, 0, 0}, rP[4] = {0, 0, 0, 0}, rO[4] = {0, 0, 0, 0};
+    double q[4], p[4], k0v[4], mii[4], cP[4], sP[4], lP[4], cO[4], sO[4], lO[4];
+    const double hk = 0.5 * e;
+    // p0 ~ N(0, M), hmc.rs:436-441: the list holds one or two whole Box-Muller pairs (Philox blocks), in row order
+    const int blk_a = own[0] >> 1;
+    int blk_b = blk_a;
+#pragma unroll
+    for (int j = 1; j < NC; ++j) if ((own[j] >> 1) != blk_a) blk_b = own[j] >> 1;
+    const FgD2 za = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)blk_a, iter, FG_RNG_HMC);
+    FgD2 zb2 = za;
+    if (NC > 2) zb2 = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)blk_b, iter, FG_RNG_HMC);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        ci[j] = own[j];
+        const FgSepCoord cd = P.sep_coord[ci[j]];
+        const FG_AS4 char *rb = (const FG_AS4 char *)(uintptr_t)(P.sep + cd.off);
+        { FG_SEP_LOAD(0) rP[j] = (int)a0[1]; cP[j] = fg_dbl(a0[2], a0[3]); sP[j] = fg_dbl(a0[4], a0[5]); lP[j] = fg_dbl(a0[6], a0[7]); (void)b0; }
+        if (OBS) { FG_SEP_LOAD(1) rO[j] = (int)a1[1]; cO[j] = fg_dbl(a1[2], a1[3]); sO[j] = fg_dbl(a1[4], a1[5]); lO[j] = fg_dbl(a1[6], a1[7]); (void)b1; }
+        const bool in_a = (ci[j] >> 1) == blk_a, second = (ci[j] & 1) != 0;
+        const double z = in_a ? (second ? za.b : za.a) : (second ? zb2.b : zb2.a);
+        mii[j] = MASS ? H.m_inv[(long long)ci[j] * X.C + c] : 1.0;
+        p[j] = MASS ? z * H.mass_sqrt[(long long)ci[j] * X.C + c] : z;
+        k0v[j] = MASS ? p[j] * p[j] * mii[j] : p[j] * p[j];          // hmc.rs:442-443
+        q[j] = fg_as_double(X.values[(long long)P.f64_site[ci[j]] * X.C + c]);
+    }
+    bool bad = false;
+    for (int gs = 0; gs <= L; ++gs) {
+        double *T = ((L - gs) & 1) ? T1 : T0;                        // the last gradient's rows (T0) are the endpoint's score terms
+        double tpP[4], tmP[4], tpO[4], tmO[4];
+#define FG_DENSE_LP(x_, c_, s_, l_, out) { const double z_ = ((x_) - (c_)) * (s_); const double lp_ = -0.5 * z_ * z_ - (l_) - 0.5 * FG_LN_2PI; \
+                                           out = lp_; if (__builtin_expect(__any(z_ != z_), 0)) out = (z_ != z_) ? FG_NEG_INF : lp_; }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const double qp = q[j] + h, qm = q[j] - h;               // the perturbed coordinate holds orig +- h (hmc.rs:317-319)
+            double t0; FG_DENSE_LP(q[j], cP[j], sP[j], lP[j], t0) T[(long long)rP[j] * tw] = t0;
+            FG_DENSE_LP(qp, cP[j], sP[j], lP[j], tpP[j]) FG_DENSE_LP(qm, cP[j], sP[j], lP[j], tmP[j])
+            if (OBS) {
+                double t1; FG_DENSE_LP(q[j], cO[j], sO[j], lO[j], t1) T[(long long)rO[j] * tw] = t1;
+                FG_DENSE_LP(qp, cO[j], sO[j], lO[j], tpO[j]) FG_DENSE_LP(qm, cO[j], sO[j], lO[j], tmO[j])
+            }
+        }
+#undef FG_DENSE_LP
+        __syncthreads();                                             // every statement's term at q is in T (the other row set is free again)
+        double Pp[4], Pm[4], Lp[4], Lm[4];
+        fg_dense_section<NC>(T, tw, 0, n_pri, rP, tpP, tmP, Pp, Pm);
+        if (OBS) fg_dense_section<NC>(T, tw, n_pri, n_s, rO, tpO, tmO, Lp, Lm);
+        else {
+            double LS = 0.0;
+            fg_dense_add_rows<0, true>(T + (long long)n_pri * tw, n_s - n_pri, tw, LS, Lp, Lm);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) { Lp[j] = LS; Lm[j] = LS; }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const double n = (Pp[j] + Lp[j] + 0.0) - (Pm[j] + Lm[j] + 0.0);   // total_log_weight at q + h e_i minus at q - h e_i (log_factors = 0)
+            double g = fg_div_const(n, two_h, rcp_2h);                  // hmc.rs:322
+            const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
+            if (__builtin_expect(__any(!((ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;
+            bad = bad || !fg_finite(g);
+            double pj = p[j] + hk * g;                                   // hmc.rs:389 / :400
+            if (gs > 0 && gs < L) pj = pj + hk * g;                      // trailing kick of this step + leading kick of the next
+            p[j] = pj;
+            if (gs < L) q[j] = q[j] + (MASS ? e * mii[j] : e) * pj;     // hmc.rs:391-393
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {                                       // the proposal row; the kinetic terms of p0 and p (the idle row set)
+        if (live) H.p0_scratch[(long long)ci[j] * X.C + c] = q[j];
+        kin0[(long long)ci[j] * tw] = k0v[j];
+        kin1[(long long)ci[j] * tw] = MASS ? p[j] * p[j] * mii[j] : p[j] * p[j];
+    }
+    return bad;
+}
+
 // DENSE = grad_log_joint verbatim (FG_GRAD_FD_DENSE, hmc.rs:304-329): g_i is the difference of two WHOLE log-joints.  Of their
 // S + O terms only the coordinate's own change with the sign of the perturbation, but every term takes part in the two in-order
 // sums.  So per gradient every wave first leaves the terms of its statements at the current q in LDS rows (double-buffered:
@@ -188,7 +309,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
                                                                              double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
     constexpr int tw = FG_WAVE >> HALF;
-    constexpr bool DENSE = MODE == 1, AN = MODE == 2;
+    constexpr bool DFAST = MODE == 3, DENSE = MODE == 1 || DFAST, AN = MODE == 2;   // (3: DENSE with the coordinates in registers, fg_dense_trajectory)
     static_assert(!HALF || MODE == 0, "half tiles: sparse finite difference only");
     const int lane = threadIdx.x & (tw - 1);                       // chain of the tile
     const int half = HALF == 1 ? (int)((threadIdx.x >> 5) & 1u) : (HALF == 2 ? (int)((threadIdx.x >> 4) & 3u) : 0);   // which of the wave's 2 / 4 coordinates this lane runs
@@ -213,7 +334,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
     // 4.3e9 / 2.2e9 leapfrog-steps/s).
     double *terms = lds + (long long)(srows + (DENSE ? 0 : 2 * d)) * tw + lane;
     double *xch = terms + (long long)n_s * tw;                      // rows: 0 step size, 1 accepted, 2 divergence bits, (sparse) 3 .. 6 three of the sums and the accept uniform
-    double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only
+    double *qrow = xch + 3 * tw, *prow = qrow + (long long)d * tw;  // DENSE only (MODE 3: the second set of term rows, which takes the kinetic terms at a trajectory's end)
     double *kin0 = DENSE ? qrow : lds + (long long)srows * tw + lane;
     double *kin1 = DENSE ? prow : kin0 + (long long)d * tw;
     const int k0 = seg.c[wv], k1 = seg.c[wv + 1];
@@ -274,7 +395,14 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         double zb = 0.0;
         FgD2 zzh = {0.0, 0.0}; bool zh_next = false;                 // half tiles: the pair a lane half generated, and whether the upper half's is the next pair
         const double *termsE = terms;                                // rows of the endpoint's score terms
-        if (DENSE) {
+        if (DFAST) {
+            const int own[4] = { seg.own[wv][0], seg.own[wv][1], seg.own[wv][2], seg.own[wv][3] };
+#define FG_DENSE_CALL(NC_, OBS_) fg_dense_trajectory<NC_, OBS_, MASS>(P, X, H, own, terms, qrow, kin0, kin1, tw, n_pri, n_s, L, e, h, two_h, rcp_2h, sk0, sk1, gchain, (uint32_t)iter, c, live)
+            const int nown = seg.n_own[wv];
+            if (n_s > n_pri) { if (nown == 4) bad = FG_DENSE_CALL(4, true); else if (nown == 3) bad = FG_DENSE_CALL(3, true); else if (nown == 2) bad = FG_DENSE_CALL(2, true); else bad = FG_DENSE_CALL(1, true); }
+            else { if (nown == 4) bad = FG_DENSE_CALL(4, false); else if (nown == 3) bad = FG_DENSE_CALL(3, false); else if (nown == 2) bad = FG_DENSE_CALL(2, false); else bad = FG_DENSE_CALL(1, false); }
+#undef FG_DENSE_CALL
+        } else if (DENSE) {
             for (int i = k0; i < k1; ++i) {                          // p0 ~ N(0, M), its kinetic term, the start position
                 double z;
                 if (!(i & 1)) { const FgD2 zz = fg_cold_normal_pair(sk0, sk1, gchain, (uint32_t)(i >> 1), (uint32_t)iter, FG_RNG_HMC); z = zz.a; zb = zz.b; }
@@ -498,7 +626,8 @@ __global__ __launch_bounds__(FG_WAVE * FG_SEP_WMAX, 4) void k_hmc_sep_steps(FgPr
         const bool acc = xch[tw] != 0.0;
         unsigned long long wn = 0;
         if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
-        for (int i0 = k0; i0 < k1; i0 += 1 << HALF) {             // commit or roll back the own f64 sites
+        for (int jo = 0; jo < (DFAST ? seg.n_own[wv] : k1 - k0); jo += 1 << HALF) {   // commit or roll back the own f64 sites
+            const int i0 = DFAST ? seg.own[wv][jo] : k0 + jo;
             const bool on = !HALF || i0 + half < d;
             const int i = HALF ? (on ? i0 + half : i0) : i0;
             const long long g = (long long)P.f64_site[i] * X.C + c;
@@ -556,8 +685,18 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     }
     const int tw = FG_WAVE >> half;
     const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
+    // dense with the coordinates in registers (fg_dense_trajectory): every coordinate one Normal prior with or without ONE observation,
+    // all sigmas powers of two, no statement that reads no coordinate
+    bool dfast = dense && e->P.n_sep_free == 0 && e->d >= 1;
+    if (dfast) {
+        const std::vector<FgSepCoord> &cd = e->prog->sep_coord;
+        for (const FgSepCoord &q : cd) dfast = dfast && (q.n & 256) && (q.n & 7) == (cd[0].n & 7) && ((q.n & 7) == 1 || (q.n & 7) == 2);
+        if (const char *dv = std::getenv("FG_HMC_DENSE_FAST")) dfast = dfast && std::atoi(dv) != 0;
+    }
     const size_t rows = (size_t)(e->P.n_sep_free > 0 ? e->n_slots : 0) + 2 * (size_t)e->d + (size_t)e->P.n_sstream + 3 +
                         (dense ? 8 : 4 + 8);     // (dense: the kinetic terms end the tile -- the in-order sums read whole chunks of eight rows; sparse: 4 exchange rows + the chunk a sum may read past them)
+    // (the register-resident dense form has two sets of n_s term rows, the second of which also takes the 2 d kinetic terms: with n_s = d
+    // or 2 d that is the 2 d + n_s rows of the row-resident form)
     const size_t lds = rows * tw * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile: aim at 4 waves per SIMD (16 per CU); the LDS tile caps the tiles resident on a CU, few tiles (small
@@ -572,6 +711,33 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     }
     while (W > 1 && unit * (W - 1) >= e->d + 1) W /= 2;          // no empty waves
     FgSegSep seg;
+    std::memset(&seg, 0, sizeof(seg));
+    if (dfast) {
+        // Whole Box-Muller pairs, at most two per wave.  A coordinate whose own row is r adds 2 (rows - r) terms behind it: the pairs go
+        // out by row, to the waves and back (0 .. W-1, W-1 .. 0), so every wave adds about the same number; within a wave by row.
+        const int np = (e->d + 1) / 2, W_plain = W;
+        W = std::min(std::max(W, (np + 1) / 2), np);
+        if (W > FG_SEP_WMAX) dfast = false;
+        else {
+            const std::vector<FgSepCoord> &cd = e->prog->sep_coord;
+            auto row_of = [&](int i, int k) { return (int)e->prog->sep[(size_t)cd[i].off + k].trow; };
+            std::vector<int> pr(np);
+            for (int q = 0; q < np; ++q) pr[q] = q;
+            std::stable_sort(pr.begin(), pr.end(), [&](int a, int b) { return row_of(2 * a, 0) < row_of(2 * b, 0); });
+            for (int q = 0; q < np; ++q) {
+                const int w = q < W ? q : 2 * W - 1 - q;
+                for (int i = 2 * pr[q]; i < std::min(e->d, 2 * pr[q] + 2); ++i) seg.own[w][seg.n_own[w]++] = i;
+            }
+            const bool obs = (cd[0].n & 7) == 2;
+            for (int w = 0; w < W && dfast; ++w) {
+                std::sort(seg.own[w], seg.own[w] + seg.n_own[w], [&](int a, int b) { return row_of(a, 0) < row_of(b, 0); });
+                for (int j = 0; j + 1 < seg.n_own[w]; ++j)
+                    if (row_of(seg.own[w][j], 0) >= row_of(seg.own[w][j + 1], 0) || (obs && row_of(seg.own[w][j], 1) >= row_of(seg.own[w][j + 1], 1))) dfast = false;
+                if (seg.n_own[w] < 1) dfast = false;
+            }
+        }
+        if (!dfast) { std::memset(&seg, 0, sizeof(seg)); W = W_plain; }       // (rows out of order within a wave, or more than 32 pairs: the row-resident form)
+    }
     seg.sum4 = (!dense && half != 0) ? 1 : 0;                    // a tile alone on its CU: the transition's four end sums on four waves
     if (const char *sv = std::getenv("FG_HMC_SUM4")) seg.sum4 = std::atoi(sv) != 0 ? 1 : 0;
     for (int w = 0; w <= FG_SEP_WMAX; ++w) seg.c[w] = e->d;
@@ -579,12 +745,13 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     if (W == 8 && !half && !(std::getenv("FG_HMC_PRIO") && std::atoi(std::getenv("FG_HMC_PRIO")) == 0)) seg.c[FG_SEP_WMAX] = -1;   // priority turns: two waves of a tile per SIMD
     if (half == 1 && (long long)tiles > n_cu && (long long)tiles <= 2 * n_cu) seg.c[FG_SEP_WMAX] = -3;                                  // two half tiles on a CU: the odd ones start late (+5 %; 64-chain tiles lose 5 % to it)
     if (const char *sg = std::getenv("FG_HMC_STAGGER")) { const int v = std::atoi(sg); seg.c[FG_SEP_WMAX] = (v == 1 || v == 2) ? -1 - v : (seg.c[FG_SEP_WMAX] <= -2 ? e->d : seg.c[FG_SEP_WMAX]); }   // experiments
-    static bool attr_set_dev[64][10];
-    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = half ? 4 + 2 * half + mass : 2 * mode + mass;
-    const void *fns[10] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
+    static bool attr_set_dev[64][12];
+    const int mass = e->H.use_mass ? 1 : 0, mode = dense ? 1 : (analytic ? 2 : 0), variant = dfast ? 10 + mass : (half ? 4 + 2 * half + mass : 2 * mode + mass);
+    const void *fns[12] = { (const void *)k_hmc_sep_steps<false, 0>, (const void *)k_hmc_sep_steps<true, 0>, (const void *)k_hmc_sep_steps<false, 1>,
                            (const void *)k_hmc_sep_steps<true, 1>, (const void *)k_hmc_sep_steps<false, 2>, (const void *)k_hmc_sep_steps<true, 2>,
                            (const void *)k_hmc_sep_steps<false, 0, 1>, (const void *)k_hmc_sep_steps<true, 0, 1>,
-                           (const void *)k_hmc_sep_steps<false, 0, 2>, (const void *)k_hmc_sep_steps<true, 0, 2> };
+                           (const void *)k_hmc_sep_steps<false, 0, 2>, (const void *)k_hmc_sep_steps<true, 0, 2>,
+                           (const void *)k_hmc_sep_steps<false, 3>, (const void *)k_hmc_sep_steps<true, 3> };
     bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set) {
         const hipError_t he = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -597,11 +764,12 @@ int fg_hmc_sep_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
         case 0: FG_SEP_LAUNCH(false, 0); break; case 1: FG_SEP_LAUNCH(true, 0); break; case 2: FG_SEP_LAUNCH(false, 1); break;
         case 3: FG_SEP_LAUNCH(true, 1); break;  case 4: FG_SEP_LAUNCH(false, 2); break; case 5: FG_SEP_LAUNCH(true, 2); break;
         case 6: FG_SEP_LAUNCH(false, 0, 1); break; case 7: FG_SEP_LAUNCH(true, 0, 1); break;
-        case 8: FG_SEP_LAUNCH(false, 0, 2); break; default: FG_SEP_LAUNCH(true, 0, 2); break;
+        case 8: FG_SEP_LAUNCH(false, 0, 2); break; case 9: FG_SEP_LAUNCH(true, 0, 2); break;
+        case 10: FG_SEP_LAUNCH(false, 3); break; default: FG_SEP_LAUNCH(true, 3); break;
     }
 #undef FG_SEP_LAUNCH
     HIPCHK(hipGetLastError());
-    e->last_hmc_kernel = std::string(dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : (half == 2 ? "k_hmc_sep_steps (quarter tiles) W=" : (half ? "k_hmc_sep_steps (half tiles) W=" : "k_hmc_sep_steps W=")))) + std::to_string(W);
+    e->last_hmc_kernel = std::string(dfast ? "k_hmc_sep_steps (dense, coordinates in registers) W=" : dense ? "k_hmc_sep_steps (dense) W=" : (analytic ? "k_hmc_sep_steps (analytic) W=" : (half == 2 ? "k_hmc_sep_steps (quarter tiles) W=" : (half ? "k_hmc_sep_steps (half tiles) W=" : "k_hmc_sep_steps W=")))) + std::to_string(W);
     return FG_OK;
 }
 

@@ -402,10 +402,14 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
     layouts = [(0, 1, 0), (1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0)]
     if mode == E.GRAD_FD_SPARSE and name in ("normal32", "indep_uniform5"):
         layouts += [(1, 1, 1), (1, 2, 1), (1, 4, 1), (1, 16, 1), (1, 1, 2), (1, 2, 2), (1, 8, 2)]      # 2: quarter tiles (16 chains, four coordinates per wave)
-    for sep, W, half in layouts:
+    layouts = [lay + (1,) for lay in layouts]
+    if mode == E.GRAD_FD_DENSE:               # the dense mode's two forms: coordinates in LDS rows (any program) and in registers (one shape of record, powers of two)
+        layouts += [(1, W, 0, 0) for W in (1, 4, 8, 16)]
+    for sep, W, half, dense_regs in layouts:
         monkeypatch.setenv("FG_HMC_SEP", str(sep))
         monkeypatch.setenv("FG_HMC_WAVES", str(W))
         monkeypatch.setenv("FG_HMC_SEP_HALF", str(half))
+        monkeypatch.setenv("FG_HMC_DENSE_FAST", str(dense_regs))
         eng = E.Engine(cp, C, seed=21, chain_offset=5)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(grad_mode=mode, n_leapfrog=7, adapt_mass=adapt_mass), ns, nw, d)
@@ -414,6 +418,8 @@ def test_hmc_sep_kernel_is_bit_identical(name, adapt_mass, mode, monkeypatch):
         pos, info = eng.hmc_step_info(3)
         assert ("half tiles" in eng.hmc_last_kernel()) == (half == 1) and ("quarter tiles" in eng.hmc_last_kernel()) == (half == 2)
         assert ("k_hmc_sep_steps" in eng.hmc_last_kernel()) == bool(sep)
+        if name == "normal32":
+            assert ("coordinates in registers" in eng.hmc_last_kernel()) == bool(sep and mode == E.GRAD_FD_DENSE and dense_regs)
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
                     eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
         eng.close()
