@@ -73,6 +73,9 @@ struct FgSmcScalars {      // device-resident scalars of one SMC run
     int n_cand, iters, first;
     unsigned int ticket;
     double dbeta;          // bnew - beta of the reweight in flight (k_smc_finish phase 3 advances beta itself; k_smc_apply uses this)
+    double fin_max;        // max of the log-weights the last reweight left (k_smc_ess2_apply -> k_smc_final_norm)
+    int need_sum, pad2;    // k_smc_ess2_apply: beta' is no candidate of the passes -- the separate reduction kernels take the step
+    double beta2[2];       // beta as the passes and k_smc_ess2_apply read / write it: two slots that swap from step to step
 };
 // rejuvenation: tempered_single_site_mh (smc.rs:631-688), one move per particle
 struct FgSmcDev {

@@ -806,6 +806,7 @@ void fg_engine_free(fg_engine *e) {
     for (void *q : e->mh_allocs) hipFree(q);
     if (e->d_rec) hipFree(e->d_rec);
     if (e->smc_arena) hipFree(e->smc_arena);
+    if (e->smc_host) (void)hipHostFree(e->smc_host);
     if (e->jit_mod) (void)hipModuleUnload(e->jit_mod);
     if (e->jit_mh_mod) (void)hipModuleUnload(e->jit_mh_mod);
     if (e->jit_mhmw_mod) (void)hipModuleUnload(e->jit_mhmw_mod);

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(ESS_THREADS) void k_smc_ess_pass_uniform(const doub
 // partials.  Bracket state and partials are double-buffered by pass parity; block 0 records the new bracket.  The decisions are
 // fg_ess_decide's: the same comparisons `ESS(mid) < target` on the reference's midpoints 0.5 (lo + hi) (smc.rs:612-619), three
 // levels per pass; pass 0 also evaluates b = 1 (smc.rs:604-607) and reduces the block maxima of ll itself.
-struct FgEssBracket { double lo, hi, bnew; int iters, done, first, pad; };
+struct FgEssBracket { double lo, hi, bnew; int iters, done, first, pad;
+                      double s1_hi, s1_one; };   // sum_i exp((b - beta)(ll_i - max ll)) at b = hi and at b = 1: the reweight's log-sum-exp needs no pass of its own (k_smc_ess2_apply)
 // Sum over the 64 lanes of a wave by DPP moves (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15 / 31 across the
 // rows): the total lands in lane 63.  No LDS round trip per step -- __shfl_down on a double is two ds_bpermute_b32 and a wait, and
 // the sixteen sums of a pass spent 4-5 us in them (tools/prof_smc_phases.sh) -- and a fixed tree: the same bits wherever it runs.
@@ -423,12 +424,13 @@ __device__ __forceinline__ int fg_ess_candidates(const FgEssBracket &B, double *
     return c0 + nn;
 }
 // the bracket after a pass whose candidates had effective sample sizes ess_c (fg_ess_decide as a pure function)
-__device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double *ess_c, double beta, double target) {
+__device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double *ess_c, const double *s1_c, double beta, double target) {
     double cand[ESS_MAXC];
     const int nc = fg_ess_candidates(B, cand);
     int c0 = 0;
     if (B.first) {                                                 // candidate 0 of the first pass is b = 1: smc.rs:604-607
         B.first = 0; c0 = 1;
+        B.s1_one = s1_c[0]; B.s1_hi = s1_c[0];                     // hi = 1 until a midpoint replaces it
         if (ess_c[0] >= target) { B.done = 1; B.bnew = 1.0; return B; }
     }
     const int ntree = nc - c0;
@@ -436,7 +438,7 @@ __device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double
     double lo = B.lo, hi = B.hi;
     while (node < ntree && B.iters + depth < 64) {                 // smc.rs:612-619, one level = one iteration
         const double mid = cand[c0 + node];
-        if (ess_c[c0 + node] < target) { hi = mid; node = 2 * node + 1; } else { lo = mid; node = 2 * node + 2; }
+        if (ess_c[c0 + node] < target) { hi = mid; B.s1_hi = s1_c[c0 + node]; node = 2 * node + 1; } else { lo = mid; node = 2 * node + 2; }
         ++depth;
     }
     // a pass that leaves the bracket where it found it has reached the fixed point of the bisection (lo and hi are adjacent doubles or
@@ -449,7 +451,7 @@ __device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double
 }
 // every candidate's ESS from the block partials of the previous pass: thread t takes blocks t, t + T, ...; lanes, then waves, in
 // index order -- the same tree, hence the same bits, in every block
-__device__ __forceinline__ void fg_ess_collect(const double *part /*[nb][ESS_MAXC][2]*/, int nb, int nc, long long n, bool allneg, double (*shl)[ESS_MAXC][2], double *ess_c) {
+__device__ __forceinline__ void fg_ess_collect(const double *part /*[nb][ESS_MAXC][2]*/, int nb, int nc, long long n, bool allneg, double (*shl)[ESS_MAXC][2], double *ess_c, double *s1_c) {
     double a[ESS_MAXC], b[ESS_MAXC];
 #pragma unroll
     for (int q = 0; q < ESS_MAXC; ++q) { a[q] = 0.0; b[q] = 0.0; }
@@ -474,6 +476,7 @@ __device__ __forceinline__ void fg_ess_collect(const double *part /*[nb][ESS_MAX
         for (int k = 1; k < nwv; ++k) { ta += shl[k][q][0]; tb += shl[k][q][1]; }
         const double e = ta * ta / tb;
         ess_c[q] = (allneg || !(ta > 0.0) || !isfinite(e)) ? (double)n : e;                       // smc.rs:598-601
+        s1_c[q] = ta;
     }
     __syncthreads();
 }
@@ -487,9 +490,9 @@ __device__ long long fg_smc_prof[64][2][8];
 #define FG_SMC_T(i)
 #endif
 __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll, long long n, int pass, const double *beta_ptr, double target, const double *part_max, int n_pmax,
-                                                                FgEssBracket *brk, double *part, double *lmax) {
+                                                                FgEssBracket *brk, double *part, double *lmax, int *host_done) {
     __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
-    __shared__ double ess_c[ESS_MAXC];
+    __shared__ double ess_c[ESS_MAXC], s1_c[ESS_MAXC];
     __shared__ FgEssBracket shB;
     __shared__ double shm[ESS2_THREADS / 64];
     FG_SMC_T(0)
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
         for (int k = threadIdx.x; k < n_pmax; k += blockDim.x) m = fmax(m, part_max[k]);
         L = block_reduce_max(m, shm);
         if (blockIdx.x == 0 && threadIdx.x == 0) lmax[0] = L;
-        B.lo = beta; B.hi = 1.0; B.bnew = 1.0; B.iters = 0; B.done = 0; B.first = 1; B.pad = 0;
+        B.lo = beta; B.hi = 1.0; B.bnew = 1.0; B.iters = 0; B.done = 0; B.first = 1; B.pad = 0; B.s1_hi = 0.0; B.s1_one = 0.0;
     } else {
         L = lmax[0];
         const FgEssBracket P = brk[(pass - 1) & 1];                 // what pass - 1 started from
@@ -511,15 +514,15 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
             double cand[ESS_MAXC];
             const int ncp = fg_ess_candidates(P, cand);
             FG_SMC_T(1)
-            fg_ess_collect(part + (size_t)((pass - 1) & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c);
+            fg_ess_collect(part + (size_t)((pass - 1) & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c, s1_c);
             FG_SMC_T(2)
-            if (threadIdx.x == 0) shB = fg_ess_step(P, ess_c, beta, target);
+            if (threadIdx.x == 0) shB = fg_ess_step(P, ess_c, s1_c, beta, target);
             __syncthreads();
             B = shB;
         }
     }
     FG_SMC_T(3)
-    if (blockIdx.x == 0 && threadIdx.x == 0) brk[pass & 1] = B;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { brk[pass & 1] = B; if (host_done) *host_done = B.done; }   // (host_done: pinned host memory -- the host looks once, after pass 1)
     if (B.done) return;
     // the candidates' sums over this block's particles (the two-exp form of k_smc_ess_pass_uniform)
     const int first = B.first;
@@ -586,14 +589,14 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, in
                                                                  const double *lmax, FgSmcScalars *st, double lw0, double *part_max, int n_pmax) {
     __shared__ double sh_bnew;
     __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
-    __shared__ double ess_c[ESS_MAXC];
+    __shared__ double ess_c[ESS_MAXC], s1_c[ESS_MAXC];
     const double beta = *beta_ptr, L = lmax[0];
     FgEssBracket P = brk[last_pass & 1];
     if (!P.done) {
         double cand[ESS_MAXC];
         const int ncp = fg_ess_candidates(P, cand);
-        fg_ess_collect(part + (size_t)(last_pass & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c);
-        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, beta, target);
+        fg_ess_collect(part + (size_t)(last_pass & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c, s1_c);
+        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, s1_c, beta, target);
     }
     if (threadIdx.x == 0) {
         if (!P.done) P.bnew = fmin(fmax(P.hi, beta + 1e-9), 1.0);    // (not reached: 22 passes cover 64 iterations)
@@ -605,6 +608,105 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, in
     __syncthreads();
     const double vmax = lw0 + (sh_bnew - beta) * L;                  // smc_v at the particle with the largest ll
     for (int k = threadIdx.x; k < n_pmax; k += blockDim.x) part_max[k] = vmax;
+}
+// What follows the last pass in ONE launch (adaptive_smc: the log-weights are uniform, lw0 = -ln N, at every step's start):
+// every block folds the last pass's decision in (fg_ess_collect / fg_ess_step: the same tree, the same bits in every block) -> beta';
+// the reweight's log-normaliser log_sum_exp(lw0 + (beta' - beta) ll) (smc.rs:512-518) is max + ln(sum) with max = lw0 + (beta' - beta)
+// max ll (rounding is monotone) and sum = sum_i exp((beta' - beta)(ll_i - max ll)) -- the sum the pass that evaluated b = beta' already
+// formed for ESS(b) and the bracket carries (s1_hi, s1_one); then lw <- v - log_norm, w <- exp(lw) (smc.rs:520-528) over the scan's
+// chunks with the chunk totals of the resampling prefix sum (k_scan_chunk_sums' additions), and on the ladder's last step the sums
+// of the final normalisation, exp(lw - max lw) (smc.rs:565-575).  Block 0 publishes the scalars -- also to pinned host memory: the host's
+// look at beta needs no copy.  (A ticket that lets the LAST block publish costs a device-scope release per block: 89 us for 512 blocks.)  beta' = beta + 1e-9 (a bracket narrower
+// than the guaranteed progress, smc.rs:621) is no candidate of any pass: need_sum is set and the host runs the separate kernels.
+struct FgSmcHostScalars { double beta, log_evidence; int need_sum, pass1_done; };
+__global__ __launch_bounds__(SCAN_THREADS) void k_smc_ess2_apply(const double *ll, long long n, int last_pass, int nb, double target, const FgEssBracket *brk, const double *part,
+                                                                  const double *lmax, FgSmcScalars *st, const double *beta_in, double *beta_out, double lw0, double *lw, double *w,
+                                                                  double *chunk_sum, double *chunk_sum2, FgSmcHostScalars *hs) {
+    __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
+    __shared__ double ess_c[ESS_MAXC], s1_c[ESS_MAXC];
+    __shared__ double sh_sc[6];
+    __shared__ double shr[SCAN_THREADS / 64];
+    const double beta = *beta_in, L = lmax[0];
+    const bool allneg = isinf(L) && L < 0.0;
+    FgEssBracket P = brk[last_pass & 1];
+    if (!P.done) {
+        double cand[ESS_MAXC];
+        const int ncp = fg_ess_candidates(P, cand);
+        fg_ess_collect(part + (size_t)(last_pass & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, allneg, shl, ess_c, s1_c);
+        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, s1_c, beta, target);
+    }
+    if (threadIdx.x == 0) {
+        if (!P.done) P.bnew = fmin(fmax(P.hi, beta + 1e-9), 1.0);    // (not reached: 22 passes cover 64 iterations)
+        const double bnew = st->force_one ? 1.0 : P.bnew;            // smc.rs:504-506: the step cap forces beta = 1
+        double s1 = 0.0; int need = 0;
+        if (bnew == 1.0) s1 = P.s1_one; else if (bnew == P.hi) s1 = P.s1_hi; else need = 1;
+        const double dbeta = bnew - beta;
+        const double vmax = lw0 + dbeta * L;                         // smc_v at the particle with the largest ll
+        const double lse1 = (allneg || s1 == 0.0) ? -INFINITY : vmax + log(s1);       // numerical.rs:33-37
+        sh_sc[0] = bnew; sh_sc[1] = dbeta; sh_sc[2] = lse1; sh_sc[3] = need ? 1.0 : 0.0;
+        sh_sc[4] = isfinite(lse1) ? vmax - lse1 : -log((double)n);   // max of the new log-weights (the same two operations as the particle's own)
+    }
+    __syncthreads();
+    const double bnew = sh_sc[0], dbeta = sh_sc[1], log_norm = sh_sc[2], mfin = sh_sc[4];
+    const bool need_sum = sh_sc[3] != 0.0, fin = isfinite(log_norm), last_step = bnew >= 1.0;
+    const long long n_chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    // Per particle the arithmetic is elementwise: global loads and stores run over consecutive addresses (thread t takes elements t,
+    // t + 256, ... of the chunk).  The chunk total keeps k_scan_chunk_sums' order -- thread t adds ITS eight consecutive weights, then the
+    // block tree -- through a copy of the weights in LDS (the prefix sum that follows forms the same partial sums).
+    __shared__ double shw[SCAN_CHUNK + SCAN_CHUNK / 8];            // (padded: row t of eight starts at 9 t)
+    if (!need_sum)
+        for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+            const long long base = ch * SCAN_CHUNK;
+            double s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) {
+                const int o = k * SCAN_THREADS + (int)threadIdx.x;
+                const long long i = base + o;
+                double wi = 0.0;
+                if (i < n) {
+                    const double v = lw0 + dbeta * ll[i];
+                    const double nl = fin ? v - log_norm : -log((double)n);
+                    wi = exp(nl);
+                    lw[i] = nl; w[i] = wi;
+                    if (last_step) s2 += exp(nl - mfin);
+                }
+                shw[o + (o >> 3)] = wi;
+            }
+            __syncthreads();
+            double sw = 0.0;
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; ++k) if (base + (long long)threadIdx.x * SCAN_ITEMS + k < n) sw += shw[9 * (int)threadIdx.x + k];
+            sw = block_reduce_sum(sw, shr);
+            if (last_step) s2 = block_reduce_sum(s2, shr);
+            if (threadIdx.x == 0) { chunk_sum[ch] = sw; if (last_step) chunk_sum2[ch] = s2; }
+        }
+    // block 0 publishes: no block of this launch reads what it writes (beta comes in through beta_in, the new one goes to beta_out --
+    // the host swaps the two slots from step to step -- and to st->beta for the rejuvenation sweeps)
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    st->bnew = bnew; st->done = 1; st->lo = P.lo; st->hi = P.hi; st->iters = P.iters;
+    st->need_sum = need_sum ? 1 : 0;
+    if (!need_sum) {
+        st->lse1 = log_norm; st->log_norm = log_norm; st->log_evidence += log_norm;     // smc.rs:517-518, :529
+        st->dbeta = dbeta; st->beta = bnew; *beta_out = bnew; st->fin_max = mfin;
+    }
+    if (hs) { hs->beta = need_sum ? beta : bnew; hs->log_evidence = st->log_evidence; hs->need_sum = need_sum ? 1 : 0; __threadfence_system(); }
+}
+// the final normalisation (smc.rs:565-575) behind k_smc_ess2_apply's last step: lse = max + ln(sum exp(lw - max)) from the chunk sums
+// (a fixed tree: the same bits in every block), lw <- lw - lse, w <- exp(lw); uniform if lse is not finite
+__global__ __launch_bounds__(SCAN_THREADS) void k_smc_final_norm(double *lw, double *w, long long n, const double *chunk_sum2, FgSmcScalars *st) {
+    __shared__ double shr[SCAN_THREADS / 64];
+    const int n_chunks = (int)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n_chunks; k += blockDim.x) s += chunk_sum2[k];
+    s = block_reduce_sum(s, shr);
+    const double m = st->fin_max;
+    const bool empty = isinf(m) && m < 0.0;
+    const double lse = (empty || s == 0.0) ? -INFINITY : m + log(s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->lse1 = lse;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (isfinite(lse)) { const double nz = lw[i] - lse; lw[i] = nz; w[i] = exp(nz); }
+        else { lw[i] = -log((double)n); w[i] = 1.0 / (double)n; }
+    }
 }
 __global__ __launch_bounds__(RED_THREADS) void k_smc_max_finish(const double *part_max, int nb, double *out) {   // max of the block maxima
     __shared__ double sh[RED_THREADS / 64];
@@ -654,6 +756,25 @@ __global__ void k_smc_split_acc(const double *acc, double *lprior, double *ll, l
     if (i >= n) return;
     lprior[i] = acc[i];
     ll[i] = acc[n + i] + acc[2 * n + i];
+}
+// the same, and the block maxima of ll for next_beta's first pass (k_smc_red_max's fold: fmax from -inf)
+__global__ __launch_bounds__(RED_THREADS) void k_smc_split_acc_max(const double *acc, double *lprior, double *ll, long long n, double *part_max) {
+    __shared__ double sh[RED_THREADS / 64];
+    double m = -INFINITY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        lprior[i] = acc[i];
+        const double v = acc[n + i] + acc[2 * n + i];
+        ll[i] = v;
+        m = fmax(m, v);
+    }
+    m = block_reduce_max(m, sh);
+    if (threadIdx.x == 0) part_max[blockIdx.x] = m;
+}
+// the run's scalars and DiminishingAdaptation::new for every site (scale 1, log-scale 0, no counts): mcmc_utils.rs:60-75
+__global__ void k_smc_init(FgSmcScalars *st, FgSmcScalars h, FgSmcDev M, long long Sn) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *st = h;
+    if (j < Sn) { M.scale[j] = 1.0; M.log_scale[j] = 0.0; M.acc[j] = 0; M.tot[j] = 0; }
 }
 __global__ void k_smc_is_weights(double *lw, const double *ll, long long n) {    // pure importance sampling  smc.rs:490
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -706,6 +827,55 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_cumsum(const double *w, l
     const double off = chunk_off[blockIdx.x] + (threadIdx.x ? sh[threadIdx.x - 1] : 0.0);
     for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) cum[base + k] = off + loc[k];
 }
+// k_scan_chunk_offsets and k_scan_cumsum in one launch: every block repeats the scan of the chunk totals (the same additions in the same
+// order: a few hundred per block) and keeps its own chunk's offset
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_cumsum_off(const double *w, long long n, const double *chunk_sum, int n_chunks, double *cum) {
+    __shared__ double sh[SCAN_THREADS];
+    __shared__ double sh_off;
+    const int per = (n_chunks + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int k0 = threadIdx.x * per, k1 = k0 + per < n_chunks ? k0 + per : n_chunks;
+    double tot = 0.0;
+    for (int k = k0; k < k1; ++k) tot += chunk_sum[k];
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = 1; o < SCAN_THREADS; o <<= 1) {             // Hillis-Steele inclusive scan of the thread totals (fixed order)
+        const double t = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    {
+        double run = threadIdx.x ? sh[threadIdx.x - 1] : 0.0;
+        for (int k = k0; k < k1; ++k) { if (k == (int)blockIdx.x) sh_off = run; run += chunk_sum[k]; }
+    }
+    __syncthreads();
+    const double chunk_off = sh_off;
+    __syncthreads();
+    // the chunk's weights through LDS: global loads and stores over consecutive addresses, thread t's eight consecutive items from row t
+    __shared__ double shw[SCAN_CHUNK + SCAN_CHUNK / 8];            // (padded: row t of eight starts at 9 t)
+    const long long cbase = (long long)blockIdx.x * SCAN_CHUNK;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const int o = k * SCAN_THREADS + (int)threadIdx.x; shw[o + (o >> 3)] = (cbase + o < n) ? w[cbase + o] : 0.0; }
+    __syncthreads();
+    double loc[SCAN_ITEMS];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { s += shw[9 * (int)threadIdx.x + k]; loc[k] = s; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_THREADS; o <<= 1) {             // Hillis-Steele inclusive scan of the thread totals
+        const double t = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0.0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    const double off = chunk_off + (threadIdx.x ? sh[threadIdx.x - 1] : 0.0);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) shw[9 * (int)threadIdx.x + k] = off + loc[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { const int o = k * SCAN_THREADS + (int)threadIdx.x; if (cbase + o < n) cum[cbase + o] = shw[o + (o >> 3)]; }
+}
 // idx_j = first k with cum[k] >= thr_j, else n-1: where `while cum < thr && i < n` stops (smc.rs:263-270)
 __global__ void k_resample_search(const double *cum, long long n, int method, double U, const double *u_arr,
                                   unsigned long long seed, uint32_t step, long long *idx) {
@@ -723,14 +893,39 @@ __global__ void k_resample_search(const double *cum, long long n, int method, do
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if (cum[mid] >= thr) hi = mid; else lo = mid + 1; }
     idx[j] = lo < n ? lo : n - 1;
 }
+// The same index in two levels: the first chunk of the prefix sum whose LAST element reaches the threshold (the chunk ends in LDS: nine
+// steps at LDS latency instead of nine round trips to L2), then the first such element inside that chunk (cum is non-decreasing: the
+// same k).  20.7 -> us per 1 048 576 outputs.
+__global__ __launch_bounds__(256) void k_resample_search2(const double *cum, long long n, int n_chunks, int method, double U, const double *u_arr,
+                                                          unsigned long long seed, uint32_t step, long long *idx) {
+    extern __shared__ double ends[];
+    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) { const long long e = (long long)(c + 1) * SCAN_CHUNK; ends[c] = cum[(e < n ? e : n) - 1]; }
+    __syncthreads();
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double thr;
+    if (method == 1) thr = U / (double)n + (double)j / (double)n;                        // systematic  smc.rs:258,264
+    else {
+        double u;
+        if (u_arr) u = u_arr[j];
+        else { FgStream s = fg_stream(seed, (uint32_t)j, step, FG_RNG_SMC_RESAMPLE); u = fg_rng_u01(s); }
+        thr = (method == 2) ? ((double)j + u) / (double)n : u;                             // stratified :284 / multinomial :300
+    }
+    int cl = 0, ch = n_chunks;                                 // first chunk whose end >= thr
+    while (cl < ch) { const int mid = (cl + ch) >> 1; if (ends[mid] >= thr) ch = mid; else cl = mid + 1; }
+    if (cl >= n_chunks) { idx[j] = n - 1; return; }
+    long long lo = (long long)cl * SCAN_CHUNK, hi = lo + SCAN_CHUNK < n ? lo + SCAN_CHUNK : n;
+    hi -= 1;                                                   // cum[hi] >= thr is known: the answer lies in [lo, hi]
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (cum[mid] >= thr) hi = mid; else lo = mid + 1; }
+    idx[j] = lo;
+}
 __global__ void k_smc_gather(const long long *src, long long *dst, const double *ll_src, double *ll_dst, const double *lp_src,
                              double *lp_dst, const long long *idx, int S, long long n) {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const long long a = idx[j];
     for (int s = 0; s < S; ++s) dst[(long long)s * n + j] = src[(long long)s * n + a];   // particles[i].clone()  smc.rs:537
-    ll_dst[j] = ll_src[a];
-    lp_dst[j] = lp_src[a];
+    if (ll_dst) { ll_dst[j] = ll_src[a]; lp_dst[j] = lp_src[a]; }   // (null: a rejuvenation sweep follows, which scores every particle again)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -743,11 +938,15 @@ __global__ void k_smc_gather(const long long *src, long long *dst, const double 
 // GT: a program whose tile exceeds a CU's LDS (or has more sites than the block histogram) -- one wave per block, the tile in the
 // engine's global scratch (fg_engine.hip), the block's counts added straight into its row of M.blk.  adaptive_smc has
 // no size limit in the reference (smc.rs:455-581, 631-713).
+// vsrc: the resampled population (k_smc_gather's buffer) when this is the first sweep behind a resampling step -- the sweep reads it and
+// leaves every site in X.values: the copy back costs no launch.  pmax: the block's maximum of the new log-likelihoods (next_beta's first
+// pass reads the block maxima: no reduction launch either); null on all sweeps but a step's last.
 template <int SCORE, bool GT = false>
 __global__ __launch_bounds__(GT ? FG_WAVE : FG_SMC_WPB(SCORE) * FG_WAVE, (GT || SCORE == 2) ? 1 : (SCORE < 0 ? FG_MIN_WAVES : 4)) void k_smc_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st,
-                                                                                                              uint32_t move_id) {
+                                                                                                              uint32_t move_id, const long long *vsrc, double *pmax) {
     extern __shared__ double lds_[];
     __shared__ unsigned int hist[2][GT ? 1 : FG_SMC_HIST];          // the block's proposal / accept counts per site
+    __shared__ double shmax[GT ? 1 : FG_SMC_WPB(SCORE)];
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
     unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
@@ -758,7 +957,8 @@ __global__ __launch_bounds__(GT ? FG_WAVE : FG_SMC_WPB(SCORE) * FG_WAVE, (GT || 
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = (GT ? X.gtile + (size_t)blockIdx.x * X.gtile_rows * FG_WAVE : lds_ + (long long)wv * P.n_slots * tw) + lane;   // one tile per wave
-    fg_load_values(P, X, c, slots, tw);
+    if (vsrc) { FgChainCtx Xs = X; Xs.values = const_cast<long long *>(vsrc); fg_load_values(P, Xs, c, slots, tw); }
+    else fg_load_values(P, X, c, slots, tw);
     const double beta = st->beta;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     FgStream rng = fg_stream(X.seed, gchain, move_id, FG_RNG_SMC_REJUV);
@@ -781,10 +981,18 @@ __global__ __launch_bounds__(GT ? FG_WAVE : FG_SMC_WPB(SCORE) * FG_WAVE, (GT || 
     const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
     const double u = fg_cold_u01_pair(sk0, sk1, gchain, 2u, move_id, FG_RNG_SMC_REJUV).a;     // block 2
     const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));                  // smc.rs:680
+    const double ll_new = accept ? lik[1] : lik[0];
     if (live) {
+        if (vsrc) for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = vsrc[(long long)j * X.C + c];
         if (accept) X.values[(long long)site * X.C + c] = fg_as_i64(prop);
         M.lprior[c] = accept ? pri[1] : pri[0];               // the freshly scored trace is returned either way
-        M.ll[c] = accept ? lik[1] : lik[0];
+        M.ll[c] = ll_new;
+    }
+    if (pmax) {                                               // block maximum of ll (fmax from -inf like k_smc_red_max; max is exact in any order)
+        double m = live ? ll_new : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+        if (GT) { if (lane == 0) pmax[blockIdx.x] = m; }
+        else if (lane == 0) shmax[wv] = m;
     }
     // per-sweep proposal / accept counts: one LDS add per distinct site in the wave, one row of counts per block in HBM
     // (k_smc_adapt adds the rows) -- a one-site model would otherwise send a million global atomics to one address
@@ -804,6 +1012,7 @@ __global__ __launch_bounds__(GT ? FG_WAVE : FG_SMC_WPB(SCORE) * FG_WAVE, (GT || 
     if (GT) return;
     __syncthreads();
     for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
+    if (pmax && threadIdx.x == 0) { double m = shmax[0]; for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, shmax[k]); pmax[blockIdx.x] = m; }
 }
 // The reference's OWN rejuvenation order (fg_smc_config.sequential_adaptation; smc.rs:482,544-553,698-713): particle-major, and ONE
 // DiminishingAdaptation that every move of every particle updates before the next one reads its scale -- a recurrence through all
@@ -937,6 +1146,14 @@ __global__ void k_copy_f64(double *dst, const double *src, long long n) {
 // ======================================================================================
 namespace {
 
+// The host's looks at a running ladder (pass 1's bracket, beta after a reweight) wait for a few microseconds of queued work: polling the
+// stream returns as soon as it drains, where hipStreamSynchronize may put the thread to sleep first (10 - 20 us per look, four per run).
+static hipError_t smc_wait(hipStream_t s) {
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipErrorNotReady) return q;
+    }
+}
 struct Reducer {     // scratch for the two-pass reductions
     double *part_max = nullptr, *part_sum = nullptr, *ess_part = nullptr;
     double *ess2 = nullptr;      // k_smc_ess2_pass: part[2][ESS2_BLOCKS][ESS_MAXC][2] | lmax[2] | FgEssBracket brk[2]
@@ -958,7 +1175,7 @@ struct Reducer {     // scratch for the two-pass reductions
         int last = 0;
         const int n_pass = 22;                               // pass 0: b = 1 and levels 1-3; passes 1..20: three levels each; pass 21: the 64th
         for (int pass = 0; pass < n_pass; ++pass) {
-            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, RED_BLOCKS, brk, part, lmax);
+            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, RED_BLOCKS, brk, part, lmax, (int *)nullptr);
             last = pass;
             if (pass == 1) {
                 FgEssBracket hb;
@@ -969,6 +1186,24 @@ struct Reducer {     // scratch for the two-pass reductions
         }
         hipLaunchKernelGGL(k_smc_ess2_final, dim3(1), dim3(ESS2_THREADS), 0, s, n, last, nb, beta_ptr, target, brk, (const double *)part, (const double *)lmax, st, lw0, part_max, RED_BLOCKS);
         HIPCHK(hipGetLastError());
+        return FG_OK;
+    }
+    // the passes alone: part_max[0 .. n_pmax) holds block maxima of ll (their producer's: k_smc_split_acc_max or the step's last
+    // rejuvenation sweep); what follows them is k_smc_ess2_apply.  The host looks at pass 1's bracket through pinned memory.
+    int ess2_passes(hipStream_t s, const double *ll, long long n, const double *beta_ptr, double target, int n_pmax, FgSmcHostScalars *hs_host,
+                    FgSmcHostScalars *hs_dev, int *last_out, int *nb_out) {
+        double *part = ess2, *lmax = ess2 + (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2;
+        FgEssBracket *brk = (FgEssBracket *)(lmax + 2);
+        const int nb = (int)std::min<long long>(ESS2_BLOCKS, (n + ESS2_THREADS - 1) / ESS2_THREADS);
+        int last = 0;
+        for (int pass = 0; pass < 22; ++pass) {
+            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, n_pmax, brk, part, lmax,
+                               pass == 1 ? &hs_dev->pass1_done : (int *)nullptr);
+            last = pass;
+            if (pass == 1) { HIPCHK(smc_wait(s)); if (hs_host->pass1_done) break; }
+        }
+        HIPCHK(hipGetLastError());
+        *last_out = last; *nb_out = nb;
         return FG_OK;
     }
     // the reweight's log-sum-exp right after next_beta_uniform: its maximum is already in part_max
@@ -1020,6 +1255,12 @@ struct Scanner {     // scratch for the prefix sum
         return FG_OK;
     }
     void free_all() { if (!external) { if (chunk) (void)hipFree(chunk); if (cum) (void)hipFree(cum); } chunk = cum = nullptr; cap = 0; }
+    void search(hipStream_t s, long long n, int method, double U, const double *d_u, unsigned long long seed, uint32_t step, long long *d_idx) {
+        const long long nc = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        if (nc <= 4096)        // (the chunk ends fit a block's LDS)
+            hipLaunchKernelGGL(k_resample_search2, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)nc * 8, s, (const double *)cum, n, (int)nc, method, U, d_u, seed, step, d_idx);
+        else hipLaunchKernelGGL(k_resample_search, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double *)cum, n, method, U, d_u, seed, step, d_idx);
+    }
     int indices(hipStream_t s, const double *w, long long n, int method, double U, const double *d_u, unsigned long long seed,
                 uint32_t step, long long *d_idx) {
         int rc = ensure(n);
@@ -1028,8 +1269,7 @@ struct Scanner {     // scratch for the prefix sum
         hipLaunchKernelGGL(k_scan_chunk_sums, dim3(nc), dim3(SCAN_THREADS), 0, s, w, n, chunk);
         hipLaunchKernelGGL(k_scan_chunk_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, chunk, nc);
         hipLaunchKernelGGL(k_scan_cumsum, dim3(nc), dim3(SCAN_THREADS), 0, s, w, n, (const double *)chunk, cum);
-        hipLaunchKernelGGL(k_resample_search, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double *)cum, n, method, U, d_u, seed,
-                           step, d_idx);
+        search(s, n, method, U, d_u, seed, step, d_idx);
         HIPCHK(hipGetLastError());
         return FG_OK;
     }
@@ -1040,7 +1280,7 @@ struct Scanner {     // scratch for the prefix sum
 // per run cost more than a run).  fg_smc_run and the standalone entry points share it.
 struct SmcWs {
     FgSmcDev M{}; FgSmcScalars *st = nullptr; Reducer R; Scanner SC;
-    double *d_lw = nullptr, *d_w = nullptr, *d_ll2 = nullptr, *d_lp2 = nullptr, *d_red = nullptr;
+    double *d_lw = nullptr, *d_w = nullptr, *d_ll2 = nullptr, *d_lp2 = nullptr, *d_red = nullptr, *d_chunk2 = nullptr;
     long long *d_vals2 = nullptr, *d_idx = nullptr;
     size_t o_ls = 0, o_st = 0;
     char *base = nullptr;
@@ -1055,9 +1295,9 @@ int smc_workspace(fg_engine *e, SmcWs &W) {
     auto carve = [&](size_t bytes) { const size_t o = arena_off; arena_off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_ll = carve(N * 8), o_lp = carve(N * 8), o_scale = carve(Sn * 8), o_ls = carve(Sn * 8), o_acc = carve(Sn * 8), o_tot = carve(Sn * 8),
                  o_st = carve(sizeof(FgSmcScalars)), o_lw = carve(N * 8), o_w = carve(N * 8), o_ll2 = carve(N * 8), o_lp2 = carve(N * 8), o_vals2 = carve(Sn * N * 8),
-                 o_idx = carve(N * 8), o_pmax = carve(RED_BLOCKS * 8), o_psum = carve(2 * RED_BLOCKS * 8), o_ess = carve(((size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) * 8),
+                 o_idx = carve(N * 8), o_pmax = carve(std::max<size_t>(RED_BLOCKS, max_blk) * 8), o_psum = carve(2 * RED_BLOCKS * 8), o_ess = carve(((size_t)ESS_BLOCKS * ESS_MAXC * 3 + 8) * 8),
                  o_ess2 = carve(Reducer::ess2_doubles() * 8),
-                 o_chunk = carve((size_t)n_chunks * 8), o_cum = carve(N * 8), o_blk = carve(max_blk * 2 * Sn * 4), o_red = carve(64);
+                 o_chunk = carve((size_t)n_chunks * 8), o_chunk2 = carve((size_t)n_chunks * 8), o_cum = carve(N * 8), o_blk = carve(max_blk * 2 * Sn * 4), o_red = carve(64);
     if (e->smc_arena_bytes < arena_off) {
         if (e->smc_arena) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipFree(e->smc_arena)); e->smc_arena = nullptr; e->smc_arena_bytes = 0; }
         HIPCHK(hipMalloc(&e->smc_arena, arena_off));
@@ -1074,6 +1314,7 @@ int smc_workspace(fg_engine *e, SmcWs &W) {
     W.d_lw = (double *)(ar + o_lw); W.d_w = (double *)(ar + o_w); W.d_ll2 = (double *)(ar + o_ll2); W.d_lp2 = (double *)(ar + o_lp2);
     W.d_vals2 = (long long *)(ar + o_vals2); W.d_idx = (long long *)(ar + o_idx); W.d_red = (double *)(ar + o_red);
     W.R.part_max = (double *)(ar + o_pmax); W.R.part_sum = (double *)(ar + o_psum); W.R.ess_part = (double *)(ar + o_ess); W.R.ess2 = (double *)(ar + o_ess2);
+    W.d_chunk2 = (double *)(ar + o_chunk2);
     W.SC.chunk = (double *)(ar + o_chunk); W.SC.cum = (double *)(ar + o_cum); W.SC.cap = N; W.SC.external = true;
     return FG_OK;
 }
@@ -1171,54 +1412,92 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
     FgSmcScalars *st = WS.st;
     double *d_lw = WS.d_lw, *d_w = WS.d_w, *d_ll2 = WS.d_ll2, *d_lp2 = WS.d_lp2;
     long long *d_vals2 = WS.d_vals2, *d_idx = WS.d_idx;
-    char *ar = WS.base; const size_t o_ls = WS.o_ls, o_st = WS.o_st;
-    HIPCHK(hipMemsetAsync(ar + o_ls, 0, o_st - o_ls, s));                   // log_scale, acc, tot start at zero (DiminishingAdaptation::new)
     int rc = FG_OK;
 #define SMC_TRY(x) do { rc = (x); if (rc) { cleanup(); SC.free_all(); return rc; } } while (0)
 #define SMC_HIP(x) do { if ((x) != hipSuccess) { fg_set_error(#x); cleanup(); SC.free_all(); return FG_E_HIP; } } while (0)
+    if (!e->smc_host) SMC_HIP(hipHostMalloc(&e->smc_host, sizeof(FgSmcHostScalars), hipHostMallocMapped));
+    FgSmcHostScalars *hs = (FgSmcHostScalars *)e->smc_host, *hs_dev = nullptr;
+    SMC_HIP(hipHostGetDevicePointer((void **)&hs_dev, hs, 0));
+    std::memset(hs, 0, sizeof(*hs));
     FgSmcScalars h; std::memset(&h, 0, sizeof(h));
     h.one = 1.0; h.beta = 0.0;
     h.target_ess = std::min(std::max(cfg->ess_threshold * (double)N, 1.0), (double)N);     // smc.rs:481
-    SMC_HIP(hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((Sn + TB - 1) / TB)), dim3(TB), 0, s, M.scale, (long long)Sn, 1.0);
+    // the run's scalars, and scale = 1, log_scale = 0, acc = tot = 0 (DiminishingAdaptation::new): one launch
+    hipLaunchKernelGGL(k_smc_init, dim3((unsigned)((Sn + TB - 1) / TB)), dim3(TB), 0, s, st, h, M, (long long)Sn);
     // smc_prior_particles (smc.rs:764-790)
     SMC_TRY(fg_launch_prior(e, 0, FG_RNG_SMC_PRIOR, e->d_acc, nullptr));
-    hipLaunchKernelGGL(k_smc_split_acc, dim3(NB), dim3(TB), 0, s, (const double *)e->d_acc, M.lprior, M.ll, N);
-    hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, -std::log((double)N));                  // smc.rs:476
+    const double lw0 = -std::log((double)N);                                // log_w = -ln N at every step's start (smc.rs:476,538-540)
     long long n_runs = N;
     int n_steps = 0;
+    bool fin_ready = false;                                  // the last reweight left the sums of the final normalisation (k_smc_ess2_apply)
+    double log_evidence = 0.0; bool have_evidence = false, evidence_late = false;   // (late: the pinned copy is read behind the final synchronisation)
     std::vector<double> betas;
     if (cfg->rejuvenation_steps == 0) {                      // single importance-sampling reweight: smc.rs:484-493
+        hipLaunchKernelGGL(k_smc_split_acc, dim3(NB), dim3(TB), 0, s, (const double *)e->d_acc, M.lprior, M.ll, N);
         hipLaunchKernelGGL(k_smc_is_weights, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, N);
         SMC_TRY(R.run(s, d_lw, nullptr, N, st, (const double *)&st->one, 3));      // log_evidence = lse(combined)
         betas.push_back(1.0); n_steps = 1;
     } else {
+        // particle_log_likelihood (smc.rs:381-383) and the block maxima of ll for the first pass of next_beta
+        hipLaunchKernelGGL(k_smc_split_acc_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, (const double *)e->d_acc, M.lprior, M.ll, N, R.part_max);
+        int n_pmax = RED_BLOCKS;
+        const int n_chunks = (int)((N + SCAN_CHUNK - 1) / SCAN_CHUNK);
+        double *lmax = R.ess2 + (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2;
+        FgEssBracket *brk = (FgEssBracket *)(lmax + 2);
         double beta = 0.0;
         int steps = 0;
         while (beta < 1.0) {                                 // smc.rs:501-560
             steps += 1;
             // next_beta: ESS at b = 1, then 64 bisections on the device (smc.rs:588-622)
             if (steps >= 10000) { int one = 1; SMC_HIP(hipMemcpyAsync(&st->force_one, &one, sizeof(int), hipMemcpyHostToDevice, s)); }
-            SMC_TRY(R.next_beta_uniform(s, M.ll, N, st, (const double *)&st->beta, h.target_ess, -std::log((double)N)));      // log_w = -ln N at every step's start (smc.rs:476,538-540)
-            // reweight + evidence (smc.rs:512-529)
-            SMC_TRY(R.run_sum_only(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
-            hipLaunchKernelGGL(k_smc_apply, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, d_w, N, (const FgSmcScalars *)st);
-            SMC_HIP(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
-            SMC_HIP(hipStreamSynchronize(s));
-            beta = h.beta;
+            int last = 0, nb = 0;
+            const double *beta_in = &st->beta2[steps & 1]; double *beta_out = &st->beta2[(steps + 1) & 1];   // (both start at 0: k_smc_init)
+            SMC_TRY(R.ess2_passes(s, M.ll, N, beta_in, h.target_ess, n_pmax, hs, hs_dev, &last, &nb));
+            // the last decision, reweight + evidence (smc.rs:512-529), weights and the chunk totals of the resampling prefix sum: one launch
+            hipLaunchKernelGGL(k_smc_ess2_apply, dim3((unsigned)n_chunks), dim3(SCAN_THREADS), 0, s, (const double *)M.ll, N, last, nb, h.target_ess,
+                               (const FgEssBracket *)brk, (const double *)R.ess2, (const double *)lmax, st, beta_in, beta_out, lw0, d_lw, d_w, SC.chunk, WS.d_chunk2, hs_dev);
+            SMC_HIP(hipGetLastError());
+            // ESS(1) >= target (pass 1 said so): beta' = 1 ends the ladder -- nothing to look at before the final normalisation is queued
+            const bool ends = hs->pass1_done != 0 && steps < 10000;
+            if (!ends) SMC_HIP(smc_wait(s));
+            const bool fused = ends || hs->need_sum == 0;
+            if (ends) { beta = 1.0; have_evidence = true; evidence_late = true; fin_ready = true; }
+            else if (fused) { beta = hs->beta; log_evidence = hs->log_evidence; have_evidence = true; fin_ready = beta >= 1.0; }
+            else {                                           // beta' = beta + 1e-9: the separate kernels (maximum, sum, finish, apply)
+                hipLaunchKernelGGL(k_smc_ess2_final, dim3(1), dim3(ESS2_THREADS), 0, s, N, last, nb, (const double *)&st->beta, h.target_ess, brk, (const double *)R.ess2,
+                                   (const double *)lmax, st, lw0, R.part_max, RED_BLOCKS);
+                hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, lw0);
+                SMC_TRY(R.run_sum_only(s, d_lw, M.ll, N, st, (const double *)&st->bnew, 3));
+                hipLaunchKernelGGL(k_smc_apply, dim3(NB), dim3(TB), 0, s, d_lw, (const double *)M.ll, d_w, N, (const FgSmcScalars *)st);
+                SMC_HIP(hipMemcpyAsync(beta_out, &st->beta, sizeof(double), hipMemcpyDeviceToDevice, s));
+                SMC_HIP(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
+                SMC_HIP(hipStreamSynchronize(s));
+                beta = h.beta; have_evidence = false; fin_ready = false;
+            }
             betas.push_back(beta); n_steps++;
             if (beta < 1.0) {                                // resample + rejuvenate (smc.rs:534-559)
                 double U = 0.0;
                 if (cfg->resampling_method == FG_RESAMPLE_SYSTEMATIC) { FgStream rs = fg_stream(e->seed, 0, (uint32_t)steps, FG_RNG_SMC_RESAMPLE); U = fg_rng_u01(rs); }
-                SMC_TRY(SC.indices(s, d_w, N, cfg->resampling_method, U, nullptr, e->seed, (uint32_t)steps, d_idx));
-                hipLaunchKernelGGL(k_smc_gather, dim3(NB), dim3(TB), 0, s, (const long long *)e->d_values, d_vals2, (const double *)M.ll, d_ll2,
-                                   (const double *)M.lprior, d_lp2, (const long long *)d_idx, S, N);
-                SMC_HIP(hipMemcpyAsync(e->d_values, d_vals2, (size_t)S * N * 8, hipMemcpyDeviceToDevice, s));
-                SMC_HIP(hipMemcpyAsync(M.ll, d_ll2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-                SMC_HIP(hipMemcpyAsync(M.lprior, d_lp2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-                hipLaunchKernelGGL(k_fill, dim3(NB), dim3(TB), 0, s, d_lw, N, -std::log((double)N));
+                if (fused) {                                 // the chunk totals are there: offsets + prefix sum in one launch, then the search
+                    hipLaunchKernelGGL(k_scan_cumsum_off, dim3((unsigned)n_chunks), dim3(SCAN_THREADS), 0, s, (const double *)d_w, N, (const double *)SC.chunk, n_chunks, SC.cum);
+                    SC.search(s, N, cfg->resampling_method, U, nullptr, (unsigned long long)e->seed, (uint32_t)steps, d_idx);
+                } else SMC_TRY(SC.indices(s, d_w, N, cfg->resampling_method, U, nullptr, e->seed, (uint32_t)steps, d_idx));
+                const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
+                // a batched sweep of a score-stream program reads the resampled population where k_smc_gather left it and writes every site
+                // back (no copy), scores every particle again (ll / log-prior need no gather) and leaves the block maxima of ll
+                const bool sweep_io = e->d > 0 && score >= 0 && !cfg->sequential_adaptation;
+                if (sweep_io)
+                    hipLaunchKernelGGL(k_smc_gather, dim3(NB), dim3(TB), 0, s, (const long long *)e->d_values, d_vals2, (const double *)nullptr, (double *)nullptr,
+                                       (const double *)nullptr, (double *)nullptr, (const long long *)d_idx, S, N);
+                else {
+                    hipLaunchKernelGGL(k_smc_gather, dim3(NB), dim3(TB), 0, s, (const long long *)e->d_values, d_vals2, (const double *)M.ll, d_ll2,
+                                       (const double *)M.lprior, d_lp2, (const long long *)d_idx, S, N);
+                    SMC_HIP(hipMemcpyAsync(e->d_values, d_vals2, (size_t)S * N * 8, hipMemcpyDeviceToDevice, s));
+                    SMC_HIP(hipMemcpyAsync(M.ll, d_ll2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+                    SMC_HIP(hipMemcpyAsync(M.lprior, d_lp2, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+                }
+                bool have_pmax = false;
                 if (e->d > 0) {
-                    const int score = !e->P.sstream ? -1 : (e->P.sstream_kinds == 0 ? 0 : (e->P.sstream_gen ? 2 : 3));
                     // tiles (waves) per block: as many as the kernel is built for and 150 KB of LDS hold; a tile beyond one CU's LDS (or more
                     // sites than the block histogram has) lives in the engine's global scratch, one wave per block
                     const bool big = e->lds_score > 150 * 1024 || S > FG_SMC_HIST;
@@ -1237,28 +1516,40 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
                     } else
                     for (int r = 0; r < cfg->rejuvenation_steps; ++r) {
                         const uint32_t mv = (uint32_t)((steps - 1) * cfg->rejuvenation_steps + r);
-#define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); \
+                        const long long *vsrc = (sweep_io && r == 0) ? (const long long *)d_vals2 : (const long long *)nullptr;
+                        double *pmax = (sweep_io && r == cfg->rejuvenation_steps - 1) ? R.part_max : (double *)nullptr;
+#define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, M, (const FgSmcScalars *)st, mv, vsrc, pmax); \
                             else { SMC_TRY(set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))); \
-                                   hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, M, (const FgSmcScalars *)st, mv); } } while (0)
+                                   hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, M, (const FgSmcScalars *)st, mv, vsrc, pmax); } } while (0)
                         unsigned nb_adapt = nblk;
                         if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2);
                         else if (big || fg_smc_jit_rejuv_launch(e, M, (const FgSmcScalars *)st, mv, &nb_adapt) != FG_OK) SMC_REJUV(-1);   // the compiled model where there is one
 #undef SMC_REJUV
+                        if (pmax) { have_pmax = true; n_pmax = (int)nblk; }
                         hipLaunchKernelGGL(k_smc_adapt, dim3((unsigned)S), dim3(256), 0, s, M, S, (int)nb_adapt);
                         n_runs += 2 * N;
                     }
+                }
+                if (!have_pmax) {                            // the block maxima of ll for the next step's first pass
+                    hipLaunchKernelGGL(k_smc_red_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, (const double *)M.ll, (const double *)nullptr, N, (const double *)&st->one, (const double *)&st->one, R.part_max);
+                    n_pmax = RED_BLOCKS;
                 }
                 SMC_HIP(hipGetLastError());
             }
         }
     }
     // attach the final normalised weights (smc.rs:565-575)
-    SMC_TRY(R.run(s, d_lw, nullptr, N, st, (const double *)&st->one, 4));
-    hipLaunchKernelGGL(k_smc_normalize, dim3(NB), dim3(TB), 0, s, d_lw, d_w, N, (const FgSmcScalars *)st);
-    SMC_HIP(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
+    if (fin_ready) hipLaunchKernelGGL(k_smc_final_norm, dim3((unsigned)std::min<long long>(1024, (N + 4 * SCAN_THREADS - 1) / (4 * SCAN_THREADS))), dim3(SCAN_THREADS), 0, s, d_lw, d_w, N, (const double *)WS.d_chunk2, st);
+    else {
+        SMC_TRY(R.run(s, d_lw, nullptr, N, st, (const double *)&st->one, 4));
+        hipLaunchKernelGGL(k_smc_normalize, dim3(NB), dim3(TB), 0, s, d_lw, d_w, N, (const FgSmcScalars *)st);
+    }
+    if (!have_evidence) SMC_HIP(hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
     if (h_log_w) SMC_HIP(hipMemcpyAsync(h_log_w, d_lw, (size_t)N * 8, hipMemcpyDeviceToHost, s));
     if (h_weights) SMC_HIP(hipMemcpyAsync(h_weights, d_w, (size_t)N * 8, hipMemcpyDeviceToHost, s));
+    SMC_HIP(hipGetLastError());
     SMC_HIP(hipStreamSynchronize(s));
+    if (have_evidence) h.log_evidence = evidence_late ? hs->log_evidence : log_evidence;
     e->smc_pop_ready = true;
     res->log_evidence = h.log_evidence; res->n_steps = n_steps; res->n_model_runs = n_runs;
     if (h_betas) for (int i = 0; i < (int)betas.size() && i < max_betas; ++i) h_betas[i] = betas[i];
@@ -1395,9 +1686,9 @@ int fg_smc_rejuvenate(fg_engine *e, double beta, int steps, uint32_t first_move_
     const unsigned nblk = (unsigned)((N + (long long)e->tw * wpb - 1) / ((long long)e->tw * wpb));
     for (int r = 0; r < steps; ++r) {
         const uint32_t mv = first_move_id + (uint32_t)r;
-#define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); \
+#define SMC_REJUV(SC_) do { if (big) hipLaunchKernelGGL((k_smc_rejuv<SC_, true>), dim3(nblk), dim3(FG_WAVE), 0, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv, (const long long *)nullptr, (double *)nullptr); \
                             else { if (int rc_ = set_lds(k_smc_rejuv<SC_>, std::max<size_t>(lds_r, 64 * 1024 + 1))) return rc_; \
-                                   hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv); } } while (0)
+                                   hipLaunchKernelGGL(k_smc_rejuv<SC_>, dim3(nblk), dim3(e->tw * wpb), lds_r, s, e->P, e->X, W.M, (const FgSmcScalars *)W.st, mv, (const long long *)nullptr, (double *)nullptr); } } while (0)
         unsigned nb_adapt = nblk;
         if (score == 0) SMC_REJUV(0); else if (score == 3) SMC_REJUV(3); else if (score == 2) SMC_REJUV(2);
         else if (big || fg_smc_jit_rejuv_launch(e, W.M, (const FgSmcScalars *)W.st, mv, &nb_adapt) != FG_OK) SMC_REJUV(-1);
