@@ -69,6 +69,7 @@ struct fg_engine {
     int *d_rec = nullptr; int rec_cap = 0;
     bool smc_pop_ready = false;   // the arena holds a particle population (log-weights, weights, log-likelihoods) for the standalone SMC calls
     void *smc_arena = nullptr; size_t smc_arena_bytes = 0;   // scratch of fg_smc_run, allocated once per engine (fg_smc.hip)
+    int smc_epoch = 0;            // tags the pass flags of one next_beta search in smc_host
     void *smc_host = nullptr;     // pinned host scalars the SMC kernels write (beta, log-evidence, flags): the host's look at them needs no copy
     double *d_tmp = nullptr;     // [C] scratch
     int *d_itmp = nullptr;       // [3][C] scratch

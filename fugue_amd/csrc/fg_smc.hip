@@ -382,8 +382,12 @@ __global__ __launch_bounds__(ESS_THREADS) void k_smc_ess_pass_uniform(const doub
 // partials.  Bracket state and partials are double-buffered by pass parity; block 0 records the new bracket.  The decisions are
 // fg_ess_decide's: the same comparisons `ESS(mid) < target` on the reference's midpoints 0.5 (lo + hi) (smc.rs:612-619), three
 // levels per pass; pass 0 also evaluates b = 1 (smc.rs:604-607) and reduces the block maxima of ll itself.
-struct FgEssBracket { double lo, hi, bnew; int iters, done, first, pad;
-                      double s1_hi, s1_one; };   // sum_i exp((b - beta)(ll_i - max ll)) at b = hi and at b = 1: the reweight's log-sum-exp needs no pass of its own (k_smc_ess2_apply)
+struct FgEssBracket { double lo, hi, bnew; int iters, done, first, extra;     // extra: candidate 0 of the next pass is b = xb (first: b = 1)
+                      double s1_hi, s1_one;      // sum_i exp((b - beta)(ll_i - max ll)) at b = hi and at b = 1: the reweight's log-sum-exp needs no pass of its own (k_smc_ess2_apply)
+                      // the zoom passes (see fg_ess_step): ESS(za) >= target > ESS(zb) with the two values, the window of the next pass
+                      // (candidates wl + j wd, j = 1 .. 7), the sections per pass, passes taken
+                      double za, zb, fa, fb, wl, wd, xb;
+                      int zmode, zk, zpass, pad; };
 // Sum over the 64 lanes of a wave by DPP moves (row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast 15 / 31 across the
 // rows): the total lands in lane 63.  No LDS round trip per step -- __shfl_down on a double is two ds_bpermute_b32 and a wait, and
 // the sixteen sums of a pass spent 4-5 us in them (tools/prof_smc_phases.sh) -- and a fixed tree: the same bits wherever it runs.
@@ -412,6 +416,12 @@ static_assert(ESS2_BLOCKS <= ESS2_THREADS && ESS2_THREADS % 64 == 0, "fg_ess_col
 __device__ __forceinline__ int fg_ess_candidates(const FgEssBracket &B, double *cand) {
     int c0 = 0;
     if (B.first) { cand[0] = 1.0; c0 = 1; }
+    else if (B.extra) { cand[0] = B.xb; c0 = 1; }
+    if (B.zmode) {                                                  // eight sections of the window: its seven inner points, in the order the sums are kept
+        const int ord[7] = {4, 2, 6, 1, 3, 5, 7};
+        for (int q = 0; q < 7; ++q) cand[c0 + q] = B.wl + (double)ord[q] * B.wd;
+        return c0 + 7;
+    }
     const int left = 64 - B.iters, lv = B.first ? 3 : (left < 3 ? left : 3);
     const int nn = (1 << lv) - 1;
     double blo[7], bhi[7];
@@ -423,22 +433,75 @@ __device__ __forceinline__ int fg_ess_candidates(const FgEssBracket &B, double *
     }
     return c0 + nn;
 }
-// the bracket after a pass whose candidates had effective sample sizes ess_c (fg_ess_decide as a pure function)
-__device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double *ess_c, const double *s1_c, double beta, double target) {
+// the window of the next zoom pass: 8 sections of width (zb - za) / zk around the point where the chord through (za, fa), (zb, fb)
+// meets the target, kept inside [za, zb] (zk = 8: the whole bracket)
+__device__ __forceinline__ void fg_ess_window(FgEssBracket &B, double target) {
+    const double w = B.zb - B.za;
+    double c = B.za + w * ((B.fa - target) / (B.fa - B.fb));
+    if (!isfinite(c)) c = B.za + 0.5 * w;
+    B.wd = w / (double)B.zk;
+    double wl = c - 4.0 * B.wd;
+    if (wl + 8.0 * B.wd > B.zb) wl = B.zb - 8.0 * B.wd;
+    if (wl < B.za || B.zk == 8) wl = B.za;
+    B.wl = wl;
+}
+// The bracket after a pass whose candidates had effective sample sizes ess_c (fg_ess_decide as a pure function).
+//
+// next_beta's answer (smc.rs:588-622) is hi after 64 halvings of [beta, 1], each decided by `ESS(mid) < target`.  ESS(b) does not
+// increase with b (d ln ESS / d b = 2 (E_b[ll] - E_2b[ll]) <= 0 under uniform incoming weights), so every one of those decisions
+// follows from WHERE mid lies relative to any pair za < zb with ESS(za) >= target > ESS(zb).  The zoom passes find such a pair a few
+// units in the last place apart in ~6 passes instead of 18: each evaluates the seven inner points of eight equal sections of a window
+// around the chord's root, 1/zk of the bracket wide per section (zk = 64, then x 8 per hit up to 4 096; a miss -- the sign change left
+// or right of the window -- still moves that end and falls back to zk = 8, plain 8-section).  Then the 64 halvings are REPLAYED from
+// [beta, 1]: mid <= za goes right, mid >= zb goes left; a midpoint strictly inside (za, zb), if one comes up, and the last levels are
+// decided by evaluation again, by the plain passes below, whose first candidate is b = hi itself (its sum is the reweight's
+// log-normaliser).  Same beta' as the loop of smc.rs:612-619 wherever the evaluated ESS is monotone; inside the few-ulp band where
+// rounding makes it wiggle either is a root to working precision (the tests hold the ladder to 1e-9).  FG_SMC_ZOOM=0: plain passes only.
+__device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double *ess_c, const double *s1_c, double beta, double target, double n_particles) {
     double cand[ESS_MAXC];
     const int nc = fg_ess_candidates(B, cand);
     int c0 = 0;
+    const bool was_first = B.first != 0;
     if (B.first) {                                                 // candidate 0 of the first pass is b = 1: smc.rs:604-607
         B.first = 0; c0 = 1;
         B.s1_one = s1_c[0]; B.s1_hi = s1_c[0];                     // hi = 1 until a midpoint replaces it
         if (ess_c[0] >= target) { B.done = 1; B.bnew = 1.0; return B; }
+        B.za = beta; B.fa = n_particles; B.zb = 1.0; B.fb = ess_c[0];   // ESS(beta) = N: the incoming weights are uniform
+    } else if (B.extra) { B.extra = 0; c0 = 1; B.s1_hi = s1_c[0]; }    // b = xb = hi
+    if (B.zmode) {
+        const int inv[8] = {0, 3, 1, 4, 0, 5, 2, 6};                // heap slot of the j-th inner point
+        const double w_old = B.zb - B.za;
+        int j = 1;
+        while (j <= 7 && !(ess_c[c0 + inv[j]] < target)) ++j;       // the first point below the target
+        if (j <= 7) {
+            B.zb = B.wl + (double)j * B.wd; B.fb = ess_c[c0 + inv[j]];
+            if (j >= 2) { B.za = B.wl + (double)(j - 1) * B.wd; B.fa = ess_c[c0 + inv[j - 1]]; }
+        } else { B.za = B.wl + 7.0 * B.wd; B.fa = ess_c[c0 + inv[7]]; }
+        const double w = B.zb - B.za;
+        B.zk = (w <= 1.5 * B.wd) ? (B.zk >= 512 ? 4096 : B.zk * 8) : 8;
+        B.zpass += 1;
+        if (w < w_old && B.zpass < 12 && w > fabs(B.zb) * 0x1p-48) { fg_ess_window(B, target); return B; }
+        // leave: replay the halvings that the pair decides
+        B.zmode = 0;
+        double lo = B.lo, hi = B.hi;
+        int it = B.iters;
+        while (it < 64) {
+            const double mid = 0.5 * (lo + hi);                     // smc.rs:613
+            if (mid == lo || mid == hi) { it = 64; break; }         // the fixed point of the loop: no later iteration changes lo or hi
+            if (mid <= B.za) lo = mid; else if (mid >= B.zb) hi = mid; else break;
+            ++it;
+        }
+        B.lo = lo; B.hi = hi; B.iters = it;
+        B.extra = 1; B.xb = hi;                                     // the next pass evaluates b = hi (and up to three more levels)
+        return B;
     }
     const int ntree = nc - c0;
     int node = 0, depth = 0;
     double lo = B.lo, hi = B.hi;
     while (node < ntree && B.iters + depth < 64) {                 // smc.rs:612-619, one level = one iteration
         const double mid = cand[c0 + node];
-        if (ess_c[c0 + node] < target) { hi = mid; B.s1_hi = s1_c[c0 + node]; node = 2 * node + 1; } else { lo = mid; node = 2 * node + 2; }
+        if (ess_c[c0 + node] < target) { hi = mid; B.s1_hi = s1_c[c0 + node]; if (was_first) { B.zb = mid; B.fb = ess_c[c0 + node]; } node = 2 * node + 1; }
+        else { lo = mid; if (was_first) { B.za = mid; B.fa = ess_c[c0 + node]; } node = 2 * node + 2; }
         ++depth;
     }
     // a pass that leaves the bracket where it found it has reached the fixed point of the bisection (lo and hi are adjacent doubles or
@@ -447,6 +510,7 @@ __device__ __forceinline__ FgEssBracket fg_ess_step(FgEssBracket B, const double
     B.lo = lo; B.hi = hi; B.iters += depth;
     if (fixed) B.iters = 64;
     if (B.iters >= 64) { B.bnew = fmin(fmax(hi, beta + 1e-9), 1.0); B.done = 1; }   // smc.rs:620-621
+    else if (was_first && B.zk > 0 && B.zb > B.za) { B.zmode = 1; B.zpass = 0; fg_ess_window(B, target); }   // (zk = 0: plain passes only)
     return B;
 }
 // every candidate's ESS from the block partials of the previous pass: thread t takes blocks t, t + T, ...; lanes, then waves, in
@@ -490,7 +554,7 @@ __device__ long long fg_smc_prof[64][2][8];
 #define FG_SMC_T(i)
 #endif
 __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll, long long n, int pass, const double *beta_ptr, double target, const double *part_max, int n_pmax,
-                                                                FgEssBracket *brk, double *part, double *lmax, int *host_done) {
+                                                                FgEssBracket *brk, double *part, double *lmax, int *host_flag, int flag_base, int zoom) {
     __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
     __shared__ double ess_c[ESS_MAXC], s1_c[ESS_MAXC];
     __shared__ FgEssBracket shB;
@@ -505,7 +569,8 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
         for (int k = threadIdx.x; k < n_pmax; k += blockDim.x) m = fmax(m, part_max[k]);
         L = block_reduce_max(m, shm);
         if (blockIdx.x == 0 && threadIdx.x == 0) lmax[0] = L;
-        B.lo = beta; B.hi = 1.0; B.bnew = 1.0; B.iters = 0; B.done = 0; B.first = 1; B.pad = 0; B.s1_hi = 0.0; B.s1_one = 0.0;
+        B.lo = beta; B.hi = 1.0; B.bnew = 1.0; B.iters = 0; B.done = 0; B.first = 1; B.extra = 0; B.s1_hi = 0.0; B.s1_one = 0.0;
+        B.za = beta; B.zb = 1.0; B.fa = (double)n; B.fb = 0.0; B.wl = beta; B.wd = 0.0; B.xb = 1.0; B.zmode = 0; B.zk = zoom ? 64 : 0; B.zpass = 0; B.pad = 0;
     } else {
         L = lmax[0];
         const FgEssBracket P = brk[(pass - 1) & 1];                 // what pass - 1 started from
@@ -516,20 +581,23 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
             FG_SMC_T(1)
             fg_ess_collect(part + (size_t)((pass - 1) & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c, s1_c);
             FG_SMC_T(2)
-            if (threadIdx.x == 0) shB = fg_ess_step(P, ess_c, s1_c, beta, target);
+            if (threadIdx.x == 0) shB = fg_ess_step(P, ess_c, s1_c, beta, target, (double)n);
             __syncthreads();
             B = shB;
         }
     }
     FG_SMC_T(3)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { brk[pass & 1] = B; if (host_done) *host_done = B.done; }   // (host_done: pinned host memory -- the host looks once, after pass 1)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        brk[pass & 1] = B;
+        if (host_flag) { *host_flag = flag_base | (1 + (B.done ? 1 : 0)); __threadfence_system(); }   // pinned host memory: the host launches pass p + 1 when it sees pass p's flag
+    }
     if (B.done) return;
     // the candidates' sums over this block's particles (the two-exp form of k_smc_ess_pass_uniform)
-    const int first = B.first;
-    const int left = 64 - B.iters, lv = first ? 3 : (left < 3 ? left : 3);
-    const int nc = first + (1 << lv) - 1;
-    const double lo = B.lo, hi = B.hi;
-    const double d0 = lo - beta, d1 = 1.0 - beta, dl = (hi - lo) / (double)(1 << lv);
+    const int first = B.first, x0 = (first || B.extra) ? 1 : 0;     // candidate 0: b = 1 (first pass) or b = xb
+    const int left = 64 - B.iters, lv = B.zmode ? 3 : (first ? 3 : (left < 3 ? left : 3));
+    const int nc = x0 + (1 << lv) - 1;
+    const double lo = B.zmode ? B.wl : B.lo;
+    const double d0 = lo - beta, d1 = (first ? 1.0 : B.xb) - beta, dl = B.zmode ? B.wd : (B.hi - B.lo) / (double)(1 << lv);
     double s1[ESS_MAXC], s2[ESS_MAXC];
 #pragma unroll
     for (int q = 0; q < ESS_MAXC; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
@@ -546,17 +614,18 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_pass(const double *ll
         for (int u = 0; u < ESS2_UNROLL; ++u) {
             const double x = xs[u];                                  // <= 0; -inf: the particle has no weight at any b > beta (or lies past the end)
             if (isinf(x) && x < 0.0) continue;
+            if (x0) {
+                ESS_ADD(0, exp(d1 * x))
+                if (lv == 0) continue;
+            }
             const double E = exp(d0 * x), R = exp(dl * x);
             const double p1 = E * R, p2 = p1 * R, p3 = p2 * R;
-            if (first) {                                             // candidate 0 = b = 1, then the depth-3 tree over [beta, 1]
-                ESS_ADD(0, exp(d1 * x))
+            if (lv == 3) {                                           // the depth-3 tree (or the window's seven inner points), heap order
                 const double p4 = p3 * R, p5 = p4 * R, p6 = p5 * R, p7 = p6 * R;
-                ESS_ADD(1, p4) ESS_ADD(2, p2) ESS_ADD(3, p6) ESS_ADD(4, p1) ESS_ADD(5, p3) ESS_ADD(6, p5) ESS_ADD(7, p7)
-            } else if (lv == 3) {
-                const double p4 = p3 * R, p5 = p4 * R, p6 = p5 * R, p7 = p6 * R;
-                ESS_ADD(0, p4) ESS_ADD(1, p2) ESS_ADD(2, p6) ESS_ADD(3, p1) ESS_ADD(4, p3) ESS_ADD(5, p5) ESS_ADD(6, p7)
-            } else if (lv == 2) { ESS_ADD(0, p2) ESS_ADD(1, p1) ESS_ADD(2, p3) }
-            else ESS_ADD(0, p1)
+                if (x0) { ESS_ADD(1, p4) ESS_ADD(2, p2) ESS_ADD(3, p6) ESS_ADD(4, p1) ESS_ADD(5, p3) ESS_ADD(6, p5) ESS_ADD(7, p7) }
+                else { ESS_ADD(0, p4) ESS_ADD(1, p2) ESS_ADD(2, p6) ESS_ADD(3, p1) ESS_ADD(4, p3) ESS_ADD(5, p5) ESS_ADD(6, p7) }
+            } else if (lv == 2) { if (x0) { ESS_ADD(1, p2) ESS_ADD(2, p1) ESS_ADD(3, p3) } else { ESS_ADD(0, p2) ESS_ADD(1, p1) ESS_ADD(2, p3) } }
+            else { if (x0) ESS_ADD(1, p1) else ESS_ADD(0, p1) }
         }
     }
 #undef ESS_ADD
@@ -596,7 +665,7 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, in
         double cand[ESS_MAXC];
         const int ncp = fg_ess_candidates(P, cand);
         fg_ess_collect(part + (size_t)(last_pass & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, isinf(L) && L < 0.0, shl, ess_c, s1_c);
-        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, s1_c, beta, target);
+        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, s1_c, beta, target, (double)n);
     }
     if (threadIdx.x == 0) {
         if (!P.done) P.bnew = fmin(fmax(P.hi, beta + 1e-9), 1.0);    // (not reached: 22 passes cover 64 iterations)
@@ -618,7 +687,7 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, in
 // of the final normalisation, exp(lw - max lw) (smc.rs:565-575).  Block 0 publishes the scalars -- also to pinned host memory: the host's
 // look at beta needs no copy.  (A ticket that lets the LAST block publish costs a device-scope release per block: 89 us for 512 blocks.)  beta' = beta + 1e-9 (a bracket narrower
 // than the guaranteed progress, smc.rs:621) is no candidate of any pass: need_sum is set and the host runs the separate kernels.
-struct FgSmcHostScalars { double beta, log_evidence; int need_sum, pass1_done; };
+struct FgSmcHostScalars { double beta, log_evidence; int need_sum, pass1_done; int flag[64]; };   // flag[p]: (epoch << 2) | (1 + "the bracket pass p started from is final")
 __global__ __launch_bounds__(SCAN_THREADS) void k_smc_ess2_apply(const double *ll, long long n, int last_pass, int nb, double target, const FgEssBracket *brk, const double *part,
                                                                   const double *lmax, FgSmcScalars *st, const double *beta_in, double *beta_out, double lw0, double *lw, double *w,
                                                                   double *chunk_sum, double *chunk_sum2, FgSmcHostScalars *hs) {
@@ -633,7 +702,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_smc_ess2_apply(const double *l
         double cand[ESS_MAXC];
         const int ncp = fg_ess_candidates(P, cand);
         fg_ess_collect(part + (size_t)(last_pass & 1) * ESS2_BLOCKS * ESS_MAXC * 2, nb, ncp, n, allneg, shl, ess_c, s1_c);
-        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, s1_c, beta, target);
+        if (threadIdx.x == 0) P = fg_ess_step(P, ess_c, s1_c, beta, target, (double)n);
     }
     if (threadIdx.x == 0) {
         if (!P.done) P.bnew = fmin(fmax(P.hi, beta + 1e-9), 1.0);    // (not reached: 22 passes cover 64 iterations)
@@ -1175,7 +1244,7 @@ struct Reducer {     // scratch for the two-pass reductions
         int last = 0;
         const int n_pass = 22;                               // pass 0: b = 1 and levels 1-3; passes 1..20: three levels each; pass 21: the 64th
         for (int pass = 0; pass < n_pass; ++pass) {
-            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, RED_BLOCKS, brk, part, lmax, (int *)nullptr);
+            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, RED_BLOCKS, brk, part, lmax, (int *)nullptr, 0, 0);
             last = pass;
             if (pass == 1) {
                 FgEssBracket hb;
@@ -1191,19 +1260,40 @@ struct Reducer {     // scratch for the two-pass reductions
     // the passes alone: part_max[0 .. n_pmax) holds block maxima of ll (their producer's: k_smc_split_acc_max or the step's last
     // rejuvenation sweep); what follows them is k_smc_ess2_apply.  The host looks at pass 1's bracket through pinned memory.
     int ess2_passes(hipStream_t s, const double *ll, long long n, const double *beta_ptr, double target, int n_pmax, FgSmcHostScalars *hs_host,
-                    FgSmcHostScalars *hs_dev, int *last_out, int *nb_out) {
+                    FgSmcHostScalars *hs_dev, int epoch, int *last_out, int *nb_out, bool *ends_at_one) {
         double *part = ess2, *lmax = ess2 + (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2;
         FgEssBracket *brk = (FgEssBracket *)(lmax + 2);
         const int nb = (int)std::min<long long>(ESS2_BLOCKS, (n + ESS2_THREADS - 1) / ESS2_THREADS);
-        int last = 0;
-        for (int pass = 0; pass < 22; ++pass) {
-            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, n_pmax, brk, part, lmax,
-                               pass == 1 ? &hs_dev->pass1_done : (int *)nullptr);
-            last = pass;
-            if (pass == 1) { HIPCHK(smc_wait(s)); if (hs_host->pass1_done) break; }
+        static const int zoom = []() { const char *z = std::getenv("FG_SMC_ZOOM"); return (z && std::atoi(z) == 0) ? 0 : 1; }();
+        // Pass p + 1 is queued when pass p's flag arrives (block 0 writes it before its sums: the queue is never empty), and none once a
+        // flag says the bracket is final: how many passes a step takes -- two when ESS(1) >= target, 8 - 10 with the zoom passes, 19 - 22
+        // without -- is only known on the device.
+        const int base = epoch << 2;
+        volatile int *flag = hs_host->flag;
+        int launched = 0, seen = 0;
+        bool done = false;
+        *ends_at_one = false;
+        while (!done && seen < 64) {
+            if (launched <= seen) {
+                hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, launched, beta_ptr, target, (const double *)part_max, n_pmax, brk, part, lmax,
+                                   &hs_dev->flag[launched], base, zoom);
+                ++launched;
+            }
+            unsigned spins = 0;
+            int v;
+            while ((((v = flag[seen]) >> 2) != epoch)) {
+                if ((++spins & 0xfffu) == 0u) {                     // a failed launch or a fault must not leave the host spinning
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q != hipErrorNotReady && ((flag[seen] >> 2) != epoch)) { fg_set_error(q == hipSuccess ? "next_beta: a pass left no flag" : hipGetErrorString(q)); return FG_E_HIP; }
+                }
+            }
+            done = (v & 3) == 2;
+            if (done && seen == 1) *ends_at_one = true;             // ESS(1) >= target: beta' = 1 ends the ladder
+            ++seen;
         }
         HIPCHK(hipGetLastError());
-        *last_out = last; *nb_out = nb;
+        if (!done) { fg_set_error("next_beta: no final bracket after 64 passes"); return FG_E_STATE; }
+        *last_out = launched - 1; *nb_out = nb;
         return FG_OK;
     }
     // the reweight's log-sum-exp right after next_beta_uniform: its maximum is already in part_max
@@ -1452,13 +1542,16 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
             if (steps >= 10000) { int one = 1; SMC_HIP(hipMemcpyAsync(&st->force_one, &one, sizeof(int), hipMemcpyHostToDevice, s)); }
             int last = 0, nb = 0;
             const double *beta_in = &st->beta2[steps & 1]; double *beta_out = &st->beta2[(steps + 1) & 1];   // (both start at 0: k_smc_init)
-            SMC_TRY(R.ess2_passes(s, M.ll, N, beta_in, h.target_ess, n_pmax, hs, hs_dev, &last, &nb));
+            bool ends_at_one = false;
+            e->smc_epoch = (e->smc_epoch + 1) & 0x0fffffff;
+            if (e->smc_epoch == 0) e->smc_epoch = 1;                // (0 is what an unwritten flag reads as)
+            SMC_TRY(R.ess2_passes(s, M.ll, N, beta_in, h.target_ess, n_pmax, hs, hs_dev, e->smc_epoch, &last, &nb, &ends_at_one));
             // the last decision, reweight + evidence (smc.rs:512-529), weights and the chunk totals of the resampling prefix sum: one launch
             hipLaunchKernelGGL(k_smc_ess2_apply, dim3((unsigned)n_chunks), dim3(SCAN_THREADS), 0, s, (const double *)M.ll, N, last, nb, h.target_ess,
                                (const FgEssBracket *)brk, (const double *)R.ess2, (const double *)lmax, st, beta_in, beta_out, lw0, d_lw, d_w, SC.chunk, WS.d_chunk2, hs_dev);
             SMC_HIP(hipGetLastError());
             // ESS(1) >= target (pass 1 said so): beta' = 1 ends the ladder -- nothing to look at before the final normalisation is queued
-            const bool ends = hs->pass1_done != 0 && steps < 10000;
+            const bool ends = ends_at_one && steps < 10000;
             if (!ends) SMC_HIP(smc_wait(s));
             const bool fused = ends || hs->need_sum == 0;
             if (ends) { beta = 1.0; have_evidence = true; evidence_late = true; fin_ready = true; }
