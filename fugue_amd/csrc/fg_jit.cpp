@@ -816,6 +816,9 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     }
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
            "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, FG_JIT_LDS(slots), FG_JIT_LDS(terms)); } while (0)\n";
+#ifdef FG_MH_PROF
+    src += "#define FG_MH_PROF 1\n";              // (experiment builds: the compiled kernel carries the phase counters too)
+#endif
     src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
     const bool pipe2 = pipe && !no_stream;       // the step loop with the serial recipe split over waves (stream programs)
     if (pipe2) src += FG_JIT_EMBED_MHMW2_BODY;   // fg_mh_mw2_body.h

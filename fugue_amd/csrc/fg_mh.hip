@@ -28,6 +28,10 @@
 
 #include "fg_mh_mw_body.h"
 #include "fg_mh_mw2_body.h"
+#ifdef FG_MH_PROF
+extern hipModule_t fg_mh_prof_module;
+static inline void fg_mh_prof_set_module(hipModule_t m) { fg_mh_prof_module = m; }
+#endif
 
 // the same step with its serial recipe split over waves (round 4, fg_mh_mw2_body.h: decider / speculative proposer); FG_MH_PIPE=0 keeps
 // the one-control-wave loop above (A/B, identity tests)
@@ -280,6 +284,9 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
         int n_warmup = e->mh_warmup;
         void *args[] = { &e->P, &e->X, &e->M, &e->d_mh_srt, &seg, &iter0, &n_steps, &n_warmup, &draws, &first_sample_t, &exp_mask, &pool_n };
         HIPCHK(hipModuleLaunchKernel(e->jit_mhmw_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
+#ifdef FG_MH_PROF
+        fg_mh_prof_set_module(e->jit_mhmw_mod);
+#endif
         e->last_mh_kernel = std::string(sh.pipe ? "k_mh_mw2_jit_steps W=" : "k_mh_mw_jit_steps W=") + std::to_string(W) + " (statements compiled at run time)";
         return FG_OK;
     }
@@ -305,12 +312,21 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
     }
 #undef FG_MH_LAUNCH
     HIPCHK(hipGetLastError());
+#ifdef FG_MH_PROF
+    fg_mh_prof_set_module(nullptr);
+#endif
     e->last_mh_kernel = std::string(sh.pipe ? "k_mh_mw2_steps W=" : "k_mh_mw_steps W=") + std::to_string(W);
     return FG_OK;
 }
 
 #ifdef FG_MH_PROF
+hipModule_t fg_mh_prof_module = nullptr;      // the module of the last launch when that was the kernel compiled at run time (its own counters)
 extern "C" int fg_debug_mh_prof(unsigned long long *out) {
+    if (fg_mh_prof_module) {
+        hipDeviceptr_t dp = nullptr; size_t bytes = 0;
+        if (hipModuleGetGlobal(&dp, &bytes, fg_mh_prof_module, "fg_mh_prof") != hipSuccess || bytes < sizeof(unsigned long long) * FG_MH_WMAX * 8) return -1;
+        return hipMemcpy(out, dp, sizeof(unsigned long long) * FG_MH_WMAX * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    }
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_mh_prof), sizeof(unsigned long long) * FG_MH_WMAX * 8) == hipSuccess ? 0 : -1;
 }
 #endif
