@@ -16,13 +16,23 @@ SIG = [0.25, 0.5, 1.0, 2.0, 0.3, 1.7, 3.0, 1e-3, 123.456, 2.0 ** -30, 1.99999999
 def random_model():
     d = int(rng.integers(1, 40))
     stm = []
+    if rng.random() < 0.4:                                     # one record shape, powers of two, no constant statement: the dense mode's register-resident form
+        nobs = int(rng.integers(0, 2))
+        d = int(rng.integers(1, 70))
+        for i in range(d):
+            mu0, s0 = (0.0, 1.0) if rng.random() < 0.3 else (float(rng.normal()), float(rng.choice(SIG[:4])))
+            stm.append((mu0, s0, [(float(rng.normal(scale=2.0)), float(rng.choice(SIG[:4])), bool(rng.integers(0, 2))) for _ in range(nobs)]))
+        return build(stm, 0), d, True
     for i in range(d):
         mu0, s0 = float(rng.normal()), float(rng.choice(SIG[:7]))
         if rng.random() < 0.35: mu0, s0 = 0.0, 1.0           # the standard-normal own record has its own instance
         obs = [(float(rng.normal(scale=2.0)), float(rng.choice(SIG)), bool(rng.integers(0, 2))) for _ in range(int(rng.integers(0, 4)))]
         stm.append((mu0, s0, obs))
     n_const = int(rng.integers(0, 3))
+    return build(stm, n_const), d, False
 
+
+def build(stm, n_const):
     def model():
         m = F.pure(None)
         for i, (mu0, s0, obs) in enumerate(stm):
@@ -33,12 +43,12 @@ def random_model():
         for k in range(n_const):
             m = m.bind(lambda _, k=k: F.observe(F.addr("c", k), F.Normal(0.3 * k, 1.5), 0.1))
         return m
-    return model, d
+    return model
 
 
 bad = 0
 for it in range(n_models):
-    model, d = random_model()
+    model, d, shaped = random_model()
     try:
         cp = E.compile_model(model)
     except Exception as ex:
@@ -51,6 +61,7 @@ for it in range(n_models):
         eps0, nw, mass = float(rng.choice([2.0, 50.0, 1e6, 1e160])), 0, False
     W = int(rng.choice([0, 1, 2, 4, 8, 16]))
     mode = [E.GRAD_FD_SPARSE, E.GRAD_FD_SPARSE, E.GRAD_FD_DENSE, E.GRAD_ANALYTIC][int(rng.integers(0, 4))]
+    if shaped and rng.random() < 0.8: mode = E.GRAD_FD_DENSE
     out = []
     for sep in (1, 0):
         os.environ["FG_HMC_SEP"] = str(sep)
@@ -59,10 +70,11 @@ for it in range(n_models):
         buf = eng.device_alloc(max(1, ns * cp.d * C) * 8)
         st = eng.hmc_run(E.hmc_config(n_leapfrog=L, adapt_mass=mass, init_step_size=eps0, grad_mode=mode), ns, nw, buf)
         out.append((eng.download(buf, (ns, cp.d, C), dtype=np.int64), eng.get_values(), eng.hmc_step_sizes(), eng.hmc_log_joint(), int(st.n_divergent), eng.hmc_mass()))
+        if sep: kern = eng.hmc_last_kernel()
         eng.device_free(buf); eng.close()
     ok = all(np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True) for a, b in zip(out[0], out[1]))
     bad += 0 if ok else 1
     n_sep = E.lib().fg_program_stream_records(cp.h, 3)
-    print(f"model {it:3d}: d={d:2d} records={cp.stream_records} sep={n_sep:3d} C={C:3d} L={L:2d} warm={nw:2d} n={ns:2d} mass={int(mass)} W={W:2d} mode={mode} eps0={eps0} div={out[0][4]:4d} -> {'identical' if ok else 'MISMATCH'}", flush=True)
+    print(f"model {it:3d}: d={d:2d} records={cp.stream_records} sep={n_sep:3d} C={C:3d} L={L:2d} warm={nw:2d} n={ns:2d} mass={int(mass)} W={W:2d} mode={mode} eps0={eps0} div={out[0][4]:4d} [{kern[16:56]}] -> {'identical' if ok else 'MISMATCH'}", flush=True)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)

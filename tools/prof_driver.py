@@ -1,5 +1,5 @@
-"""One profiled configuration per invocation (rocprofv3 sits in front: tools/prof_round3.sh).  Every dispatch of the kernel under
-study covers a known number of units (transitions / chain steps / runs); tools/prof_round3_collect.py divides by them.
+"""One profiled configuration per invocation (rocprofv3 sits in front: tools/prof_round.sh).  Every dispatch of the kernel under
+study covers a known number of units (transitions / chain steps / runs); tools/prof_round_collect.py divides by them.
 usage: python tools/prof_driver.py <key>      keys: see CONFIGS"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,8 @@ CONFIGS = {
     "hmc|normal32|65536|fd_dense|L16": ("k_hmc_sep_steps", 25, 3, "transition"),
     "hmc|c3|65536|fd_sparse|L16": ("k_hmc_lin_steps", 1, 2, "transition"),
     "hmc|c3|8192|fd_sparse|L16": ("k_hmc_lin_steps", 1, 3, "transition"),
-    "mh|refmodel20|65536": ("k_mh_mw_steps", 100, 6, "chain step of every chain"),
+    "mh|refmodel20|65536": ("k_mh_mw", 100, 6, "chain step of every chain"),   # k_mh_mw_jit_steps since round 4 (every statement compiled at run time)
+    "mh|refmodel20|8192": ("k_mh_mw", 100, 6, "chain step of every chain"),
     "mh|c5|262144": ("k_mh_mw", 100, 2, "chain step of every chain"),       # k_mh_mw_jit_steps since the general records are compiled at run time
     # the pipelined multi-wave MH kernel around statements compiled at run time (k_mh_mw_jit_steps): general stream records, no stream at all
     "mh|zoo:hier_scale|65536": ("_steps", 100, 2, "chain step of every chain"),
@@ -74,8 +75,8 @@ def main(key):
             eng.hmc_step(1)
         eng.synchronize()
         print(key, eng.hmc_last_kernel())
-    elif key == "mh|refmodel20|65536":
-        eng = E.Engine(E.compile_model(W.reference_model(20)), 65536, seed=1)
+    elif key in ("mh|refmodel20|65536", "mh|refmodel20|8192"):
+        eng = E.Engine(E.compile_model(W.reference_model(20)), int(parts[2]), seed=1)
         eng.mh_init(200)
         eng.mh_step(100)
         eng.mh_init(200)
@@ -91,7 +92,7 @@ def main(key):
         eng.synchronize()
     elif key == "smc|c4|1048576":
         eng = E.Engine(E.compile_model(W.smc_normal()), 1 << 20, seed=42)
-        for _ in range(3):                           # the collector keeps the last run (from its k_prior_init on)
+        for _ in range(3):                           # the collector keeps the last run (from its k_smc_init on)
             r = eng.smc_run(rejuvenation_steps=3, download=False)
         print(key, len(r["betas"]), "tempering steps")
     else:

@@ -1,11 +1,12 @@
 #!/bin/bash
-# Profiles committed under profiles/round3_*: per configuration, kernel-trace stats + five rocprofv3 --pmc passes (instruction
+# Profiles committed under profiles/<round>_* (FG_PROF_ROUND, default round4): per configuration, kernel-trace stats + five rocprofv3 --pmc passes (instruction
 # counts, activity / wait cycles, f64 instruction mix, FETCH_SIZE, WRITE_SIZE -- counters always in their own runs with
-# --kernel-trace only; the program sits directly after `--`).  usage: prof_round3.sh <tag> <key> [<key> ...]
+# --kernel-trace only; the program sits directly after `--`).  usage: prof_round.sh <tag> <key> [<key> ...]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
-O=$R/gpurun_out/r3prof_$TAG
+export FG_PROF_ROUND=${FG_PROF_ROUND:-round4}
+O=$R/gpurun_out/prof_${FG_PROF_ROUND}_$TAG
 mkdir -p $O
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH"
 P2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU"
@@ -22,4 +23,4 @@ for KEY in "$@"; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/write -- python3 $R/tools/prof_driver.py "$KEY" > $D/write.log 2>&1 || { echo "[prof] $KEY write FAILED"; exit 1; }
   echo "[prof] $KEY done"
 done
-cd $R && python3 tools/prof_round3_collect.py $O
+cd $R && python3 tools/prof_round_collect.py $O

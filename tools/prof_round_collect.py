@@ -1,11 +1,12 @@
-"""Condenses the raw rocprofv3 output of tools/prof_round3.sh into small files: <out>/summary/round3_pmc_part.json (entries keyed
+"""Condenses the raw rocprofv3 output of tools/prof_round.sh into small files: <out>/summary/pmc_part.json (entries keyed
 like bench.py's pmc_entry keys: counters per unit, FETCH / WRITE bytes per unit, kernel-trace average duration) and a text
-summary per configuration.  tools/prof_round3_merge.py merges the parts of several runs into profiles/round3_pmc.json."""
+summary per configuration.  tools/prof_round_merge.py merges the parts of several runs into profiles/<round>_pmc.json (FG_PROF_ROUND, default round4)."""
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from prof_driver import CONFIGS
 
 O = sys.argv[1]
+ROUND = os.environ.get("FG_PROF_ROUND", "round4")
 S = os.path.join(O, "summary")
 os.makedirs(S, exist_ok=True)
 KIB = 1024.0
@@ -37,7 +38,7 @@ def trace(d, last_run_from=None):
     return out
 
 
-doc = {"_about": "rocprofv3 --kernel-trace [--stats | --pmc ...] passes of tools/prof_driver.py configurations on MI355X (tools/prof_round3.sh); counters are "
+doc = {"_about": "rocprofv3 --kernel-trace [--stats | --pmc ...] passes of tools/prof_driver.py configurations on MI355X (tools/prof_round.sh); counters are "
                  "per UNIT of the entry (a transition / a chain step of every chain / a run), averaged over the kept dispatches.  FETCH_SIZE / WRITE_SIZE are in KiB "
                  "(x 1024 = bytes; MI355X_MICROARCH.md HBM section: FETCH_SIZE under-counts 16 B/lane streaming reads 2x, these kernels move 8 B/lane rows -- "
                  "reported raw)", "entries": {}}
@@ -47,7 +48,7 @@ for kd in sorted(glob.glob(os.path.join(O, "*", "key.txt"))):
     match, units, keep, unit = CONFIGS[key]
     ent = {"unit": unit, "units_per_dispatch": units, "dispatches_kept": keep}
     lines = [f"== {key}  (unit = {unit}; {units} per dispatch)"]
-    whole = "k_prior_init" if not match else None          # a whole run (SMC): the LAST run of the driver, which starts with its prior draw
+    whole = "k_smc_init" if not match else None            # a whole run (SMC): the LAST run of the driver, which starts with k_smc_init
     tr = trace(os.path.join(D, "stats"), whole)
     if match:
         names = [k for k in tr if match in k]
@@ -101,4 +102,4 @@ for kd in sorted(glob.glob(os.path.join(O, "*", "key.txt"))):
     # the --stats table of the stats pass, as rocprofv3 wrote it
     for f in glob.glob(os.path.join(D, "stats", "**", "*kernel_stats.csv"), recursive=True):
         os.system(f"cp '{f}' '{os.path.join(S, 'kernel_stats_' + os.path.basename(D) + '.csv')}'")
-json.dump(doc, open(os.path.join(S, "round3_pmc_part.json"), "w"), indent=1)
+json.dump(doc, open(os.path.join(S, "pmc_part.json"), "w"), indent=1)
