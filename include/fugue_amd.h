@@ -171,12 +171,14 @@ int fg_log_joint_stream(fg_engine *e, double *h_acc, double *h_rec_lp);
 enum { FG_GRAD_FD_DENSE = 0,   /* hmc.rs:304-329 verbatim: 2d full model runs per gradient */
        FG_GRAD_FD_SPARSE = 1,  /* same central difference, re-evaluating only the terms that
                                   depend on the perturbed coordinate */
-       FG_GRAD_ANALYTIC = 2    /* closed-form derivative where the model allows it (every force term a Normal with
-                                  constant sigma whose mean is a site, a constant or a linear predictor):
-                                  d/dq_i sum of -(x - mu)^2 / (2 sigma^2).  NOT the reference's arithmetic (it has
-                                  no analytic mode): agrees with the finite difference to its O(h^2) + rounding
-                                  error; the step-size search still uses FG_GRAD_FD_SPARSE.  fg_hmc_init returns
-                                  FG_E_UNSUPPORTED for other programs. */ };
+       FG_GRAD_ANALYTIC = 2    /* the derivative itself.  Programs whose force terms are all Normals with constant
+                                  sigma whose mean is a site, a constant or a linear predictor: the closed form
+                                  d/dq_i sum of -(x - mu)^2 / (2 sigma^2).  Every other program: the forward-mode
+                                  derivative of each coordinate's sub-program in the unit compiled at run time
+                                  (all 17 log-densities in value and parameters).  NOT the reference's arithmetic
+                                  (it has no analytic mode): agrees with the finite difference to its O(h^2) +
+                                  rounding error; the step-size search still uses FG_GRAD_FD_SPARSE.  fg_hmc_init
+                                  returns FG_E_UNSUPPORTED where neither applies (no run-time compiler, FG_JIT=0). */ };
 typedef struct fg_hmc_config {      /* HMCConfig, hmc.rs:106-135 (same defaults) */
     int32_t n_leapfrog;             /* 16 */
     double  target_accept;          /* 0.8 */

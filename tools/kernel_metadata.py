@@ -4,7 +4,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fugue_amd import build as B
-out = os.path.join(ROOT, "profiles", os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else "round3_kernel_metadata.txt")   # never outside profiles/
+out = os.path.join(ROOT, "profiles", os.path.basename(sys.argv[1]) if len(sys.argv) > 1 else "round4_kernel_metadata.txt")   # never outside profiles/
 flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-DFG_BUILD", "-Wno-unused-function", "-w"]
 rows = []
 for src in [s for s in B.SOURCES if s.endswith(".hip")]:
