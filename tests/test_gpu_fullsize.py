@@ -3,6 +3,7 @@ oracle to run at that size: closed-form posteriors, independence of results from
 over engines (the multi-GPU layout), agreement with a numpy evaluation of the same density, and the
 oracle on a handful of chains of the full-size model."""
 import numpy as np
+from tests import knife
 import pytest
 
 from fugue_amd import diagnostics as D
@@ -200,6 +201,7 @@ def test_c5_mixture_64_points_categorical_indices_exact_vs_oracle(oracle):
             bad |= (~np.isclose(draws[:, j].view(np.float64), odraws[:, j].view(np.float64), rtol=1e-9, atol=1e-12)).any(axis=0)
         else:
             bad |= (draws[:, j] != odraws[:, j]).any(axis=0)
+    if bad.any(): knife.used("C5 mixture at full size: MH draws", chains=np.nonzero(bad)[0].tolist())
     assert bad.sum() <= 1, np.nonzero(bad)[0]                       # <= 1 acceptance on a 1e-13 knife edge
 
 
@@ -269,6 +271,7 @@ def test_models_larger_than_one_lds_tile(oracle):
         assert got["log_evidence"] == pytest.approx(exp["log_evidence"], rel=1e-9), name
         g, o = got["values"].view(np.float64), exp["values"].view(np.float64)
         bad = (~np.isclose(g, o, rtol=1e-8, atol=1e-11)).any(axis=0)
+        if bad.any(): knife.used("adaptive_smc beyond one LDS tile: particle values", model=name, particles=np.nonzero(bad)[0][:8].tolist())
         assert bad.sum() <= 4, (name, int(bad.sum()))                 # a knife-edge accept / resample boundary
         assert got["n_model_runs"] == exp["n_model_evals"], name
         eng.close()

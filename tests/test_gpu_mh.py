@@ -33,6 +33,9 @@ def _compare(cp, draws, odraws, max_bad_chains=0):
             bad |= (~np.isclose(g, o, rtol=1e-9, atol=1e-12)).any(axis=0)
         else:
             bad |= (draws[:, j, :] != odraws[:, j, :]).any(axis=0)
+    if bad.any() and max_bad_chains > 0:
+        from tests import knife
+        knife.used("MH draws against the oracle", chains=np.nonzero(bad)[0][:10].tolist())
     assert bad.sum() <= max_bad_chains, np.nonzero(bad)[0][:10]
     return bad
 

@@ -2,6 +2,7 @@
 the same seeded inputs.  Integer / index results must match exactly; floating-point results
 within the tolerances written beside each assertion."""
 import numpy as np
+from tests import knife
 import pytest
 
 from fugue_amd import engine as E
@@ -123,6 +124,7 @@ def test_hmc_transition_injected(oracle, name, mode):
         _close(alpha[c], oalpha, 1e-6, 1e-9)
         if oacc != bool(acc[c]):                       # only possible on a knife edge |u - alpha| ~ 1e-7
             assert abs(u[c] - oalpha) < 1e-6
+            knife.used("test_hmc_transition_injected: accept decision", model=name, mode=mode, chain=c, u_minus_alpha=float(u[c] - oalpha))
             n_flip += 1
             continue
         _close(_f64(nxt[om.f64_sites, c]), qo, 1e-7, 1e-9)
@@ -146,6 +148,8 @@ def test_find_reasonable_epsilon_injected(oracle, name):
         q = _f64(cells[om.f64_sites, c])
         lj0 = om.log_joint_at(cells[:, c], q)
         oe = om.find_reasonable_epsilon(cells[:, c], q, lj0, p0[:, c])
+        if eps[c] != oe:
+            knife.used("test_find_reasonable_epsilon_injected: step size", model=name, chain=c, gpu=float(eps[c]), oracle=float(oe))
         mism += int(eps[c] != oe)
     assert mism <= 1, mism        # a log-ratio within 1e-9 of ln 0.5 / ln 2 may tip the other way
 
@@ -175,6 +179,7 @@ def _replay_chain(oracle, om, cp, seed, chain, cells0, pos, info, cfg_L, nw, tar
             _close(info["accept_prob"][t, chain], oalpha, 1e-6, 1e-9)
             if oacc != bool(info["accepted"][t, chain]):
                 assert abs(u - oalpha) < 1e-6
+                knife.used("teacher-forced replay: accept decision", chain=chain, transition=t, u_minus_alpha=float(u - oalpha))
                 flips += 1
             else:
                 # the force is a central difference with h = 1e-5: one ulp of log pi (|lj| ~ 1e2 -> 1e-14) becomes
@@ -261,6 +266,7 @@ def test_hmc_free_running_short_chain_matches_oracle(oracle):
     eng.device_free(d_draws)
     odraws, _, oeps, ost = om.hmc_run(5, C, nw, ns, oracle.HmcConfig.default(n_leapfrog=8), chain0=7, n_threads=8)
     bad_chains = np.unique(np.nonzero(~np.isclose(draws, odraws, rtol=1e-4, atol=1e-5))[2])
+    if len(bad_chains): knife.used("free-running adaptive hmc_chain: draws", chains=bad_chains.tolist(), max_abs_diff=float(np.abs(draws - odraws).max()))
     assert len(bad_chains) <= 1, (bad_chains, np.abs(draws - odraws).max())
     assert abs(st.accept_rate - ost.accept_rate) < 1e-3
 
@@ -277,6 +283,7 @@ def test_hmc_fixed_step_long_chain_matches_oracle(oracle, name):
     draws = eng.download(d_draws, (ns, cp.d, C))
     odraws, _, _, _ = om.hmc_run(11, C, 0, ns, oracle.HmcConfig.default(n_leapfrog=8, init_step_size=0.15), n_threads=8)
     bad_chains = np.unique(np.nonzero(~np.isclose(draws, odraws, rtol=1e-6, atol=1e-8))[2])
+    if len(bad_chains): knife.used("fixed-step free-running hmc_chain: draws", model=name, chains=bad_chains.tolist(), max_abs_diff=float(np.abs(draws - odraws).max()))
     assert len(bad_chains) <= 1, bad_chains
 
 

@@ -4,6 +4,7 @@ against the CPU oracle.  Resample indices are integer work: exact."""
 import math
 
 import numpy as np
+from tests import knife
 import pytest
 
 from fugue_amd import engine as E
@@ -55,6 +56,7 @@ def test_resample_indices_exact(oracle, method, n):
     for j in diff:
         thr = (u[0] / n + j / n) if method == 1 else ((j + u[j]) / n if method == 2 else u[j])
         assert abs(int(got[j]) - int(exp[j])) == 1 and abs(cum[min(got[j], exp[j])] - thr) < 1e-12
+        knife.used("resampling indices", method=method, slot=int(j), gpu=int(got[j]), oracle=int(exp[j]), threshold_minus_cum=float(thr - cum[min(got[j], exp[j])]))
     assert len(diff) <= 1
 
 
@@ -98,6 +100,7 @@ def test_smc_tempered_matches_oracle(oracle, method):
     assert got["log_evidence"] == pytest.approx(exp["log_evidence"], rel=1e-9)
     g, o = got["values"].view(np.float64)[0], exp["values"].view(np.float64)[0]
     bad = ~np.isclose(g, o, rtol=1e-9, atol=1e-12)
+    if bad.any(): knife.used("adaptive_smc: particle values", method=method, particles=np.nonzero(bad)[0].tolist())
     assert bad.sum() <= 3, bad.sum()                   # a knife-edge accept / resample boundary
     np.testing.assert_allclose(got["weights"][~bad], exp["weights"][~bad], rtol=1e-8)
     assert got["n_model_runs"] == exp["n_model_evals"]
