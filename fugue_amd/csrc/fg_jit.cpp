@@ -773,6 +773,45 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
         fns += "static __device__ __noinline__ void fg_jit_mhb_" + std::to_string(sg) + "(const FG_LDSQ double *__restrict__ slots, FG_LDSQ double *__restrict__ terms) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc; (void)pr; (void)lk; (void)fc;\n}\n";
     }
+    // A Categorical site whose table is computed (expressions of other sites): its prior-resample proposal (mh.rs:516-530) needs the model.
+    // The multi-wave kernel interprets the target's own statement for such lanes (fg_mhmw_model_proposals) -- on the control wave's path,
+    // some lane of nearly every wave, every step.  Here the statement's expressions are generated like any scoring statement (temporaries
+    // as locals) and the distribution instruction becomes the interpreter's resample code over those locals: the same operations on the
+    // same numbers.  fg_jit_prop(site, ...) returns false for every other site (undecided kinds, PriorResample overrides: interpreted).
+    std::string prop_cases;
+    if (no_stream)
+        for (int k = 0; k < n_stmt; ++k) {
+            const size_t a = ins_at(k), b = ins_at(k + 1);
+            const FgIns &L = p->ins_fast[b - 1];
+            if (FG_INS_OPCODE(L.op) != 3u || (L.op & (FG_F_OBSERVE | FG_F_INVALID)) != 0u) continue;
+            if (FG_OPND_KIND(L.opnd[1]) == FG_OPND_POOL || FG_OPND_KIND(L.opnd[0]) != FG_OPND_SLOT_I) continue;        // constant tables are resampled by the random-number wave
+            int site = -1;
+            for (int j = 0; j < (int)p->site_slot.size(); ++j) if (p->site_slot[(size_t)j] == (int)L.aux) site = j;
+            const int K = (int)L.opnd[2], base = (int)FG_OPND_IDX(L.opnd[1]);
+            if (site < 0 || K < 1 || K > 64 || (int)FG_OPND_IDX(L.opnd[0]) != (int)L.aux) continue;
+            Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.ctabs = nullptr;
+            for (size_t q = a; q + 1 < b; ++q) g.ins(p->ins_fast[q]);
+            if (!g.ok) continue;
+            const std::string cell = "slots[" + std::to_string((int)L.aux) + " * FG_WAVE]";
+            std::string c = "    FgJitProp out = {0.0, 0.0, 2};\n    if (is_t) {\n        FgStream s1 = rng;\n        const double u = fg_rng_u01(s1);\n        double cum = 0.0; int idx = " + std::to_string(K) + ";\n";
+            for (int i = 0; i < K; ++i) c += "        cum += " + g.slot((uint32_t)(base + i)) + "; if (idx == " + std::to_string(K) + " && !(cum < u)) idx = " + std::to_string(i) + ";\n";
+            c += "        const long long prop = idx < " + std::to_string(K - 1) + " ? idx : " + std::to_string(K - 1) + ";\n"
+                 "        const long long xi = fg_as_i64(" + cell + ");\n"
+                 "        const bool cur_ok = !(xi < 0 || xi >= " + std::to_string(K) + "LL);\n"
+                 "        const int jp = (int)prop, jc = cur_ok ? (int)xi : 0;\n        " + g.pick(base, K, "jp", "pp") + "\n        " + g.pick(base, K, "jc", "pc0") + "\n"
+                 "        const double pc = cur_ok ? pc0 : 0.0;\n"
+                 "        out.f = !(pp > 0.0) ? FG_NEG_INF : log(pp);\n        out.r = !(pc > 0.0) ? FG_NEG_INF : log(pc);\n"
+                 "        out.nb = (int)s1.c1;\n        " + cell + " = fg_as_double(prop);\n    }\n";
+            fns += "static __device__ __noinline__ FgJitProp fg_jit_prop_" + std::to_string(site) + "(FG_LDSQ double *slots, FgStream rng, bool is_t) {\n    const double pert = 0.0; (void)pert;\n" +
+                   g.decls() + g.body + c + "    (void)acc; (void)pr; (void)lk; (void)fc;\n    return out;\n}\n";
+            prop_cases += "    case " + std::to_string(site) + ": { const bool is_t = mh.target == " + std::to_string((int)L.aux) + "; const FgJitProp r = fg_jit_prop_" + std::to_string(site) +
+                          "(slots, mh.rng, is_t); if (is_t) { mh.lqf += r.f; mh.lqr += r.r; mh.next_block = r.nb; } return true; }\n";
+        }
+    if (!prop_cases.empty())
+        fns = "struct FgJitProp { double f, r; int nb; };\n" + fns;
+    if (!prop_cases.empty())
+        fns += "static __device__ __forceinline__ bool fg_jit_prop(int site, FG_LDSQ double *slots, FgMhCtx &mh) {\n    switch (site) {\n" + prop_cases + "    default: return false;\n    }\n}\n"
+               "#define FG_MHMW_JIT_PROP(site, slots, mh) fg_jit_prop(site, FG_JIT_LDS(slots), mh)\n";
     fns += "static __device__ __forceinline__ void fg_jit_mhb(int sg, const FG_LDSQ double *slots, FG_LDSQ double *terms) {\n    switch (sg) {\n";
     for (int sg = 0; sg < NSEG; ++sg) fns += "    case " + std::to_string(sg) + ": fg_jit_mhb_" + std::to_string(sg) + "(slots, terms); break;\n";
     fns += "    default: break;\n    }\n}\n";

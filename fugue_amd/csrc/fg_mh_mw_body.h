@@ -155,6 +155,9 @@ static __device__ __noinline__ FgMhmwPre fg_mhmw_model_proposals(const FgIns *in
         const int tl = __builtin_amdgcn_readlane(target, leader);
         const unsigned long long same = __ballot(!walk && target == tl);
         FgAcc3 A = {0.0, 0.0, 0.0};
+#ifdef FG_MHMW_JIT_PROP      /* Categorical sites with a computed table: the statement as generated code (fg_jit.cpp) */
+        if (!FG_MHMW_JIT_PROP(tl, slots, pre))
+#endif
         fg_exec<FG_MODE_MH, false>(ins + site_ins[2 * tl], site_ins[2 * tl + 1], pool, slots, FG_WAVE, A, nullptr, nullptr, 0, live, &pre);
         todo &= ~same;
     }
