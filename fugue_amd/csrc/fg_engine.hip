@@ -838,7 +838,8 @@ int fg_engine_set_values(fg_engine *e, const void *h) {
     // a live sampler session caches the log-joint of its current state: re-score it at the new values (what the reference's
     // callers do after editing a trace: crates/fugue-wasm/src/mh.rs:239-255 runs ScoreGivenTrace)
     for (double *lj : { e->mh_ready ? e->M.lw : (double *)nullptr, e->hmc_ready ? e->H.lj : (double *)nullptr })
-        if (lj) FG_LAUNCH_GT(e, k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
+        if (lj && (e->gt || fg_jit_log_joint_launch(e, e->d_acc, lj, false) != FG_OK))
+            FG_LAUNCH_GT(e, k_log_joint, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, e->d_acc,
                                    (double *)nullptr, lj);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -873,6 +874,14 @@ int fg_device_upload(fg_engine *e, void *d, const void *h, size_t bytes) {
 }
 
 int fg_launch_prior(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj) {
+    // the compiled model where there is one (fg_hmc_jit_body.h: k_prior_jit -- the same draws).  A program without a record stream will
+    // step through the compiled unit anyway: it is built here, one call earlier; other programs use it only once it exists (adaptive_smc
+    // asks for it when the population is large: fg_smc.hip)
+    if (!e->gt) {
+        const int rj = fg_jit_prior_launch(e, iteration, purpose, d_acc, d_lj, e->prog->n_gstream == 0 && e->prog->n_sstream == 0);
+        if (rj == FG_OK) return FG_OK;
+        if (rj != FG_E_UNSUPPORTED) return rj;
+    }
     FG_LAUNCH_GT(e, k_prior_init, dim3((unsigned)((e->C + e->tw - 1) / e->tw)), dim3(e->tw), e->lds_score, e->stream, e->P, e->X, iteration,
                        purpose, d_acc, d_lj);
     HIPCHK(hipGetLastError());

@@ -361,9 +361,36 @@ static int jit_hmc_module(fg_engine *e) {
             e->jit_log = "hipModuleLoadData / hipModuleGetFunction / table upload failed"; (void)hipGetLastError();
             return FG_E_UNSUPPORTED;
         }
+        // (optional entry points: a unit whose generic program the generator does not cover has no k_prior_jit)
+        if (hipModuleGetFunction(&e->jit_fn_prior, e->jit_mod, "k_prior_jit") != hipSuccess) { e->jit_fn_prior = nullptr; (void)hipGetLastError(); }
+        if (hipModuleGetFunction(&e->jit_fn_lj, e->jit_mod, "k_log_joint_jit") != hipSuccess) { e->jit_fn_lj = nullptr; (void)hipGetLastError(); }
         e->jit_state = 1; e->jit_has_ad = has_ad;
     }
     return FG_OK;
+}
+
+// run(PriorHandler) / run(ScoreGivenTrace) of every chain through the compiled model (k_prior_jit / k_log_joint_jit): FG_E_UNSUPPORTED when
+// there is none (the caller takes the interpreter kernels).  `compile`: build the unit now if it is not there yet (callers for which the
+// draw is a visible part of the work: adaptive_smc, sessions of programs that will step through the unit anyway).
+static int jit_tile_launch(fg_engine *e, hipFunction_t fn, void **args) {
+    const size_t tile = (size_t)e->S * FG_WAVE * sizeof(double);
+    if (!fn || tile == 0 || tile > 64 * 1024) return FG_E_UNSUPPORTED;
+    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / tile));
+    const unsigned nblk = (unsigned)((e->C + (long long)FG_WAVE * wpb - 1) / ((long long)FG_WAVE * wpb));
+    HIPCHK(hipModuleLaunchKernel(fn, nblk, 1, 1, FG_WAVE * wpb, 1, 1, (unsigned)(tile * wpb), e->stream, args, nullptr));
+    return FG_OK;
+}
+int fg_jit_prior_launch(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj, bool compile) {
+    if (e->jit_state != 1 && !(compile && e->jit_state == 0)) return FG_E_UNSUPPORTED;
+    if (int rc = jit_hmc_module(e)) return rc;
+    void *args[] = { &e->P, &e->X, &iteration, &purpose, &d_acc, &d_lj };
+    return jit_tile_launch(e, e->jit_fn_prior, args);
+}
+int fg_jit_log_joint_launch(fg_engine *e, double *d_acc, double *d_lj, bool compile) {
+    if (e->jit_state != 1 && !(compile && e->jit_state == 0)) return FG_E_UNSUPPORTED;
+    if (int rc = jit_hmc_module(e)) return rc;
+    void *args[] = { &e->P, &e->X, &d_acc, &d_lj };
+    return jit_tile_launch(e, e->jit_fn_lj, args);
 }
 
 // does the compiled module hold the analytic gradient of this program (FG_GRAD_ANALYTIC beyond Normal force terms)?  Compiles it if need be.

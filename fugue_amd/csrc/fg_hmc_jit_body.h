@@ -324,3 +324,46 @@ void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalar
     unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
     for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
 }
+
+
+// ---- run(PriorHandler, model) and run(ScoreGivenTrace, model) per chain (interpreters.rs:88-104, 138-163) as generated code: k_prior_init /
+// k_log_joint (fg_engine.hip) with fg_jit_prior / fg_jit_score instead of the interpreter -- the same draws from the same stream in the
+// same order, the same accumulators.  One tile (S site rows) per wave, blockDim.x / 64 tiles per block.
+#ifdef FG_JIT_HAS_PRIOR
+extern "C" __global__ __launch_bounds__(FG_WAVE * 4)
+void k_prior_jit(FgProgramDev P, FgChainCtx X, uint32_t iteration, uint32_t purpose, double *acc_out /*[3][C] or null*/, double *lj_out /*[C] or null*/) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
+    const long long chain = ((long long)blockIdx.x * (blockDim.x >> 6) + wv) * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + (long long)wv * P.S * tw + lane;
+    for (int j = 0; j < P.S; ++j) slots[j * tw] = 0.0;
+    const FgStream rng = fg_stream(X.seed, X.chain0 + (uint32_t)c, iteration, purpose);
+    double pr, lk, fc;
+    fg_jit_prior(FG_JIT_LDS(slots), rng, pr, lk, fc);
+    if (live) {
+        for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = fg_as_i64(slots[P.site_slot[j] * tw]);
+        if (acc_out) { acc_out[c] = pr; acc_out[X.C + c] = lk; acc_out[2 * X.C + c] = fc; }
+        if (lj_out) lj_out[c] = pr + lk + fc;
+    }
+}
+#endif
+extern "C" __global__ __launch_bounds__(FG_WAVE * 4)
+void k_log_joint_jit(FgProgramDev P, FgChainCtx X, double *acc_out /*[3][C] or null*/, double *lj_out /*[C] or null*/) {
+    extern __shared__ double lds[];
+    constexpr int tw = FG_WAVE;
+    const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
+    const long long chain = ((long long)blockIdx.x * (blockDim.x >> 6) + wv) * tw + lane;
+    const bool live = chain < X.C;
+    const long long c = live ? chain : X.C - 1;
+    double *slots = lds + (long long)wv * P.S * tw + lane;
+    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    double pr, lk, fc;
+    fg_jit_score(FG_JIT_LDS(slots), pr, lk, fc);
+    if (live) {
+        if (acc_out) { acc_out[c] = pr; acc_out[X.C + c] = lk; acc_out[2 * X.C + c] = fc; }
+        if (lj_out) lj_out[c] = pr + lk + fc;
+    }
+}

@@ -83,6 +83,7 @@ struct Gen {
     bool coop = false;
     bool ring_term = false;                      // the statement being emitted writes its term to ring row (buf * CH + rr)
     bool mh_terms = false;                       // the multi-wave MH kernel's phase B: a term row may hold NaN for -inf (see FG_OP_NORMAL_FAST)
+    bool prior = false;                          // run(PriorHandler): every sample statement first DRAWS its value from `rng` (interpreters.rs:88-104), then scores it
     const std::vector<int> *rows = nullptr;      // TM mode: term row of statement k when it is not k itself (the multi-wave stream kernel's rows: log_prior
                                                  // terms first, then log_likelihood terms)
 
@@ -362,6 +363,20 @@ struct Gen {
         if (code < 17u) {
             const bool hoisted = (op & FG_F_HOISTED) != 0u, invalid = (op & FG_F_INVALID) != 0u;
             const uint32_t vtype = FG_INS_VTYPE(op), xw = I.opnd[0];
+            if (prior && !observe) {                                          // the draw (fg_exec's FG_MODE_PRIOR): the value cell, then the statement scores it
+                const std::string cell = slot(I.aux);
+                if (cell.rfind("slots[", 0) != 0) { ok = false; return; }
+                if (code == 3u) {                                             // first i with cumulative[i] >= u, clamped to K - 1
+                    const uint32_t bw = I.opnd[1]; const int K = (int)I.opnd[2];
+                    const bool in_pool = FG_OPND_KIND(bw) == FG_OPND_POOL; const int base = (int)FG_OPND_IDX(bw);
+                    std::string c = "{ const double u = fg_rng_u01(rng); double cum = 0.0; int idx = " + std::to_string(K) + "; ";
+                    for (int i = 0; i < K; ++i)
+                        c += "cum += " + (in_pool ? lit(p.pool[(size_t)base + i]) : slot((uint32_t)(base + i))) + "; if (idx == " + std::to_string(K) + " && !(cum < u)) idx = " + std::to_string(i) + "; ";
+                    add(c + cell + " = fg_as_double((long long)(idx < " + std::to_string(K - 1) + " ? idx : " + std::to_string(K - 1) + ")); }");
+                } else
+                    add("{ const long long cell_ = fg_jit_sample(" + std::to_string(code) + "u, " + (hoisted ? "true" : "false") + ", " + opnd(I.opnd[1], I.imm[1]) + ", " + opnd(I.opnd[2], I.imm[2]) + ", " +
+                        opnd(I.opnd[3], I.imm[3]) + ", rng); " + cell + " = fg_as_double(cell_); }");
+            }
             if (code == 3u) {                                                 // Categorical: distribution.rs:771-791
                 const uint32_t bw = I.opnd[1]; const int K = (int)I.opnd[2];
                 const bool in_pool = FG_OPND_KIND(bw) == FG_OPND_POOL; const int base = (int)FG_OPND_IDX(bw);
@@ -561,6 +576,8 @@ static __device__ FG_JIT_CALL double fg_jit_pow(double x, double y) { return pow
 #define FG_JIT_AS4 __attribute__((address_space(4)))
 __device__ const double *fg_jit_ctab_ptr = nullptr;
 static __device__ __forceinline__ const FG_JIT_AS4 double *fg_jit_ctab() { return (const FG_JIT_AS4 double *)(unsigned long)fg_jit_ctab_ptr; }
+// the 17 samplers behind one call, like the interpreter's fg_sample_cold (the same fg_sample_dist: the same draws)
+static __device__ __noinline__ long long fg_jit_sample(uint32_t kind, bool hoisted, double p0, double p1, double p2, FgStream &s) { return fg_sample_dist(kind, hoisted, p0, p1, p2, s); }
 // fg_int_of (fg_interp.h): the integer value of an observed expression
 static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vtype) { if (vtype == 1u) return v != 0.0; return fg_finite(v) ? (long long)v : 0; }
 )FGJ";
@@ -617,6 +634,13 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         if (!g.ok) return "";
         fns += "static __device__ __noinline__ void fg_jit_score(const FG_LDSQ double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
+    }
+    {   // run(PriorHandler) (interpreters.rs:88-104) from the generic program: every sample statement draws, then scores (k_prior_jit)
+        Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.prior = true;
+        for (size_t q = 0; q < p->ins.size() && g.ok; ++q) g.ins(p->ins[q]);
+        if (g.ok)
+            fns += "#define FG_JIT_HAS_PRIOR 1\nstatic __device__ __noinline__ void fg_jit_prior(FG_LDSQ double *slots, FgStream rng, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" +
+                   g.decls() + g.body + "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
     std::string src = PROLOGUE;
     if (fg_jit_inlined()) src += "#define FG_JIT_INLINED 1\n";

@@ -1514,8 +1514,10 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
     h.target_ess = std::min(std::max(cfg->ess_threshold * (double)N, 1.0), (double)N);     // smc.rs:481
     // the run's scalars, and scale = 1, log_scale = 0, acc = tot = 0 (DiminishingAdaptation::new): one launch
     hipLaunchKernelGGL(k_smc_init, dim3((unsigned)((Sn + TB - 1) / TB)), dim3(TB), 0, s, st, h, M, (long long)Sn);
-    // smc_prior_particles (smc.rs:764-790)
-    SMC_TRY(fg_launch_prior(e, 0, FG_RNG_SMC_PRIOR, e->d_acc, nullptr));
+    // smc_prior_particles (smc.rs:764-790): through the compiled model for a large population (the draw is a tenth of a 1 048 576-particle
+    // run on the interpreter kernel; the unit is compiled once per program and cached)
+    if (e->gt || N < (1LL << 18) || fg_jit_prior_launch(e, 0, FG_RNG_SMC_PRIOR, e->d_acc, nullptr, true) != FG_OK)
+        SMC_TRY(fg_launch_prior(e, 0, FG_RNG_SMC_PRIOR, e->d_acc, nullptr));
     const double lw0 = -std::log((double)N);                                // log_w = -ln N at every step's start (smc.rs:476,538-540)
     long long n_runs = N;
     int n_steps = 0;
