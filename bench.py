@@ -642,6 +642,7 @@ def compact(full):
     line["check"] = {k: _sig(ck[k], 3) if isinstance(ck[k], float) else ck[k] for k in ("posterior_mean_max_abs_err", "accept_rate", "n_divergent", "split_rhat_max", "chains_in_rhat",
                                                                                        "diagnostics_path", "diagnostics_exchange_bytes_per_rank") if k in ck}
     line["check"]["diagnostics_path"] = str(line["check"].get("diagnostics_path", ""))[:200]
+    line["check"] = dict({"of": f"the {full.get('steps')} timed draws behind {full.get('warmup')} warmup transitions from the prior draw (no convergence claim at this length: see validity)"}, **line["check"])
     if "validity" in full:
         v = full["validity"]
         line["validity"] = {"posterior_mean_max_abs_err": _sig(v["posterior_mean_max_abs_err"], 3), "target_1e-3": v["target_1e-3"], "split_rhat_max": _sig(v["split_rhat_max"], 5),
