@@ -1,15 +1,15 @@
 """The timed region of `python bench.py` in a rocprofv3 --kernel-trace: the 25-transition sampling launches of the headline kernel.
 The bench issues, in order: spin-up launches of 100 transitions on a scratch engine (> 3 ms each), ceil(W / 25) adaptive warmup
-launches, then R x (K / 25) timed sampling launches.  usage: prof_bench_region.py <rocprof dir> <bench json> <out txt>"""
+launches, then R x (K / 25) timed sampling launches.  usage: prof_bench_region.py <rocprof dir> <full bench document> <out txt>"""
 import csv, glob, json, sys
 d, jf, out = sys.argv[1:4]
-j = json.loads(open(jf).read().strip().splitlines()[-1])
+j = json.load(open(jf))          # the full document (bench.py --full-out)
 K, W, R, per = j["steps"], j["warmup"], j["timed_regions"]["repeats"], j["config"]["transitions_per_launch"]
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-hk = [r for r in rows if "k_hmc_sep_steps<false, 0, false>" in r["Kernel_Name"]]
+hk = [r for r in rows if "k_hmc_sep_steps<false, 0, 0>" in r["Kernel_Name"]]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in hk]
 last_spin = max(i for i, t in enumerate(dur) if t > 3.0 and i < len(dur) - R * (K // per))
 n_warm = (W + per - 1) // per
