@@ -205,13 +205,13 @@ def test_next_beta_zoom_passes_agree_with_the_plain_passes():
     """next_beta brackets the ESS crossing by zoom passes and replays the reference's 64 halvings from the bracket (DESIGN 3.4, round 4);
     FG_SMC_ZOOM=0 evaluates every halving (three levels per pass).  Both follow the same comparisons `ESS(mid) < target` wherever the
     evaluated ESS is monotone: the ladders agree to a few units in the last place, the evidence to rounding.  (The switch is read once per
-    process: tools/ab_smc_zoom.py runs each setting in a child process -- four models, up to 1 048 576 particles.)"""
+    process: tools/ab_smc_zoom.py runs each setting in a child process -- six models, ladders of 2 to ~20 steps, up to 1 048 576 particles.)"""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_smc_zoom.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rows = re.findall(r"^(\S+)\s+steps (\d+)/(\d+)\s+max \|d beta\| (\S+)\s+d logZ (\S+)", out.stdout, flags=re.M)
-    assert len(rows) == 4, out.stdout
+    assert len(rows) == 6, out.stdout
     for name, s0, s1, db, dz in rows:
         assert s0 == s1, (name, s0, s1)
         assert float(db) <= 1e-14 and float(dz) <= 1e-12, (name, db, dz)
