@@ -382,7 +382,11 @@ static int jit_tile_launch(fg_engine *e, hipFunction_t fn, void **args) {
 }
 int fg_jit_prior_launch(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj, bool compile) {
     if (e->jit_state != 1 && !(compile && e->jit_state == 0)) return FG_E_UNSUPPORTED;
-    if (int rc = jit_hmc_module(e)) return rc;
+    if (int rc = jit_hmc_module(e)) {
+        if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: no compiled prior draw (state %d, d %d, S %d, tw %d, gt %d: %s)\n", e->jit_state, e->d, e->S, e->tw, (int)(e->gt != 0), e->jit_log.c_str());
+        return rc;
+    }
+    if (!e->jit_fn_prior && std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: the compiled unit has no k_prior_jit\n");
     void *args[] = { &e->P, &e->X, &iteration, &purpose, &d_acc, &d_lj };
     return jit_tile_launch(e, e->jit_fn_prior, args);
 }

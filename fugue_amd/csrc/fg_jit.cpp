@@ -637,7 +637,10 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
     }
     {   // run(PriorHandler) (interpreters.rs:88-104) from the generic program: every sample statement draws, then scores (k_prior_jit)
         Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.prior = true;
-        for (size_t q = 0; q < p->ins.size() && g.ok; ++q) g.ins(p->ins[q]);
+        for (size_t q = 0; q < (size_t)p->n_ins && q < p->ins.size() && g.ok; ++q) {     // (the program ends with a stop instruction behind n_ins)
+            g.ins(p->ins[q]);
+            if (!g.ok && std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: no compiled prior draw: instruction %zu (opcode %u, flags %#x) is not covered\n", q, FG_INS_OPCODE(p->ins[q].op), p->ins[q].op);
+        }
         if (g.ok)
             fns += "#define FG_JIT_HAS_PRIOR 1\nstatic __device__ __noinline__ void fg_jit_prior(FG_LDSQ double *slots, FgStream rng, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" +
                    g.decls() + g.body + "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
