@@ -964,7 +964,9 @@ __global__ void k_resample_search(const double *cum, long long n, int method, do
 }
 // The same index in two levels: the first chunk of the prefix sum whose LAST element reaches the threshold (the chunk ends in LDS: nine
 // steps at LDS latency instead of nine round trips to L2), then the first such element inside that chunk (cum is non-decreasing: the
-// same k).  20.7 -> us per 1 048 576 outputs.
+// same k).  20.7 -> 19.2 us per 1 048 576 outputs.  (Tried on top: the block's stretch of the prefix sum -- its 256 rising thresholds land in
+// ~256 consecutive entries -- staged in LDS behind the searches of its first and last output, every thread searching there: 22.6 - 29.6 us,
+// the two searches ahead of the staging are a serial prologue per block and the LDS for the stretch costs occupancy.)
 __global__ __launch_bounds__(256) void k_resample_search2(const double *cum, long long n, int n_chunks, int method, double U, const double *u_arr,
                                                           unsigned long long seed, uint32_t step, long long *idx) {
     extern __shared__ double ends[];
