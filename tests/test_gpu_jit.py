@@ -164,6 +164,27 @@ def test_jit_smc_rejuvenation_is_identical_to_the_interpreter(name, monkeypatch)
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
+@pytest.mark.parametrize("name", ["alldists", "poisson_glm", "hier_logsigma", "logistic", "coin", "mixture", "rand0", "rand3"])
+def test_jit_prior_draw_is_identical_to_the_interpreter(name, monkeypatch):
+    """run(PriorHandler) through the model compiled at run time (k_prior_jit: every sample statement draws through the same fg_sample_dist
+    from the same stream, then scores) against the interpreter kernel k_prior_init: the same cells of every site of every chain and the
+    same three accumulators, bit for bit; likewise the re-score of a session's log-joint after set_values (k_log_joint_jit).  Programs
+    with a record stream only use the compiled draw once the unit exists: an HMC step in the compiled mode builds it first."""
+    cp = E.compile_model(ZOO[name]())
+    out = []
+    for jit in ("0", "1"):
+        monkeypatch.setenv("FG_JIT", jit)
+        eng = E.Engine(cp, 700, seed=29, chain_offset=3)
+        if jit == "1" and cp.d > 0:                          # build the unit: the step-size search of a session runs on the compiled kernel here
+            eng.hmc_init(E.hmc_config(n_leapfrog=2), 0)       # (few tiles: the compiled form is the engine's choice for stream programs too)
+        acc = eng.prior_init(5)
+        vals = eng.get_values()
+        out.append((acc, vals))
+        eng.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0], equal_nan=True)
+
+
 @pytest.mark.parametrize("name", ["alldists", "logistic", "poisson_glm", "hier_logsigma", "hier_scale", "mixture", "coin", "rand3"])
 def test_analytic_gradients_of_any_program_match_the_finite_difference(name):
     """FG_GRAD_ANALYTIC beyond Normal force terms (north_star: "finite-difference (and where available analytic) gradients"; opt-in):
