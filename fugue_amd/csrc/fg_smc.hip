@@ -690,7 +690,7 @@ __global__ __launch_bounds__(ESS2_THREADS) void k_smc_ess2_final(long long n, in
 struct FgSmcHostScalars { double beta, log_evidence; int need_sum, pass1_done; int flag[64]; };   // flag[p]: (epoch << 2) | (1 + "the bracket pass p started from is final")
 __global__ __launch_bounds__(SCAN_THREADS) void k_smc_ess2_apply(const double *ll, long long n, int last_pass, int nb, double target, const FgEssBracket *brk, const double *part,
                                                                   const double *lmax, FgSmcScalars *st, const double *beta_in, double *beta_out, double lw0, double *lw, double *w,
-                                                                  double *chunk_sum, double *chunk_sum2, FgSmcHostScalars *hs) {
+                                                                  double *chunk_sum, double *chunk_sum2, FgSmcHostScalars *hs, int force_sum) {
     __shared__ double shl[ESS2_THREADS / 64][ESS_MAXC][2];
     __shared__ double ess_c[ESS_MAXC], s1_c[ESS_MAXC];
     __shared__ double sh_sc[6];
@@ -709,6 +709,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_smc_ess2_apply(const double *l
         const double bnew = st->force_one ? 1.0 : P.bnew;            // smc.rs:504-506: the step cap forces beta = 1
         double s1 = 0.0; int need = 0;
         if (bnew == 1.0) s1 = P.s1_one; else if (bnew == P.hi) s1 = P.s1_hi; else need = 1;
+        if (force_sum) need = 1;                                     // (FG_SMC_FORCE_SUM=1: tests of the separate-kernels path)
         const double dbeta = bnew - beta;
         const double vmax = lw0 + dbeta * L;                         // smc_v at the particle with the largest ll
         const double lse1 = (allneg || s1 == 0.0) ? -INFINITY : vmax + log(s1);       // numerical.rs:33-37
@@ -812,7 +813,6 @@ __global__ void k_smc_apply(double *lw, const double *ll, double *w, long long n
     lw[i] = nl;
     if (w) w[i] = exp(nl);
 }
-__global__ void k_smc_set_beta(FgSmcScalars *st) { if (threadIdx.x == 0 && blockIdx.x == 0) st->beta = st->bnew; }
 // final normalisation (smc.rs:565-575): lw <- lw - lse(lw), w <- exp(lw); uniform if lse is not finite
 __global__ void k_smc_normalize(double *lw, double *w, long long n, const FgSmcScalars *st) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1235,30 +1235,6 @@ struct Reducer {     // scratch for the two-pass reductions
     }
     void free_all() { if (part_max) (void)hipFree(part_max); if (part_sum) (void)hipFree(part_sum); if (ess_part) (void)hipFree(ess_part); if (ess2) (void)hipFree(ess2);
                       part_max = part_sum = ess_part = ess2 = nullptr; }
-    // next_beta for uniform incoming weights (adaptive_smc: always) -> st->bnew.  beta_ptr: device address of the current beta.  The
-    // host looks at the bracket once, after the pass that folds in the decision about b = 1: a step that ends the ladder (ESS(1)
-    // >= target -- every run's last step) skips the other twenty launches.
-    int next_beta_uniform(hipStream_t s, const double *ll, long long n, FgSmcScalars *st, const double *beta_ptr, double target, double lw0) {
-        double *part = ess2, *lmax = ess2 + (size_t)2 * ESS2_BLOCKS * ESS_MAXC * 2;
-        FgEssBracket *brk = (FgEssBracket *)(lmax + 2);
-        const int nb = (int)std::min<long long>(ESS2_BLOCKS, (n + ESS2_THREADS - 1) / ESS2_THREADS);
-        hipLaunchKernelGGL(k_smc_red_max, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, ll, (const double *)nullptr, n, (const double *)&st->one, (const double *)&st->one, part_max);
-        int last = 0;
-        const int n_pass = 22;                               // pass 0: b = 1 and levels 1-3; passes 1..20: three levels each; pass 21: the 64th
-        for (int pass = 0; pass < n_pass; ++pass) {
-            hipLaunchKernelGGL(k_smc_ess2_pass, dim3(nb), dim3(ESS2_THREADS), 0, s, ll, n, pass, beta_ptr, target, (const double *)part_max, RED_BLOCKS, brk, part, lmax, (int *)nullptr, 0, 0);
-            last = pass;
-            if (pass == 1) {
-                FgEssBracket hb;
-                HIPCHK(hipMemcpyAsync(&hb, &brk[1], sizeof(hb), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-                if (hb.done) break;
-            }
-        }
-        hipLaunchKernelGGL(k_smc_ess2_final, dim3(1), dim3(ESS2_THREADS), 0, s, n, last, nb, beta_ptr, target, brk, (const double *)part, (const double *)lmax, st, lw0, part_max, RED_BLOCKS);
-        HIPCHK(hipGetLastError());
-        return FG_OK;
-    }
     // the passes alone: part_max[0 .. n_pmax) holds block maxima of ll (their producer's: k_smc_split_acc_max or the step's last
     // rejuvenation sweep); what follows them is k_smc_ess2_apply.  The host looks at pass 1's bracket through pinned memory.
     int ess2_passes(hipStream_t s, const double *ll, long long n, const double *beta_ptr, double target, int n_pmax, FgSmcHostScalars *hs_host,
@@ -1298,7 +1274,7 @@ struct Reducer {     // scratch for the two-pass reductions
         *last_out = launched - 1; *nb_out = nb;
         return FG_OK;
     }
-    // the reweight's log-sum-exp right after next_beta_uniform: its maximum is already in part_max
+    // the reweight's log-sum-exp behind k_smc_ess2_final (the beta' = beta + 1e-9 corner): its maximum is already in part_max
     int run_sum_only(hipStream_t s, const double *lw, const double *ll, long long n, FgSmcScalars *st, const double *b_ptr, int phase) {
         hipLaunchKernelGGL(k_smc_red_sum, dim3(RED_BLOCKS), dim3(RED_THREADS), 0, s, lw, ll, n, b_ptr, (const double *)&st->beta,
                            (const double *)part_max, part_sum);
@@ -1552,10 +1528,11 @@ int fg_smc_run(fg_engine *e, const fg_smc_config *cfg, double *h_log_w, double *
             SMC_TRY(R.ess2_passes(s, M.ll, N, beta_in, h.target_ess, n_pmax, hs, hs_dev, e->smc_epoch, &last, &nb, &ends_at_one));
             // the last decision, reweight + evidence (smc.rs:512-529), weights and the chunk totals of the resampling prefix sum: one launch
             hipLaunchKernelGGL(k_smc_ess2_apply, dim3((unsigned)n_chunks), dim3(SCAN_THREADS), 0, s, (const double *)M.ll, N, last, nb, h.target_ess,
-                               (const FgEssBracket *)brk, (const double *)R.ess2, (const double *)lmax, st, beta_in, beta_out, lw0, d_lw, d_w, SC.chunk, WS.d_chunk2, hs_dev);
+                               (const FgEssBracket *)brk, (const double *)R.ess2, (const double *)lmax, st, beta_in, beta_out, lw0, d_lw, d_w, SC.chunk, WS.d_chunk2, hs_dev,
+                               (std::getenv("FG_SMC_FORCE_SUM") && std::atoi(std::getenv("FG_SMC_FORCE_SUM")) != 0) ? 1 : 0);
             SMC_HIP(hipGetLastError());
             // ESS(1) >= target (pass 1 said so): beta' = 1 ends the ladder -- nothing to look at before the final normalisation is queued
-            const bool ends = ends_at_one && steps < 10000;
+            const bool ends = ends_at_one && steps < 10000 && !(std::getenv("FG_SMC_FORCE_SUM") && std::atoi(std::getenv("FG_SMC_FORCE_SUM")) != 0);
             if (!ends) SMC_HIP(smc_wait(s));
             const bool fused = ends || hs->need_sum == 0;
             if (ends) { beta = 1.0; have_evidence = true; evidence_late = true; fin_ready = true; }

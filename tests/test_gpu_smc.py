@@ -215,3 +215,23 @@ def test_next_beta_zoom_passes_agree_with_the_plain_passes():
     for name, s0, s1, db, dz in rows:
         assert s0 == s1, (name, s0, s1)
         assert float(db) <= 1e-14 and float(dz) <= 1e-12, (name, db, dz)
+
+
+def test_smc_separate_kernels_path_agrees_with_the_fused_launch(monkeypatch):
+    """What follows next_beta's last pass is one launch (k_smc_ess2_apply) unless beta' = beta + 1e-9 -- no candidate of any pass -- when the
+    separate maximum / sum / finish / apply / scan kernels take the step.  FG_SMC_FORCE_SUM=1 sends every step down that path: the same
+    ladder, the evidence and the weights to rounding (the fused launch takes the reweight's sum from the pass that evaluated beta')."""
+    cp = E.compile_model(W.normal_sites(8))
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("FG_SMC_FORCE_SUM", force)
+        eng = E.Engine(cp, 20000, seed=9)
+        r = eng.smc_run(rejuvenation_steps=2, ess_threshold=0.5)
+        out.append(r)
+        eng.close()
+    a, b = out
+    assert len(a["betas"]) >= 3 and np.array_equal(a["betas"], b["betas"])
+    assert a["log_evidence"] == pytest.approx(b["log_evidence"], rel=1e-13)
+    bad = ~np.isclose(a["values"].view(np.float64), b["values"].view(np.float64), rtol=1e-12, atol=0).all(axis=0)
+    assert bad.sum() <= 2, int(bad.sum())                 # (a resampling threshold within rounding of a cumulative weight)
+    np.testing.assert_allclose(a["weights"][~bad], b["weights"][~bad], rtol=1e-10)
