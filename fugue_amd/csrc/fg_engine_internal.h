@@ -84,7 +84,7 @@ struct fg_engine {
     int *d_mwi_order = nullptr; long long *d_mwi_prof = nullptr; std::vector<int> mwi_off, mwi_off_an; std::vector<long long> mwi_cost; int mwi_W = 0, mwi_sparse = -1, mwi_calibrated = 0;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
     int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; bool mhi_setup_done = false; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr; std::vector<int> mhi_stmt_end; std::vector<unsigned char> mhi_acc_host;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
     int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)
-    hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr, jit_fn_rejuv = nullptr, jit_fn_prior = nullptr, jit_fn_lj = nullptr; std::string jit_log; bool jit_lds_attr = false, jit_rejuv_attr = false, jit_has_ad = false, an_jit = false /* FG_GRAD_ANALYTIC runs on the compiled unit's derivative code */; double *d_jit_tab = nullptr, *d_jit_mh_tab = nullptr;   // the modules' constant tables (fg_jit_bind_tables)
+    hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr, jit_fn_rejuv = nullptr, jit_fn_prior = nullptr, jit_fn_lj = nullptr; std::string jit_log; bool jit_lds_attr = false, jit_rejuv_attr = false, jit_has_ad = false, jit_has_dense = false, an_jit = false /* FG_GRAD_ANALYTIC runs on the compiled unit's derivative code */; double *d_jit_tab = nullptr, *d_jit_mh_tab = nullptr;   // the modules' constant tables (fg_jit_bind_tables)
     int mh_ncu = -1, mh_catu_same = 0; double mh_catu_c0 = 0.0; double *d_mh_catu_c = nullptr; void *d_mh_catu = nullptr;   // row-less uniform Categorical terms of the multi-wave MH kernel (FgMhSeg; -1: not decided)
     int jit_mhns_state = 0, jit_mhns_split = 0; hipModule_t jit_mhns_mod = nullptr; hipFunction_t jit_mhns_fn = nullptr; double *d_jit_mhns_tab = nullptr;   // ... the same kernel for a program without a score stream
     int jit_mhmw_state = 0; hipModule_t jit_mhmw_mod = nullptr; hipFunction_t jit_mhmw_fn = nullptr; double *d_jit_mhmw_tab = nullptr;   // ... the multi-wave stream MH kernel with phase B generated (fg_mh.hip)

@@ -345,8 +345,8 @@ static int jit_hmc_module(fg_engine *e) {
         for (int k = 0; k < e->d; ++k) if (e->prog->coord[k].slot != k) return FG_E_UNSUPPORTED;
         if (e->prog->sub.size() + e->prog->ins_fast.size() > 64000000) return FG_E_UNSUPPORTED;
         std::vector<double> ctab;
-        bool has_ad = false;
-        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad);
+        bool has_ad = false, has_dense = false;
+        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
@@ -364,7 +364,7 @@ static int jit_hmc_module(fg_engine *e) {
         // (optional entry points: a unit whose generic program the generator does not cover has no k_prior_jit)
         if (hipModuleGetFunction(&e->jit_fn_prior, e->jit_mod, "k_prior_jit") != hipSuccess) { e->jit_fn_prior = nullptr; (void)hipGetLastError(); }
         if (hipModuleGetFunction(&e->jit_fn_lj, e->jit_mod, "k_log_joint_jit") != hipSuccess) { e->jit_fn_lj = nullptr; (void)hipGetLastError(); }
-        e->jit_state = 1; e->jit_has_ad = has_ad;
+        e->jit_state = 1; e->jit_has_ad = has_ad; e->jit_has_dense = has_dense;
     }
     return FG_OK;
 }
@@ -423,8 +423,9 @@ int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars 
 
 // ... and the task split of its HMC kernels; FG_E_UNSUPPORTED when there is none
 static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
-    if (e->cfg.grad_mode == FG_GRAD_FD_DENSE) return FG_E_UNSUPPORTED;
     if (int rc = jit_hmc_module(e)) return rc;
+    const bool dense = e->cfg.grad_mode == FG_GRAD_FD_DENSE;
+    if (dense && !e->jit_has_dense) return FG_E_UNSUPPORTED;      // (d copies of the program were too much to compile: the interpreter kernels)
     const int n_tasks = 2 * e->d;
     {   // LDS: S site rows + d momentum rows + 2 d evaluation rows + exchange rows; beyond 64 KB the module's functions need the attribute
         const size_t lds_max = (size_t)((long long)e->S + 3LL * e->d + 2 + FG_MWI_MAX) * FG_WAVE * sizeof(double);
@@ -439,9 +440,10 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         HIPCHK(hipMalloc((void **)&e->d_mwi_order, (size_t)2 * n_tasks * sizeof(int)));      // (the second half: the split of the analytic mode)
         HIPCHK(hipMalloc((void **)&e->d_mwi_prof, (size_t)n_tasks * sizeof(long long)));
     }
-    if (e->mwi_sparse != 2 || e->mwi_W <= 0) {             // (2: the split of the compiled kernel)
+    const int split_key = dense ? 4 : 2;                   // (2: the split of the compiled kernel; 4: its dense mode -- every task is the whole program)
+    if (e->mwi_sparse != split_key || e->mwi_W <= 0) {
         e->mwi_cost.assign(e->d, 1);
-        for (int k = 0; k < e->d; ++k) {
+        for (int k = 0; k < e->d && !dense; ++k) {
             long long cs = 0;
             for (int q = 0; q < e->prog->coord[k].sub_n; ++q) cs += mwi_ins_cost(e->prog->sub[e->prog->coord[k].sub_off + q]);
             e->mwi_cost[k] = std::max(1LL, cs);
@@ -476,7 +478,7 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         }
         HIPCHK(hipMemcpyAsync(e->d_mwi_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        e->mwi_W = W; e->mwi_sparse = 2;
+        e->mwi_W = W; e->mwi_sparse = split_key;
     }
     return FG_OK;
 }
@@ -508,6 +510,6 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     int n_warmup = e->n_warmup;
     void *args[] = { &e->P, &e->X, &e->H, &seg, &iter0, &n, &n_warmup, &welford_on, &draws, &first_sample_t, &pos_all, &info };
     HIPCHK(hipModuleLaunchKernel(e->jit_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds_for(W), e->stream, args, nullptr));
-    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + " (compiled at run time)";
+    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + (e->cfg.grad_mode == FG_GRAD_FD_DENSE ? " (dense; compiled at run time)" : " (compiled at run time)");
     return FG_OK;
 }

@@ -37,6 +37,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     const double h = H.h;
     const bool analytic = H.grad_mode == 2 /* FG_GRAD_ANALYTIC */;      // (the step-size search keeps the finite difference, like the stream kernels')
+    const bool dense = H.grad_mode == 0 /* FG_GRAD_FD_DENSE */; (void)dense;
     for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
@@ -80,6 +81,9 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
                 if (analytic) { if (!(task & 1)) ev_lp[task * tw] = fg_jit_dtask(k, FG_JIT_LDS(slots)); continue; }
 #endif
                 const double orig = slots[k * tw];
+#ifdef FG_JIT_HAS_DENSE    /* FG_GRAD_FD_DENSE: the whole log-joint at q +- h e_k (grad_log_joint verbatim, hmc.rs:304-329) */
+                if (dense) { ev_lp[task * tw] = fg_jit_dense_task(k, (task & 1) ? orig - h : orig + h, FG_JIT_LDS(slots)); continue; }
+#endif
                 ev_lp[task * tw] = fg_jit_task(k, (task & 1) ? orig - h : orig + h, FG_JIT_LDS(slots));      // hmc.rs:317-321
             }
             __syncthreads();                                  // every evaluation of this gradient done, every read of q done

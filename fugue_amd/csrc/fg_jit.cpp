@@ -591,7 +591,7 @@ static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vty
 static bool fg_jit_inlined() { const char *v = std::getenv("FG_JIT_INLINE"); return v && std::atoi(v) != 0; }
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
-std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out) {
+std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out, bool *has_dense_out) {
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
     std::vector<std::string> tables;
@@ -635,6 +635,32 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         fns += "static __device__ __noinline__ void fg_jit_score(const FG_LDSQ double *slots, double &pr_out, double &lk_out, double &fc_out) {\n    const double pert = 0.0; (void)pert;\n" + g.decls() + g.body +
                "    (void)acc;\n    pr_out = pr; lk_out = lk; fc_out = fc;\n}\n";
     }
+    // FG_GRAD_FD_DENSE (grad_log_joint verbatim, hmc.rs:304-329): the WHOLE program at q +- h e_k, one function per coordinate with the
+    // reads of its slot replaced (plates stay rolled: their constant tables are shared between the d copies).  Only while d copies of the
+    // program stay compilable in seconds; beyond that the dense mode keeps the interpreter kernels.
+    bool has_dense = false;
+    {
+        size_t n_stmt = 0;
+        for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) ++n_stmt;
+        if (d >= 1 && (size_t)d * (size_t)p->n_ins <= 60000 && !(std::getenv("FG_JIT_DENSE") && std::atoi(std::getenv("FG_JIT_DENSE")) == 0)) {
+            std::string ffns;
+            has_dense = true;
+            for (int k = 0; k < d && has_dense; ++k) {
+                Gen g{*p}; g.pert_slot = p->coord[k].slot; g.lp_fns = &lp_fns; g.tables = &tables; g.ctabs = &ctabs;
+                g.emit(p->ins_fast, 0, (size_t)p->n_ins);
+                if (!g.ok) { has_dense = false; break; }
+                ffns += "static __device__ __noinline__ double fg_jit_full_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
+                        "    (void)acc;\n    return pr + lk + fc;\n}\n";
+            }
+            if (has_dense) {
+                fns += ffns;
+                fns += "#define FG_JIT_HAS_DENSE 1\nstatic __device__ __forceinline__ double fg_jit_dense_task(int k, double pert, const FG_LDSQ double *slots) {\n    switch (k) {\n";
+                for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_full_" + std::to_string(k) + "(pert, slots);\n";
+                fns += "    default: return 0.0;\n    }\n}\n";
+            }
+        }
+    }
+    if (has_dense_out) *has_dense_out = has_dense;
     {   // run(PriorHandler) (interpreters.rs:88-104) from the generic program: every sample statement draws, then scores (k_prior_jit)
         Gen g{*p}; g.lp_fns = &lp_fns; g.tables = &tables; g.prior = true;
         for (size_t q = 0; q < (size_t)p->n_ins && q < p->ins.size() && g.ok; ++q) {     // (the program ends with a stop instruction behind n_ins)

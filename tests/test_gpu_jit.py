@@ -37,6 +37,36 @@ def test_jit_hmc_is_bit_identical_to_the_interpreter(name, adapt_mass, monkeypat
     assert np.isfinite(out[0][0]).all()
 
 
+@pytest.mark.parametrize("name,adapt_mass", [("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("logistic", False), ("coin", False), ("hier_scale", False),
+                                             ("mixture", True), ("rand3", False)])
+def test_jit_dense_mode_is_bit_identical_to_the_interpreter(name, adapt_mass, monkeypatch):
+    """FG_GRAD_FD_DENSE -- grad_log_joint verbatim (hmc.rs:304-329): two WHOLE log-joints per coordinate and gradient -- through the unit
+    compiled at run time (fg_jit_full_k: the whole program with the reads of coordinate k's slot replaced, one function per coordinate)
+    against the interpreter kernels, W = 1 ... 16: programs without a record stream, and stream programs whose dense mode the dense
+    stream does not take (general records, option selects)."""
+    cp = E.compile_model(ZOO[name]())
+    C, nw, ns = 130, 24, 12
+    out, kernels = [], []
+    for jit, W in [(0, 0), (1, 0), (1, 1), (1, 3), (1, 16)]:
+        monkeypatch.setenv("FG_JIT", str(jit))
+        if W: monkeypatch.setenv("FG_HMC_INTERP_WAVES", str(W))
+        else: monkeypatch.delenv("FG_HMC_INTERP_WAVES", raising=False)
+        eng = E.Engine(cp, C, seed=31, chain_offset=2)
+        d = eng.device_alloc(ns * cp.d * C * 8)
+        st = eng.hmc_run(E.hmc_config(n_leapfrog=4, adapt_mass=adapt_mass, grad_mode=E.GRAD_FD_DENSE), ns, nw, d)
+        kernels.append(eng.hmc_last_kernel())
+        draws = eng.download(d, (ns, cp.d, C))
+        eng.device_free(d)
+        out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
+                    eng.hmc_mass() if adapt_mass else None))
+        eng.close()
+    assert not kernels[0].startswith("k_hmc_jit_steps") and all(k.startswith("k_hmc_jit_steps W=") and "dense" in k for k in kernels[1:]), kernels
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert np.isfinite(out[0][0]).all()
+
+
 @pytest.mark.parametrize("name,adapt_mass", [("hier_scale", True), ("mixture", False), ("linreg", True), ("refmodel8", False), ("hier", True), ("ridge7", False),
                                              ("rand1", False), ("rand3", True), ("rand4", False)])
 def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkeypatch):
