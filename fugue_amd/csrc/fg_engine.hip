@@ -1059,6 +1059,14 @@ static int hmc_launch_steps(fg_engine *e, int iter0, int n, int welford_on, doub
             if (rc != FG_E_UNSUPPORTED) return rc;
         }
     }
+    if (e->cfg.grad_mode == FG_GRAD_FD_DENSE && e->P.gstream && e->jit_state >= 0) {
+        // The dense mode of gradient-stream programs: the whole program per (coordinate, sign) as generated code (fg_jit_full_k) beats the dense
+        // stream at every size measured (reference_model(32) 3.6e8 -> 7.6e8 leapfrog-steps/s, reference_model(8) 4.6e9 -> 8.9e9, hier 2.6e9 ->
+        // 5.5e9; at 8 192 chains 1.7e8 -> 3.7e8, 1.1e9 -> 3.6e9, 4.4e8 -> 2.5e9: profiles/round4_jit_dense.txt), bit-identical; FG_JIT=0 (or
+        // a program whose d copies are too much to compile) keeps the dense stream / the interpreter kernels.
+        const int rc = fg_hmc_jit_launch(e, iter0, n, welford_on, draws, first_sample_t, pos_all, info);
+        if (rc != FG_E_UNSUPPORTED) return rc;
+    }
     if ((((e->cfg.grad_mode == FG_GRAD_FD_SPARSE || analytic) && e->P.gstream) || dense_stream) && e->tw == FG_WAVE && !e->gt) {
         // waves per tile: aim at 4 waves per SIMD (16 per CU, see k_hmc_stream_steps).  The LDS tile caps the tiles
         // resident on a CU (160 KB / lds_bytes -- 4 for the 32-site model), so the waves have to come from sharing

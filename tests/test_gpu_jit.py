@@ -38,12 +38,12 @@ def test_jit_hmc_is_bit_identical_to_the_interpreter(name, adapt_mass, monkeypat
 
 
 @pytest.mark.parametrize("name,adapt_mass", [("alldists", True), ("poisson_glm", False), ("hier_logsigma", True), ("logistic", False), ("coin", False), ("hier_scale", False),
-                                             ("mixture", True), ("rand3", False)])
+                                             ("mixture", True), ("rand3", False), ("refmodel8", True), ("hier", False), ("linreg", True), ("ridge7", False)])
 def test_jit_dense_mode_is_bit_identical_to_the_interpreter(name, adapt_mass, monkeypatch):
     """FG_GRAD_FD_DENSE -- grad_log_joint verbatim (hmc.rs:304-329): two WHOLE log-joints per coordinate and gradient -- through the unit
     compiled at run time (fg_jit_full_k: the whole program with the reads of coordinate k's slot replaced, one function per coordinate)
-    against the interpreter kernels, W = 1 ... 16: programs without a record stream, and stream programs whose dense mode the dense
-    stream does not take (general records, option selects)."""
+    against what FG_JIT=0 runs, W = 1 ... 16: the interpreter kernels for programs without a record stream and for stream programs with
+    general records / option selects, the dense stream (k_hmc_stream_steps) for programs of fast-Normal records."""
     cp = E.compile_model(ZOO[name]())
     C, nw, ns = 130, 24, 12
     out, kernels = [], []
@@ -93,15 +93,17 @@ def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkey
 
 
 def test_jit_is_not_used_where_a_faster_kernel_exists(monkeypatch):
-    """Independent-sites programs and dense regressions keep their hand-written kernels (whole trajectories in registers, the
-    observation-major gradient); the dense mode (the reference's whole-program finite difference) keeps the interpreter."""
+    """Independent-sites programs and dense regressions keep their hand-written kernels (whole trajectories in registers -- in the sparse
+    AND in the dense mode --, the observation-major gradient).  The dense mode of every other program is the compiled unit's since round 4
+    (the whole program per coordinate: test_jit_dense_mode_is_bit_identical_to_the_interpreter)."""
     monkeypatch.delenv("FG_JIT", raising=False)
-    for name, mode in [("normal32", E.GRAD_FD_SPARSE), ("ridge8", E.GRAD_FD_SPARSE), ("poisson_glm", E.GRAD_FD_DENSE)]:
+    for name, mode, jit in [("normal32", E.GRAD_FD_SPARSE, False), ("normal32", E.GRAD_FD_DENSE, False), ("ridge8", E.GRAD_FD_SPARSE, False),
+                            ("poisson_glm", E.GRAD_FD_DENSE, True), ("refmodel8", E.GRAD_FD_DENSE, True)]:
         cp = E.compile_model(ZOO[name]())
         eng = E.Engine(cp, 64, seed=1)
         eng.hmc_init(E.hmc_config(grad_mode=mode, n_leapfrog=3), 2)
         eng.hmc_step(2)
-        assert not eng.hmc_last_kernel().startswith("k_hmc_jit_steps"), (name, eng.hmc_last_kernel())
+        assert eng.hmc_last_kernel().startswith("k_hmc_jit_steps") == jit, (name, eng.hmc_last_kernel())
         eng.close()
 
 
