@@ -642,7 +642,7 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
     {
         size_t n_stmt = 0;
         for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) ++n_stmt;
-        if (d >= 1 && (size_t)d * (size_t)p->n_ins <= 60000 && !(std::getenv("FG_JIT_DENSE") && std::atoi(std::getenv("FG_JIT_DENSE")) == 0)) {
+        if (d >= 1 && (size_t)d * (size_t)p->n_ins <= 24000 && !(std::getenv("FG_JIT_DENSE") && std::atoi(std::getenv("FG_JIT_DENSE")) == 0)) {
             std::string ffns;
             has_dense = true;
             for (int k = 0; k < d && has_dense; ++k) {
@@ -652,6 +652,7 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
                 ffns += "static __device__ __noinline__ double fg_jit_full_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
                         "    (void)acc;\n    return pr + lk + fc;\n}\n";
             }
+            if (has_dense && fns.size() + ffns.size() > (2u << 20)) has_dense = false;     // (the unit as a whole must stay well inside what compiles in seconds: the sparse mode is the default's)
             if (has_dense) {
                 fns += ffns;
                 fns += "#define FG_JIT_HAS_DENSE 1\nstatic __device__ __forceinline__ double fg_jit_dense_task(int k, double pert, const FG_LDSQ double *slots) {\n    switch (k) {\n";
