@@ -141,7 +141,7 @@ int dev_upload(T **p, const std::vector<T> &v) {
 
 // fg_hmc_interp.hip: adaptive_smc's rejuvenation move through the model compiled at run time (FG_E_UNSUPPORTED: the interpreter kernel)
 struct FgSmcDev; struct FgSmcScalars;
-int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars *st, uint32_t move_id, unsigned *n_blk_out);
+int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars *st, uint32_t move_id, unsigned *n_blk_out, const long long *vsrc = nullptr, double *pmax = nullptr);
 int fg_jit_prior_launch(fg_engine *e, uint32_t iteration, uint32_t purpose, double *d_acc, double *d_lj, bool compile);   // k_prior_jit, or FG_E_UNSUPPORTED
 int fg_jit_log_joint_launch(fg_engine *e, double *d_acc, double *d_lj, bool compile);                                     // k_log_joint_jit, or FG_E_UNSUPPORTED
 bool fg_hmc_jit_has_ad(fg_engine *e);      // the compiled module holds the forward-mode derivative of every sub-program (FG_GRAD_ANALYTIC for any program)

@@ -402,7 +402,7 @@ bool fg_hmc_jit_has_ad(fg_engine *e) { return jit_hmc_module(e) == FG_OK && e->j
 
 // adaptive_smc's rejuvenation move of a program without a score stream through the compiled model (k_smc_jit_rejuv, fg_hmc_jit_body.h);
 // FG_E_UNSUPPORTED: the interpreter kernel k_smc_rejuv<-1> takes it.  n_blk_out: blocks launched (rows of M.blk that k_smc_adapt adds).
-int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars *st, uint32_t move_id, unsigned *n_blk_out) {
+int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars *st, uint32_t move_id, unsigned *n_blk_out, const long long *vsrc, double *pmax) {
     if (e->S > FG_SMC_HIST) return FG_E_UNSUPPORTED;
     if (int rc = jit_hmc_module(e)) return rc;
     const size_t tile = (size_t)e->S * FG_WAVE * sizeof(double);
@@ -415,7 +415,7 @@ int fg_smc_jit_rejuv_launch(fg_engine *e, const FgSmcDev &M, const FgSmcScalars 
     }
     const unsigned nblk = (unsigned)((e->C + (long long)FG_WAVE * wpb - 1) / ((long long)FG_WAVE * wpb));
     FgSmcDev Mv = M;
-    void *args[] = { &e->P, &e->X, &Mv, &st, &move_id };
+    void *args[] = { &e->P, &e->X, &Mv, &st, &move_id, &vsrc, &pmax };
     HIPCHK(hipModuleLaunchKernel(e->jit_fn_rejuv, nblk, 1, 1, FG_WAVE * wpb, 1, 1, (unsigned)lds, e->stream, args, nullptr));
     if (n_blk_out) *n_blk_out = nblk;
     return FG_OK;

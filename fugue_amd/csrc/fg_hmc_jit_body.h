@@ -273,9 +273,11 @@ void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, 
 // (fg_smc.hip) with the two scoring runs of a move as fg_jit_score instead of the interpreter -- the same operations in the same order,
 // so the same particles, decisions and counts (tests/test_gpu_jit.py).  One tile (S site rows) per wave, `blockDim.x / 64` tiles per block.
 extern "C" __global__ __launch_bounds__(FG_WAVE * 16)
-void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st, uint32_t move_id) {
+void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalars *st, uint32_t move_id, const long long *vsrc /* the resampled population, or null: X.values */,
+                     double *pmax /* the block maxima of the new log-likelihoods, or null (fg_smc.hip: k_smc_rejuv's two extras) */) {
     extern __shared__ double lds[];
     __shared__ unsigned int hist[2][FG_SMC_HIST];                   // the block's proposal / accept counts per site
+    __shared__ double shmax[16];
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1), wv = (int)(threadIdx.x >> 6);
     for (int j = (int)threadIdx.x; j < 2 * FG_SMC_HIST; j += (int)blockDim.x) (&hist[0][0])[j] = 0u;
@@ -284,7 +286,8 @@ void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalar
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
     double *slots = lds + (long long)wv * P.S * tw + lane;                // one tile per wave: the site rows (expression temporaries are registers here)
-    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    const long long *vin = vsrc ? vsrc : X.values;
+    for (int j = 0; j < P.S; ++j) slots[P.site_slot[j] * tw] = fg_as_double(vin[(long long)j * X.C + c]);
     const double beta = st->beta;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     FgStream rng = fg_stream(X.seed, gchain, move_id, FG_RNG_SMC_REJUV);
@@ -306,10 +309,17 @@ void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalar
     const double log_alpha = (pri[1] - pri[0]) + beta * (lik[1] - lik[0]);                   // smc.rs:678-679
     const double u = fg_cold_u01_pair(sk0, sk1, gchain, 2u, move_id, FG_RNG_SMC_REJUV).a;     // block 2
     const bool accept = (log_alpha >= 0.0) || (u < fg_cold_exp(log_alpha));                  // smc.rs:680
+    const double ll_new = accept ? lik[1] : lik[0];
     if (live) {
+        if (vsrc) for (int j = 0; j < P.S; ++j) X.values[(long long)j * X.C + c] = vsrc[(long long)j * X.C + c];
         if (accept) X.values[(long long)site * X.C + c] = fg_as_i64(prop);
         M.lprior[c] = accept ? pri[1] : pri[0];               // the freshly scored trace is returned either way
-        M.ll[c] = accept ? lik[1] : lik[0];
+        M.ll[c] = ll_new;
+    }
+    if (pmax) {                                               // (fmax from -inf, like k_smc_red_max)
+        double m = live ? ll_new : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+        if (lane == 0) shmax[wv] = m;
     }
     unsigned long long todo = __ballot(live);
     const unsigned long long acc_mask = __ballot(live && accept);
@@ -327,6 +337,7 @@ void k_smc_jit_rejuv(FgProgramDev P, FgChainCtx X, FgSmcDev M, const FgSmcScalar
     __syncthreads();
     unsigned int *row = M.blk + (long long)blockIdx.x * 2 * M.S;
     for (int j = (int)threadIdx.x; j < M.S; j += (int)blockDim.x) { row[j] = hist[0][j]; row[M.S + j] = hist[1][j]; }
+    if (pmax && threadIdx.x == 0) { double m = shmax[0]; for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmax(m, shmax[k]); pmax[blockIdx.x] = m; }
 }
 
 

@@ -179,10 +179,11 @@ def test_jit_mh_pipelined_kernel_for_programs_without_a_stream(name, with_overri
 
 
 
-@pytest.mark.parametrize("name", ["alldists", "poisson_glm", "hier_logsigma", "logistic"])
+@pytest.mark.parametrize("name", ["alldists", "poisson_glm", "hier_logsigma", "logistic", "hier_scale", "mixture", "linreg"])
 def test_jit_smc_rejuvenation_is_identical_to_the_interpreter(name, monkeypatch):
-    """adaptive_smc on a program without a score stream: the rejuvenation move's two scoring runs through the model compiled at run time
-    (k_smc_jit_rejuv) against the interpreter kernel (k_smc_rejuv<-1>) -- the same ladder, evidence, particles and weights, bit for bit."""
+    """adaptive_smc: the rejuvenation move's two scoring runs through the model compiled at run time (k_smc_jit_rejuv) against what FG_JIT=0
+    runs -- the interpreter kernel (k_smc_rejuv<-1>) for a program without a score stream, the score-stream kernels (k_smc_rejuv<2 / 3>) for
+    stream programs with general / option-select / linear-predictor records -- the same ladder, evidence, particles and weights, bit for bit."""
     cp = E.compile_model(ZOO[name]())
     out = []
     for jit in ("0", "1"):
