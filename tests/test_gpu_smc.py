@@ -235,3 +235,17 @@ def test_smc_separate_kernels_path_agrees_with_the_fused_launch(monkeypatch):
     bad = ~np.isclose(a["values"].view(np.float64), b["values"].view(np.float64), rtol=1e-12, atol=0).all(axis=0)
     assert bad.sum() <= 2, int(bad.sum())                 # (a resampling threshold within rounding of a cumulative weight)
     np.testing.assert_allclose(a["weights"][~bad], b["weights"][~bad], rtol=1e-10)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_adaptive_smc_edge_population_sizes(method):
+    """Populations around every grain of the kernels -- one particle, a wave, a scan chunk of 2 048, their neighbours, a prime -- for the
+    three resamplers: a finite evidence, weights that sum to one, a strictly increasing ladder that ends at one."""
+    cp = E.compile_model(W.normal_sites(8))
+    for N in (1, 2, 63, 64, 65, 2047, 2048, 2049, 4097, 100003):
+        eng = E.Engine(cp, N, seed=11)
+        r = eng.smc_run(rejuvenation_steps=2, ess_threshold=0.5, resampling_method=method)
+        eng.close()
+        assert np.isfinite(r["log_evidence"]), N
+        assert abs(r["weights"].sum() - 1.0) < 1e-9 and (r["weights"] >= 0).all(), N
+        assert r["betas"][-1] == 1.0 and (np.diff(r["betas"]) > 0).all(), (N, r["betas"])
