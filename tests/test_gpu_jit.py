@@ -197,6 +197,24 @@ def test_jit_smc_rejuvenation_is_identical_to_the_interpreter(name, monkeypatch)
         assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
+@pytest.mark.parametrize("name", ["refmodel8", "hier"])
+def test_jit_smc_of_a_large_population_is_identical(name, monkeypatch):
+    """From 262 144 particles on adaptive_smc builds the compiled unit for the prior draw and then rejuvenates through it whatever the
+    program's records (fast-Normal score streams included): against FG_JIT=0 (k_prior_init, k_smc_rejuv<0>) the same ladder, evidence,
+    particles and weights, bit for bit."""
+    cp = E.compile_model(ZOO[name]())
+    out = []
+    for jit in ("0", "1"):
+        monkeypatch.setenv("FG_JIT", jit)
+        eng = E.Engine(cp, 1 << 18, seed=19)
+        r = eng.smc_run(rejuvenation_steps=2, ess_threshold=0.5)
+        out.append((r["betas"], r["log_evidence"], r["values"], r["weights"], r["n_model_runs"]))
+        eng.close()
+    assert len(out[0][0]) >= 2
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 @pytest.mark.parametrize("name", ["alldists", "poisson_glm", "hier_logsigma", "logistic", "coin", "mixture", "rand0", "rand3"])
 def test_jit_prior_draw_is_identical_to_the_interpreter(name, monkeypatch):
     """run(PriorHandler) through the model compiled at run time (k_prior_jit: every sample statement draws through the same fg_sample_dist
