@@ -963,7 +963,10 @@ static bool hmc_jit_preferred(const fg_engine *e) {
     const std::vector<FgGradRec> &gsj = e->prog->gstream;
     for (int k = 0; k < e->prog->n_gstream && rkj < 2; ++k) rkj = std::max(rkj, (gsj[k].flags & (FG_G_GEN | FG_G_NSEL | FG_G_CATC)) ? 2 : ((gsj[k].flags & FG_G_LIN) ? 1 : 0));
     const long long tiles = (e->C + e->tw - 1) / e->tw;
-    return forced || rkj >= 1 || tiles <= std::max(1, e->n_simd / 4);
+    // ... and for programs of fewer than eight coordinates: the stream kernel gives a tile at most two waves there (a wave owns whole coordinates, >= 4
+    // of them), the compiled unit deals 2 d (coordinate, sign) tasks over up to eight (hier, d = 6: 1.22e10 -> 1.40e10 leapfrog-steps/s at 65 536
+    // chains; one-coordinate programs with discrete sites 3.4 - 5.4e10 -> 6.4 - 7.5e10; reference_model(8), d = 8, four waves: the stream kernel keeps 16 %)
+    return forced || rkj >= 1 || e->d < 8 || tiles <= std::max(1, e->n_simd / 4);
 }
 
 static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
