@@ -258,7 +258,9 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             // statements, one segment per wave, win (reference_model(20): sampling 2.24e10 -> 2.70e10 at 65 536 chains, 3.9e9 -> 4.6e9 at 8 192;
             // reference_model(8) 3.0e10 -> 3.4e10 / 4.4e9 -> 5.6e9; normal32, reference_model(50) +13 %) -- not where phase B is table lookups
             // (C5: -19 %): profiles/round4_mh_generated_statements.txt.  FG_MH_GEN_ALL = 0 / 1 forces either.
-            bool gen_all = n_gen == 0 && n_s >= (std::getenv("FG_MH_GEN_MIN") ? std::atoi(std::getenv("FG_MH_GEN_MIN")) : 8) && e->mh_cls_off[2] == 0;              // (no class-0 / class-1 lookup records)
+            // ... and whatever the mix of pattern and general records, down to two statements (a survey of the test zoo at 65 536 chains,
+            // profiles/round4_zoo_mh.txt: a program of 5 pattern + 5 general records 2.3e10 -> 4.0e10, the README model 3.4e10 -> 4.0e10, none slower).
+            bool gen_all = n_s >= (std::getenv("FG_MH_GEN_MIN") ? std::atoi(std::getenv("FG_MH_GEN_MIN")) : 1) && e->mh_cls_off[2] == 0;              // (no class-0 / class-1 lookup records)
             if (const char *gv = std::getenv("FG_MH_GEN_ALL")) gen_all = std::atoi(gv) != 0;
             // one segment per wave of this launch shape (all of a wave's statements in one straight-line function) where every statement
             // is generated; the control wave takes `ctl16` sixteenths of a share

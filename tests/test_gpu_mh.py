@@ -167,7 +167,7 @@ def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeyp
     """The same kernel with the general records of its phase B (those fg_score_one evaluates; the operand-pattern runs of plain
     Normal records stay hand-written) generated from the program and compiled at run time (fg_jit_mhmw_source; sixteen statement
     segments dealt to the waves): the one-wave kernel's draws, state, scales, log-weights and accept counts, for every W.
-    Short programs of pattern records only keep the hand-written kernel."""
+    (Short programs of pattern records only kept the hand-written kernel until round 4's survey: profiles/round4_zoo_mh.txt.)"""
     if name == "hier_mixed":                            # pattern records (sigma = 1, 2) and general ones (sigma a site, sigma = 0.7) in one program
         prog = M.Program()
         tau = prog.sample(M.addr("tau"), M.Gamma(2.0, 1.5))
@@ -196,8 +196,8 @@ def test_mh_multiwave_kernel_with_compiled_statements_is_identical(name, monkeyp
         kernels.append(eng.mh_last_kernel())
         out.append((draws, eng.get_values(), eng.mh_scales(), eng.mh_log_weight(), st.accept_rate))
         eng.close()
-    # (a pattern-only program of >= 8 statements has its statements generated too since round 4; a two-statement one keeps the record runs)
-    want = ("k_mh_mw2_steps", "k_mh_mw_steps") if name == "readme" else ("k_mh_mw2_jit_steps", "k_mh_mw_jit_steps")
+    # (every program without lookup records has all its statements generated since round 4, the two-statement README model included)
+    want = ("k_mh_mw2_jit_steps", "k_mh_mw_jit_steps")
     assert all(k.startswith(want[0]) for k in kernels[1:6]) and all(k.startswith(want[1]) for k in kernels[6:]), kernels
     for o in out[1:]:
         for a, b in zip(out[0], o):
