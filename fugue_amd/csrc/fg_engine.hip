@@ -966,7 +966,9 @@ static bool hmc_jit_preferred(const fg_engine *e) {
     // ... and for programs of fewer than eight coordinates: the stream kernel gives a tile at most two waves there (a wave owns whole coordinates, >= 4
     // of them), the compiled unit deals 2 d (coordinate, sign) tasks over up to eight (hier, d = 6: 1.22e10 -> 1.40e10 leapfrog-steps/s at 65 536
     // chains; one-coordinate programs with discrete sites 3.4 - 5.4e10 -> 6.4 - 7.5e10; reference_model(8), d = 8, four waves: the stream kernel keeps 16 %)
-    return forced || rkj >= 1 || e->d < 8 || tiles <= std::max(1, e->n_simd / 4);
+    // (two tiles per CU or fewer: reference_model(8) at 32 768 chains 1.27e10 -> 1.57e10, reference_model(20) 6.7e9 -> 7.2e9; at 65 536 chains the stream
+    // kernel keeps 16 % on both -- profiles/round4_jit_vs_stream_sparse.txt)
+    return forced || rkj >= 1 || e->d < 8 || tiles <= 2 * std::max(1, e->n_simd / 4);
 }
 
 static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {
