@@ -315,7 +315,7 @@ struct FgLinDispatch<D, W, P2, HALF, W> {
 // HALF: 32 chains per workgroup (fg_lin_grad_half); everything outside the gradient runs in both lane halves on the same chain
 // (same values to the same LDS cells), only the lower half stores to global memory; the halves share the momentum pairs.
 template <int D, int W, bool P2, bool HALF>
-__global__ __launch_bounds__(FG_WAVE * W) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(FG_WAVE * W) __attribute__((amdgpu_waves_per_eu(D / W >= 8 ? 2 : 4, D / W >= 8 ? 2 : 4)))
 void k_hmc_lin_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, int iter0, int n_steps, int n_warmup, int welford_on, double *draws, int first_sample_t,
                      double *pos_all /*[n][d][C] or null*/, double *info /*[n][4][C] or null*/) {
     extern __shared__ double lds[];
@@ -471,34 +471,39 @@ int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     const unsigned tiles = (unsigned)((e->C + tw - 1) / tw);
     const size_t lds = (size_t)(e->n_slots + e->d + 2 + FG_LIN_WMAX) * tw * sizeof(double);
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
-    // waves per tile: D / 4 -- four coordinates per wave.  Two coordinates per wave (D / 2 waves) share a tile's products and
-    // prefix sums between fewer suffix chains (77 instead of 64 instructions per (coordinate, observation) pair) and measured
-    // slower at every chain count, also where they double the waves per SIMD (8 192 chains: 5.9e6 against 7.0e6 leapfrog-steps/s);
-    // FG_HMC_WAVES = D / 2 keeps that layout reachable for the bit-identity tests.
-    int W = D / 4;
-    if (D < 64 && (e->mw_override == D / 4 || e->mw_override == D / 2)) W = e->mw_override;
-    const int variant = D == 64 ? 24 + (e->P.lin_p2 ? 1 : 0) : 2 * ((D == 32 ? 0 : (D == 16 ? 4 : 8)) + (W == D / 2 ? 2 : 0) + (e->P.lin_p2 ? 1 : 0)) + (half ? 1 : 0);
-    static bool attr_set_dev[64][26];
-#define FG_LIN_KERNELS2(X, H, O) X(0 + O, 32, 8, false, H) X(2 + O, 32, 8, true, H) X(4 + O, 32, 16, false, H) X(6 + O, 32, 16, true, H) X(8 + O, 16, 4, false, H) \
-                                 X(10 + O, 16, 4, true, H) X(12 + O, 16, 8, false, H) X(14 + O, 16, 8, true, H) X(16 + O, 8, 2, false, H) X(18 + O, 8, 2, true, H) \
-                                 X(20 + O, 8, 4, false, H) X(22 + O, 8, 4, true, H)
-#define FG_LIN_KERNELS(X) FG_LIN_KERNELS2(X, false, 0) FG_LIN_KERNELS2(X, true, 1) X(24, 64, 16, false, false) X(25, 64, 16, true, false)
+    // waves per tile.  Every wave of a tile forms all D products and the shared prefix sums again, so fewer waves with more coordinates
+    // each execute fewer instructions per observation: W (2 D + 16 M) + D (D + 1) for M = D / W coordinates per wave.
+    //   M = 8 (D / 8 waves; 256 VGPRs, two waves per SIMD): the default for D >= 32 -- C3 at 65 536 chains 1.55e7 -> 1.69e7 leapfrog-steps/s, half tiles
+    //         at 8 192 chains 9.2e6 -> 1.12e7 (one wave per SIMD: a wave's 8 or 16 suffix sums are independent, they fill the issue slots), 64 coefficients
+    //         3.6e6 -> 4.2e6; D = 16 (two waves per tile) loses: 4.76e7 -> 4.72e7, half tiles 2.4e7 -> 1.7e7 (profiles/round4_lin_eight_per_wave.txt);
+    //   M = 4 (D / 4 waves; 128 VGPRs): round 3's layout, the default for D = 8, 16; M = 2 (D / 2 waves) measured slower at every chain count.
+    // FG_HMC_WAVES = D / 8, D / 4, D / 2 picks one for the bit-identity tests.
+    int W = D >= 32 ? D / 8 : D / 4;
+    if (e->mw_override == D / 4 || (D < 64 && e->mw_override == D / 2) || (D >= 16 && e->mw_override == D / 8)) W = e->mw_override;
+    const bool p2 = e->P.lin_p2 != 0;
+#define FG_LIN_KERNELS_D(X, DD, HH) X(DD, DD / 8, false, HH) X(DD, DD / 8, true, HH) X(DD, DD / 4, false, HH) X(DD, DD / 4, true, HH) X(DD, DD / 2, false, HH) X(DD, DD / 2, true, HH)
+#define FG_LIN_KERNELS(X) FG_LIN_KERNELS_D(X, 32, false) FG_LIN_KERNELS_D(X, 32, true) FG_LIN_KERNELS_D(X, 16, false) FG_LIN_KERNELS_D(X, 16, true)      \
+                          X(8, 2, false, false) X(8, 2, true, false) X(8, 4, false, false) X(8, 4, true, false) X(8, 2, false, true) X(8, 2, true, true)    \
+                          X(8, 4, false, true) X(8, 4, true, true) X(64, 8, false, false) X(64, 8, true, false) X(64, 16, false, false) X(64, 16, true, false)
     const void *fn = nullptr;
-#define FG_LIN_FN(V, DD, WW, PP, HH) if (variant == V) fn = (const void *)k_hmc_lin_steps<DD, WW, PP, HH>;
+    int variant = -1, idx = 0;
+#define FG_LIN_FN(DD, WW, PP, HH) if (D == DD && W == WW && p2 == PP && half == HH) { fn = (const void *)k_hmc_lin_steps<DD, WW, PP, HH>; variant = idx; } ++idx;
     FG_LIN_KERNELS(FG_LIN_FN)
 #undef FG_LIN_FN
+    if (!fn) return FG_E_UNSUPPORTED;
+    static bool attr_set_dev[64][64];
     bool &attr_set = attr_set_dev[e->device & 63][variant];
     if (!attr_set && lds > 64 * 1024) {
         const hipError_t he = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (he != hipSuccess) { fg_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(he)); return FG_E_HIP; }
         attr_set = true;
     }
-#define FG_LIN_GO(V, DD, WW, PP, HH) if (variant == V) hipLaunchKernelGGL((k_hmc_lin_steps<DD, WW, PP, HH>), dim3(tiles), dim3(FG_WAVE * WW), lds, e->stream, e->P, e->X, e->H, \
-                                                                           iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
+#define FG_LIN_GO(DD, WW, PP, HH) if (D == DD && W == WW && p2 == PP && half == HH) hipLaunchKernelGGL((k_hmc_lin_steps<DD, WW, PP, HH>), dim3(tiles), dim3(FG_WAVE * WW), lds, e->stream, e->P, e->X, e->H, \
+                                                                                                        iter0, n, e->n_warmup, welford_on, draws, first_sample_t, pos_all, info);
     FG_LIN_KERNELS(FG_LIN_GO)
 #undef FG_LIN_GO
 #undef FG_LIN_KERNELS
-#undef FG_LIN_KERNELS2
+#undef FG_LIN_KERNELS_D
     HIPCHK(hipGetLastError());
     e->last_hmc_kernel = std::string(half ? "k_hmc_lin_steps (half tiles) W=" : "k_hmc_lin_steps W=") + std::to_string(W);
     return FG_OK;

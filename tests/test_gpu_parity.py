@@ -453,7 +453,8 @@ def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
     out = []
     dp = 8 if cp.d <= 8 else (16 if cp.d <= 16 else (32 if cp.d <= 32 else 64))
     layouts = ((0, 1, 0), (1, dp // 4, 0), (1, dp // 2, 0), (1, dp // 4, 1), (1, dp // 2, 1))
-    if dp == 64: layouts = ((0, 1, 0), (1, 16, 0))          # 33 .. 64 coefficients: sixteen waves of four positions, q read from LDS a chunk at a time; full tiles
+    if dp == 64: layouts = ((0, 1, 0), (1, 16, 0), (1, 8, 0))   # 33 .. 64 coefficients: q read from LDS a chunk at a time; full tiles
+    elif dp >= 16: layouts += ((1, dp // 8, 0), (1, dp // 8, 1))   # eight positions per wave (256 VGPRs, two waves per SIMD): the default since round 4
     for lin, W_, half in layouts:
         monkeypatch.setenv("FG_HMC_LIN", str(lin))
         monkeypatch.setenv("FG_HMC_WAVES", str(W_))
@@ -465,6 +466,7 @@ def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
         eng.device_free(d)
         pos, info = eng.hmc_step_info(3)
         assert ("k_hmc_lin_steps" in eng.hmc_last_kernel()) == bool(lin), eng.hmc_last_kernel()
+        if lin: assert eng.hmc_last_kernel().endswith(f"W={W_}"), eng.hmc_last_kernel()
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent,
                     eng.hmc_mass() if adapt_mass else None, pos, info["accept_prob"], info["accepted"], info["step_size"]))
         eng.close()
