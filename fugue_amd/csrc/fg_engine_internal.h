@@ -87,6 +87,7 @@ struct fg_engine {
     hipModule_t jit_mod = nullptr; hipFunction_t jit_fn = nullptr, jit_fn_eps = nullptr, jit_fn_rejuv = nullptr, jit_fn_prior = nullptr, jit_fn_lj = nullptr; std::string jit_log; bool jit_lds_attr = false, jit_rejuv_attr = false, jit_has_ad = false, jit_has_dense = false, an_jit = false /* FG_GRAD_ANALYTIC runs on the compiled unit's derivative code */; double *d_jit_tab = nullptr, *d_jit_mh_tab = nullptr;   // the modules' constant tables (fg_jit_bind_tables)
     int mh_ncu = -1, mh_catu_same = 0; double mh_catu_c0 = 0.0; double *d_mh_catu_c = nullptr; void *d_mh_catu = nullptr;   // row-less uniform Categorical terms of the multi-wave MH kernel (FgMhSeg; -1: not decided)
     int jit_mhns_state = 0, jit_mhns_split = 0; hipModule_t jit_mhns_mod = nullptr; hipFunction_t jit_mhns_fn = nullptr; double *d_jit_mhns_tab = nullptr;   // ... the same kernel for a program without a score stream
+    int jit_mhmw_baked[7] = {0, 0, 0, 0, 0, 0, 0}; bool jit_mhmw_has_baked = false;   // the launch shape the unit below was generated for (fg_jit_mhmw_source)
     int jit_mhmw_state = 0; hipModule_t jit_mhmw_mod = nullptr; hipFunction_t jit_mhmw_fn = nullptr; double *d_jit_mhmw_tab = nullptr;   // ... the multi-wave stream MH kernel with phase B generated (fg_mh.hip)
     int jit_mh_state = 0, jit_mh_W = 1, jit_mh_direct = 0; size_t jit_mh_lds = 0; hipModule_t jit_mh_mod = nullptr; hipFunction_t jit_mh_fn[2] = {nullptr, nullptr};   // ... and its MH kernel (128- and 256-VGPR builds)
     std::string last_mh_kernel;  // kernel the last fg_mh_step launch ran (fg_mh_last_kernel)

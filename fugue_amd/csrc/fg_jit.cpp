@@ -758,7 +758,7 @@ void k_mh_jit_steps_occ##OCC(FgProgramDev P, FgChainCtx X, FgMhDev M, FgMhi seg,
 // records of phase B (generated[k] != 0: statement k's log-density term into its LDS row) as FG_JIT_NSEG generated statement
 // segments instead of fg_score_one over the record stream.
 std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split, std::vector<double> *ctab_out,
-                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream, bool pipe, int nseg, int ctl_share16, int sum_pri, int sum_lik) {
+                               const std::vector<int> *rows_in, int n_pri, int n_fac, bool no_stream, bool pipe, int nseg, int ctl_share16, int sum_pri, int sum_lik, const int *baked, int sums_form) {
     // statement segments: sixteen dealt to the waves (sg = wave, wave + W, ...), or -- nseg = the launch's waves per tile -- ONE per wave:
     // a wave's statements are then one straight-line function whose LDS reads are all in flight together
     const int NSEG = (nseg >= 2 && nseg <= 16) ? nseg : 16;
@@ -893,6 +893,41 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     // added in program order from 0.0 -- fg_inorder_sums2's additions -- without chunk loops, tails of selected zeros or address arithmetic)
     if (!no_stream && sum_pri >= 0 && sum_lik >= 0 && sum_pri + sum_lik <= 48) {     // (short programs: reference_model(50) and normal32 -- 64 and 99 rows -- measured 8-12 % slower with straight-line sums than with the chunked loops)
         std::string f = "static __device__ __forceinline__ void fg_jit_sums2(const FG_LDSQ double *terms, double &pri_out, double &lik_out) {\n    double a = 0.0, b = 0.0;\n";   // (inline: a call would drain the control wave's adaptation-state gather, which is in flight across the sums)
+        const int form = std::getenv("FG_MH_SUMS_FORM") ? std::atoi(std::getenv("FG_MH_SUMS_FORM")) : sums_form;   // (0: plain statements; 1, 2: every row first; 3: pinned, no prefetch; n >= 4: pinned, rows n pairs ahead -- profiles/round4_mh_sums_form.txt)
+        if (form >= 3) {
+            // the two chains pinned side by side (b is only used behind the branches that follow: the sink pass moves its whole chain there, and the scheduler
+            // runs a to its end first -- 39 dependent additions where 20 pairs do); loads do not cross the pins, so the rows are requested `form` pairs ahead
+            const int ahead = form == 3 ? 0 : form, n = std::max(sum_pri, sum_lik);
+            auto ld = [&](int k) {
+                std::string o;
+                if (k < sum_pri) o += "    const double y" + std::to_string(k) + " = terms[" + std::to_string(k) + " * FG_WAVE];";
+                if (k < sum_lik) o += "    const double y" + std::to_string(sum_pri + k) + " = terms[" + std::to_string(sum_pri + k) + " * FG_WAVE];";
+                return o + "\n";
+            };
+            for (int k = 0; k < std::min(ahead, n); ++k) f += ld(k);
+            for (int k = 0; k < n; ++k) {
+                if (ahead == 0) f += ld(k);
+                if (k < sum_pri) f += "    a += y" + std::to_string(k) + ";";
+                if (k < sum_lik) f += "    b += y" + std::to_string(sum_pri + k) + ";";
+                f += "\n";
+                if (ahead > 0 && k + ahead < n) f += ld(k + ahead);
+                f += "    asm volatile(\"\" : \"+v\"(a), \"+v\"(b));\n";
+            }
+        } else if (form >= 1) {
+            // every row requested first, then the two chains side by side: left alone, the scheduler finishes chain a (loads two rows ahead) before it starts chain b
+            // (b is only used behind the branches that follow: the sink pass moves its whole chain there; the empty asm pins both chains to this point, pair by pair)
+            for (int k = 0; k < sum_pri + sum_lik; ++k) f += "    " + std::string(form >= 2 ? "const " : "") + "double y" + std::to_string(k) + " = terms[" + std::to_string(k) + " * FG_WAVE];\n";
+            if (form == 1) {
+                f += "    asm volatile(\"\" : ";
+                for (int k = 0; k < sum_pri + sum_lik; ++k) f += std::string(k ? ", " : "") + "\"+v\"(y" + std::to_string(k) + ")";
+                f += ");\n";
+            }
+            for (int k = 0; k < std::max(sum_pri, sum_lik); ++k) {
+                if (k < sum_pri) f += "    a += y" + std::to_string(k) + ";";
+                if (k < sum_lik) f += "    b += y" + std::to_string(sum_pri + k) + ";";
+                f += "    asm volatile(\"\" : \"+v\"(a), \"+v\"(b));\n";
+            }
+        } else
         for (int k = 0; k < std::max(sum_pri, sum_lik); ++k) {
             if (k < sum_pri) f += "    a += terms[" + std::to_string(k) + " * FG_WAVE];";
             if (k < sum_lik) f += "    b += terms[" + std::to_string(sum_pri + k) + " * FG_WAVE];";
@@ -907,6 +942,13 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
         src += f;
         src += "#define FG_MHMW_SUMS2(PRI, LIK) fg_jit_sums2(FG_JIT_LDS(terms), PRI, LIK)\n#define FG_MHMW_SUM_PRI() fg_jit_sum_pri(FG_JIT_LDS(terms))\n#define FG_MHMW_SUM_LIK() fg_jit_sum_lik(FG_JIT_LDS(terms))\n";
     }
+    // what every launch of this unit passes anyway (the engine checks it does): row counts, tile layout, waves per tile and the mode bits as literals --
+    // the step loop loses their scalar tests and branches, LDS addresses become instruction offsets
+    if (baked && !pipe) {
+        if (!no_stream) src += "#define FG_MHMW_K_NCU " + std::to_string(baked[0]) + "\n#define FG_MHMW_K_NS " + std::to_string(baked[1]) + "\n#define FG_MHMW_K_NPRI " + std::to_string(baked[2]) + "\n";
+        src += "#define FG_MHMW_K_NSLOTS " + std::to_string(baked[3]) + "\n#define FG_MHMW_K_W " + std::to_string(baked[4]) + "\n#define FG_MHMW_K_EXP " + std::to_string(baked[5]) +
+               "\n#define FG_MHMW_K_POOLN " + std::to_string(baked[6]) + "\n";
+    }
     src += "#define FG_JIT_NSEG " + std::to_string(NSEG) + "\n"
            "#define FG_MHMW_PHASE_B5() do { for (int sg_ = wv; sg_ < FG_JIT_NSEG; sg_ += W) fg_jit_mhb(sg_, FG_JIT_LDS(slots), FG_JIT_LDS(terms)); } while (0)\n";
 #ifdef FG_MH_PROF
@@ -915,7 +957,10 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
     const bool pipe2 = pipe && !no_stream;       // the step loop with the serial recipe split over waves (stream programs)
     if (pipe2) src += FG_JIT_EMBED_MHMW2_BODY;   // fg_mh_mw2_body.h
-    src += "extern \"C\" __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_jit_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps,\n"
+    // register budget: 128 VGPRs (four waves per SIMD) unless the unit is built for a launch of <= 8 waves per tile (nseg = W) and asked for more
+    std::string lb = "FG_WAVE * FG_MH_WMAX, 4";
+    if (nseg >= 2 && nseg <= 8 && std::getenv("FG_MH_JIT_VGPR") && std::atoi(std::getenv("FG_MH_JIT_VGPR")) >= 256) lb = "FG_WAVE * " + std::to_string(nseg) + ", 2";
+    src += "extern \"C\" __global__ __launch_bounds__(" + lb + ") void k_mh_mw_jit_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps,\n"
            "        int n_warmup, long long *draws, int first_sample_t, int exp_mask, int pool_n) {\n"
            "    " + std::string(pipe2 ? "fg_mh_mw2_body<" : "fg_mh_mw_body<") + std::to_string(rk) + ", " + (split ? "true" : "false") + ">(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);\n}\n";
     if (std::getenv("FG_JIT_BREAK")) src += "\n#error FG_JIT_BREAK: a compilation that fails (tests of the fallback to the interpreter kernels)\n";
@@ -1072,7 +1117,9 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     const bool mh = std::getenv("FG_DEBUG_JIT_MH") != nullptr;            // the MH unit instead of the HMC one
     if (std::getenv("FG_DEBUG_JIT_MHMW")) {                                // the multi-wave stream MH unit
         std::string s2;
-        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false, std::getenv("FG_MH_PIPE") && std::atoi(std::getenv("FG_MH_PIPE")) == 1, std::getenv("FG_DEBUG_JIT_NSEG") ? std::atoi(std::getenv("FG_DEBUG_JIT_NSEG")) : 0, 16, p->n_prior_terms, p->n_sstream - p->n_prior_terms);
+        // FG_DEBUG_JIT_BAKE="exp_mask": the launch shape as literals (FG_DEBUG_JIT_NSEG waves per tile, no row-less terms, no staged pool)
+        const int dbg_baked[7] = { 0, p->n_sstream, p->n_prior_terms, p->n_slots, std::getenv("FG_DEBUG_JIT_NSEG") ? std::atoi(std::getenv("FG_DEBUG_JIT_NSEG")) : 0, std::getenv("FG_DEBUG_JIT_BAKE") ? std::atoi(std::getenv("FG_DEBUG_JIT_BAKE")) : 0, 0 };
+        if (p->n_sstream > 0) s2 = fg_jit_mhmw_source(p, std::vector<long long>((size_t)p->n_ins, 1), std::vector<char>((size_t)p->n_sstream, 1), p->sstream_has_gen ? (p->sstream_has_genrec ? 2 : 3) : 0, p->n_sstream >= 64, nullptr, nullptr, -1, 0, false, std::getenv("FG_MH_PIPE") && std::atoi(std::getenv("FG_MH_PIPE")) == 1, std::getenv("FG_DEBUG_JIT_NSEG") ? std::atoi(std::getenv("FG_DEBUG_JIT_NSEG")) : 0, 16, p->n_prior_terms, p->n_sstream - p->n_prior_terms, std::getenv("FG_DEBUG_JIT_BAKE") ? dbg_baked : nullptr, std::getenv("FG_MH_SUMS_FORM") ? std::atoi(std::getenv("FG_MH_SUMS_FORM")) : 0);
         else {                                                             // a program without a score stream: rows in accumulator order (fg_mh_mw_nostream_launch)
             std::vector<int> rows; int n_pri = 0, n_lik = 0, n_fac = 0;
             for (int k = 0; k < p->n_ins; ++k) if (Gen::ends_statement(p->ins_fast[(size_t)k])) {

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(FG_WAVE * FG_MH_WMAX, 4) void k_mh_mw_steps(FgProgr
 
 // Launch shape of the multi-wave kernel for a program of n_s statements: LDS bytes, waves per tile, the experiment / priority mask,
 // whether the two in-order sums run on two waves.
-struct FgMhMwShape { size_t lds; int W, exp_mask, split_sums, pool_n, pipe; unsigned tiles; };
+struct FgMhMwShape { size_t lds; int W, exp_mask, split_sums, pool_n, pipe, resident; unsigned tiles; };
 static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape &sh, bool pipe_ok = false) {
     const fg_program *p = e->prog;
     // the pipelined step loop (fg_mh_mw2_body.h): stream programs
@@ -73,8 +73,11 @@ static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape
     sh.tiles = (unsigned)((e->C + FG_WAVE - 1) / FG_WAVE);
     const long long n_cu = std::max(1, e->n_simd / 4);
     const long long resident = std::max(1LL, std::min<long long>((160 * 1024) / (long long)sh.lds, ((long long)sh.tiles + n_cu - 1) / n_cu));
+    sh.resident = (int)resident;
     int W = e->mw_override > 0 ? e->mw_override : 2;
-    if (e->mw_override <= 0) while (W < FG_MH_WMAX && resident * W < 16 && n_s >= 4 * W) W *= 2;
+    // (sixteen waves only pay with >= 6 rows per wave where the rows are a score stream's records: reference_model(20), 39 rows, one tile per CU at 8 192 chains:
+    // W = 8 4.30 / 6.24e9 adapting / sampling, W = 16 4.18 / 5.93e9; the statements of a program without a stream are whole expression programs -- rule unchanged)
+    if (e->mw_override <= 0) while (W < FG_MH_WMAX && resident * W < 16 && n_s >= ((pipe_ok && W >= 8) ? 12 : 4) * W) W *= 2;
     sh.W = std::max(W, 2);                                                  // control wave + random-number wave
     sh.exp_mask = (std::getenv("FG_MH_EXP") ? std::atoi(std::getenv("FG_MH_EXP")) : 0) | pipe_bits;
     if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) sh.exp_mask |= 32;
@@ -114,7 +117,11 @@ int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *dr
         for (int k = 0; k < p->n_ins; ++k) cost[(size_t)k] = fg_mhi_ins_cost(p->ins_fast[(size_t)k]);
         std::vector<double> ctab;
         const int nseg_ns = (std::getenv("FG_MH_NSEG_NS") && std::atoi(std::getenv("FG_MH_NSEG_NS")) == 0) ? 0 : sh.W;       // one statement segment per wave (logistic +12 %, poisson_glm +16 %, hier_logsigma +8 %, alldists level)
-        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac, true, false, nseg_ns);
+        // (the launch shape as literals, as for stream programs below)
+        const int baked[7] = { 0, n_s, n_pri, e->n_slots, sh.W, sh.exp_mask, sh.pool_n };
+        const bool bake = nseg_ns == sh.W && !(std::getenv("FG_MH_BAKE") && std::atoi(std::getenv("FG_MH_BAKE")) == 0);
+        if (bake) { std::memcpy(e->jit_mhmw_baked, baked, sizeof baked); e->jit_mhmw_has_baked = true; }
+        const std::string src = fg_jit_mhmw_source(p, cost, std::vector<char>((size_t)n_s, 1), 3, sh.split_sums, &ctab, &rows, n_pri, n_fac, true, false, nseg_ns, 16, -1, -1, bake ? baked : nullptr);
         std::vector<char> code;
         if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
             hipModuleLoadData(&e->jit_mhns_mod, code.data()) == hipSuccess &&
@@ -126,6 +133,9 @@ int fg_mh_mw_nostream_launch(fg_engine *e, int iter0, int n_steps, long long *dr
             if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: multi-wave MH kernel not compiled at run time (%s)\n", e->jit_log.c_str());
             return FG_E_UNSUPPORTED;
         }
+    }
+    if (e->jit_mhmw_has_baked && (e->jit_mhmw_baked[3] != e->n_slots || e->jit_mhmw_baked[4] != sh.W || e->jit_mhmw_baked[5] != sh.exp_mask || e->jit_mhmw_baked[6] != sh.pool_n)) {
+        fg_set_error("the compiled multi-wave MH kernel was generated for another launch shape"); return FG_E_STATE;
     }
     FgMhSeg seg;
     std::memset(&seg, 0, sizeof(seg));
@@ -270,9 +280,16 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
             if (gen_all) n_gen = n_s;
             if (2 * n_gen >= n_s) for (int k = 0; k < n_s; ++k) generated[(size_t)k] = (n_cu > 0 && (p->sstream[k].flags & FG_G_CATC)) ? 0 : 1;   // (row-less terms have no statement to run)
             std::vector<double> ctab;
+            // the launch shape as literals in the unit (one segment per wave only: the unit is then this W's anyway); FG_MH_BAKE=0: kernel arguments as before
+            // [7]: the form of the control wave's in-order sums -- the two chains pinned side by side with the rows requested four pairs ahead where a CU holds ONE
+            // tile (nothing else fills the control wave's waits: 8 192 chains +8 %); with two tiles per CU the plain statements measured 4 % faster in the sampling phase
+            const int baked[8] = { n_cu, n_s - n_cu, n_pri - n_cu, e->n_slots, W, exp_mask, pool_n, sh.resident <= 1 ? 4 : 0 };
+            const bool bake = nseg == W && !sh.pipe && !(std::getenv("FG_MH_BAKE") && std::atoi(std::getenv("FG_MH_BAKE")) == 0);
+            if (bake) { std::memcpy(e->jit_mhmw_baked, baked, 7 * sizeof(int)); e->jit_mhmw_has_baked = true; }
             // (a handful of general records among many pattern records: the runs alone -- C5 with two tiles on a CU: 7.0e9 against 6.7e9)
-            const std::string src = 8 * n_gen >= n_s ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false, sh.pipe != 0, (2 * n_gen >= n_s) ? nseg : 0, ctl16,
-                                                                       (std::getenv("FG_MH_JIT_SUMS") && std::atoi(std::getenv("FG_MH_JIT_SUMS")) == 0) ? -1 : n_pri - n_cu, n_s - n_pri) : std::string();   // (the control wave's in-order sums as inlined straight-line code with the row counts as literals: reference_model(20) sampling 2.71e10 -> 2.89e10; behind a CALL they lost -- a call drains the adaptation-state gather that is in flight across the sums)
+            const bool jit_any = std::getenv("FG_MH_JIT_ANY") && std::atoi(std::getenv("FG_MH_JIT_ANY")) != 0;
+            const std::string src = (8 * n_gen >= n_s || jit_any) ? fg_jit_mhmw_source(p, cost, generated, rk, split_sums, &ctab, &rows, -1, 0, false, sh.pipe != 0, (2 * n_gen >= n_s) ? nseg : 0, ctl16,
+                                                                       (std::getenv("FG_MH_JIT_SUMS") && std::atoi(std::getenv("FG_MH_JIT_SUMS")) == 0) ? -1 : n_pri - n_cu, n_s - n_pri, bake ? baked : nullptr, baked[7]) : std::string();   // (the control wave's in-order sums as inlined straight-line code with the row counts as literals: reference_model(20) sampling 2.71e10 -> 2.89e10; behind a CALL they lost -- a call drains the adaptation-state gather that is in flight across the sums)
             std::vector<char> code;
             if (!src.empty() && src.size() <= (6u << 20) && fg_jit_get_code(src, code, e->jit_log) == FG_OK &&
                 hipModuleLoadData(&e->jit_mhmw_mod, code.data()) == hipSuccess &&
@@ -281,6 +298,10 @@ int fg_mh_mw_launch(fg_engine *e, int iter0, int n_steps, long long *draws, int 
                 fg_jit_bind_tables(e->jit_mhmw_mod, ctab, &e->d_jit_mhmw_tab, e->stream) == FG_OK) e->jit_mhmw_state = 1;
             else { (void)hipGetLastError(); if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: multi-wave MH kernel not compiled at run time (%s)\n", e->jit_log.c_str()); }
         }
+    }
+    if (e->jit_mhmw_state == 1 && e->jit_mhmw_has_baked) {          // a launch the unit was not generated for (the shape is a function of the engine: never)
+        const int now[7] = { n_cu, n_s - n_cu, n_pri - n_cu, e->n_slots, W, exp_mask, pool_n };
+        if (std::memcmp(now, e->jit_mhmw_baked, sizeof now) != 0) { fg_set_error("the compiled multi-wave MH kernel was generated for another launch shape"); return FG_E_STATE; }
     }
     if (e->jit_mhmw_state == 1) {
         int n_warmup = e->mh_warmup;

@@ -174,18 +174,25 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
     constexpr int tw = FG_WAVE;
     const int lane = threadIdx.x & (FG_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = (int)(blockDim.x >> 6);
+#ifdef FG_MHMW_K_W        /* a unit compiled at run time for ONE launch shape (fg_jit.cpp): literals */
+    constexpr int W = FG_MHMW_K_W, n_slots_ = FG_MHMW_K_NSLOTS;
+    exp_mask = FG_MHMW_K_EXP; pool_n = FG_MHMW_K_POOLN;
+#else
+    const int W = (int)(blockDim.x >> 6), n_slots_ = P.n_slots;
+#endif
     const long long chain = (long long)blockIdx.x * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
 #ifdef FG_MHMW_NS          /* a compiled unit of a program without a score stream: its statements, log_prior rows first */
     constexpr int n_s = FG_MHMW_NS, n_pri = FG_MHMW_NPRI, n_fac = FG_MHMW_NFAC /* `factor` statements: the last rows */, n_lik = n_s - n_pri - n_fac, n_cu = 0;
+#elif defined(FG_MHMW_K_NS)
+    constexpr int n_cu = FG_MHMW_K_NCU, n_s = FG_MHMW_K_NS, n_pri = FG_MHMW_K_NPRI, n_lik = n_s - n_pri;
 #else
     const int n_cu = seg.n_cu;                                      // (terms without a row: FgMhSeg)
     const int n_s = P.n_sstream - n_cu, n_pri = P.n_prior_terms - n_cu, n_lik = n_s - n_pri;
 #endif
     double *slots = lds + lane;
-    double *terms = lds + (long long)P.n_slots * tw + lane;
+    double *terms = lds + (long long)n_slots_ * tw + lane;
     // exchange rows, double-buffered by step parity (8 rows each; row 16: the log_likelihood sum on its way to the control wave):
     // 0 target site, 1 gaussian_z, 2 u(block 1), 3 u(block 2),
     // 4 {LDS slot, value type} of the target, 5 Categorical targets: {pool base, K} of the constant table, 6 their proposed
@@ -199,7 +206,7 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
 
     // small constant pools (Categorical tables, option lists) are read per lane: from the LDS copy a lookup costs an LDS round
     // trip instead of a vector-memory one
-    double *pool_l = lds + (long long)(P.n_slots + n_s + 17) * tw;
+    double *pool_l = lds + (long long)(n_slots_ + n_s + 17) * tw;
     auto pool_rd = [&](int idx) __attribute__((always_inline)) { return pool_n > 0 ? pool_l[idx] : P.pool[idx]; };
 
     // Everything of step `it` that does not depend on the chain's state -> buffer (it & 1).
