@@ -958,17 +958,13 @@ static bool hmc_jit_preferred(const fg_engine *e) {
     if (e->gt || e->tw != FG_WAVE) return false;
     if (e->P.sep && !e->sep_disabled && e->d >= 1) return false;                                     // fg_hmc_sep_launch takes it
     if (e->P.lin_tab && !e->lin_disabled && e->d >= 2 && e->d <= 64) return false;   // fg_hmc_lin_launch takes it
-    const bool forced = std::getenv("FG_JIT") && std::atoi(std::getenv("FG_JIT")) == 2;
-    int rkj = 0;
-    const std::vector<FgGradRec> &gsj = e->prog->gstream;
-    for (int k = 0; k < e->prog->n_gstream && rkj < 2; ++k) rkj = std::max(rkj, (gsj[k].flags & (FG_G_GEN | FG_G_NSEL | FG_G_CATC)) ? 2 : ((gsj[k].flags & FG_G_LIN) ? 1 : 0));
-    const long long tiles = (e->C + e->tw - 1) / e->tw;
-    // ... and for programs of fewer than eight coordinates: the stream kernel gives a tile at most two waves there (a wave owns whole coordinates, >= 4
-    // of them), the compiled unit deals 2 d (coordinate, sign) tasks over up to eight (hier, d = 6: 1.22e10 -> 1.40e10 leapfrog-steps/s at 65 536
-    // chains; one-coordinate programs with discrete sites 3.4 - 5.4e10 -> 6.4 - 7.5e10; reference_model(8), d = 8, four waves: the stream kernel keeps 16 %)
-    // (two tiles per CU or fewer: reference_model(8) at 32 768 chains 1.27e10 -> 1.57e10, reference_model(20) 6.7e9 -> 7.2e9; at 65 536 chains the stream
-    // kernel keeps 16 % on both -- profiles/round4_jit_vs_stream_sparse.txt)
-    return forced || rkj >= 1 || e->d < 8 || tiles <= 2 * std::max(1, e->n_simd / 4);
+    // Every other gradient-stream program, at every chain count.  Round 3 sent only linear-predictor / general / option-select records here, round 4 first
+    // added programs of fewer than eight coordinates and launches of two tiles per CU or fewer (the stream kernel kept 16 % on reference_model(8) at
+    // 65 536 chains).  Since the unit holds its task split as straight-line code per wave (fg_jit_wave_tasks: no task list in memory, no dispatch on the
+    // coordinate, short sub-programs inlined) it wins everywhere measured -- reference_model(8) 1.85e10 -> 2.26e10 leapfrog-steps/s at 65 536 chains,
+    // 2.48e10 -> 2.57e10 at 524 288; reference_model(20) 8.4e9 -> 1.07e10; reference_model(32) 4.5e9 -> 7.2e9 (profiles/round4_jit_vs_stream_tasks.txt).
+    // FG_JIT=0 keeps k_hmc_stream_steps (bit-identity tests, a box without hiprtc).
+    return true;
 }
 
 static int hmc_find_eps(fg_engine *e, uint32_t instance, int injected, double *d_eps_out) {

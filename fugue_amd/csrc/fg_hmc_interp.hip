@@ -333,7 +333,32 @@ int fg_hmc_interp_launch(fg_engine *e, int iter0, int n, int welford_on, double 
 }
 
 // ---- the same kernel around a model compiled at run time (fg_jit.cpp, fg_hmc_jit_body.h) --------------------------------------
-struct FgJitSeg { int off[FG_MWI_MAX + 1]; const int *order; };
+struct FgJitSeg { int off[FG_MWI_MAX + 1]; const int *order; int baked; };   // (fg_hmc_jit_body.h's)
+
+// waves per tile of the compiled HMC kernels and the split of the sparse finite difference's 2 d tasks over them -- a function of the engine alone
+// (program, chain count, FG_HMC_WAVES / FG_HMC_INTERP_WAVES / FG_HMC_JIT_OCC at the time): the unit is generated BEHIND it (fg_jit_wave_tasks)
+static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long> &cost, std::vector<std::vector<int>> &bins) {
+    const int n_tasks = 2 * e->d;
+    cost.assign(e->d, 1);
+    for (int k = 0; k < e->d; ++k) {
+        long long cs = 0;
+        for (int q = 0; q < e->prog->coord[k].sub_n; ++q) cs += mwi_ins_cost(e->prog->sub[e->prog->coord[k].sub_off + q]);
+        cost[k] = std::max(1LL, cs);
+    }
+    int forced = e->mw_override;
+    if (const char *sp = std::getenv("FG_HMC_INTERP_WAVES")) forced = std::atoi(sp);
+    int jocc = 4;
+    if (const char *oc = std::getenv("FG_HMC_JIT_OCC")) { const int o = std::atoi(oc); if (o >= 2 && o <= 4) jocc = o; }
+    const int wcap = std::min(std::min(FG_MWI_MAX, 4 * jocc), n_tasks);
+    int W = 1;
+    const long long n_cu = std::max(1, e->n_simd / 4);
+    if (forced > 0) W = std::max(1, std::min(forced, wcap));
+    else if ((long long)tiles <= n_cu) W = wcap;             // a CU has at most one tile: a wave per task (logistic regression, 8 192 chains: W = 6 beats 4 by 45 %)
+    else while (2 * W <= std::min(8, wcap)) W *= 2;         // several tiles per CU: a power of two up to eight (measured on four models)
+    mwi_split(cost, W, &bins);
+    for (int w = 0; w < W; ++w) std::sort(bins[w].begin(), bins[w].end());
+    return W;
+}
 
 // the program's compiled module (once per engine): HMC transitions, the step-size search, adaptive_smc's rejuvenation move
 static int jit_hmc_module(fg_engine *e) {
@@ -346,7 +371,10 @@ static int jit_hmc_module(fg_engine *e) {
         if (e->prog->sub.size() + e->prog->ins_fast.size() > 64000000) return FG_E_UNSUPPORTED;
         std::vector<double> ctab;
         bool has_ad = false, has_dense = false;
-        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense);
+        std::vector<long long> cost0;
+        e->jit_baked_bins.clear();
+        if (!(std::getenv("FG_JIT_TASKS") && std::atoi(std::getenv("FG_JIT_TASKS")) == 0)) jit_sparse_split(e, (unsigned)((e->C + e->tw - 1) / e->tw), cost0, e->jit_baked_bins);
+        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense, e->jit_baked_bins.empty() ? nullptr : &e->jit_baked_bins);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
@@ -444,24 +472,11 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
     }
     const int split_key = dense ? 4 : 2;                   // (2: the split of the compiled kernel; 4: its dense mode -- every task is the whole program)
     if (e->mwi_sparse != split_key || e->mwi_W <= 0) {
-        e->mwi_cost.assign(e->d, 1);
-        for (int k = 0; k < e->d && !dense; ++k) {
-            long long cs = 0;
-            for (int q = 0; q < e->prog->coord[k].sub_n; ++q) cs += mwi_ins_cost(e->prog->sub[e->prog->coord[k].sub_off + q]);
-            e->mwi_cost[k] = std::max(1LL, cs);
-        }
-        int forced = e->mw_override;
-        if (const char *sp = std::getenv("FG_HMC_INTERP_WAVES")) forced = std::atoi(sp);
-        int jocc = 4;
-        if (const char *oc = std::getenv("FG_HMC_JIT_OCC")) { const int o = std::atoi(oc); if (o >= 2 && o <= 4) jocc = o; }
-        const int wcap = std::min(std::min(FG_MWI_MAX, 4 * jocc), n_tasks);
-        int W = 1;
-        const long long n_cu = std::max(1, e->n_simd / 4);
-        if (forced > 0) W = std::max(1, std::min(forced, wcap));
-        else if ((long long)tiles <= n_cu) W = wcap;             // a CU has at most one tile: a wave per task (logistic regression, 8 192 chains: W = 6 beats 4 by 45 %)
-        else while (2 * W <= std::min(8, wcap)) W *= 2;         // several tiles per CU: a power of two up to eight (measured on four models)
         std::vector<std::vector<int>> bins;
-        mwi_split(e->mwi_cost, W, &bins);
+        int W = jit_sparse_split(e, tiles, e->mwi_cost, bins);
+        if (dense) { e->mwi_cost.assign(e->d, 1); mwi_split(e->mwi_cost, W, &bins); }      // (every task is the whole program)
+        e->mwi_baked = !dense && !e->jit_baked_bins.empty() && (int)e->jit_baked_bins.size() == W;
+        for (int w = 0; w < W && e->mwi_baked; ++w) { std::vector<int> b = bins[w]; std::sort(b.begin(), b.end()); e->mwi_baked = b == e->jit_baked_bins[w]; }
         std::vector<int> order;
         e->mwi_off.assign(FG_MWI_MAX + 1, n_tasks);
         for (int w = 0; w < W; ++w) {
@@ -493,7 +508,7 @@ int fg_hmc_jit_find_eps(fg_engine *e, uint32_t instance, int injected, double *d
     const int W = e->mwi_W;
     FgJitSeg seg;
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
-    seg.order = e->d_mwi_order;
+    seg.order = e->d_mwi_order; seg.baked = 0;
     const size_t lds = (size_t)((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * sizeof(double);
     void *args[] = { &e->P, &e->X, &e->H, &seg, &instance, &injected, &d_eps_out };
     HIPCHK(hipModuleLaunchKernel(e->jit_fn_eps, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
@@ -508,6 +523,7 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     FgJitSeg seg;
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
     seg.order = e->d_mwi_order;
+    seg.baked = (e->mwi_baked && e->cfg.grad_mode == FG_GRAD_FD_SPARSE) ? 1 : 0;      // the unit holds this very split as straight-line code (fg_jit_wave_tasks)
     if (e->cfg.grad_mode == FG_GRAD_ANALYTIC && e->jit_has_ad) for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off_an[w];
     int n_warmup = e->n_warmup;
     void *args[] = { &e->P, &e->X, &e->H, &seg, &iter0, &n, &n_warmup, &welford_on, &draws, &first_sample_t, &pos_all, &info };

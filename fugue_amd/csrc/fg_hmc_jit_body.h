@@ -13,7 +13,7 @@
 #ifndef FG_JIT_OCC          /* waves per SIMD the register budget allows: 4 = 128 VGPRs (fg_jit.cpp may define 2 or 3 for register-hungry programs) */
 #define FG_JIT_OCC 4
 #endif
-struct FgJitSeg { int off[FG_JIT_WMAX + 1]; const int *order; };   // wave w owns tasks order[off[w] .. off[w + 1]): 2 k + sign
+struct FgJitSeg { int off[FG_JIT_WMAX + 1]; const int *order; int baked; };   // wave w owns tasks order[off[w] .. off[w + 1]): 2 k + sign; baked: this IS the split fg_jit_wave_tasks was generated for
 
 extern "C" __global__ __attribute__((amdgpu_waves_per_eu(FG_JIT_OCC, FG_JIT_OCC))) __launch_bounds__(FG_WAVE * 4 * FG_JIT_OCC)
 void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int iter0, int n_steps, int n_warmup, int welford_on, double *draws,
@@ -26,11 +26,16 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
     const long long chain = (long long)blockIdx.x * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
-    const int d = P.d, L = H.L;
+#ifdef FG_JIT_K_D          /* the program's own constants as literals (fg_jit.cpp): LDS rows at instruction offsets, loop bounds known */
+    constexpr int d = FG_JIT_K_D, S_ = FG_JIT_K_S;
+    const int L = H.L;
+#else
+    const int d = P.d, L = H.L, S_ = P.S;
+#endif
     double *slots = lds + lane;                                                      // site rows [0, S)
-    double *pl = lds + (long long)P.S * tw + lane;                                   // momentum rows
-    double *ev_lp = lds + (long long)(P.S + d) * tw + lane;                          // log-joint of evaluation (coordinate k, sign): row 2 k + sign
-    double *xch = lds + (long long)(P.S + 3 * d) * tw + lane;                        // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
+    double *pl = lds + (long long)S_ * tw + lane;                                   // momentum rows
+    double *ev_lp = lds + (long long)(S_ + d) * tw + lane;                          // log-joint of evaluation (coordinate k, sign): row 2 k + sign
+    double *xch = lds + (long long)(S_ + 3 * d) * tw + lane;                        // rows: 0 step size, 1 accepted, 2.. per-wave divergence flags
     const int j0 = seg.off[wv], j1 = seg.off[wv + 1];
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
@@ -38,7 +43,10 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
     const double h = H.h;
     const bool analytic = H.grad_mode == 2 /* FG_GRAD_ANALYTIC */;      // (the step-size search keeps the finite difference, like the stream kernels')
     const bool dense = H.grad_mode == 0 /* FG_GRAD_FD_DENSE */; (void)dense;
-    for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+#ifdef FG_JIT_BAKED_W
+    const bool baked = seg.baked != 0 && W == FG_JIT_BAKED_W && !analytic && !dense;
+#endif
+    for (int j = wv; j < S_; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
     if (wv == 0) {
@@ -74,6 +82,10 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         const double e = xch[0], hk = 0.5 * e;
         bool bad = false;
         for (int s = 0; s <= L; ++s) {                        // gradients 0 .. L of the leapfrog (hmc.rs:353-407)
+#ifdef FG_JIT_BAKED_W
+            if (baked) fg_jit_wave_tasks(wv, h, FG_JIT_LDS(slots), FG_JIT_LDS(ev_lp));      // hmc.rs:317-321, this wave's tasks as straight-line code
+            else
+#endif
             for (int jj = j0; jj < j1; ++jj) {
                 const int task = seg.order[jj];
                 const int k = task >> 1;
@@ -180,17 +192,21 @@ void k_hmc_jit_find_eps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, 
     const long long chain = (long long)blockIdx.x * tw + lane;
     const bool live = chain < X.C;
     const long long c = live ? chain : X.C - 1;
-    const int d = P.d;
+#ifdef FG_JIT_K_D
+    constexpr int d = FG_JIT_K_D, S_ = FG_JIT_K_S;
+#else
+    const int d = P.d, S_ = P.S;
+#endif
     double *slots = lds + lane;
-    double *pl = lds + (long long)P.S * tw + lane;
-    double *ev_lp = lds + (long long)(P.S + d) * tw + lane;
-    double *xch = lds + (long long)(P.S + 3 * d) * tw + lane;                        // rows: 0 the trial's log-ratio, 2.. per-wave divergence flags
+    double *pl = lds + (long long)S_ * tw + lane;
+    double *ev_lp = lds + (long long)(S_ + d) * tw + lane;
+    double *xch = lds + (long long)(S_ + 3 * d) * tw + lane;                        // rows: 0 the trial's log-ratio, 2.. per-wave divergence flags
     const int j0 = seg.off[wv], j1 = seg.off[wv + 1];
     const double *mi = H.use_mass ? H.m_inv + c : nullptr;
     const double *ms = H.use_mass ? H.mass_sqrt + c : nullptr;
     const uint32_t sk0 = (uint32_t)X.seed, sk1 = (uint32_t)(X.seed >> 32), gchain = X.chain0 + (uint32_t)c;
     const double h = H.h;
-    for (int j = wv; j < P.S; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+    for (int j = wv; j < S_; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
     const int n_pairs = (d + 1) >> 1;
     if (!injected) {                                          // p0 from the chain's (instance) EPS stream: pair j = Philox block j
         for (int j = wv; j < n_pairs; j += W) {

@@ -591,7 +591,7 @@ static __device__ __forceinline__ long long fg_jit_int_of(double v, unsigned vty
 static bool fg_jit_inlined() { const char *v = std::getenv("FG_JIT_INLINE"); return v && std::atoi(v) != 0; }
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
-std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out, bool *has_dense_out) {
+std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out, bool *has_dense_out, const std::vector<std::vector<int>> *wave_tasks) {
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
     std::vector<std::string> tables;
@@ -602,8 +602,10 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         g.ctabs = &ctabs;
         g.emit(p->sub, (size_t)p->coord[k].sub_off, (size_t)p->coord[k].sub_off + (size_t)p->coord[k].sub_n);
         if (!g.ok) return "";
-        fns += "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
-               "    (void)acc;\n    return pr + lk + fc;\n}\n";
+        // (the body once, inlinable: the per-wave task lists below inline short sub-programs; everything else calls the out-of-line copy)
+        fns += "static __device__ __forceinline__ double fg_jit_subi_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) {\n" + g.decls() + g.body +
+               "    (void)acc;\n    return pr + lk + fc;\n}\n"
+               "static __device__ __noinline__ double fg_jit_sub_" + std::to_string(k) + "(double pert, const FG_LDSQ double *slots) { return fg_jit_subi_" + std::to_string(k) + "(pert, slots); }\n";
     }
     // FG_GRAD_ANALYTIC: d/dq_k of the same sub-program (forward mode; Gen::ins_ad).  A program the derivative emission does not cover keeps
     // the finite difference only (the engine then refuses the analytic mode for it, as before).
@@ -623,6 +625,26 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
         fns += "#define FG_JIT_HAS_AD 1\nstatic __device__ __forceinline__ double fg_jit_dtask(int k, const FG_LDSQ double *slots) {\n    switch (k) {\n";
         for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_dsub_" + std::to_string(k) + "(slots);\n";
         fns += "    default: return 0.0;\n    }\n}\n";
+    }
+    // The tasks of every wave as straight-line code (the engine's launches all use ONE split: fg_hmc_interp.hip generates the unit behind it): no task
+    // list in memory, no dispatch on the coordinate, and a short sub-program (<= 64 instructions) inlined -- its LDS reads overlap the previous task's
+    // arithmetic.  Per task the operations are fg_jit_sub_k's: identical results.
+    fns += "#define FG_JIT_K_D " + std::to_string(d) + "\n#define FG_JIT_K_S " + std::to_string(p->sorted_stmt.size()) + "\n";      // (the kernels' row offsets and loop bounds as literals)
+    if (wave_tasks && !wave_tasks->empty() && wave_tasks->size() <= 16) {
+        const char *im = std::getenv("FG_JIT_TASK_INLINE");
+        const int inline_max = im ? std::atoi(im) : 64;                  // (16 and 64 measured alike but for linreg at 8 192 chains: +8 % with 64)
+        fns += "#define FG_JIT_BAKED_W " + std::to_string(wave_tasks->size()) + "\nstatic __device__ __forceinline__ void fg_jit_wave_tasks(int wv, double h, const FG_LDSQ double *slots, FG_LDSQ double *ev) {\n    switch (wv) {\n";
+        for (size_t w = 0; w < wave_tasks->size(); ++w) {
+            fns += "    case " + std::to_string(w) + ": {\n";
+            for (int task : (*wave_tasks)[w]) {
+                const int k = task >> 1;
+                if (k < 0 || k >= d) return "";
+                fns += "        ev[" + std::to_string(task) + " * FG_WAVE] = fg_jit_sub" + (p->coord[k].sub_n <= inline_max ? "i_" : "_") + std::to_string(k) + "(slots[" + std::to_string(k) + " * FG_WAVE] " +
+                       ((task & 1) ? "-" : "+") + " h, slots);\n";
+            }
+            fns += "    } break;\n";
+        }
+        fns += "    default: break;\n    }\n}\n";
     }
     fns += "static __device__ __forceinline__ double fg_jit_task(int k, double pert, const FG_LDSQ double *slots) {\n    switch (k) {\n";
     for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_sub_" + std::to_string(k) + "(pert, slots);\n";
@@ -1140,7 +1162,9 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
         if (const char *out = std::getenv("FG_DEBUG_JIT_OUT")) if (rc2 == FG_OK) if (FILE *f = std::fopen(out, "wb")) { std::fwrite(code2.data(), 1, code2.size(), f); std::fclose(f); }
         return rc2;
     }
-    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr, nullptr);
+    std::vector<std::vector<int>> dbg_bins;                               // FG_DEBUG_JIT_TASKS=W: the 2 d tasks dealt round-robin over W waves as straight-line code (fg_jit_wave_tasks)
+    if (const char *tw_ = std::getenv("FG_DEBUG_JIT_TASKS")) { const int W_ = std::max(1, std::min(16, std::atoi(tw_))); dbg_bins.resize((size_t)W_); for (int t = 0; t < 2 * (int)p->coord.size(); ++t) dbg_bins[(size_t)(t % W_)].push_back(t); }
+    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr, nullptr, nullptr, dbg_bins.empty() ? nullptr : &dbg_bins);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;
     if (src.empty()) return FG_E_UNSUPPORTED;

@@ -70,15 +70,16 @@ def test_jit_dense_mode_is_bit_identical_to_the_interpreter(name, adapt_mass, mo
 @pytest.mark.parametrize("name,adapt_mass", [("hier_scale", True), ("mixture", False), ("linreg", True), ("refmodel8", False), ("hier", True), ("ridge7", False),
                                              ("rand1", False), ("rand3", True), ("rand4", False)])
 def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkeypatch):
-    """Gradient-stream programs: the compiled form (the engine's choice for linear-predictor / general / option-select records and for
-    small chain counts) against k_hmc_stream_steps -- the same arithmetic per coordinate, so every bit agrees."""
+    """Gradient-stream programs: the compiled form (the engine's choice for every one of them since round 4) against k_hmc_stream_steps
+    (FG_JIT=0) -- the same arithmetic per coordinate, so every bit agrees."""
     cp = E.compile_model(ZOO[name]())
     assert cp.stream_records[0] > 0
     C, nw, ns = 150, 30, 20
     out, kernels = [], []
     monkeypatch.setenv("FG_HMC_LIN", "0")                                   # (ridge7 is a dense regression: its own kernel would take it)
-    for jit in (0, 2):
+    for jit, tasks in ((0, 1), (1, 1), (1, 0)):      # tasks: the unit's task split as straight-line code per wave (default) / a task list in memory
         monkeypatch.setenv("FG_JIT", str(jit))
+        monkeypatch.setenv("FG_JIT_TASKS", str(tasks))
         eng = E.Engine(cp, C, seed=31, chain_offset=2)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(n_leapfrog=6, adapt_mass=adapt_mass), ns, nw, d)
@@ -87,9 +88,10 @@ def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkey
         eng.device_free(d)
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent, eng.hmc_mass() if adapt_mass else None))
         eng.close()
-    assert kernels[0].startswith("k_hmc_stream_steps") and kernels[1].startswith("k_hmc_jit_steps"), kernels
-    for a, b in zip(out[0], out[1]):
-        assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert kernels[0].startswith("k_hmc_stream_steps") and kernels[1].startswith("k_hmc_jit_steps") and kernels[2].startswith("k_hmc_jit_steps"), kernels
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
 def test_jit_is_not_used_where_a_faster_kernel_exists(monkeypatch):
@@ -98,7 +100,7 @@ def test_jit_is_not_used_where_a_faster_kernel_exists(monkeypatch):
     (the whole program per coordinate: test_jit_dense_mode_is_bit_identical_to_the_interpreter)."""
     monkeypatch.delenv("FG_JIT", raising=False)
     for name, mode, jit in [("normal32", E.GRAD_FD_SPARSE, False), ("normal32", E.GRAD_FD_DENSE, False), ("ridge8", E.GRAD_FD_SPARSE, False),
-                            ("poisson_glm", E.GRAD_FD_DENSE, True), ("refmodel8", E.GRAD_FD_DENSE, True)]:
+                            ("poisson_glm", E.GRAD_FD_DENSE, True), ("refmodel8", E.GRAD_FD_DENSE, True), ("refmodel8", E.GRAD_FD_SPARSE, True)]:
         cp = E.compile_model(ZOO[name]())
         eng = E.Engine(cp, 64, seed=1)
         eng.hmc_init(E.hmc_config(grad_mode=mode, n_leapfrog=3), 2)
