@@ -83,6 +83,7 @@ static int mh_mw_shape(const fg_engine *e, int n_s, bool stage_pool, FgMhMwShape
     if (std::getenv("FG_MH_PRIO") && std::atoi(std::getenv("FG_MH_PRIO")) == 0) sh.exp_mask |= 32;
     else if (resident >= 2) sh.exp_mask |= 64;
     if (resident >= 3 && !(std::getenv("FG_MH_STAGGER") && std::atoi(std::getenv("FG_MH_STAGGER")) == 0)) sh.exp_mask |= 128;   // bit 128: the tiles of a CU start a quarter of a step apart (reference_model(20), four tiles per CU: +4.7 %; two tiles: nothing)   // bit 64: phase-B waves ahead of the random-number waves of the OTHER tiles on the CU (reference_model(20) +3 %; a lone tile loses 2 %)
+    if (std::getenv("FG_MH_PRIO2") && std::atoi(std::getenv("FG_MH_PRIO2")) == 0) sh.exp_mask |= 16384;
     // long programs: log_prior and log_likelihood are added by two waves (C5: +11 %); a short one pays more for the extra barrier than
     // the second wave returns (reference_model(20), 4 tiles per CU: -3 %) -- split_sums, above
     return FG_OK;

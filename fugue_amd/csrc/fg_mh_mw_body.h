@@ -351,7 +351,12 @@ __device__ __forceinline__ void fg_mh_mw_body(const FgProgramDev &P, const FgCha
                 else if (wv == 1) xch[16 * tw] = FG_MHMW_SUM_LIK();
 #else
                 if (wv == 0) { pri = fg_inorder_sum1(terms, n_pri, tw); FG_MH_CATU_TAIL }
-                else if (wv == 1) xch[16 * tw] = fg_inorder_sum1(terms + (long long)n_pri * tw, n_lik, tw);
+                else if (wv == 1) {
+                    // the second adder is on its tile's path like the control wave: served first while it adds (exp_mask bit 16384 switches this off: A/B)
+                    if (!(exp_mask & (32 | 16384))) __builtin_amdgcn_s_setprio(2);
+                    xch[16 * tw] = fg_inorder_sum1(terms + (long long)n_pri * tw, n_lik, tw);
+                    if (!(exp_mask & (32 | 16384))) __builtin_amdgcn_s_setprio(0);
+                }
 #endif
                 // LDS only crosses this barrier: wait for the LDS counter and leave the control wave's adaptation-state gather (64
                 // lines from L2, issued above) in flight -- __syncthreads() would drain it here
