@@ -153,3 +153,36 @@ def test_jit_source_compiles_for_gfx950(name):
     assert rc == 0 and n.value > 0, log.value.decode()[:2000]
     text = src.value.decode()
     assert "fg_jit_task" in text and "fg_jit_score" in text and "k_hmc_jit_steps" in text
+
+
+@pytest.mark.parametrize("name,W", [("refmodel8", 8), ("hier_scale", 4), ("alldists", 16)])
+def test_jit_task_code_compiles_for_gfx950(name, W, monkeypatch):
+    """The compiled HMC unit generated behind a task split (round 4: every wave's (coordinate, sign) tasks as straight-line code,
+    fg_jit_wave_tasks; the program's d and S as literals) goes through hiprtc; every task appears exactly once."""
+    lib = E.lib()
+    lib.fg_debug_jit_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    monkeypatch.setenv("FG_DEBUG_JIT_TASKS", str(W))
+    cp = E.compile_model(ZOO[name]())
+    src = ctypes.create_string_buffer(8 << 20); log = ctypes.create_string_buffer(1 << 20); n = ctypes.c_longlong()
+    rc = lib.fg_debug_jit_compile(cp.h, src, len(src), log, len(log), ctypes.byref(n))
+    assert rc == 0 and n.value > 0, log.value.decode()[:2000]
+    text = src.value.decode()
+    assert f"#define FG_JIT_BAKED_W {min(W, 2 * cp.d)}" in text and f"#define FG_JIT_K_D {cp.d}\n" in text and f"#define FG_JIT_K_S {cp.S}\n" in text
+    body = text[text.index("void fg_jit_wave_tasks("):text.index("double fg_jit_task(")]
+    for t in range(2 * cp.d):
+        assert body.count(f"ev[{t} * FG_WAVE] = ") == 1, t
+
+
+@pytest.mark.parametrize("name", ["refmodel8", "mixture"])
+def test_jit_mh_unit_with_the_launch_shape_as_literals_compiles(name, monkeypatch):
+    """The multi-wave MH unit of a score-stream program with the launch shape as literals (FG_MHMW_K_*) and the control wave's in-order sums
+    pinned side by side (the form an engine with one tile per CU gets) goes through hiprtc."""
+    lib = E.lib()
+    lib.fg_debug_jit_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    for k, v in (("FG_DEBUG_JIT_MHMW", "1"), ("FG_DEBUG_JIT_NSEG", "8"), ("FG_DEBUG_JIT_BAKE", "4160"), ("FG_MH_SUMS_FORM", "4")): monkeypatch.setenv(k, v)
+    cp = E.compile_model(ZOO[name]())
+    src = ctypes.create_string_buffer(8 << 20); log = ctypes.create_string_buffer(1 << 20); n = ctypes.c_longlong()
+    rc = lib.fg_debug_jit_compile(cp.h, src, len(src), log, len(log), ctypes.byref(n))
+    assert rc == 0 and n.value > 0, log.value.decode()[:2000]
+    text = src.value.decode()
+    assert "#define FG_MHMW_K_W 8\n" in text and "#define FG_MHMW_K_EXP 4160\n" in text and 'asm volatile("" : "+v"(a), "+v"(b));' in text
