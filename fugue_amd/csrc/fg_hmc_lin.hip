@@ -86,7 +86,11 @@ __device__ __forceinline__ void fg_lin_prior_pair(const fg_u32x16 &r, double qv,
 
 // One gradient for the M own coordinates of wave WV: g_k = (lp(q + h e_k) - lp(q - h e_k)) / (2h) over the coordinate's prior
 // record(s) and the N observe statements, then the half-kick(s) on p_k.  Returns "some own force component was non-finite".
-template <int D, int W, int WV, bool P2>
+// FUSED: -0.5 z z - ln sigma as ONE fma with an exact product (fg_hmc_sep.hip's FG_SEP_LPF: the same bits except for z z in [2^1024, 2^1025), where the
+// fused form is -inf and the reference's (-0.5 z) z still finite) -- a non-finite force component in the fused instance sends the wave through the
+// unfused one again before any momentum is kicked (q is not written during a gradient, a wave's coordinates are its own): 16 of 453 instructions per
+// observation of the eight-coordinate layout.
+template <int D, int W, int WV, bool P2, bool FUSED = false>
 __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const int *meta_v, const FgGradRec *gs_v, const fg_lds_double *slots,
                                          fg_lds_double *pl, double h_v, double hk, int two_kicks_v, int d_v) {
     // a row's coefficients arrive in NC chunks of CS (two SGPR buffers, the next chunk requested while the current one is used);
@@ -163,8 +167,8 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
                 if (fl & FG_G_DIV) { zp = dlp / sg; zm = dlm / sg; }
                 else { zp = fg_div_const(dlp, sg, inv); zm = fg_div_const(dlm, sg, inv); }
             }
-            const double lpp = -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;     // distribution.rs:207
-            const double lpm = -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
+            const double lpp = FUSED ? __builtin_fma(-0.5, zp * zp, -lns) - 0.5 * FG_LN_2PI : -0.5 * zp * zp - lns - 0.5 * FG_LN_2PI;     // distribution.rs:207
+            const double lpm = FUSED ? __builtin_fma(-0.5, zm * zm, -lns) - 0.5 * FG_LN_2PI : -0.5 * zm * zm - lns - 0.5 * FG_LN_2PI;
             sp[a] += lpp; sm[a] += lpm;
         }
         row += ROWB;
@@ -174,9 +178,11 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
     // the central difference and the kick(s): fg_grec_math's FG_G_END
     const FG_AS4 char *gs = fg_uniform_ptr(gs_v);
     bool bad = false;
+    double gk[M];
 #pragma unroll
     for (int a = 0; a < M; ++a) {
         const int pos = fg_lin_pos(W, WV, a);
+        gk[a] = 0.0;
         if (pos >= d_real) continue;                                         // a padded term position (d < D): no coordinate
         const int k = meta[pos], r0 = meta[D + 2 * k], nr = meta[D + 2 * k + 1];
         double prip = 0.0, prim = 0.0;
@@ -192,8 +198,16 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
         const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
         if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953]
         bad = bad || !fg_finite(g);
-        double p = pl[k * tw] + hk * g;                                      // hmc.rs:389 / :400
-        if (two_kicks) p += hk * g;
+        gk[a] = g;
+    }
+    if (FUSED) { if (__builtin_expect(__any(bad), 0)) return fg_lin_grad<D, W, WV, P2, false>(tab_v, n_obs_v, meta_v, gs_v, slots, pl, h_v, hk, two_kicks_v, d_v); }
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const int pos = fg_lin_pos(W, WV, a);
+        if (pos >= d_real) continue;
+        const int k = meta[pos];
+        double p = pl[k * tw] + hk * gk[a];                                  // hmc.rs:389 / :400
+        if (two_kicks) p += hk * gk[a];
         pl[k * tw] = p;
     }
     return bad;
@@ -205,7 +219,7 @@ __device__ __noinline__ bool fg_lin_grad(const double *tab_v, int n_obs_v, const
 // two totals meet in one cross-lane exchange per coordinate and gradient.  Products and prefix sums are formed by both halves,
 // so a wave issues ~0.64 of the full tile's instructions for half the chains: worth it exactly when 64-chain tiles would leave
 // CUs idle (8 192 chains = 128 tiles on 256 CUs: BASELINE's 8-GPU sharding of C3).
-template <int D, int W, int WV, bool P2>
+template <int D, int W, int WV, bool P2, bool FUSED = false>
 __device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, const int *meta_v, const FgGradRec *gs_v, const fg_lds_double *slots,
                                               fg_lds_double *pl, double h_v, double hk, int two_kicks_v, int d_v) {
     constexpr int M = D / W, HB = D / 2, ROWB = FG_LIN_ROW_DOUBLES(D) * 8, tw = FG_WAVE / 2;
@@ -263,16 +277,18 @@ __device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, 
                 const double sg = fg_dbl(hb[6], hb[7]);
                 z = (fl & FG_G_DIV) ? dl / sg : fg_div_const(dl, sg, inv);
             }
-            sa[a] += -0.5 * z * z - lns - 0.5 * FG_LN_2PI;
+            sa[a] += FUSED ? __builtin_fma(-0.5, z * z, -lns) - 0.5 * FG_LN_2PI : -0.5 * z * z - lns - 0.5 * FG_LN_2PI;
         }
         row += ROWB;
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     const FG_AS4 char *gs = fg_uniform_ptr(gs_v);
     bool bad = false;
+    double gk[M];
 #pragma unroll
     for (int a = 0; a < M; ++a) {
         const int pos = fg_lin_pos(W, WV, a);
+        gk[a] = 0.0;
         if (pos >= d_real) continue;                                         // a padded term position (d < D): no coordinate
         const int k = meta[pos], r0 = meta[D + 2 * k], nr = meta[D + 2 * k + 1];
         double pri = 0.0;
@@ -289,8 +305,16 @@ __device__ __noinline__ bool fg_lin_grad_half(const double *tab_v, int n_obs_v, 
         const uint32_t ne = (uint32_t)(__double_as_longlong(n) >> 32) & 0x7fffffffu;
         if (__builtin_expect(__any(!(n == 0.0 || (ne - 0x0c800000u) < 0x6f000000u)), 0)) g = n / two_h;   // |n| outside [2^-823, 2^953]
         bad = bad || !fg_finite(g);
-        double p = pl[k * tw] + hk * g;                                      // hmc.rs:389 / :400 (both halves: the same value to the same cell)
-        if (two_kicks) p += hk * g;
+        gk[a] = g;
+    }
+    if (FUSED) { if (__builtin_expect(__any(bad), 0)) return fg_lin_grad_half<D, W, WV, P2, false>(tab_v, n_obs_v, meta_v, gs_v, slots, pl, h_v, hk, two_kicks_v, d_v); }
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+        const int pos = fg_lin_pos(W, WV, a);
+        if (pos >= d_real) continue;
+        const int k = meta[pos];
+        double p = pl[k * tw] + hk * gk[a];                                  // hmc.rs:389 / :400 (both halves: the same value to the same cell)
+        if (two_kicks) p += hk * gk[a];
         pl[k * tw] = p;
     }
     return bad;
@@ -301,8 +325,9 @@ struct FgLinDispatch {
     static __device__ __forceinline__ bool run(int wv, const double *tab, int n_obs, const int *meta, const FgGradRec *gs, const fg_lds_double *slots,
                                                fg_lds_double *pl, double h, double hk, int two_kicks, int d) {
         if (wv == WV) {
-            if constexpr (HALF) return fg_lin_grad_half<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
-            else return fg_lin_grad<D, W, WV, P2>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
+            constexpr bool FUSED = D / W == 8;                    // (the default layouts of D >= 32; the others keep the unfused form only)
+            if constexpr (HALF) return fg_lin_grad_half<D, W, WV, P2, FUSED>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
+            else return fg_lin_grad<D, W, WV, P2, FUSED>(tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
         }
         return FgLinDispatch<D, W, P2, HALF, WV + 1>::run(wv, tab, n_obs, meta, gs, slots, pl, h, hk, two_kicks, d);
     }
@@ -473,12 +498,14 @@ int fg_hmc_lin_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     if (lds > 160 * 1024) return FG_E_UNSUPPORTED;
     // waves per tile.  Every wave of a tile forms all D products and the shared prefix sums again, so fewer waves with more coordinates
     // each execute fewer instructions per observation: W (2 D + 16 M) + D (D + 1) for M = D / W coordinates per wave.
-    //   M = 8 (D / 8 waves; 256 VGPRs, two waves per SIMD): the default for D >= 32 -- C3 at 65 536 chains 1.55e7 -> 1.69e7 leapfrog-steps/s, half tiles
-    //         at 8 192 chains 9.2e6 -> 1.12e7 (one wave per SIMD: a wave's 8 or 16 suffix sums are independent, they fill the issue slots), 64 coefficients
-    //         3.6e6 -> 4.2e6; D = 16 (two waves per tile) loses: 4.76e7 -> 4.72e7, half tiles 2.4e7 -> 1.7e7 (profiles/round4_lin_eight_per_wave.txt);
-    //   M = 4 (D / 4 waves; 128 VGPRs): round 3's layout, the default for D = 8, 16; M = 2 (D / 2 waves) measured slower at every chain count.
+    //   M = 8 (D / 8 waves; 256 VGPRs, two waves per SIMD): the default for D >= 32 and for full tiles of D = 16 -- C3 at 65 536 chains 1.55e7 -> 1.69e7
+    //         leapfrog-steps/s (1.77e7 with the one-fma density of fg_lin_grad's FUSED instances), half tiles at 8 192 chains 9.2e6 -> 1.17e7 (one wave per
+    //         SIMD: a wave's 8 or 16 suffix sums are independent, they fill the issue slots), 64 coefficients 3.6e6 -> 4.2e6, 16 coefficients 4.8e7 -> 5.1e7
+    //         (but half tiles of D = 16, two waves per tile: 2.2e7 -> 1.8e7) (profiles/round4_lin_eight_per_wave.txt);
+    //   M = 4 (D / 4 waves; 128 VGPRs): round 3's layout, the default for D = 8 and for half tiles of D = 16; M = 2 (D / 2 waves) measured slower at every
+    //         chain count; M = 16 (two waves of 256 VGPRs + 184 spilled: one wave per SIMD) loses a third.
     // FG_HMC_WAVES = D / 8, D / 4, D / 2 picks one for the bit-identity tests.
-    int W = D >= 32 ? D / 8 : D / 4;
+    int W = (D >= 32 || (D == 16 && !half)) ? D / 8 : D / 4;
     if (e->mw_override == D / 4 || (D < 64 && e->mw_override == D / 2) || (D >= 16 && e->mw_override == D / 8)) W = e->mw_override;
     const bool p2 = e->P.lin_p2 != 0;
 #define FG_LIN_KERNELS_D(X, DD, HH) X(DD, DD / 8, false, HH) X(DD, DD / 8, true, HH) X(DD, DD / 4, false, HH) X(DD, DD / 4, true, HH) X(DD, DD / 2, false, HH) X(DD, DD / 2, true, HH)

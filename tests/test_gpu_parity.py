@@ -476,6 +476,38 @@ def test_hmc_lin_kernel_is_bit_identical(name, adapt_mass, monkeypatch):
     assert np.isfinite(out[0][0]).all() and 0.5 < out[0][4] <= 1.0
 
 
+def test_hmc_lin_kernel_with_huge_positions_is_bit_identical(monkeypatch):
+    """The eight-coordinate layout forms -0.5 z z - ln sigma as one fma (exact product) and re-runs a wave's gradient through the unfused
+    instance when a force component comes out non-finite -- the one place the two forms can differ is z z in [2^1024, 2^1025).  Chains started
+    from |beta| ~ 1e152 ... 1e200 (standardised residuals around and beyond that window, sums that overflow, NaN differences) must leave the
+    observation-major kernel in exactly the state the gradient stream leaves them in: values, step sizes, log-joint, divergence counts."""
+    monkeypatch.setenv("FG_JIT", "0")
+    cp = E.compile_model(ZOO["ridge32"]())
+    C = 128
+    out = []
+    for lin, half in ((0, 0), (1, 0), (1, 1)):
+        monkeypatch.setenv("FG_HMC_LIN", str(lin))
+        monkeypatch.setenv("FG_HMC_LIN_HALF", str(half))
+        eng = E.Engine(cp, C, seed=11)
+        eng.prior_init(0)
+        cells = _f64(eng.get_values()).copy()
+        rs = np.random.RandomState(5)
+        for c in range(0, C, 2):                                   # every other chain: one or a few coefficients far out
+            for j in rs.choice(cp.S, size=1 + (c // 2) % 3, replace=False):
+                cells[j, c] = rs.choice([-1.0, 1.0]) * 10.0 ** rs.uniform(152.0, 156.0 if c % 4 == 0 else 200.0)
+        eng.hmc_init(E.hmc_config(n_leapfrog=5, init_step_size=1e-3), 0)      # (draws the initial state from the prior)
+        eng.set_values(cells.view(np.int64))                                   # ... replaced here; the log-joint is re-scored
+        eng.hmc_step(4)
+        if lin: assert "k_hmc_lin_steps" in eng.hmc_last_kernel() and ("half" in eng.hmc_last_kernel()) == bool(half), eng.hmc_last_kernel()
+        st = eng.hmc_stats()
+        out.append((eng.get_values(), eng.hmc_step_sizes(), eng.hmc_log_joint(), st.n_divergent, st.accept_rate))
+        eng.close()
+    assert out[0][3] > 0                                           # the far-out chains do diverge
+    for o in out[1:]:
+        for a, b in zip(out[0], o):
+            assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
 def lib_sep_records(cp):
     return E.lib().fg_program_stream_records(cp.h, 3)
 
