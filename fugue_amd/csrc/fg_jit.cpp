@@ -967,7 +967,7 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     // what every launch of this unit passes anyway (the engine checks it does): row counts, tile layout, waves per tile and the mode bits as literals --
     // the step loop loses their scalar tests and branches, LDS addresses become instruction offsets
     if (baked && !pipe) {
-        if (!no_stream) src += "#define FG_MHMW_K_NCU " + std::to_string(baked[0]) + "\n#define FG_MHMW_K_NS " + std::to_string(baked[1]) + "\n#define FG_MHMW_K_NPRI " + std::to_string(baked[2]) + "\n";
+        if (!no_stream && !(std::getenv("FG_MH_BAKE") && std::atoi(std::getenv("FG_MH_BAKE")) == 2)) src += "#define FG_MHMW_K_NCU " + std::to_string(baked[0]) + "\n#define FG_MHMW_K_NS " + std::to_string(baked[1]) + "\n#define FG_MHMW_K_NPRI " + std::to_string(baked[2]) + "\n";
         src += "#define FG_MHMW_K_NSLOTS " + std::to_string(baked[3]) + "\n#define FG_MHMW_K_W " + std::to_string(baked[4]) + "\n#define FG_MHMW_K_EXP " + std::to_string(baked[5]) +
                "\n#define FG_MHMW_K_POOLN " + std::to_string(baked[6]) + "\n";
     }
