@@ -354,7 +354,17 @@ static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long>
     const long long n_cu = std::max(1, e->n_simd / 4);
     if (forced > 0) W = std::max(1, std::min(forced, wcap));
     else if ((long long)tiles <= n_cu) W = wcap;             // a CU has at most one tile: a wave per task (logistic regression, 8 192 chains: W = 6 beats 4 by 45 %)
-    else while (2 * W <= std::min(8, wcap)) W *= 2;         // several tiles per CU: a power of two up to eight (measured on four models)
+    else {
+        // several tiles per CU: sixteen waves per CU is all that is ever resident (128 VGPRs), so four tiles of four waves where the LDS holds four tiles and a tile has at most sixteen tasks --
+        // fewer, longer task lists per wave and half the waves at every barrier (reference_model(8) at 65 536 chains 2.32e10 -> 2.81e10 leapfrog-steps/s,
+        // hier 1.75e10 -> 2.05e10, mixture +6 %) -- and eight waves where it holds two or three (reference_model(20): 1.02e10 with four, 1.12e10 with eight;
+        // reference_model(32) 6.1e9 / 7.4e9): profiles/round4_hmc_jit_waves.txt
+        const long long lds8 = ((long long)e->S + 3LL * e->d + 2 + 8) * FG_WAVE * (long long)sizeof(double);
+        const long long resident = std::min<long long>((160 * 1024) / std::max<long long>(1, lds8), ((long long)tiles + n_cu - 1) / n_cu);
+        const int target = (resident >= 4 && n_tasks <= 16) ? 4 : 8;     // (alldists, 24 heavy tasks, four tiles per CU: 9.3e8 with eight waves, 8.7e8 with four)
+        while (2 * W <= std::min(target, wcap)) W *= 2;
+        if (std::getenv("FG_JIT_VERBOSE")) { long long tot = 0; for (long long c : cost) tot += 2 * c; fprintf(stderr, "fugue_amd: compiled HMC unit: d %d, task cost %lld, resident %lld, W %d\n", e->d, tot, resident, W); }
+    }
     mwi_split(cost, W, &bins);
     for (int w = 0; w < W; ++w) std::sort(bins[w].begin(), bins[w].end());
     return W;
