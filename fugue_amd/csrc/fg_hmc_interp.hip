@@ -337,7 +337,7 @@ struct FgJitSeg { int off[FG_MWI_MAX + 1]; const int *order; int baked; };   // 
 
 // waves per tile of the compiled HMC kernels and the split of the sparse finite difference's 2 d tasks over them -- a function of the engine alone
 // (program, chain count, FG_HMC_WAVES / FG_HMC_INTERP_WAVES / FG_HMC_JIT_OCC at the time): the unit is generated BEHIND it (fg_jit_wave_tasks)
-static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long> &cost, std::vector<std::vector<int>> &bins) {
+static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long> &cost, std::vector<std::vector<int>> &bins, std::vector<std::vector<int>> *cbins = nullptr) {
     const int n_tasks = 2 * e->d;
     cost.assign(e->d, 1);
     for (int k = 0; k < e->d; ++k) {
@@ -365,8 +365,27 @@ static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long>
         while (2 * W <= std::min(target, wcap)) W *= 2;
         if (std::getenv("FG_JIT_VERBOSE")) { long long tot = 0; for (long long c : cost) tot += 2 * c; fprintf(stderr, "fugue_amd: compiled HMC unit: d %d, task cost %lld, resident %lld, W %d\n", e->d, tot, resident, W); }
     }
-    mwi_split(cost, W, &bins);
+    const long long span_tasks = mwi_split(cost, W, &bins);
     for (int w = 0; w < W; ++w) std::sort(bins[w].begin(), bins[w].end());
+    if (cbins) {
+        // whole coordinates per wave (the one-barrier gradient of fg_jit_wave_grad): both evaluations of a coordinate on one wave.  Taken where the coarser
+        // split stretches the longest wave by less than a barrier costs; FG_JIT_FUSED=0 / 1 forces.
+        std::vector<std::vector<int>> pb;
+        const long long span_coords = 2 * mwi_split(cost, W, &pb, true);
+        cbins->assign((size_t)W, std::vector<int>());
+        for (int w = 0; w < W; ++w) { for (int t : pb[w]) (*cbins)[(size_t)w].push_back(t >> 1); std::sort((*cbins)[(size_t)w].begin(), (*cbins)[(size_t)w].end()); }
+        const long long lds1 = ((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * (long long)sizeof(double), lds2 = lds1 + (long long)e->S * FG_WAVE * (long long)sizeof(double);
+        const long long per_cu = ((long long)tiles + n_cu - 1) / n_cu;
+        // (a barrier is worth about 64 cost units of the longest wave: reference_model(8) 36 -> 48 units +8 %, reference_model(20) 60 -> 120 +7 % / +15 % at 8 192
+        // chains, hier_scale 74 -> 148 -8 %, logistic regression 465 -> 930 -29 %; the second copy may cost a resident tile but not the last but one:
+        // reference_model(32), two tiles -> one, -14 % -- profiles/round4_hmc_jit_one_barrier.txt)
+        const long long t1 = std::min<long long>((160 * 1024) / lds1, per_cu), t2 = lds2 <= 160 * 1024 ? std::min<long long>((160 * 1024) / lds2, per_cu) : 0;
+        bool ok = t2 >= std::min<long long>(2, t1) && span_coords - span_tasks <= 64;
+        if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: compiled HMC unit: W %d, longest wave %lld (tasks) / %lld (whole coordinates), tiles per CU %lld / %lld\n", W, span_tasks, span_coords,
+                                                   std::min<long long>((160 * 1024) / lds1, per_cu), std::min<long long>((160 * 1024) / lds2, per_cu));
+        if (const char *fv = std::getenv("FG_JIT_FUSED")) ok = std::atoi(fv) != 0 && lds2 <= 160 * 1024;
+        if (!ok) cbins->clear();
+    }
     return W;
 }
 
@@ -383,8 +402,9 @@ static int jit_hmc_module(fg_engine *e) {
         bool has_ad = false, has_dense = false;
         std::vector<long long> cost0;
         e->jit_baked_bins.clear();
-        if (!(std::getenv("FG_JIT_TASKS") && std::atoi(std::getenv("FG_JIT_TASKS")) == 0)) jit_sparse_split(e, (unsigned)((e->C + e->tw - 1) / e->tw), cost0, e->jit_baked_bins);
-        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense, e->jit_baked_bins.empty() ? nullptr : &e->jit_baked_bins);
+        e->jit_baked_cbins.clear();
+        if (!(std::getenv("FG_JIT_TASKS") && std::atoi(std::getenv("FG_JIT_TASKS")) == 0)) jit_sparse_split(e, (unsigned)((e->C + e->tw - 1) / e->tw), cost0, e->jit_baked_bins, &e->jit_baked_cbins);
+        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense, e->jit_baked_bins.empty() ? nullptr : &e->jit_baked_bins, e->jit_baked_cbins.empty() ? nullptr : &e->jit_baked_cbins);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
@@ -470,7 +490,7 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
     {   // LDS: S site rows + d momentum rows + 2 d evaluation rows + exchange rows; beyond 64 KB the module's functions need the attribute
         const size_t lds_max = (size_t)((long long)e->S + 3LL * e->d + 2 + FG_MWI_MAX) * FG_WAVE * sizeof(double);
         if (lds_max > 160 * 1024) return FG_E_UNSUPPORTED;
-        if (lds_max > 64 * 1024 && !e->jit_lds_attr) {
+        if (lds_max + (size_t)e->S * FG_WAVE * sizeof(double) > 64 * 1024 && !e->jit_lds_attr) {      // (+ the second copy of the site rows of the one-barrier gradient)
             if (hipFuncSetAttribute((const void *)e->jit_fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute((const void *)e->jit_fn_eps, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { (void)hipGetLastError(); e->jit_state = -1; return FG_E_UNSUPPORTED; }
             e->jit_lds_attr = true;
@@ -482,8 +502,9 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
     }
     const int split_key = dense ? 4 : 2;                   // (2: the split of the compiled kernel; 4: its dense mode -- every task is the whole program)
     if (e->mwi_sparse != split_key || e->mwi_W <= 0) {
-        std::vector<std::vector<int>> bins;
-        int W = jit_sparse_split(e, tiles, e->mwi_cost, bins);
+        std::vector<std::vector<int>> bins, cbins;
+        int W = jit_sparse_split(e, tiles, e->mwi_cost, bins, &cbins);
+        e->mwi_fused = !dense && !cbins.empty() && cbins == e->jit_baked_cbins;
         if (dense) { e->mwi_cost.assign(e->d, 1); mwi_split(e->mwi_cost, W, &bins); }      // (every task is the whole program)
         e->mwi_baked = !dense && !e->jit_baked_bins.empty() && (int)e->jit_baked_bins.size() == W;
         for (int w = 0; w < W && e->mwi_baked; ++w) { std::vector<int> b = bins[w]; std::sort(b.begin(), b.end()); e->mwi_baked = b == e->jit_baked_bins[w]; }
@@ -534,10 +555,13 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
     seg.order = e->d_mwi_order;
     seg.baked = (e->mwi_baked && e->cfg.grad_mode == FG_GRAD_FD_SPARSE) ? 1 : 0;      // the unit holds this very split as straight-line code (fg_jit_wave_tasks)
+    const bool fused = e->mwi_fused && e->cfg.grad_mode == FG_GRAD_FD_SPARSE;          // ... or whole coordinates per wave (fg_jit_wave_grad): a second copy of the site rows
+    if (fused) seg.baked = 2;
     if (e->cfg.grad_mode == FG_GRAD_ANALYTIC && e->jit_has_ad) for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off_an[w];
     int n_warmup = e->n_warmup;
     void *args[] = { &e->P, &e->X, &e->H, &seg, &iter0, &n, &n_warmup, &welford_on, &draws, &first_sample_t, &pos_all, &info };
-    HIPCHK(hipModuleLaunchKernel(e->jit_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds_for(W), e->stream, args, nullptr));
-    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + (e->cfg.grad_mode == FG_GRAD_FD_DENSE ? " (dense; compiled at run time)" : " (compiled at run time)");
+    const size_t lds = lds_for(W) + (fused ? (size_t)e->S * FG_WAVE * sizeof(double) : 0);
+    HIPCHK(hipModuleLaunchKernel(e->jit_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
+    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + (e->cfg.grad_mode == FG_GRAD_FD_DENSE ? " (dense; compiled at run time)" : fused ? " (compiled at run time, one barrier per gradient)" : " (compiled at run time)");
     return FG_OK;
 }

@@ -13,7 +13,8 @@
 #ifndef FG_JIT_OCC          /* waves per SIMD the register budget allows: 4 = 128 VGPRs (fg_jit.cpp may define 2 or 3 for register-hungry programs) */
 #define FG_JIT_OCC 4
 #endif
-struct FgJitSeg { int off[FG_JIT_WMAX + 1]; const int *order; int baked; };   // wave w owns tasks order[off[w] .. off[w + 1]): 2 k + sign; baked: this IS the split fg_jit_wave_tasks was generated for
+struct FgJitSeg { int off[FG_JIT_WMAX + 1]; const int *order; int baked; };   // wave w owns tasks order[off[w] .. off[w + 1]): 2 k + sign; baked: 1 = this IS the split fg_jit_wave_tasks was generated for,
+                                                                           // 2 = whole coordinates per wave as fg_jit_wave_grad holds them (one barrier per gradient; S more rows of LDS)
 
 extern "C" __global__ __attribute__((amdgpu_waves_per_eu(FG_JIT_OCC, FG_JIT_OCC))) __launch_bounds__(FG_WAVE * 4 * FG_JIT_OCC)
 void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int iter0, int n_steps, int n_warmup, int welford_on, double *draws,
@@ -44,9 +45,20 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
     const bool analytic = H.grad_mode == 2 /* FG_GRAD_ANALYTIC */;      // (the step-size search keeps the finite difference, like the stream kernels')
     const bool dense = H.grad_mode == 0 /* FG_GRAD_FD_DENSE */; (void)dense;
 #ifdef FG_JIT_BAKED_W
-    const bool baked = seg.baked != 0 && W == FG_JIT_BAKED_W && !analytic && !dense;
+    const bool baked = seg.baked == 1 && W == FG_JIT_BAKED_W && !analytic && !dense;
+#endif
+#ifdef FG_JIT_FUSED_W
+    // one barrier per gradient: a wave runs whole coordinates (both evaluations, force, kick, drift) and writes the new position into the second copy of
+    // the site rows; the two copies change roles at the barrier.  Sites that are not coordinates never change during a transition: equal in both copies.
+    const bool fused = seg.baked == 2 && W == FG_JIT_FUSED_W && !analytic && !dense;
+    double *slots2 = lds + (long long)(S_ + 3 * d + 2 + W) * tw + lane;
+#else
+    const bool fused = false;
 #endif
     for (int j = wv; j < S_; j += W) slots[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+#ifdef FG_JIT_FUSED_W
+    if (fused) for (int j = wv; j < S_; j += W) slots2[P.site_slot[j] * tw] = fg_as_double(X.values[(long long)j * X.C + c]);
+#endif
     double lj = 0.0, eps = 0.0, frozen = 0.0, da_mu = 0.0, da_leb = 0.0, da_hbar = 0.0, asum = 0.0;
     unsigned long long da_m = 0, ndiv = 0;
     if (wv == 0) {
@@ -81,7 +93,19 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         __syncthreads();
         const double e = xch[0], hk = 0.5 * e;
         bool bad = false;
+        double *cur = slots;                                  // the copy of the site rows that holds the current position
+#ifdef FG_JIT_FUSED_W
+        double *alt = slots2;
+#endif
         for (int s = 0; s <= L; ++s) {                        // gradients 0 .. L of the leapfrog (hmc.rs:353-407)
+#ifdef FG_JIT_FUSED_W
+            if (fused) {
+                const bool b_ = fg_jit_wave_grad(wv, h, hk, e, s > 0 && s < L, s < L, FG_JIT_LDS(cur), FG_JIT_LDS(alt), FG_JIT_LDS(pl), mi, X.C);
+                bad = bad || b_;
+                if (s < L) { __syncthreads(); double *t_ = cur; cur = alt; alt = t_; }      // every new position written, every read of the old one done
+                continue;
+            }
+#endif
 #ifdef FG_JIT_BAKED_W
             if (baked) fg_jit_wave_tasks(wv, h, FG_JIT_LDS(slots), FG_JIT_LDS(ev_lp));      // hmc.rs:317-321, this wave's tasks as straight-line code
             else
@@ -116,7 +140,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         double lj_new = FG_NEG_INF;
         if (wv == 0) {
             double pr = 0.0, lk = 0.0, fc = 0.0;
-            fg_jit_score(FG_JIT_LDS(slots), pr, lk, fc);
+            fg_jit_score(FG_JIT_LDS(cur), pr, lk, fc);
             lj_new = pr + lk + fc;                            // total_log_weight (trace.rs:198-200)
         }
         xch[(2 + wv) * tw] = bad ? 1.0 : 0.0;
@@ -150,7 +174,7 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         if (warming && welford_on) wn = H.w_n[c] + 1ull;          // every wave reads the old count before wave 0 bumps it below
         for (int k = wv; k < d; k += W) {                         // commit or roll back: coordinate k by wave k mod W
             const long long g = (long long)P.f64_site[k] * X.C + c;
-            if (acc) { if (live) X.values[g] = fg_as_i64(slots[k * tw]); }
+            if (acc) { const double v = cur[k * tw]; if (live) X.values[g] = fg_as_i64(v); slots[k * tw] = v; }      // (the next transition starts from the first copy)
             else slots[k * tw] = fg_as_double(X.values[g]);
             const double x = slots[k * tw];
             if (live && pos_all) pos_all[((long long)t * d + k) * X.C + c] = x;

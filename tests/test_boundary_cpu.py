@@ -162,15 +162,19 @@ def test_jit_task_code_compiles_for_gfx950(name, W, monkeypatch):
     lib = E.lib()
     lib.fg_debug_jit_compile.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong, ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
     monkeypatch.setenv("FG_DEBUG_JIT_TASKS", str(W))
+    monkeypatch.setenv("FG_DEBUG_JIT_COORDS", str(W))
     cp = E.compile_model(ZOO[name]())
     src = ctypes.create_string_buffer(8 << 20); log = ctypes.create_string_buffer(1 << 20); n = ctypes.c_longlong()
     rc = lib.fg_debug_jit_compile(cp.h, src, len(src), log, len(log), ctypes.byref(n))
     assert rc == 0 and n.value > 0, log.value.decode()[:2000]
     text = src.value.decode()
     assert f"#define FG_JIT_BAKED_W {min(W, 2 * cp.d)}" in text and f"#define FG_JIT_K_D {cp.d}\n" in text and f"#define FG_JIT_K_S {cp.S}\n" in text
-    body = text[text.index("void fg_jit_wave_tasks("):text.index("double fg_jit_task(")]
+    body = text[text.index("void fg_jit_wave_tasks("):text.index("#define FG_JIT_FUSED_W")]
     for t in range(2 * cp.d):
         assert body.count(f"ev[{t} * FG_WAVE] = ") == 1, t
+    grad = text[text.index("bool fg_jit_wave_grad("):text.index("double fg_jit_task(")]      # whole coordinates per wave (the one-barrier gradient)
+    for k in range(cp.d):
+        assert grad.count(f"FG_JIT_GRAD_COORD({k}, ") == 1, k
 
 
 @pytest.mark.parametrize("name", ["refmodel8", "mixture"])

@@ -77,9 +77,13 @@ def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkey
     C, nw, ns = 150, 30, 20
     out, kernels = [], []
     monkeypatch.setenv("FG_HMC_LIN", "0")                                   # (ridge7 is a dense regression: its own kernel would take it)
-    for jit, tasks in ((0, 1), (1, 1), (1, 0)):      # tasks: the unit's task split as straight-line code per wave (default) / a task list in memory
+    # tasks: the unit's task split as straight-line code per wave (default) / a task list in memory; fused: whole coordinates per wave and ONE barrier per
+    # gradient (a second copy of the site rows) forced on / off (the host's choice otherwise)
+    for jit, tasks, fused in ((0, 1, None), (1, 1, "1"), (1, 1, "0"), (1, 0, None)):
         monkeypatch.setenv("FG_JIT", str(jit))
         monkeypatch.setenv("FG_JIT_TASKS", str(tasks))
+        if fused is None: monkeypatch.delenv("FG_JIT_FUSED", raising=False)
+        else: monkeypatch.setenv("FG_JIT_FUSED", fused)
         eng = E.Engine(cp, C, seed=31, chain_offset=2)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(n_leapfrog=6, adapt_mass=adapt_mass), ns, nw, d)
@@ -88,7 +92,8 @@ def test_jit_hmc_is_bit_identical_to_the_stream_kernels(name, adapt_mass, monkey
         eng.device_free(d)
         out.append((draws, eng.hmc_step_sizes(), eng.hmc_log_joint(), eng.get_values(), st.accept_rate, st.n_divergent, eng.hmc_mass() if adapt_mass else None))
         eng.close()
-    assert kernels[0].startswith("k_hmc_stream_steps") and kernels[1].startswith("k_hmc_jit_steps") and kernels[2].startswith("k_hmc_jit_steps"), kernels
+    assert kernels[0].startswith("k_hmc_stream_steps") and all(k.startswith("k_hmc_jit_steps") for k in kernels[1:]), kernels
+    assert "one barrier per gradient" in kernels[1] and "one barrier" not in kernels[2] and "one barrier" not in kernels[3], kernels
     for o in out[1:]:
         for a, b in zip(out[0], o):
             assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)

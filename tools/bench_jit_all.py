@@ -7,7 +7,7 @@ from fugue_amd import engine as E, workloads as W
 from tests.models import ZOO
 which = sys.argv[1:] or ["alldists", "logistic", "poisson_glm", "hier_logsigma", "hier_scale", "linreg", "mixture", "refmodel8"]
 for name in which:
-    cp = E.compile_model(ZOO[name]() if name in ZOO else W.reference_model(20))
+    cp = E.compile_model(ZOO[name]() if name in ZOO else W.reference_model(int(name[8:]) if name.startswith("refmodel") else 20))
     for C in (65536, 8192):
         eng = E.Engine(cp, C, seed=1)
         out = f"{name:14s} C={C:6d}"
