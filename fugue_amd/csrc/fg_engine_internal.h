@@ -81,7 +81,7 @@ struct fg_engine {
     long long diag_bytes = 0;  // bytes this rank put into collectives during the last fg_diag_rhat_ess
     std::string last_hmc_kernel;   // kernel (and waves per tile) the last fg_hmc_step launch ran (fg_hmc_last_kernel)
     bool interp_mw_disabled = false;   // FG_HMC_INTERP_MW=0: keep interpreter programs on the one-wave-per-tile HMC kernel (A/B tests)
-    std::vector<std::vector<int>> jit_baked_bins, jit_baked_cbins; bool mwi_baked = false, mwi_fused = false;   // the task split the compiled HMC unit was generated behind; does the current split equal it
+    std::vector<std::vector<int>> jit_baked_bins, jit_baked_cbins, jit_baked_cbins_dense; bool mwi_baked = false, mwi_fused = false;   // the task split the compiled HMC unit was generated behind; does the current split equal it
     int *d_mwi_order = nullptr; long long *d_mwi_prof = nullptr; std::vector<int> mwi_off, mwi_off_an; std::vector<long long> mwi_cost; int mwi_W = 0, mwi_sparse = -1, mwi_calibrated = 0;   // coordinate split of k_hmc_interp_mw_steps (fg_hmc_interp.hip)
     int mhi_W = 0, mhi_n_stmt = 0, mhi_occ = 2; bool mhi_setup_done = false; size_t mhi_lds = 0; std::vector<int> mhi_ins_off, mhi_stmt_off; unsigned char *d_mhi_acc = nullptr; int *d_mhi_site_ins = nullptr; std::vector<int> mhi_stmt_end; std::vector<unsigned char> mhi_acc_host;   // statement split of k_mh_interp_mw_steps (fg_mh_interp.hip)
     int jit_state = 0;           // run-time compiled HMC kernel of this program: 0 not tried, 1 loaded, -1 unavailable (fg_jit.cpp; FG_JIT=0 switches it off)

@@ -389,6 +389,22 @@ static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long>
     return W;
 }
 
+// the dense mode's one-barrier gradient: every (coordinate, sign) task is the whole program, so whole coordinates per wave cost nothing exactly when
+// 2 ceil(d / W) = ceil(2 d / W); the second copy of the site rows under the same LDS rule as the sparse form's
+static void jit_dense_coord_split(fg_engine *e, unsigned tiles, int W, std::vector<std::vector<int>> &cbins) {
+    cbins.clear();
+    const int d = e->d;
+    if (W < 1 || 2 * ((d + W - 1) / W) != (2 * d + W - 1) / W) return;
+    const long long n_cu = std::max(1, e->n_simd / 4), per_cu = ((long long)tiles + n_cu - 1) / n_cu;
+    const long long lds1 = ((long long)e->S + 3LL * d + 2 + W) * FG_WAVE * (long long)sizeof(double), lds2 = lds1 + (long long)e->S * FG_WAVE * (long long)sizeof(double);
+    const long long t1 = std::min<long long>((160 * 1024) / lds1, per_cu), t2 = lds2 <= 160 * 1024 ? std::min<long long>((160 * 1024) / lds2, per_cu) : 0;
+    bool ok = t2 >= std::min<long long>(2, t1);
+    if (const char *fv = std::getenv("FG_JIT_FUSED")) ok = std::atoi(fv) != 0 && lds2 <= 160 * 1024;
+    if (!ok) return;
+    cbins.assign((size_t)W, std::vector<int>());
+    for (int k = 0; k < d; ++k) cbins[(size_t)(k % W)].push_back(k);
+}
+
 // the program's compiled module (once per engine): HMC transitions, the step-size search, adaptive_smc's rejuvenation move
 static int jit_hmc_module(fg_engine *e) {
     if (e->jit_state < 0 || e->gt || e->tw != FG_WAVE || e->d < 1) return FG_E_UNSUPPORTED;
@@ -403,8 +419,14 @@ static int jit_hmc_module(fg_engine *e) {
         std::vector<long long> cost0;
         e->jit_baked_bins.clear();
         e->jit_baked_cbins.clear();
-        if (!(std::getenv("FG_JIT_TASKS") && std::atoi(std::getenv("FG_JIT_TASKS")) == 0)) jit_sparse_split(e, (unsigned)((e->C + e->tw - 1) / e->tw), cost0, e->jit_baked_bins, &e->jit_baked_cbins);
-        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense, e->jit_baked_bins.empty() ? nullptr : &e->jit_baked_bins, e->jit_baked_cbins.empty() ? nullptr : &e->jit_baked_cbins);
+        e->jit_baked_cbins_dense.clear();
+        if (!(std::getenv("FG_JIT_TASKS") && std::atoi(std::getenv("FG_JIT_TASKS")) == 0)) {
+            const unsigned tiles0 = (unsigned)((e->C + e->tw - 1) / e->tw);
+            const int W0 = jit_sparse_split(e, tiles0, cost0, e->jit_baked_bins, &e->jit_baked_cbins);
+            jit_dense_coord_split(e, tiles0, W0, e->jit_baked_cbins_dense);
+        }
+        const std::string src = fg_jit_hmc_source(e->prog, &ctab, &has_ad, &has_dense, e->jit_baked_bins.empty() ? nullptr : &e->jit_baked_bins, e->jit_baked_cbins.empty() ? nullptr : &e->jit_baked_cbins,
+                                                  e->jit_baked_cbins_dense.empty() ? nullptr : &e->jit_baked_cbins_dense);
         if (src.empty() || src.size() > (6u << 20)) return FG_E_UNSUPPORTED;                            // plates roll into loops; what stays straight-line must stay compilable in seconds
         std::vector<char> code;
         const int rc = fg_jit_get_code(src, code, e->jit_log);
@@ -505,6 +527,7 @@ static int jit_hmc_prepare(fg_engine *e, unsigned tiles) {
         std::vector<std::vector<int>> bins, cbins;
         int W = jit_sparse_split(e, tiles, e->mwi_cost, bins, &cbins);
         e->mwi_fused = !dense && !cbins.empty() && cbins == e->jit_baked_cbins;
+        if (dense) { std::vector<std::vector<int>> dc; jit_dense_coord_split(e, tiles, W, dc); e->mwi_fused = !dc.empty() && dc == e->jit_baked_cbins_dense; }
         if (dense) { e->mwi_cost.assign(e->d, 1); mwi_split(e->mwi_cost, W, &bins); }      // (every task is the whole program)
         e->mwi_baked = !dense && !e->jit_baked_bins.empty() && (int)e->jit_baked_bins.size() == W;
         for (int w = 0; w < W && e->mwi_baked; ++w) { std::vector<int> b = bins[w]; std::sort(b.begin(), b.end()); e->mwi_baked = b == e->jit_baked_bins[w]; }
@@ -555,13 +578,13 @@ int fg_hmc_jit_launch(fg_engine *e, int iter0, int n, int welford_on, double *dr
     for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off[w];
     seg.order = e->d_mwi_order;
     seg.baked = (e->mwi_baked && e->cfg.grad_mode == FG_GRAD_FD_SPARSE) ? 1 : 0;      // the unit holds this very split as straight-line code (fg_jit_wave_tasks)
-    const bool fused = e->mwi_fused && e->cfg.grad_mode == FG_GRAD_FD_SPARSE;          // ... or whole coordinates per wave (fg_jit_wave_grad): a second copy of the site rows
-    if (fused) seg.baked = 2;
+    const bool fused = e->mwi_fused && (e->cfg.grad_mode == FG_GRAD_FD_SPARSE || e->cfg.grad_mode == FG_GRAD_FD_DENSE);   // ... or whole coordinates per wave (fg_jit_wave_grad / _dense): a second copy of the site rows
+    if (fused) seg.baked = e->cfg.grad_mode == FG_GRAD_FD_DENSE ? 3 : 2;
     if (e->cfg.grad_mode == FG_GRAD_ANALYTIC && e->jit_has_ad) for (int w = 0; w <= FG_MWI_MAX; ++w) seg.off[w] = e->mwi_off_an[w];
     int n_warmup = e->n_warmup;
     void *args[] = { &e->P, &e->X, &e->H, &seg, &iter0, &n, &n_warmup, &welford_on, &draws, &first_sample_t, &pos_all, &info };
     const size_t lds = lds_for(W) + (fused ? (size_t)e->S * FG_WAVE * sizeof(double) : 0);
     HIPCHK(hipModuleLaunchKernel(e->jit_fn, tiles, 1, 1, FG_WAVE * W, 1, 1, (unsigned)lds, e->stream, args, nullptr));
-    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + (e->cfg.grad_mode == FG_GRAD_FD_DENSE ? " (dense; compiled at run time)" : fused ? " (compiled at run time, one barrier per gradient)" : " (compiled at run time)");
+    e->last_hmc_kernel = "k_hmc_jit_steps W=" + std::to_string(W) + (e->cfg.grad_mode == FG_GRAD_FD_DENSE ? (fused ? " (dense; compiled at run time, one barrier per gradient)" : " (dense; compiled at run time)") : fused ? " (compiled at run time, one barrier per gradient)" : " (compiled at run time)");
     return FG_OK;
 }

@@ -47,10 +47,19 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
 #ifdef FG_JIT_BAKED_W
     const bool baked = seg.baked == 1 && W == FG_JIT_BAKED_W && !analytic && !dense;
 #endif
+#if defined(FG_JIT_FUSED_DENSE_W) && !defined(FG_JIT_FUSED_W)
+#define FG_JIT_FUSED_W 0   /* (a unit with the dense form only: the sparse one never matches) */
+#define FG_JIT_NO_SPARSE_FUSED 1
+#endif
 #ifdef FG_JIT_FUSED_W
     // one barrier per gradient: a wave runs whole coordinates (both evaluations, force, kick, drift) and writes the new position into the second copy of
     // the site rows; the two copies change roles at the barrier.  Sites that are not coordinates never change during a transition: equal in both copies.
-    const bool fused = seg.baked == 2 && W == FG_JIT_FUSED_W && !analytic && !dense;
+#ifdef FG_JIT_FUSED_DENSE_W
+    const bool fused_dense = seg.baked == 3 && W == FG_JIT_FUSED_DENSE_W && dense;      // the same for the dense mode (whole-program evaluations)
+#else
+    const bool fused_dense = false;
+#endif
+    const bool fused = (seg.baked == 2 && W == FG_JIT_FUSED_W && !analytic && !dense) || fused_dense;
     double *slots2 = lds + (long long)(S_ + 3 * d + 2 + W) * tw + lane;
 #else
     const bool fused = false;
@@ -100,7 +109,16 @@ void k_hmc_jit_steps(FgProgramDev P, FgChainCtx X, FgHmcDev H, FgJitSeg seg, int
         for (int s = 0; s <= L; ++s) {                        // gradients 0 .. L of the leapfrog (hmc.rs:353-407)
 #ifdef FG_JIT_FUSED_W
             if (fused) {
-                const bool b_ = fg_jit_wave_grad(wv, h, hk, e, s > 0 && s < L, s < L, FG_JIT_LDS(cur), FG_JIT_LDS(alt), FG_JIT_LDS(pl), mi, X.C);
+                bool b_ = false;
+#ifdef FG_JIT_FUSED_DENSE_W
+                if (fused_dense) b_ = fg_jit_wave_grad_dense(wv, h, hk, e, s > 0 && s < L, s < L, FG_JIT_LDS(cur), FG_JIT_LDS(alt), FG_JIT_LDS(pl), mi, X.C);
+                else
+#endif
+#ifndef FG_JIT_NO_SPARSE_FUSED
+                b_ = fg_jit_wave_grad(wv, h, hk, e, s > 0 && s < L, s < L, FG_JIT_LDS(cur), FG_JIT_LDS(alt), FG_JIT_LDS(pl), mi, X.C);
+#else
+                { }
+#endif
                 bad = bad || b_;
                 if (s < L) { __syncthreads(); double *t_ = cur; cur = alt; alt = t_; }      // every new position written, every read of the old one done
                 continue;

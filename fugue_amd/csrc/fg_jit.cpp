@@ -592,7 +592,7 @@ static bool fg_jit_inlined() { const char *v = std::getenv("FG_JIT_INLINE"); ret
 
 // The generated translation unit of one program's HMC kernel, or "" when the program holds something the generator does not cover.
 std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out, bool *has_dense_out, const std::vector<std::vector<int>> *wave_tasks,
-                              const std::vector<std::vector<int>> *wave_coords) {
+                              const std::vector<std::vector<int>> *wave_coords, const std::vector<std::vector<int>> *wave_coords_dense) {
     std::map<std::string, std::string> lp_fns;
     FgJitTabs ctabs;
     std::vector<std::string> tables;
@@ -706,6 +706,31 @@ std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out
                 fns += "#define FG_JIT_HAS_DENSE 1\nstatic __device__ __forceinline__ double fg_jit_dense_task(int k, double pert, const FG_LDSQ double *slots) {\n    switch (k) {\n";
                 for (int k = 0; k < d; ++k) fns += "    case " + std::to_string(k) + ": return fg_jit_full_" + std::to_string(k) + "(pert, slots);\n";
                 fns += "    default: return 0.0;\n    }\n}\n";
+                // ... and the one-barrier gradient of the dense mode: whole coordinates per wave, the two WHOLE log-joints of a coordinate in registers
+                if (wave_coords_dense && !wave_coords_dense->empty() && wave_coords_dense->size() <= 16) {
+                    std::string gf = "#define FG_JIT_FUSED_DENSE_W " + std::to_string(wave_coords_dense->size()) + "\n"
+                                     "#ifndef FG_JIT_GRAD_COORD\n"
+                                     "#define FG_JIT_GRAD_COORD(K, SUB) { const double q_ = cur[(K) * FG_WAVE]; const double tp_ = SUB(q_ + h, cur); const double tm_ = SUB(q_ - h, cur); \\\n"
+                                     "        const double g_ = (tp_ - tm_) / (2.0 * h); bad = bad || !fg_finite(g_); double p_ = pl[(K) * FG_WAVE]; p_ += hk * g_; if (two_kicks) p_ += hk * g_; pl[(K) * FG_WAVE] = p_; \\\n"
+                                     "        if (drift) { const double mk_ = mi ? mi[(long long)(K) * XC] : 1.0; alt[(K) * FG_WAVE] = q_ + e * mk_ * p_; } }\n"
+                                     "#endif\n"
+                                     "static __device__ __forceinline__ bool fg_jit_wave_grad_dense(int wv, double h, double hk, double e, bool two_kicks, bool drift, const FG_LDSQ double *cur, FG_LDSQ double *alt,\n"
+                                     "                                                              FG_LDSQ double *pl, const double *mi, long long XC) {\n    bool bad = false;\n    switch (wv) {\n";
+                    std::vector<char> seen((size_t)d, 0);
+                    bool okd = true;
+                    for (size_t w = 0; w < wave_coords_dense->size() && okd; ++w) {
+                        gf += "    case " + std::to_string(w) + ": {\n";
+                        for (int k : (*wave_coords_dense)[w]) {
+                            if (k < 0 || k >= d || seen[(size_t)k]) { okd = false; break; }
+                            seen[(size_t)k] = 1;
+                            gf += "        FG_JIT_GRAD_COORD(" + std::to_string(k) + ", fg_jit_full_" + std::to_string(k) + ")\n";
+                        }
+                        gf += "    } break;\n";
+                    }
+                    for (int k = 0; k < d; ++k) okd = okd && seen[(size_t)k];
+                    if (!okd) return "";
+                    fns += gf + "    default: break;\n    }\n    return bad;\n}\n";
+                }
             }
         }
     }
@@ -1192,7 +1217,7 @@ extern "C" int fg_debug_jit_compile(const fg_program *p, char *src_out, long lon
     if (const char *tw_ = std::getenv("FG_DEBUG_JIT_TASKS")) { const int W_ = std::max(1, std::min(16, std::atoi(tw_))); dbg_bins.resize((size_t)W_); for (int t = 0; t < 2 * (int)p->coord.size(); ++t) dbg_bins[(size_t)(t % W_)].push_back(t); }
     std::vector<std::vector<int>> dbg_cbins;                              // FG_DEBUG_JIT_COORDS=W: whole coordinates dealt round-robin over W waves (fg_jit_wave_grad)
     if (const char *cw_ = std::getenv("FG_DEBUG_JIT_COORDS")) { const int W_ = std::max(1, std::min(16, std::atoi(cw_))); dbg_cbins.resize((size_t)W_); for (int k = 0; k < (int)p->coord.size(); ++k) dbg_cbins[(size_t)(k % W_)].push_back(k); }
-    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr, nullptr, nullptr, dbg_bins.empty() ? nullptr : &dbg_bins, dbg_cbins.empty() ? nullptr : &dbg_cbins);
+    const std::string src = mh ? fg_jit_mh_source(p, std::vector<long long>((size_t)p->n_ins, 1), 4, nullptr) : fg_jit_hmc_source(p, nullptr, nullptr, nullptr, dbg_bins.empty() ? nullptr : &dbg_bins, dbg_cbins.empty() ? nullptr : &dbg_cbins, dbg_cbins.empty() ? nullptr : &dbg_cbins);
     if (src_out && src_cap > 0) { std::snprintf(src_out, (size_t)src_cap, "%s", src.c_str()); }
     if (code_bytes) *code_bytes = 0;
     if (src.empty()) return FG_E_UNSUPPORTED;

@@ -8,7 +8,8 @@ struct fg_program;
 // loaded module's global `fg_jit_ctab_ptr` (fg_jit_bind_tables)
 std::string fg_jit_hmc_source(const fg_program *p, std::vector<double> *ctab_out, bool *has_ad_out = nullptr, bool *has_dense_out = nullptr,
                               const std::vector<std::vector<int>> *wave_tasks = nullptr /* the sparse finite difference's tasks (2 k + sign) of every wave of the engine's launches: straight-line code per wave */,
-                              const std::vector<std::vector<int>> *wave_coords = nullptr /* ... or whole coordinates per wave: both evaluations, the kick and the drift of a coordinate in one piece (fg_jit_wave_grad) */);       // "" = not covered by the generator; has_ad: the unit also holds the forward-mode derivative of every sub-program (FG_GRAD_ANALYTIC)
+                              const std::vector<std::vector<int>> *wave_coords = nullptr /* ... or whole coordinates per wave: both evaluations, the kick and the drift of a coordinate in one piece (fg_jit_wave_grad) */,
+                              const std::vector<std::vector<int>> *wave_coords_dense = nullptr /* the same for the dense mode (whole-program evaluations: fg_jit_wave_grad_dense) */);       // "" = not covered by the generator; has_ad: the unit also holds the forward-mode derivative of every sub-program (FG_GRAD_ANALYTIC)
 std::string fg_jit_mh_source(const fg_program *p, const std::vector<long long> &ins_cost, int occ, std::vector<double> *ctab_out);   // ins_cost[k]: relative cost of instruction k of ins_fast; occ: 2 / 4 waves per SIMD (256 / 128 VGPRs)
 std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long> &ins_cost, const std::vector<char> &generated, int rk, int split,
                                std::vector<double> *ctab_out, const std::vector<int> *rows_in = nullptr, int n_pri = -1, int n_fac = 0, bool no_stream = false, bool pipe = false, int nseg = 0 /* 2 .. 16: one statement segment per wave of a launch with that many waves per tile; else sixteen */, int ctl_share16 = 16 /* ... the control wave's share of a wave's statements, in sixteenths */,

@@ -47,10 +47,13 @@ def test_jit_dense_mode_is_bit_identical_to_the_interpreter(name, adapt_mass, mo
     cp = E.compile_model(ZOO[name]())
     C, nw, ns = 130, 24, 12
     out, kernels = [], []
-    for jit, W in [(0, 0), (1, 0), (1, 1), (1, 3), (1, 16)]:
+    # fused: the one-barrier gradient (whole coordinates per wave, a second copy of the site rows) forced on / off; None: the host's rule
+    for jit, W, fused in [(0, 0, None), (1, 0, None), (1, 1, "1"), (1, 3, "0"), (1, 3, "1"), (1, 16, None), (1, 4, "1")]:
         monkeypatch.setenv("FG_JIT", str(jit))
         if W: monkeypatch.setenv("FG_HMC_INTERP_WAVES", str(W))
         else: monkeypatch.delenv("FG_HMC_INTERP_WAVES", raising=False)
+        if fused is None: monkeypatch.delenv("FG_JIT_FUSED", raising=False)
+        else: monkeypatch.setenv("FG_JIT_FUSED", fused)
         eng = E.Engine(cp, C, seed=31, chain_offset=2)
         d = eng.device_alloc(ns * cp.d * C * 8)
         st = eng.hmc_run(E.hmc_config(n_leapfrog=4, adapt_mass=adapt_mass, grad_mode=E.GRAD_FD_DENSE), ns, nw, d)
