@@ -27,6 +27,10 @@ CONFIGS = {
     "hmc|zoo:hier_logsigma|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
     "hmc|zoo:poisson_glm|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
     "hmc|zoo:logistic100|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    # gradient-stream programs on the compiled unit (task code per wave, one barrier per gradient): the engine's choice since the end of round 4
+    "hmc|zoo:refmodel8|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    "hmc|zoo:refmodel8|8192|fd_sparse|L16": ("_steps", 5, 2, "transition"),
+    "hmc|zoo:hier|65536|fd_sparse|L16": ("_steps", 5, 2, "transition"),
 }
 
 
