@@ -371,17 +371,33 @@ static int jit_sparse_split(fg_engine *e, unsigned tiles, std::vector<long long>
         // whole coordinates per wave (the one-barrier gradient of fg_jit_wave_grad): both evaluations of a coordinate on one wave.  Taken where the coarser
         // split stretches the longest wave by less than a barrier costs; FG_JIT_FUSED=0 / 1 forces.
         std::vector<std::vector<int>> pb;
-        const long long span_coords = 2 * mwi_split(cost, W, &pb, true);
+        mwi_split(cost, W, &pb, true);
+        // the stretch in the units the rule below was measured in: the split's costs are the interpreter's, where a general density is 10 - 16 against a fast
+        // Normal's 3; compiled, the ratio is about twice that
+        std::vector<long long> tcost((size_t)e->d, 1);
+        for (int k = 0; k < e->d; ++k) {
+            long long cs = 0;
+            for (int q = 0; q < e->prog->coord[k].sub_n; ++q) { const FgIns &in = e->prog->sub[e->prog->coord[k].sub_off + q]; cs += mwi_ins_cost(in) * ((FG_INS_OPCODE(in.op) < 17u) ? 2 : 1); }
+            tcost[(size_t)k] = std::max(1LL, cs);
+        }
+        long long span_tasks_t = 0, span_coords_t = 0;
+        for (int w = 0; w < W; ++w) {
+            long long a = 0, b = 0;
+            for (int t : bins[(size_t)w]) a += tcost[(size_t)(t >> 1)];
+            for (int t : pb[(size_t)w]) b += 2 * tcost[(size_t)(t >> 1)];
+            span_tasks_t = std::max(span_tasks_t, a); span_coords_t = std::max(span_coords_t, b);
+        }
+        const long long span_coords = span_coords_t; (void)span_tasks;
         cbins->assign((size_t)W, std::vector<int>());
         for (int w = 0; w < W; ++w) { for (int t : pb[w]) (*cbins)[(size_t)w].push_back(t >> 1); std::sort((*cbins)[(size_t)w].begin(), (*cbins)[(size_t)w].end()); }
         const long long lds1 = ((long long)e->S + 3LL * e->d + 2 + W) * FG_WAVE * (long long)sizeof(double), lds2 = lds1 + (long long)e->S * FG_WAVE * (long long)sizeof(double);
         const long long per_cu = ((long long)tiles + n_cu - 1) / n_cu;
-        // (a barrier is worth about 64 cost units of the longest wave: reference_model(8) 36 -> 48 units +8 %, reference_model(20) 60 -> 120 +7 % / +15 % at 8 192
-        // chains, hier_scale 74 -> 148 -8 %, logistic regression 465 -> 930 -29 %; the second copy may cost a resident tile but not the last but one:
+        // (a barrier is worth about 96 such units of the longest wave: reference_model(8) 36 -> 48 units +8 %, reference_model(20) 60 -> 120 +7 % / +15 % at 8 192
+        // chains, reference_model(32) 96 -> 192 +8 %, hier_scale 74 -> 148 of the split's units (general densities) -8 %, logistic regression 465 -> 930 -29 %; the second copy may cost a resident tile but not the last but one:
         // reference_model(32), two tiles -> one, -14 % -- profiles/round4_hmc_jit_one_barrier.txt)
         const long long t1 = std::min<long long>((160 * 1024) / lds1, per_cu), t2 = lds2 <= 160 * 1024 ? std::min<long long>((160 * 1024) / lds2, per_cu) : 0;
-        bool ok = t2 >= std::min<long long>(2, t1) && span_coords - span_tasks <= 64;
-        if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: compiled HMC unit: W %d, longest wave %lld (tasks) / %lld (whole coordinates), tiles per CU %lld / %lld\n", W, span_tasks, span_coords,
+        bool ok = t2 >= std::min<long long>(2, t1) && span_coords_t - span_tasks_t <= 96;
+        if (std::getenv("FG_JIT_VERBOSE")) fprintf(stderr, "fugue_amd: compiled HMC unit: W %d, longest wave %lld (tasks) / %lld (whole coordinates), tiles per CU %lld / %lld\n", W, span_tasks_t, span_coords,
                                                    std::min<long long>((160 * 1024) / lds1, per_cu), std::min<long long>((160 * 1024) / lds2, per_cu));
         if (const char *fv = std::getenv("FG_JIT_FUSED")) ok = std::atoi(fv) != 0 && lds2 <= 160 * 1024;
         if (!ok) cbins->clear();
