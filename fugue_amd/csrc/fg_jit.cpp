@@ -966,8 +966,8 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     // added in program order from 0.0 -- fg_inorder_sums2's additions -- without chunk loops, tails of selected zeros or address arithmetic)
     if (!no_stream && sum_pri >= 0 && sum_lik >= 0 && sum_pri + sum_lik <= 48) {     // (short programs: reference_model(50) and normal32 -- 64 and 99 rows -- measured 8-12 % slower with straight-line sums than with the chunked loops)
         std::string f = "static __device__ __forceinline__ void fg_jit_sums2(const FG_LDSQ double *terms, double &pri_out, double &lik_out) {\n    double a = 0.0, b = 0.0;\n";   // (inline: a call would drain the control wave's adaptation-state gather, which is in flight across the sums)
-        const int form = std::getenv("FG_MH_SUMS_FORM") ? std::atoi(std::getenv("FG_MH_SUMS_FORM")) : sums_form;   // (0: plain statements; 1, 2: every row first; 3: pinned, no prefetch; n >= 4: pinned, rows n pairs ahead -- profiles/round4_mh_sums_form.txt)
-        if (form >= 3) {
+        const int form = std::getenv("FG_MH_SUMS_FORM") ? std::atoi(std::getenv("FG_MH_SUMS_FORM")) : sums_form;   // (0: plain statements; 3: pinned, no prefetch; n >= 4: pinned, rows n pairs ahead -- profiles/round4_mh_sums_form.txt)
+        if (form >= 3) {         // (every row requested first instead -- 78 live VGPRs -- spilled 36 registers and lost 7 %: profiles/round4_mh_sums_form.txt)
             // the two chains pinned side by side (b is only used behind the branches that follow: the sink pass moves its whole chain there, and the scheduler
             // runs a to its end first -- 39 dependent additions where 20 pairs do); loads do not cross the pins, so the rows are requested `form` pairs ahead
             const int ahead = form == 3 ? 0 : form, n = std::max(sum_pri, sum_lik);
@@ -984,20 +984,6 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
                 if (k < sum_lik) f += "    b += y" + std::to_string(sum_pri + k) + ";";
                 f += "\n";
                 if (ahead > 0 && k + ahead < n) f += ld(k + ahead);
-                f += "    asm volatile(\"\" : \"+v\"(a), \"+v\"(b));\n";
-            }
-        } else if (form >= 1) {
-            // every row requested first, then the two chains side by side: left alone, the scheduler finishes chain a (loads two rows ahead) before it starts chain b
-            // (b is only used behind the branches that follow: the sink pass moves its whole chain there; the empty asm pins both chains to this point, pair by pair)
-            for (int k = 0; k < sum_pri + sum_lik; ++k) f += "    " + std::string(form >= 2 ? "const " : "") + "double y" + std::to_string(k) + " = terms[" + std::to_string(k) + " * FG_WAVE];\n";
-            if (form == 1) {
-                f += "    asm volatile(\"\" : ";
-                for (int k = 0; k < sum_pri + sum_lik; ++k) f += std::string(k ? ", " : "") + "\"+v\"(y" + std::to_string(k) + ")";
-                f += ");\n";
-            }
-            for (int k = 0; k < std::max(sum_pri, sum_lik); ++k) {
-                if (k < sum_pri) f += "    a += y" + std::to_string(k) + ";";
-                if (k < sum_lik) f += "    b += y" + std::to_string(sum_pri + k) + ";";
                 f += "    asm volatile(\"\" : \"+v\"(a), \"+v\"(b));\n";
             }
         } else
@@ -1030,9 +1016,8 @@ std::string fg_jit_mhmw_source(const fg_program *p, const std::vector<long long>
     src += FG_JIT_EMBED_MHMW_BODY;               // fg_mh_mw_body.h
     const bool pipe2 = pipe && !no_stream;       // the step loop with the serial recipe split over waves (stream programs)
     if (pipe2) src += FG_JIT_EMBED_MHMW2_BODY;   // fg_mh_mw2_body.h
-    // register budget: 128 VGPRs (four waves per SIMD) unless the unit is built for a launch of <= 8 waves per tile (nseg = W) and asked for more
-    std::string lb = "FG_WAVE * FG_MH_WMAX, 4";
-    if (nseg >= 2 && nseg <= 8 && std::getenv("FG_MH_JIT_VGPR") && std::atoi(std::getenv("FG_MH_JIT_VGPR")) >= 256) lb = "FG_WAVE * " + std::to_string(nseg) + ", 2";
+    // (128 VGPRs, four waves per SIMD: a 256-register budget for launches of <= 8 waves per tile -- 135 - 165 used -- lost 40 % at 65 536 chains)
+    const std::string lb = "FG_WAVE * FG_MH_WMAX, 4";
     src += "extern \"C\" __global__ __launch_bounds__(" + lb + ") void k_mh_mw_jit_steps(FgProgramDev P, FgChainCtx X, FgMhDev M, const FgGradRec *srt, FgMhSeg seg, int iter0, int n_steps,\n"
            "        int n_warmup, long long *draws, int first_sample_t, int exp_mask, int pool_n) {\n"
            "    " + std::string(pipe2 ? "fg_mh_mw2_body<" : "fg_mh_mw_body<") + std::to_string(rk) + ", " + (split ? "true" : "false") + ">(P, X, M, srt, seg, iter0, n_steps, n_warmup, draws, first_sample_t, exp_mask, pool_n);\n}\n";
